@@ -1,0 +1,773 @@
+/*
+ * gs_oracle.c — CPU ORACLE for the gradslam dense-SLAM hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The product (gradslam_amd/) never links, imports
+ * or falls back to anything in oracle/.
+ *
+ * It restates, in plain C with one float operation per line of the reference's arithmetic,
+ * what the reference's Python/PyTorch functions compute on the CPU.  Operation order and
+ * FMA usage were determined by bit-comparison against the reference itself imported from
+ * /root/reference (torch 2.10 CPU) on the reference's own fixture tests/data/msrd_b2s3
+ * (oracle/pin_arithmetic.py re-runs that comparison):
+ *   - large batched matmuls/einsums ([HW,3]x[3,3], [N,3]x[3,3]) : FMA chain, ascending k
+ *   - tiny matmuls (4x4 . 4x1 per point, 3x3 . 3x1)              : plain mul/add, ascending k
+ *   - torch.cross                                              : fma(a1,b2, -(a2*b1))
+ *   - tensor.norm(dim) over 3                                  : FMA chain then sqrt
+ *   - (a*b).sum(-1), (a**2).sum(-1) over 3                     : plain, left to right
+ * Parity status: PINNED against the reference on golden vectors (tests/golden/, generated
+ * by oracle/make_golden.py) for everything except chamferdist.knn_points, which is a
+ * third-party dependency (chamferdist==1.0.0) absent from /root/reference: its tie-break and
+ * the unit of dist_thresh are PARITY UNPINNED.
+ *
+ * Each function cites the reference file:line it follows (paths relative to the reference).
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -mfma -fopenmp)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ small helpers ---- */
+
+/* FMA-chain dot of a 3-vector with a matrix row (torch CPU bmm for large batches). */
+static inline float dot3_fma(float a0, float a1, float a2, float b0, float b1, float b2) {
+  float acc = a0 * b0;
+  acc = fmaf(a1, b1, acc);
+  acc = fmaf(a2, b2, acc);
+  return acc;
+}
+/* plain left-to-right dot (tiny matmuls, (a*b).sum(-1)). */
+static inline float dot3_plain(float a0, float a1, float a2, float b0, float b1, float b2) {
+  float p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
+  float s = p0 + p1;
+  return s + p2;
+}
+/* tensor.norm(dim=-1) over 3 components. */
+static inline float norm3(float x, float y, float z) {
+  float acc = x * x;
+  acc = fmaf(y, y, acc);
+  acc = fmaf(z, z, acc);
+  return sqrtf(acc);
+}
+
+/* Specified single-precision exp shared (as an algorithm, re-typed) with the HIP kernels so
+ * that alpha is bit-identical on both sides: Cody-Waite reduction + degree-6 Horner with
+ * FMA.  Differs from torch.exp (SLEEF) by <= 1 ulp; tests compare alpha to the reference
+ * with rtol 1e-6. */
+static inline float gs_expf_spec(float x) {
+  if (x < -87.0f) return 0.0f;
+  if (x > 88.0f) return INFINITY;
+  float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(-n, 0.693359375f, x);
+  r = fmaf(-n, -2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  float r2 = r * r;
+  float y = fmaf(p, r2, r);
+  y = y + 1.0f;
+  union { float f; int32_t i; } u;
+  u.f = y;
+  u.i += ((int32_t)n) << 23;
+  return u.f;
+}
+
+/* inverse_intrinsics (geometry/projutils.py:437-449); only the entries it sets. */
+static void kinv_of(const float* K, float* k00, float* k11, float* k02, float* k12) {
+  const float eps = 1e-6f;
+  float fx = K[0], fy = K[5], cx = K[2], cy = K[6];
+  *k00 = 1.0f / (fx + eps);
+  *k11 = 1.0f / (fy + eps);
+  *k02 = (-1.0f * cx) / (fx + eps);
+  *k12 = (-1.0f * cy) / (fy + eps);
+}
+
+/* local vertex of pixel (h,w): structures/rgbdimages.py:662-679.
+ * einsum(Kinv3x3, (u,v,1)) as FMA chain with Kinv = [[k00,0,k02],[0,k11,k12],[0,0,1]]. */
+static inline void vertex_at(const float* depth, int W, int h, int w, float k00, float k11,
+                             float k02, float k12, float* out) {
+  float d = depth[(size_t)h * W + w];
+  float u = (float)w, v = (float)h;
+  float x = k00 * u;          /* k=0 */
+  x = fmaf(0.0f, v, x);       /* k=1 */
+  x = fmaf(k02, 1.0f, x);     /* k=2 */
+  float y = 0.0f * u;
+  y = fmaf(k11, v, y);
+  y = fmaf(k12, 1.0f, y);
+  float z = 0.0f * u;
+  z = fmaf(0.0f, v, z);
+  z = fmaf(1.0f, 1.0f, z);
+  float validf = d > 0.0f ? 1.0f : 0.0f;
+  out[0] = (x * d) * validf;
+  out[1] = (y * d) * validf;
+  out[2] = (z * d) * validf;
+}
+
+/* ---------------------------------------------------------------- K1: frame maps ------ */
+
+/* structures/rgbdimages.py:643-679 (vertex), :710-743 (normal), :320-332 (valid),
+ * slam/fusionutils.py:69-72 with dim=4 (alpha, called at :657). */
+EXPORT void gs_or_frame_maps(const float* depth, const float* K16, int H, int W,
+                             float two_sigma_sq, float* vertex, float* normal, float* alpha,
+                             uint8_t* valid) {
+  float k00, k11, k02, k12;
+  kinv_of(K16, &k00, &k11, &k02, &k12);
+#pragma omp parallel for schedule(static)
+  for (int h = 0; h < H; ++h) {
+    for (int w = 0; w < W; ++w) {
+      size_t p = (size_t)h * W + w;
+      float v[3];
+      vertex_at(depth, W, h, w, k00, k11, k02, k12, v);
+      float d = depth[p];
+      float validf = d > 0.0f ? 1.0f : 0.0f;
+      if (vertex) { vertex[3 * p] = v[0]; vertex[3 * p + 1] = v[1]; vertex[3 * p + 2] = v[2]; }
+      if (valid) valid[p] = d > 0.0f;
+      if (alpha) {
+        /* exp(-sum(points**2, dim)/(2*sigma**2)), clamp(1e-7, 1.01) */
+        float s = v[0] * v[0] + v[1] * v[1];
+        s = s + v[2] * v[2];
+        float a = gs_expf_spec((-s) / two_sigma_sq);
+        a = a < 1e-7f ? 1e-7f : a;
+        a = a > 1.01f ? 1.01f : a;
+        alpha[p] = a;
+      }
+      if (normal) {
+        /* forward differences; last column/row reuse the previous difference (:730-731) */
+        int w0 = (w < W - 1) ? w : W - 2;
+        int h0 = (h < H - 1) ? h : H - 2;
+        float a0[3], a1[3], b0[3], b1[3];
+        vertex_at(depth, W, h, w0, k00, k11, k02, k12, a0);
+        vertex_at(depth, W, h, w0 + 1, k00, k11, k02, k12, a1);
+        vertex_at(depth, W, h0, w, k00, k11, k02, k12, b0);
+        vertex_at(depth, W, h0 + 1, w, k00, k11, k02, k12, b1);
+        float dh[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]};
+        float dv[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
+        /* torch.cross: a1*b2 - a2*b1 with the second product rounded first */
+        float nx = fmaf(dh[1], dv[2], -(dh[2] * dv[1]));
+        float ny = fmaf(dh[2], dv[0], -(dh[0] * dv[2]));
+        float nz = fmaf(dh[0], dv[1], -(dh[1] * dv[0]));
+        float nrm = norm3(nx, ny, nz);
+        float den = (nrm == 0.0f) ? 1.0f : nrm;
+        normal[3 * p] = (nx / den) * validf;
+        normal[3 * p + 1] = (ny / den) * validf;
+        normal[3 * p + 2] = (nz / den) * validf;
+      }
+    }
+  }
+}
+
+/* structures/rgbdimages.py:681-708 (vertex: R v + t, re-masked), :745-762 (normal: R n). */
+EXPORT void gs_or_global_maps(const float* vertex, const float* normal, const float* depth,
+                              const float* pose16, int H, int W, float* gvertex,
+                              float* gnormal) {
+  size_t P = (size_t)H * W;
+  if (!pose16) {
+    if (gvertex) memcpy(gvertex, vertex, P * 3 * sizeof(float));
+    if (gnormal && normal) memcpy(gnormal, normal, P * 3 * sizeof(float));
+    return;
+  }
+  const float* T = pose16;
+#pragma omp parallel for schedule(static)
+  for (size_t p = 0; p < P; ++p) {
+    float validf = depth[p] > 0.0f ? 1.0f : 0.0f;
+    if (gvertex) {
+      const float* v = vertex + 3 * p;
+      for (int j = 0; j < 3; ++j) {
+        float r = dot3_fma(T[4 * j], T[4 * j + 1], T[4 * j + 2], v[0], v[1], v[2]);
+        gvertex[3 * p + j] = (r + T[4 * j + 3]) * validf;
+      }
+    }
+    if (gnormal && normal) {
+      const float* n = normal + 3 * p;
+      for (int j = 0; j < 3; ++j)
+        gnormal[3 * p + j] = dot3_fma(T[4 * j], T[4 * j + 1], T[4 * j + 2], n[0], n[1], n[2]);
+    }
+  }
+}
+
+/* slam/fusionutils.py:69-72 on (n,3) points, dim=-1. */
+EXPORT void gs_or_alpha(const float* points, int64_t n, float two_sigma_sq, float eps,
+                        float* alpha) {
+  for (int64_t i = 0; i < n; ++i) {
+    const float* v = points + 3 * i;
+    float s = v[0] * v[0] + v[1] * v[1];
+    s = s + v[2] * v[2];
+    float a = gs_expf_spec((-s) / two_sigma_sq);
+    a = a < eps ? eps : a;
+    a = a > 1.01f ? 1.01f : a;
+    alpha[i] = a;
+  }
+}
+
+/* ------------------------------------------------------- K2: ICP source / target sets -- */
+
+/* odometry/icputils.py:654-668: valid pixels of [::ds, ::ds], raster order. */
+EXPORT int64_t gs_or_downsample_frame(const float* gvertex, const float* gnormal,
+                                      const float* rgb, const float* depth, int H, int W, int ds,
+                                      float* out_pts, float* out_nrm, float* out_rgb) {
+  int64_t c = 0;
+  for (int h = 0; h < H; h += ds)
+    for (int w = 0; w < W; w += ds) {
+      size_t p = (size_t)h * W + w;
+      if (!(depth[p] > 0.0f)) continue;
+      for (int k = 0; k < 3; ++k) {
+        out_pts[3 * c + k] = gvertex[3 * p + k];
+        if (out_nrm && gnormal) out_nrm[3 * c + k] = gnormal[3 * p + k];
+        if (out_rgb && rgb) out_rgb[3 * c + k] = rgb[3 * p + k];
+      }
+      ++c;
+    }
+  return c;
+}
+
+/* slam/fusionutils.py:249-274.  kornia inverse_transformation ([R^T, -R^T t], tiny matmul:
+ * plain), Pointclouds.transform = rotate_ (einsum over [N,3]x[3,3]: FMA chain) + offset_
+ * (structures/pointclouds.py:466-573), is_front_of_plane (:251-253), project_points as a
+ * 4x4 . (x,y,z,1) tiny matmul (geometry/projutils.py:225-238: plain, ascending k), the
+ * in-frame window with thresholds cast to float32 (:259-264), round half-to-even + clamp
+ * (:267-274). */
+EXPORT void gs_or_project_map(const float* points, int64_t n_map, const float* pose16,
+                              const float* K16, int H, int W, int32_t* pix) {
+  const float* T = pose16;
+  float Ri[9], ti[3];
+  for (int j = 0; j < 3; ++j)
+    for (int k = 0; k < 3; ++k) Ri[3 * j + k] = T[4 * k + j]; /* R^T */
+  for (int j = 0; j < 3; ++j) {
+    float m0 = -Ri[3 * j], m1 = -Ri[3 * j + 1], m2 = -Ri[3 * j + 2];
+    ti[j] = dot3_plain(m0, m1, m2, T[3], T[7], T[11]);
+  }
+  const float u_lo = -1e-3f, u_hi = (float)((double)W - 0.999), v_hi = (float)((double)H - 0.999);
+#pragma omp parallel for schedule(static)
+  for (int64_t n = 0; n < n_map; ++n) {
+    const float* p = points + 3 * n;
+    float q[3];
+    for (int k = 0; k < 3; ++k)
+      q[k] = dot3_fma(p[0], p[1], p[2], Ri[3 * k], Ri[3 * k + 1], Ri[3 * k + 2]) + ti[k];
+    int front = q[2] > 0.0f;
+    float r[3];
+    for (int j = 0; j < 3; ++j) {
+      const float* Kr = K16 + 4 * j;
+      float acc = Kr[0] * q[0];
+      acc = acc + Kr[1] * q[1];
+      acc = acc + Kr[2] * q[2];
+      acc = acc + Kr[3] * 1.0f;
+      r[j] = acc;
+    }
+    float zz = (r[2] != 0.0f) ? r[2] : 1.0f;
+    float u = r[0] / zz, v = r[1] / zz;
+    int in_frame = (u > u_lo) && (u < u_hi) && (v > u_lo) && (v < v_hi) && front;
+    if (!in_frame) { pix[n] = -1; continue; }
+    int64_t wi = (int64_t)rintf(u), hi = (int64_t)rintf(v);
+    wi = wi < 0 ? 0 : (wi > W - 1 ? W - 1 : wi);
+    hi = hi < 0 ? 0 : (hi > H - 1 ? H - 1 : hi);
+    pix[n] = (int32_t)(hi * W + wi);
+  }
+}
+
+/* slam/fusionutils.py:276-282: rows [b, n, h, w] of in-frame points, ordered by n. */
+EXPORT int64_t gs_or_active_table(const int32_t* pix, int64_t n_map, int W, int64_t b,
+                                  int64_t* rows_out) {
+  int64_t c = 0;
+  for (int64_t n = 0; n < n_map; ++n)
+    if (pix[n] >= 0) {
+      rows_out[4 * c] = b; rows_out[4 * c + 1] = n;
+      rows_out[4 * c + 2] = pix[n] / W; rows_out[4 * c + 3] = pix[n] % W;
+      ++c;
+    }
+  return c;
+}
+
+/* odometry/icputils.py:596-620 applied to rows of one sequence. */
+EXPORT int64_t gs_or_downsample_table(const int64_t* rows, int64_t n_rows, int ds,
+                                      const float* points, const float* normals,
+                                      const float* colors, float* out_pts, float* out_nrm,
+                                      float* out_rgb) {
+  int64_t c = 0;
+  for (int64_t r = 0; r < n_rows; ++r) {
+    if (rows[4 * r + 2] % ds != 0 || rows[4 * r + 3] % ds != 0) continue;
+    int64_t n = rows[4 * r + 1];
+    for (int k = 0; k < 3; ++k) {
+      out_pts[3 * c + k] = points[3 * n + k];
+      if (out_nrm && normals) out_nrm[3 * c + k] = normals[3 * n + k];
+      if (out_rgb && colors) out_rgb[3 * c + k] = colors[3 * n + k];
+    }
+    ++c;
+  }
+  return c;
+}
+
+EXPORT int64_t gs_or_select_targets(const int32_t* pix, int64_t n_map, int W, int ds,
+                                    const float* points, const float* normals,
+                                    const float* colors, float* out_pts, float* out_nrm,
+                                    float* out_rgb) {
+  int64_t c = 0;
+  for (int64_t n = 0; n < n_map; ++n) {
+    if (pix[n] < 0) continue;
+    int h = pix[n] / W, w = pix[n] % W;
+    if (h % ds != 0 || w % ds != 0) continue;
+    for (int k = 0; k < 3; ++k) {
+      out_pts[3 * c + k] = points[3 * n + k];
+      if (out_nrm && normals) out_nrm[3 * c + k] = normals[3 * n + k];
+      if (out_rgb && colors) out_rgb[3 * c + k] = colors[3 * n + k];
+    }
+    ++c;
+  }
+  return c;
+}
+
+/* ------------------------------------------------------------------ K3: exact 1-NN ----- */
+
+/* chamferdist.chamfer.knn_points(src, tgt) as used at odometry/icputils.py:200-208 (K=1).
+ * chamferdist==1.0.0 is NOT under /root/reference; semantics restated from pytorch3d's
+ * knn_points (which chamferdist 1.0.0 wraps): squared L2 accumulated over d=0..2 as
+ * dist += diff*diff with diff = p1 - p2, lowest index on ties.  Arithmetic fixed here as
+ * d = fma(dz,dz, fma(dy,dy, dx*dx)).  PARITY UNPINNED (tie-break, dist unit). */
+EXPORT void gs_or_knn1(const float* src, int64_t ns, const float* tgt, int64_t nt,
+                       int64_t* idx, float* d2) {
+  enum { SB = 64 };
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int64_t s0 = 0; s0 < ns; s0 += SB) {
+    float sx[SB], sy[SB], sz[SB], best[SB];
+    int32_t bi[SB];
+    int m = (int)((ns - s0) < SB ? (ns - s0) : SB);
+    for (int i = 0; i < SB; ++i) {
+      int64_t s = s0 + (i < m ? i : 0);
+      sx[i] = src[3 * s]; sy[i] = src[3 * s + 1]; sz[i] = src[3 * s + 2];
+      best[i] = INFINITY; bi[i] = 0;
+    }
+    for (int64_t j = 0; j < nt; ++j) {
+      float tx = tgt[3 * j], ty = tgt[3 * j + 1], tz = tgt[3 * j + 2];
+      for (int i = 0; i < SB; ++i) {
+        float dx = sx[i] - tx, dy = sy[i] - ty, dz = sz[i] - tz;
+        float d = dx * dx;
+        d = fmaf(dy, dy, d);
+        d = fmaf(dz, dz, d);
+        int lt = d < best[i];
+        best[i] = lt ? d : best[i];
+        bi[i] = lt ? (int32_t)j : bi[i];
+      }
+    }
+    for (int i = 0; i < m; ++i) {
+      idx[s0 + i] = bi[i];
+      if (d2) d2[s0 + i] = best[i];
+    }
+  }
+}
+
+/* --------------------------------------------------------- K4: Gauss-Newton system ----- */
+
+/* odometry/icputils.py:200-230.  Rows are produced for every src point; keep[] carries the
+ * dist filter (:203-208) so that callers can compact like the reference does. */
+EXPORT void gs_or_gauss_newton_rows(const float* src, int64_t ns, const float* tgt,
+                                    const float* tn, int64_t nt, float dist_thresh, float* A,
+                                    float* b, int64_t* idx, uint8_t* keep) {
+  float* d2 = (float*)malloc(sizeof(float) * (size_t)(ns > 0 ? ns : 1));
+  gs_or_knn1(src, ns, tgt, nt, idx, d2);
+  for (int64_t i = 0; i < ns; ++i) {
+    int64_t j = idx[i];
+    float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+    float dx = tgt[3 * j], dy = tgt[3 * j + 1], dz = tgt[3 * j + 2];
+    float nx = tn[3 * j], ny = tn[3 * j + 1], nz = tn[3 * j + 2];
+    float* a = A + 6 * i;
+    a[0] = nx; a[1] = ny; a[2] = nz;
+    a[3] = nz * sy - ny * sz;
+    a[4] = nx * sz - nz * sx;
+    a[5] = ny * sx - nx * sy;
+    float t = nx * (dx - sx) + ny * (dy - sy);
+    b[i] = t + nz * (dz - sz);
+    if (keep) keep[i] = (dist_thresh < 0.0f) ? 1 : (d2[i] < dist_thresh);
+  }
+  free(d2);
+}
+
+/* 6x6 inverse by Gauss-Jordan with partial pivoting in double (torch.inverse at
+ * odometry/icputils.py:90 is LAPACK LU in float32; double here keeps HIP and oracle within
+ * one rounding of each other and is closer to the exact inverse than the reference). */
+static void inv6_f64(const double* M, double* Minv) {
+  double a[6][12];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) { a[i][j] = M[6 * i + j]; a[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+  for (int c = 0; c < 6; ++c) {
+    int piv = c; double best = fabs(a[c][c]);
+    for (int r = c + 1; r < 6; ++r) if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
+    if (piv != c) for (int j = 0; j < 12; ++j) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+    double inv = 1.0 / a[c][c];
+    for (int j = 0; j < 12; ++j) a[c][j] *= inv;
+    for (int r = 0; r < 6; ++r) {
+      if (r == c) continue;
+      double f = a[r][c];
+      for (int j = 0; j < 12; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Minv[6 * i + j] = a[i][6 + j];
+}
+
+/* solve from float32 normal equations: (AtA + damp*I)^-1 Atb, odometry/icputils.py:85-90. */
+static void solve_from_normal_eq(const float* AtA, const float* Atb, float damp, float* x6) {
+  double M[36], Mi[36];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      float e = (i == j) ? 1.0f : 0.0f;
+      float m = AtA[6 * i + j] + e * damp; /* At_A + damp_matrix * damp in float32 */
+      M[6 * i + j] = (double)m;
+    }
+  inv6_f64(M, Mi);
+  for (int i = 0; i < 6; ++i) {
+    /* matmul(inverse, Atb): tiny matmul, plain, ascending k, float32 */
+    float acc = (float)Mi[6 * i] * Atb[0];
+    for (int k = 1; k < 6; ++k) acc = acc + (float)Mi[6 * i + k] * Atb[k];
+    x6[i] = acc;
+  }
+}
+
+/* A^T A, A^T b and b.b accumulated in double from float32 products, rounded once. */
+static void normal_eq_f64(const float* A, const float* b, const uint8_t* keep, int64_t n,
+                          float* AtA, float* Atb, float* err) {
+  double S[36] = {0}, v[6] = {0}, e = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (keep && !keep[i]) continue;
+    const float* a = A + 6 * i;
+    for (int r = 0; r < 6; ++r) {
+      for (int c = r; c < 6; ++c) S[6 * r + c] += (double)a[r] * (double)a[c];
+      v[r] += (double)a[r] * (double)b[i];
+    }
+    e += (double)b[i] * (double)b[i];
+  }
+  for (int r = 0; r < 6; ++r) {
+    for (int c = r; c < 6; ++c) AtA[6 * r + c] = AtA[6 * c + r] = (float)S[6 * r + c];
+    Atb[r] = (float)v[r];
+  }
+  if (err) *err = (float)e;
+}
+
+EXPORT void gs_or_solve_normal_eq(const float* A, const float* b, const uint8_t* keep,
+                                  int64_t n_rows, float damp, float* x6) {
+  float AtA[36], Atb[6];
+  normal_eq_f64(A, b, keep, n_rows, AtA, Atb, NULL);
+  solve_from_normal_eq(AtA, Atb, damp, x6);
+}
+
+/* geometry/se3utils.py:77-115, evaluated in double from the float32 xi and rounded once. */
+EXPORT void gs_or_se3_exp(const float* xi6, float* T16) {
+  double v[3] = {xi6[0], xi6[1], xi6[2]}, w[3] = {xi6[3], xi6[4], xi6[5]};
+  double wh[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  double R[9], V[9];
+  double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  if ((float)theta < 1e-6f) {
+    for (int i = 0; i < 9; ++i) { R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + wh[i]; V[i] = R[i]; }
+  } else {
+    double wh2[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += wh[3 * i + k] * wh[3 * k + j];
+        wh2[3 * i + j] = s;
+      }
+    double s = sin(theta), c = cos(theta);
+    double Ac = s / theta, Bc = (1 - c) / (theta * theta), Cc = (theta - s) / (theta * theta * theta);
+    for (int i = 0; i < 9; ++i) {
+      double I = (i % 4 == 0) ? 1.0 : 0.0;
+      R[i] = I + Ac * wh[i] + Bc * wh2[i];
+      V[i] = I + Bc * wh[i] + Cc * wh2[i];
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T16[4 * i + j] = (float)R[3 * i + j];
+    T16[4 * i + 3] = (float)(V[3 * i] * v[0] + V[3 * i + 1] * v[1] + V[3 * i + 2] * v[2]);
+  }
+  T16[12] = 0; T16[13] = 0; T16[14] = 0; T16[15] = 1;
+}
+
+/* geometry/geometryutils.py:781-794: matmul(R, P^T) + t (sgemm over N: FMA chain). */
+EXPORT void gs_or_transform_points(const float* pts, int64_t n, const float* T, float* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    float p0 = pts[3 * i], p1 = pts[3 * i + 1], p2 = pts[3 * i + 2];
+    for (int j = 0; j < 3; ++j)
+      out[3 * i + j] = dot3_fma(T[4 * j], T[4 * j + 1], T[4 * j + 2], p0, p1, p2) + T[4 * j + 3];
+  }
+}
+
+/* 4x4 . 4x4 tiny matmul (torch.mm at odometry/icputils.py:362,543): plain, ascending k. */
+static void mm4(const float* A, const float* B, float* C) {
+  float t[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float acc = A[4 * i] * B[j];
+      for (int k = 1; k < 4; ++k) acc = acc + A[4 * i + k] * B[4 * k + j];
+      t[4 * i + j] = acc;
+    }
+  memcpy(C, t, sizeof(t));
+}
+
+/* kornia compose_transformations as called at slam/icpslam.py:245-247. */
+static void compose_rigid(const float* A, const float* B, float* C) {
+  float t[16] = {0};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      float acc = A[4 * i] * B[j];
+      for (int k = 1; k < 3; ++k) acc = acc + A[4 * i + k] * B[4 * k + j];
+      t[4 * i + j] = acc;
+    }
+    float acc = A[4 * i] * B[3];
+    for (int k = 1; k < 3; ++k) acc = acc + A[4 * i + k] * B[4 * k + 3];
+    t[4 * i + 3] = acc + A[4 * i + 3];
+  }
+  t[15] = 1.0f;
+  memcpy(C, t, sizeof(t));
+}
+
+typedef struct gs_icp_params {
+  int mode; int numiters; float damp; float dist_thresh; float lambda_max; float B; float B2; float nu;
+} gs_icp_params;
+
+/* point_to_plane_ICP (odometry/icputils.py:310-367, mode 0) and point_to_plane_gradICP
+ * (:479-545, mode 1).  trace (may be NULL): numiters x 12 floats
+ * [err, new_err, damp_after, sigmoid, xi0..5, 0, 0]. */
+EXPORT void gs_or_icp(const float* src_in, int64_t ns, const float* tgt, const float* tn,
+                      int64_t nt, const float* init16, const float* compose16,
+                      const gs_icp_params* prm, float* out_T16, int64_t* out_idx, float* trace) {
+  size_t nsz = (size_t)(ns > 0 ? ns : 1);
+  float* src = (float*)malloc(sizeof(float) * 3 * nsz);
+  float* one = (float*)malloc(sizeof(float) * 3 * nsz);
+  float* A = (float*)malloc(sizeof(float) * 6 * nsz);
+  float* b = (float*)malloc(sizeof(float) * nsz);
+  float* b1 = (float*)malloc(sizeof(float) * nsz);
+  int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * nsz);
+  int64_t* idx1 = (int64_t*)malloc(sizeof(int64_t) * nsz);
+  uint8_t* keep = (uint8_t*)malloc(nsz);
+  uint8_t* keep1 = (uint8_t*)malloc(nsz);
+  float T[16];
+  memcpy(T, init16, sizeof(T));
+  gs_or_transform_points(src_in, ns, init16, src);
+  float damp = prm->damp;
+  const float lmax = prm->lambda_max, lmin = (float)(1.0 / (double)prm->lambda_max);
+  const float lrange = (float)((double)prm->lambda_max - 1.0 / (double)prm->lambda_max);
+  for (int it = 0; it < prm->numiters; ++it) {
+    gs_or_gauss_newton_rows(src, ns, tgt, tn, nt, prm->dist_thresh, A, b, idx, keep);
+    float AtA[36], Atb[6], err, xi[6], Tr[16];
+    normal_eq_f64(A, b, keep, ns, AtA, Atb, &err);
+    solve_from_normal_eq(AtA, Atb, damp, xi);
+    gs_or_se3_exp(xi, Tr);
+    gs_or_transform_points(src, ns, Tr, one);
+    gs_or_gauss_newton_rows(one, ns, tgt, tn, nt, prm->dist_thresh, A, b1, idx1, keep1);
+    double e1 = 0;
+    for (int64_t i = 0; i < ns; ++i) if (keep1[i]) e1 += (double)b1[i] * (double)b1[i];
+    float new_err = (float)e1;
+    float sig = 1.0f;
+    if (prm->mode == 0) {
+      if (new_err < err) {
+        memcpy(src, one, sizeof(float) * 3 * nsz);
+        damp = damp / 2;
+        mm4(Tr, T, T);
+      } else {
+        damp = damp * 2;
+      }
+    } else {
+      float errdiff = new_err - err;
+      errdiff = errdiff < -70.0f ? -70.0f : (errdiff > 70.0f ? 70.0f : errdiff);
+      float e_b = (float)exp((double)((float)(-(double)prm->B) * errdiff));
+      float damp_new = lmin + lrange / (1.0f + e_b);
+      damp = damp * damp_new;
+      float e_b2 = (float)exp((double)((float)(-(double)prm->B2) * errdiff));
+      float pw = (float)pow((double)(1.0f + e_b2), (double)(float)(1.0 / (double)prm->nu));
+      sig = 1.0f / pw;
+      float xs[6];
+      for (int k = 0; k < 6; ++k) xs[k] = sig * xi[k];
+      gs_or_se3_exp(xs, Tr);
+      gs_or_transform_points(src, ns, Tr, one);
+      memcpy(src, one, sizeof(float) * 3 * nsz);
+      mm4(Tr, T, T);
+    }
+    (void)lmax;
+    if (trace) {
+      float* t = trace + 12 * it;
+      t[0] = err; t[1] = new_err; t[2] = damp; t[3] = sig;
+      for (int k = 0; k < 6; ++k) t[4 + k] = xi[k];
+      t[10] = 0; t[11] = 0;
+    }
+  }
+  if (out_idx) memcpy(out_idx, idx, sizeof(int64_t) * (size_t)ns);
+  if (compose16) compose_rigid(T, compose16, out_T16); else memcpy(out_T16, T, sizeof(T));
+  free(src); free(one); free(A); free(b); free(b1); free(idx); free(idx1); free(keep); free(keep1);
+}
+
+/* ------------------------------------------------- K5: surfel association (PointFusion) - */
+
+/* slam/fusionutils.py:381-401 with are_points_close (:130) and are_normals_similar (:187-195). */
+EXPORT void gs_or_similar_rows(const int64_t* rows, int64_t n_rows, const float* points,
+                               const float* normals, const float* gvertex, const float* gnormal,
+                               int W, float dist_th, float dot_th, uint8_t* mask) {
+  for (int64_t r = 0; r < n_rows; ++r) {
+    int64_t n = rows[4 * r + 1];
+    size_t p = (size_t)rows[4 * r + 2] * W + rows[4 * r + 3];
+    const float* f = gvertex + 3 * p; const float* fn = gnormal + 3 * p;
+    const float* q = points + 3 * n; const float* qn = normals + 3 * n;
+    float dist = norm3(f[0] - q[0], f[1] - q[1], f[2] - q[2]);
+    float dot = dot3_plain(fn[0], fn[1], fn[2], qn[0], qn[1], qn[2]);
+    mask[r] = (dist < dist_th) && (dot > dot_th);
+  }
+}
+
+typedef struct { float k[6]; } crit_row; /* [b, h, w, 1/cc, ray, n] as float32 */
+static int crit_cmp(const void* a, const void* b) {
+  const float* x = ((const crit_row*)a)->k; const float* y = ((const crit_row*)b)->k;
+  for (int i = 0; i < 6; ++i) { if (x[i] < y[i]) return -1; if (x[i] > y[i]) return 1; }
+  return 0;
+}
+
+/* slam/fusionutils.py:489-544: sort rows of [b,h,w,1/(cc+1e-20),|p-f|^2,n] (all float32)
+ * lexicographically (torch.unique(dim=0)), drop exact duplicates, keep the first row of each
+ * (b,h,w) run, return [b, n, h, w]. */
+EXPORT int64_t gs_or_best_unique_rows(const int64_t* rows, int64_t n_rows, const float* points,
+                                      const float* ccounts, const float* gvertex, int H, int W,
+                                      int64_t* rows_out) {
+  (void)H;
+  if (n_rows == 0) return 0;
+  crit_row* c = (crit_row*)malloc(sizeof(crit_row) * (size_t)n_rows);
+  for (int64_t r = 0; r < n_rows; ++r) {
+    int64_t n = rows[4 * r + 1];
+    size_t p = (size_t)rows[4 * r + 2] * W + rows[4 * r + 3];
+    const float* f = gvertex + 3 * p; const float* q = points + 3 * n;
+    float d0 = q[0] - f[0], d1 = q[1] - f[1], d2 = q[2] - f[2];
+    float ray = d0 * d0 + d1 * d1;
+    ray = ray + d2 * d2;
+    c[r].k[0] = (float)rows[4 * r]; c[r].k[1] = (float)rows[4 * r + 2];
+    c[r].k[2] = (float)rows[4 * r + 3];
+    c[r].k[3] = 1.0f / (ccounts[n] + 1e-20f);
+    c[r].k[4] = ray; c[r].k[5] = (float)n;
+  }
+  qsort(c, (size_t)n_rows, sizeof(crit_row), crit_cmp);
+  int64_t m = 0;
+  for (int64_t r = 0; r < n_rows; ++r) {
+    if (r > 0 && c[r].k[0] == c[r - 1].k[0] && c[r].k[1] == c[r - 1].k[1] &&
+        c[r].k[2] == c[r - 1].k[2]) continue;
+    rows_out[4 * m] = (int64_t)c[r].k[0]; rows_out[4 * m + 1] = (int64_t)c[r].k[5];
+    rows_out[4 * m + 2] = (int64_t)c[r].k[1]; rows_out[4 * m + 3] = (int64_t)c[r].k[2];
+    ++m;
+  }
+  free(c);
+  return m;
+}
+
+/* find_correspondences (slam/fusionutils.py:572-577) for one sequence, expressed on the
+ * per-point / per-pixel arrays the HIP path uses. */
+EXPORT void gs_or_associate(const int32_t* pix, int64_t n_map, const float* points,
+                            const float* normals, const float* ccounts, const float* gvertex,
+                            const float* gnormal, int H, int W, float dist_th, float dot_th,
+                            int32_t* best_pix, uint8_t* similar) {
+  int64_t* rows = (int64_t*)malloc(sizeof(int64_t) * 4 * (size_t)(n_map > 0 ? n_map : 1));
+  int64_t na = gs_or_active_table(pix, n_map, W, 0, rows);
+  uint8_t* mask = (uint8_t*)malloc((size_t)(na > 0 ? na : 1));
+  gs_or_similar_rows(rows, na, points, normals, gvertex, gnormal, W, dist_th, dot_th, mask);
+  if (similar) memset(similar, 0, (size_t)n_map);
+  int64_t ns = 0;
+  for (int64_t r = 0; r < na; ++r)
+    if (mask[r]) {
+      if (similar) similar[rows[4 * r + 1]] = 1;
+      memmove(rows + 4 * ns, rows + 4 * r, 4 * sizeof(int64_t));
+      ++ns;
+    }
+  int64_t* uniq = (int64_t*)malloc(sizeof(int64_t) * 4 * (size_t)(ns > 0 ? ns : 1));
+  int64_t nu = gs_or_best_unique_rows(rows, ns, points, ccounts, gvertex, H, W, uniq);
+  for (size_t p = 0; p < (size_t)H * W; ++p) best_pix[p] = -1;
+  for (int64_t r = 0; r < nu; ++r)
+    best_pix[uniq[4 * r + 2] * W + uniq[4 * r + 3]] = (int32_t)uniq[4 * r + 1];
+  free(rows); free(mask); free(uniq);
+}
+
+EXPORT int64_t gs_or_best_table(const int32_t* best_pix, int H, int W, int64_t b,
+                                int64_t* rows_out) {
+  int64_t c = 0;
+  for (int h = 0; h < H; ++h)
+    for (int w = 0; w < W; ++w) {
+      int32_t n = best_pix[(size_t)h * W + w];
+      if (n < 0) continue;
+      rows_out[4 * c] = b; rows_out[4 * c + 1] = n; rows_out[4 * c + 2] = h; rows_out[4 * c + 3] = w;
+      ++c;
+    }
+  return c;
+}
+
+EXPORT void gs_or_rows_to_best_pix(const int64_t* rows, int64_t n_rows, int H, int W,
+                                   int32_t* best_pix) {
+  for (size_t p = 0; p < (size_t)H * W; ++p) best_pix[p] = -1;
+  for (int64_t r = 0; r < n_rows; ++r)
+    best_pix[rows[4 * r + 2] * W + rows[4 * r + 3]] = (int32_t)rows[4 * r + 1];
+}
+
+/* ------------------------------------------------------ K6: merge + append ------------- */
+
+/* slam/fusionutils.py:659-720: weighted merge applied to ALL rows (unmatched rows have
+ * alpha = 0 and frame value 0), then raster-order append of valid unmatched pixels
+ * (structures/pointclouds.py:1117-1237). */
+EXPORT int64_t gs_or_fuse_append(float* points, float* normals, float* colors, float* ccounts,
+                                 int64_t n_map, int64_t capacity, const int32_t* best_pix,
+                                 const float* gvertex, const float* gnormal, const float* rgb,
+                                 const float* alpha, const float* depth, int H, int W,
+                                 int renorm_all) {
+  size_t P = (size_t)H * W;
+  int any = 0;
+  for (size_t p = 0; p < P; ++p) if (best_pix[p] >= 0) { any = 1; break; }
+  if (n_map > 0 && any) { /* :659 merge branch only when the table is non-empty */
+    int32_t* pix_of = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_map);
+    for (int64_t n = 0; n < n_map; ++n) pix_of[n] = -1;
+    for (size_t p = 0; p < P; ++p) if (best_pix[p] >= 0) pix_of[best_pix[p]] = (int32_t)p;
+    for (int64_t n = 0; n < n_map; ++n) {
+      int32_t p = pix_of[n];
+      if (p < 0 && !renorm_all) continue;
+      float a = p >= 0 ? alpha[p] : 0.0f;
+      float cc = ccounts[n];
+      float cc2 = cc + a;
+      float inv = 1.0f / (cc2 == 0.0f ? 1.0f : cc2);
+      for (int k = 0; k < 3; ++k) {
+        float fp = p >= 0 ? gvertex[3 * (size_t)p + k] : 0.0f;
+        float fn = p >= 0 ? gnormal[3 * (size_t)p + k] : 0.0f;
+        float fc = p >= 0 ? rgb[3 * (size_t)p + k] : 0.0f;
+        points[3 * n + k] = ((cc * points[3 * n + k]) + (a * fp)) * inv;
+        normals[3 * n + k] = ((cc * normals[3 * n + k]) + (a * fn)) * inv;
+        colors[3 * n + k] = ((cc * colors[3 * n + k]) + (a * fc)) * inv;
+      }
+      ccounts[n] = cc2;
+    }
+    free(pix_of);
+  }
+  int64_t c = n_map;
+  for (size_t p = 0; p < P; ++p) {
+    if (best_pix[p] >= 0 || !(depth[p] > 0.0f)) continue;
+    if (c >= capacity) return -1;
+    for (int k = 0; k < 3; ++k) {
+      points[3 * c + k] = gvertex[3 * p + k];
+      normals[3 * c + k] = gnormal[3 * p + k];
+      colors[3 * c + k] = rgb[3 * p + k];
+    }
+    ccounts[c] = alpha[p];
+    ++c;
+  }
+  return c;
+}
+
+/* slam/fusionutils.py:754-757 / structures/utils.py:39-57. */
+EXPORT int64_t gs_or_append_valid(float* points, float* normals, float* colors, float* ccounts,
+                                  int64_t n_map, int64_t capacity, const float* gvertex,
+                                  const float* gnormal, const float* rgb, const float* alpha,
+                                  const float* depth, int H, int W) {
+  int64_t c = n_map;
+  for (size_t p = 0; p < (size_t)H * W; ++p) {
+    if (!(depth[p] > 0.0f)) continue;
+    if (c >= capacity) return -1;
+    for (int k = 0; k < 3; ++k) {
+      points[3 * c + k] = gvertex[3 * p + k];
+      if (normals && gnormal) normals[3 * c + k] = gnormal[3 * p + k];
+      if (colors && rgb) colors[3 * c + k] = rgb[3 * p + k];
+    }
+    if (ccounts && alpha) ccounts[c] = alpha[p];
+    ++c;
+  }
+  return c;
+}

@@ -1,0 +1,184 @@
+"""Generates tests/golden/*.npz by running the REAL reference (imported from /root/reference via
+oracle/refimport.py) on fixed inputs.  Build-container only; the produced fixtures travel with
+the repo so that tests can pin the oracle (and, on the GPU box, the HIP path) without the
+reference being present.
+
+    python -m oracle.make_golden            # regenerate everything
+
+Fixtures
+  msrd_b0.npz     reference fixture tests/data/msrd_b2s3 (sequence 0, frames 0-1): inputs and the
+                  reference's vertex/normal/global maps, alpha, the PointFusion map after frame 0,
+                  the three correspondence tables for frame 1 and the fused map after frame 1.
+  synth64.npz     seeded synthetic 64x64x3 sequence (config C1 size): inputs, recovered poses of
+                  PointFusion(gradicp|icp|gt) and ICPSLAM(gradicp), final maps.
+  synth120.npz    seeded synthetic 120x160x4 sequence: depths + poses/counts of PointFusion(gradicp).
+  icp_unit.npz    gauss_newton_solve / solve_linear_system / se3_exp / ICP / gradICP on small clouds.
+  fusion_kat.npz  hand-made known-answer cases for find_best_unique_correspondences and
+                  fuse_with_map (mirrors tests/slam/test_fusionutils.py:672-750, :918-986).
+"""
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+from oracle import refimport  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def main():
+    refimport.import_reference()
+    import torch
+    from gradslam.geometry.se3utils import se3_exp
+    from gradslam.odometry import icputils
+    from gradslam.slam import fusionutils as fu
+    from gradslam.slam.icpslam import ICPSLAM
+    from gradslam.slam.pointfusion import PointFusion
+    from gradslam.structures.pointclouds import Pointclouds
+    from gradslam.structures.rgbdimages import RGBDImages
+    from gradslam_amd.datasets.synthetic import make_sequence
+
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    dist_th, dot_th, sigma = 0.05, math.cos(20 * math.pi / 180), 0.6
+    T = torch.from_numpy
+
+    # ------------------------------------------------------------------ msrd_b0
+    d = os.path.join(refimport.REFERENCE_ROOT, "tests", "data", "msrd_b2s3")
+    colors = np.load(os.path.join(d, "colors.npy"))[:1, :2]
+    depths = np.load(os.path.join(d, "depths.npy"))[:1, :2]
+    K = np.load(os.path.join(d, "intrinsics.npy"))[:1]
+    poses = np.load(os.path.join(d, "poses.npy"))[:1, :2]
+    r = RGBDImages(T(colors), T(depths), T(K), T(poses))
+    f0, f1 = r[:, 0], r[:, 1]
+    g = dict(colors=colors[0], depths=depths[0], intrinsics=K[0, 0], poses=poses[0])
+    g["vertex_map"] = r.vertex_map[0].numpy()
+    g["normal_map"] = r.normal_map[0].numpy()
+    g["global_vertex_map"] = r.global_vertex_map[0].numpy()
+    g["global_normal_map"] = r.global_normal_map[0].numpy()
+    g["alpha"] = fu.get_alpha(r.vertex_map, dim=4, keepdim=True, sigma=sigma)[0, ..., 0].numpy()
+    pc0 = fu.update_map_fusion(Pointclouds(), f0, dist_th, dot_th, sigma)
+    for k, lst in (("points", pc0.points_list), ("normals", pc0.normals_list),
+                   ("colors", pc0.colors_list), ("ccounts", pc0.features_list)):
+        g["map0_" + k] = lst[0].numpy()
+    act = fu.find_active_map_points(pc0, f1)
+    sim, mask = fu.find_similar_map_points(pc0, f1, act, dist_th, dot_th)
+    uniq = fu.find_best_unique_correspondences(pc0, f1, sim)
+    g["active"], g["similar_mask"], g["similar"], g["unique"] = act.numpy(), mask.numpy(), sim.numpy(), uniq.numpy()
+    ds_pc = icputils.downsample_pointclouds(pc0, act, 4)
+    g["ds4_map_points"], g["ds4_map_normals"] = ds_pc.points_list[0].numpy(), ds_pc.normals_list[0].numpy()
+    ds_fr = icputils.downsample_rgbdimages(f1, 4)
+    g["ds4_frame_points"], g["ds4_frame_normals"] = ds_fr.points_list[0].numpy(), ds_fr.normals_list[0].numpy()
+    # NB: fuse_with_map mutates its input even with inplace=False (the merge assigns to the
+    # argument before it is cloned, slam/fusionutils.py:696-719), so everything that reads pc0 is above.
+    pc1 = fu.fuse_with_map(pc0, f1, uniq, sigma)
+    for k, lst in (("points", pc1.points_list), ("normals", pc1.normals_list),
+                   ("colors", pc1.colors_list), ("ccounts", pc1.features_list)):
+        g["map1_" + k] = lst[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "msrd_b0.npz"), **g)
+
+    # ------------------------------------------------------------------ synth64 / synth120
+    def run(cls, s, odom, **kw):
+        p = T(s["poses"][None]).clone()
+        if odom != "gt":
+            p[:, 1:] = p[:, :1]
+        fr = RGBDImages(T(s["colors"][None]), T(s["depths"][None]), T(s["intrinsics"][None]), p)
+        pc, rp = cls(odom=odom, **kw)(fr)
+        return pc, rp[0].numpy()
+
+    s = make_sequence(3, 64, 64, seed=1)
+    g = dict(colors=s["colors"], depths=s["depths"], intrinsics=s["intrinsics"][0], poses=s["poses"])
+    for cls, name, odom in ((PointFusion, "pf", "gradicp"), (PointFusion, "pf", "icp"),
+                            (PointFusion, "pf", "gt"), (ICPSLAM, "icpslam", "gradicp")):
+        pc, rp = run(cls, s, odom)
+        key = name + "_" + odom
+        g[key + "_poses"] = rp
+        g[key + "_points"] = pc.points_list[0].numpy()
+        g[key + "_normals"] = pc.normals_list[0].numpy()
+        g[key + "_colors"] = pc.colors_list[0].numpy()
+        if pc.features_list is not None:
+            g[key + "_ccounts"] = pc.features_list[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "synth64.npz"), **g)
+
+    s = make_sequence(4, 120, 160, seed=2)
+    pc, rp = run(PointFusion, s, "gradicp")
+    np.savez_compressed(os.path.join(OUT, "synth120.npz"), depths=s["depths"], intrinsics=s["intrinsics"][0],
+                        poses=s["poses"], pf_gradicp_poses=rp,
+                        pf_gradicp_count=np.int64(pc.points_list[0].shape[0]),
+                        pf_gradicp_points_sum=pc.points_list[0].double().sum(0).numpy(),
+                        colors_seed=np.int64(2))
+
+    # ------------------------------------------------------------------ icp_unit
+    s = make_sequence(2, 96, 128, seed=3)
+    fr = RGBDImages(T(s["colors"][None]), T(s["depths"][None]), T(s["intrinsics"][None]),
+                    T(s["poses"][None, :1].repeat(2, 1)))
+    tgt_pc = icputils.downsample_rgbdimages(fr[:, 0], 4)
+    src_pc = icputils.downsample_rgbdimages(fr[:, 1], 4)
+    src, tgt, tn = src_pc.points_list[0], tgt_pc.points_list[0], tgt_pc.normals_list[0]
+    g = dict(src=src.numpy(), tgt=tgt.numpy(), tgt_normals=tn.numpy())
+    A, b, idx = icputils.gauss_newton_solve(src[None], tgt[None], tn[None])
+    g["gn_A"], g["gn_b"], g["gn_idx"] = A.numpy(), b.numpy(), idx.numpy()
+    A2, b2, idx2 = icputils.gauss_newton_solve(src[None], tgt[None], tn[None], 1e-4)
+    g["gn_thr"] = np.float32(1e-4)
+    g["gn_thr_A"], g["gn_thr_b"], g["gn_thr_idx"] = A2.numpy(), b2.numpy(), idx2.numpy()
+    g["solve_x"] = icputils.solve_linear_system(A, b, 1e-8).numpy()
+    # the reference's own KAT (tests/odometry/test_icputils.py:18-49): A (5,4), b (5,1)
+    kA = T(np.array([[0.1, 0.7, 0.3, 0.6], [0.5, 0.2, 0.4, 0.8], [0.3, 0.9, 0.5, 0.2], [0.8, 0.2, 0.3, 0.4],
+                     [0.7, 0.9, 0.3, 0.8]], np.float32))
+    kb = T(np.array([[0.7], [0.2], [0.9], [0.2], [0.9]], np.float32))
+    g["kat_A"], g["kat_b"], g["kat_x"] = kA.numpy(), kb.numpy(), icputils.solve_linear_system(kA, kb, 1e-8).numpy()
+    xis = np.array([[0.01, -0.02, 0.03, 0.002, -0.001, 0.003], [0.5, 0.1, -0.3, 0.4, -0.2, 0.1],
+                    [0.1, 0.2, 0.3, 1e-8, 0, 0], [0, 0, 0, 0, 0, 0], [1, 2, 3, 1.5, -2.0, 0.7]], np.float32)
+    g["se3_xi"] = xis
+    g["se3_T"] = np.stack([se3_exp(T(x).view(6, 1)).numpy() for x in xis])
+    eye = torch.eye(4)
+    for it in (3, 20):
+        Ti, ii = icputils.point_to_plane_ICP(src[None], tgt[None], tn[None], eye, numiters=it)
+        Tg, ig = icputils.point_to_plane_gradICP(src[None], tgt[None], tn[None], eye, numiters=it)
+        g["icp%d_T" % it], g["icp%d_idx" % it] = Ti.numpy(), ii.numpy()
+        g["gradicp%d_T" % it], g["gradicp%d_idx" % it] = Tg.numpy(), ig.numpy()
+    g["true_T"] = (np.linalg.inv(s["poses"][0].astype(np.float64)) @ s["poses"][1].astype(np.float64)).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "icp_unit.npz"), **g)
+
+    # ------------------------------------------------------------------ fusion_kat
+    rng = np.random.default_rng(7)
+    H, W = 3, 4
+    pts = np.array([[5, 5, 5], [3, 3, 3], [1, 2, 3], [-0.5, -0.5, 1], [-1, 0, 1], [0, 0, 0], [0.2, 0.1, 1.1],
+                    [0.25, 0.1, 1.0]], np.float32)
+    rows = np.array([[0, 4, 0, 0], [0, 0, 1, 1], [0, 5, 1, 0], [0, 1, 0, 0], [0, 2, 1, 1], [0, 3, 0, 0],
+                     [0, 6, 2, 3], [0, 7, 2, 3]], np.int64)
+    feats = fu.get_alpha(T(pts)[None], sigma, keepdim=True)
+    feats[0, 3] = 1e-12
+    feats[0, 7] = feats[0, 6]  # equal confidence: the ray distance must break the tie
+    nrm = rng.standard_normal((8, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    col = (rng.random((8, 3)) * 255).astype(np.float32)
+    pcs = Pointclouds(points=T(pts)[None], normals=T(nrm)[None], colors=T(col)[None], features=feats)
+    img = (rng.random((1, 1, H, W, 3)) * 255).astype(np.float32)
+    dep = (1.0 + rng.random((1, 1, H, W, 1))).astype(np.float32)
+    dep[0, 0, 1, 2, 0] = 0.0
+    Kk = np.array([[2, 0, 1, 0], [0, 2, 1, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)[None, None]
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, 3] = [0.01, -0.02, 0.03]
+    fr = RGBDImages(T(img), T(dep), T(Kk), T(pose[None, None]))
+    uq = fu.find_best_unique_correspondences(pcs, fr, T(rows))
+    fused = fu.fuse_with_map(pcs.clone(), fr, uq, sigma)  # clone: the reference mutates its input
+    g = dict(points=pts, normals=nrm, colors=col, ccounts=feats[0].numpy(), rows=rows, rgb=img[0, 0], depth=dep[0, 0],
+             intrinsics=Kk[0, 0], pose=pose, unique=uq.numpy(), sigma=np.float32(sigma),
+             fused_points=fused.points_list[0].numpy(), fused_normals=fused.normals_list[0].numpy(),
+             fused_colors=fused.colors_list[0].numpy(), fused_ccounts=fused.features_list[0].numpy())
+    # empty-table case (tests/slam/test_fusionutils.py:988-1040): pure append
+    fused0 = fu.fuse_with_map(pcs.clone(), fr, torch.empty((0, 4), dtype=torch.int64), sigma)
+    g["fused0_points"], g["fused0_ccounts"] = fused0.points_list[0].numpy(), fused0.features_list[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "fusion_kat.npz"), **g)
+
+    for f in sorted(os.listdir(OUT)):
+        print("%-18s %8.1f KiB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,1 @@
+# Test-infrastructure shim: the reference imports open3d only for visualisation.

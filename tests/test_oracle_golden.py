@@ -1,0 +1,172 @@
+"""Pins the CPU oracle (oracle/gs_oracle.c) against golden vectors produced by the REAL
+reference (oracle/make_golden.py).  Integer / index / mask outputs must be bit-exact; float
+maps are bit-exact wherever the reference's arithmetic could be replicated operation by
+operation (everything except exp() inside alpha, which is within 1 ulp).  CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from oracle import slam as oslam
+from tests.conftest import ate
+
+DIST_TH, DOT_TH, SIGMA = 0.05, math.cos(20 * math.pi / 180), 0.6
+
+
+def ulp_diff(a, b):
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+def test_frame_maps_bit_exact(golden):
+    g = golden("msrd_b0")
+    for s in range(2):
+        depth = g["depths"][s, ..., 0]
+        v, n, a, valid = o.frame_maps(depth, g["intrinsics"], SIGMA)
+        assert np.array_equal(v, g["vertex_map"][s])
+        assert np.array_equal(n, g["normal_map"][s])
+        assert np.array_equal(valid, depth > 0)
+        gv, gn = o.global_maps(v, n, depth, g["poses"][s])
+        assert np.array_equal(gv, g["global_vertex_map"][s])
+        assert np.array_equal(gn, g["global_normal_map"][s])
+        # alpha: exp() differs from torch's SLEEF exp by at most 1 ulp
+        assert ulp_diff(a, g["alpha"][s]).max() <= 1
+        np.testing.assert_allclose(a, g["alpha"][s], rtol=2e-7, atol=0)
+
+
+def test_reference_tolerances_of_its_own_tests(golden):
+    """tests/structures/test_rgbdimages.py:56-165 criteria, applied to the oracle."""
+    g = golden("msrd_b0")
+    v, n, _, _ = o.frame_maps(g["depths"][0, ..., 0], g["intrinsics"], SIGMA)
+    assert ((g["vertex_map"][0] - v) ** 2).sum() < 1e-2
+    assert (((g["normal_map"][0] - n) ** 2) < 1e-5).mean() >= 0.99
+
+
+def test_first_frame_map(golden):
+    g = golden("msrd_b0")
+    depth = g["depths"][0, ..., 0]
+    v, n, a, _ = o.frame_maps(depth, g["intrinsics"], SIGMA)
+    gv, gn = o.global_maps(v, n, depth, g["poses"][0])
+    e3, e1 = np.zeros((0, 3), np.float32), np.zeros((0, 1), np.float32)
+    P, N, C, F = o.fuse_append(e3, e3, e3, e1, np.full(depth.size, -1, np.int32), gv, gn, g["colors"][0],
+                               g["alpha"][0], depth)
+    assert np.array_equal(P, g["map0_points"]) and np.array_equal(N, g["map0_normals"])
+    assert np.array_equal(C, g["map0_colors"]) and np.array_equal(F, g["map0_ccounts"])
+
+
+def test_correspondence_tables_bit_exact(golden):
+    g = golden("msrd_b0")
+    H, W = g["depths"].shape[1:3]
+    P, N, F = g["map0_points"], g["map0_normals"], g["map0_ccounts"]
+    gv1, gn1 = g["global_vertex_map"][1], g["global_normal_map"][1]
+    pix = o.project_map(P, g["poses"][1], g["intrinsics"], H, W)
+    act = o.active_table(pix, W)
+    assert np.array_equal(act, g["active"])
+    mask = o.similar_rows(act, P, N, gv1, gn1, DIST_TH, DOT_TH)
+    assert np.array_equal(mask, g["similar_mask"])
+    uq = o.best_unique_rows(act[mask], P, F, gv1)
+    assert np.array_equal(uq, g["unique"])
+    best, sim = o.associate(pix, P, N, F, gv1, gn1, DIST_TH, DOT_TH)
+    assert np.array_equal(o.best_table(best, H, W), g["unique"])
+    assert np.array_equal(o.rows_to_best_pix(g["unique"], H, W), best)
+    assert sim.sum() == mask.sum()
+
+
+def test_fuse_with_map_bit_exact(golden):
+    g = golden("msrd_b0")
+    H, W = g["depths"].shape[1:3]
+    best = o.rows_to_best_pix(g["unique"], H, W)
+    P, N, C, F = o.fuse_append(g["map0_points"], g["map0_normals"], g["map0_colors"], g["map0_ccounts"], best,
+                               g["global_vertex_map"][1], g["global_normal_map"][1], g["colors"][1],
+                               g["alpha"][1], g["depths"][1, ..., 0])
+    for a, k in ((P, "points"), (N, "normals"), (C, "colors"), (F, "ccounts")):
+        assert np.array_equal(a, g["map1_" + k]), k
+
+
+def test_downsamplers(golden):
+    g = golden("msrd_b0")
+    p, n, _ = o.downsample_table(g["active"], 4, g["map0_points"], g["map0_normals"])
+    assert np.array_equal(p, g["ds4_map_points"]) and np.array_equal(n, g["ds4_map_normals"])
+    H, W = g["depths"].shape[1:3]
+    pix = o.project_map(g["map0_points"], g["poses"][1], g["intrinsics"], H, W)
+    p2, n2, _ = o.select_targets(pix, W, 4, g["map0_points"], g["map0_normals"])
+    assert np.array_equal(p2, p) and np.array_equal(n2, n)
+    fp, fn, _ = o.downsample_frame(g["global_vertex_map"][1], g["global_normal_map"][1], g["colors"][1],
+                                   g["depths"][1, ..., 0], 4)
+    assert np.array_equal(fp, g["ds4_frame_points"]) and np.array_equal(fn, g["ds4_frame_normals"])
+
+
+def test_fusion_kat(golden):
+    g = golden("fusion_kat")
+    H, W = g["depth"].shape[:2]
+    depth = g["depth"][..., 0]
+    v, n, a, _ = o.frame_maps(depth, g["intrinsics"], float(g["sigma"]))
+    gv, gn = o.global_maps(v, n, depth, g["pose"])
+    uq = o.best_unique_rows(g["rows"], g["points"], g["ccounts"], gv)
+    assert np.array_equal(uq, g["unique"])
+    best = o.rows_to_best_pix(uq, H, W)
+    P, N, C, F = o.fuse_append(g["points"], g["normals"], g["colors"], g["ccounts"], best, gv, gn, g["rgb"], a,
+                               depth)
+    assert P.shape == g["fused_points"].shape
+    np.testing.assert_allclose(P, g["fused_points"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(N, g["fused_normals"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(C, g["fused_colors"], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(F, g["fused_ccounts"], rtol=1e-6, atol=1e-9)
+    P0, _, _, F0 = o.fuse_append(g["points"], g["normals"], g["colors"], g["ccounts"],
+                                 np.full(H * W, -1, np.int32), gv, gn, g["rgb"], a, depth)
+    np.testing.assert_allclose(P0, g["fused0_points"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(F0, g["fused0_ccounts"], rtol=1e-6, atol=1e-9)
+
+
+def test_gauss_newton_and_solve(golden):
+    g = golden("icp_unit")
+    A, b, idx, keep = o.gauss_newton_rows(g["src"], g["tgt"], g["tgt_normals"])
+    assert np.array_equal(idx, g["gn_idx"]) and keep.all()
+    assert np.array_equal(A, g["gn_A"]) and np.array_equal(b, g["gn_b"][:, 0])
+    A2, b2, idx2, keep2 = o.gauss_newton_rows(g["src"], g["tgt"], g["tgt_normals"], float(g["gn_thr"]))
+    assert np.array_equal(idx2[keep2], g["gn_thr_idx"]) and np.array_equal(A2[keep2], g["gn_thr_A"])
+    x = o.solve_normal_eq(A, b, 1e-8)
+    np.testing.assert_allclose(x, g["solve_x"][:, 0], rtol=2e-3, atol=2e-6)
+
+
+def test_se3_exp(golden):
+    g = golden("icp_unit")
+    for xi, T in zip(g["se3_xi"], g["se3_T"]):
+        np.testing.assert_allclose(o.se3_exp(xi), T, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode,key", [(0, "icp"), (1, "gradicp")])
+@pytest.mark.parametrize("iters", [3, 20])
+def test_icp_transforms(golden, mode, key, iters):
+    g = golden("icp_unit")
+    T, idx = o.icp(g["src"], g["tgt"], g["tgt_normals"], mode=mode, numiters=iters)
+    Tref = g["%s%d_T" % (key, iters)]
+    np.testing.assert_allclose(T, Tref, rtol=0, atol=2e-5)
+    assert (idx == g["%s%d_idx" % (key, iters)]).mean() > 0.995
+
+
+@pytest.mark.parametrize("key,slam,odom", [("pf_gradicp", "pointfusion", "gradicp"), ("pf_icp", "pointfusion", "icp"),
+                                           ("pf_gt", "pointfusion", "gt"), ("icpslam_gradicp", "icpslam", "gradicp")])
+def test_sequences_64(golden, key, slam, odom):
+    """Config C1 size: recovered poses within ATE 1e-4 m of the reference, identical map size."""
+    g = golden("synth64")
+    poses = g["poses"].copy()
+    if odom != "gt":
+        poses[1:] = poses[:1]
+    m, rp = oslam.run_sequence(g["colors"], g["depths"], g["intrinsics"], poses, slam=slam, odom=odom)
+    assert ate(rp, g[key + "_poses"]) <= 1e-4
+    np.testing.assert_allclose(rp, g[key + "_poses"], rtol=0, atol=2e-5)
+    assert len(m) == g[key + "_points"].shape[0]
+    np.testing.assert_allclose(m.points, g[key + "_points"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(m.normals, g[key + "_normals"], rtol=1e-4, atol=1e-4)
+
+
+def test_sequence_120(golden):
+    g = golden("synth120")
+    from gradslam_amd.datasets.synthetic import make_sequence
+    s = make_sequence(4, 120, 160, seed=int(g["colors_seed"]))
+    poses = g["poses"].copy()
+    poses[1:] = poses[:1]
+    m, rp = oslam.run_sequence(s["colors"], g["depths"], g["intrinsics"], poses)
+    assert ate(rp, g["pf_gradicp_poses"]) <= 1e-4
+    assert len(m) == int(g["pf_gradicp_count"])
