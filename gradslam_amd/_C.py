@@ -1,0 +1,152 @@
+"""ctypes binding of libgradslam_hip.so (include/gradslam_hip.h).
+
+The HIP library is the product: there is NO CPU or PyTorch fallback.  `lib()` raises if the
+shared object is missing, and every wrapper raises if it is handed a tensor that does not live
+on a HIP device.  torch is used only for device memory, streams and dtype plumbing.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgradslam_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+_vp, _i64, _i32, _f = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("mode", C.c_int), ("numiters", C.c_int), ("damp", C.c_float),
+                ("dist_thresh", C.c_float), ("lambda_max", C.c_float), ("B", C.c_float),
+                ("B2", C.c_float), ("nu", C.c_float)]
+
+
+# name -> argtypes (return type is int unless listed in _RESTYPE)
+_PROTOS = {
+    "gs_abi_version": [],
+    "gs_last_error": [],
+    "gs_scratch_bytes": [_i64, _i64],
+    "gs_frame_maps_f32": [_vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp],
+    "gs_global_maps_f32": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
+    "gs_alpha_f32": [_vp, _i64, _f, _f, _vp, _vp],
+    "gs_downsample_frame_f32": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gs_project_map_f32": [_vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp],
+    "gs_active_table_i64": [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp],
+    "gs_select_targets_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "gs_downsample_table_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gs_knn1_f32": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
+    "gs_gauss_newton_rows_f32": [_vp, _i64, _vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gs_solve_normal_eq_f32": [_vp, _vp, _vp, _i64, _i32, _f, _vp, _vp],
+    "gs_se3_exp_f32": [_vp, _vp, _vp],
+    "gs_transform_points_f32": [_vp, _i64, _vp, _vp, _vp],
+    "gs_icp_scratch_bytes": [_i64, _i64],
+    "gs_icp_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, C.POINTER(IcpParams), _vp, _vp, _vp, _vp],
+    "gs_icp_trace_f32": [_vp, _i32, _vp, _vp],
+    "gs_similar_rows_f32": [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f, _f, _vp, _vp],
+    "gs_best_unique_rows_f32": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
+    "gs_associate_f32": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp],
+    "gs_best_table_i64": [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp],
+    "gs_rows_to_best_pix": [_vp, _i64, _i32, _i32, _vp, _vp],
+    "gs_fuse_append_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
+                           _vp, _vp, _vp],
+    "gs_append_valid_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
+}
+_RESTYPE = {"gs_last_error": C.c_char_p, "gs_scratch_bytes": _i64, "gs_icp_scratch_bytes": _i64}
+EXPORTS = tuple(_PROTOS)
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libgradslam_hip.so (once).  Fails loudly: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionError(
+                "gradslam_amd: %s is missing. Build it with `python -m gradslam_amd.csrc.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU / PyTorch fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in _PROTOS.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export it
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, C.c_int)
+        if handle.gs_abi_version() != ABI_VERSION:
+            raise HipExtensionError("libgradslam_hip.so ABI %d != expected %d; rebuild"
+                                    % (handle.gs_abi_version(), ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise HipExtensionError("%s failed (code %d): %s" % (what, status, lib().gs_last_error().decode()))
+
+
+def require_device(*tensors):
+    """Every tensor handed to the HIP library must be a contiguous tensor on a HIP device."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HipExtensionError(
+                "gradslam_amd kernels run on the GPU only (got a %s tensor). Move the data to a HIP "
+                "device; there is no CPU fallback." % t.device)
+        if not t.is_contiguous():
+            raise HipExtensionError("internal error: non-contiguous tensor passed to the HIP library")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise HipExtensionError("tensors live on different devices: %s vs %s" % (dev, t.device))
+    return dev
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Workspace:
+    """Per-device scratch buffers, grown on demand and reused every frame (the library never
+    allocates)."""
+    _instances = {}
+
+    def __init__(self, device):
+        self.device = device
+        self._bufs = {}
+
+    @classmethod
+    def get(cls, device):
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        ws = cls._instances.get(device)
+        if ws is None:
+            ws = cls._instances[device] = Workspace(device)
+        return ws
+
+    def bytes(self, name, nbytes):
+        buf = self._bufs.get(name)
+        if buf is None or buf.numel() < nbytes:
+            nbytes = int(nbytes * 1.5) + 4096
+            buf = self._bufs[name] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return buf
+
+    def scratch(self, n_map, n_pix):
+        return self.bytes("scratch", lib().gs_scratch_bytes(int(n_map), int(n_pix)))
+
+    def tensor(self, name, shape, dtype):
+        n = 1
+        for s in shape:
+            n *= int(s)
+        item = torch.empty((), dtype=dtype).element_size()
+        buf = self.bytes(name, max(n, 1) * item)
+        return buf[: n * item].view(dtype).view(*shape)

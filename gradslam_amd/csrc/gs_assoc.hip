@@ -1,0 +1,416 @@
+// gs_assoc.hip — K2 (ordered down-samplers) and K5 (projective surfel association).
+// All kernels stream the surfel arrays once, fully coalesced (12 B/point AoS rows are
+// contiguous across lanes); frame look-ups are 12 B gathers that hit L2 because projected
+// neighbours land on neighbouring pixels.  HBM-bound (28 B/point + 24 B per
+// in-frame point + 8 B/pixel key traffic).
+#include "gs_compact.h"
+
+// ---------------------------------------------------------------- K5a: projection ------
+struct GsCamera {
+  float Ri[9];  // R^T
+  float ti[3];  // -R^T t   (kornia inverse_transformation: tiny matmul, plain arithmetic)
+  float K[12];  // rows 0..2 of the 4x4 intrinsics
+};
+
+GS_DEV GsCamera gs_camera(const float* __restrict__ pose16, const float* __restrict__ K16) {
+  GsCamera c;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c.Ri[3 * j + k] = pose16[4 * k + j];
+  const float t0 = pose16[3], t1 = pose16[7], t2 = pose16[11];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    c.ti[j] = gs_dot3_plain(-c.Ri[3 * j], -c.Ri[3 * j + 1], -c.Ri[3 * j + 2], t0, t1, t2);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) c.K[i] = K16[i];
+  return c;
+}
+
+// slam/fusionutils.py:250-274 for one point; returns h*W+w or -1.
+GS_DEV int32_t gs_project_point(const GsCamera& c, float p0, float p1, float p2, int H, int W,
+                                float u_hi, float v_hi) {
+  // Pointclouds.transform: rotate_ (einsum over N: FMA chain) then offset_
+  const float q0 = gs_dot3_fma(p0, p1, p2, c.Ri[0], c.Ri[1], c.Ri[2]) + c.ti[0];
+  const float q1 = gs_dot3_fma(p0, p1, p2, c.Ri[3], c.Ri[4], c.Ri[5]) + c.ti[1];
+  const float q2 = gs_dot3_fma(p0, p1, p2, c.Ri[6], c.Ri[7], c.Ri[8]) + c.ti[2];
+  const bool front = q2 > 0.0f;
+  // project_points: 4x4 . (x, y, z, 1), tiny matmul: plain, ascending k
+  float r[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float acc = c.K[4 * j] * q0;
+    acc = acc + c.K[4 * j + 1] * q1;
+    acc = acc + c.K[4 * j + 2] * q2;
+    acc = acc + c.K[4 * j + 3] * 1.0f;
+    r[j] = acc;
+  }
+  const float zz = (r[2] != 0.0f) ? r[2] : 1.0f;
+  const float u = r[0] / zz, v = r[1] / zz;
+  const bool in_frame = (u > -1e-3f) && (u < u_hi) && (v > -1e-3f) && (v < v_hi) && front;
+  if (!in_frame) return -1;
+  int64_t wi = (int64_t)__builtin_rintf(u), hi = (int64_t)__builtin_rintf(v);
+  wi = wi < 0 ? 0 : (wi > W - 1 ? W - 1 : wi);
+  hi = hi < 0 ? 0 : (hi > H - 1 ? H - 1 : hi);
+  return (int32_t)(hi * W + wi);
+}
+
+__global__ void __launch_bounds__(256) gs_project_map_kernel(
+    const float* __restrict__ points, int64_t n_map, const float* __restrict__ pose16,
+    const float* __restrict__ K16, int H, int W, float u_hi, float v_hi, int32_t* __restrict__ pix) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_map) return;
+  const GsCamera c = gs_camera(pose16, K16);
+  pix[n] = gs_project_point(c, points[3 * n], points[3 * n + 1], points[3 * n + 2], H, W, u_hi, v_hi);
+}
+
+extern "C" int gs_project_map_f32(const float* points, int64_t n_map, const float* pose16,
+                                  const float* K16, int H, int W, int32_t* pix, void* stream) {
+  GS_REQUIRE(n_map >= 0 && H > 0 && W > 0, "bad sizes");
+  if (n_map == 0) return GS_OK;
+  GS_REQUIRE(points && pose16 && K16 && pix, "NULL pointer");
+  GS_REQUIRE((int64_t)H * W < (1ll << 31), "image too large for int32 pixel ids");
+  const float u_hi = (float)((double)W - 0.999), v_hi = (float)((double)H - 0.999);
+  hipLaunchKernelGGL(gs_project_map_kernel, dim3((unsigned)gs_ceil_div(n_map, 256)), dim3(256), 0,
+                     gs_stream(stream), points, n_map, pose16, K16, H, W, u_hi, v_hi, pix);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// ---------------------------------------------------------------- ordered tables -------
+struct PredActive {
+  const int32_t* pix;
+  __device__ bool operator()(int64_t n) const { return pix[n] >= 0; }
+};
+struct EmitActiveRow {
+  const int32_t* pix;
+  int W;
+  int64_t b;
+  int64_t* rows;
+  __device__ void operator()(int64_t n, int64_t pos) const {
+    const int32_t p = pix[n];
+    rows[4 * pos] = b;
+    rows[4 * pos + 1] = n;
+    rows[4 * pos + 2] = p / W;
+    rows[4 * pos + 3] = p % W;
+  }
+};
+
+extern "C" int gs_active_table_i64(const int32_t* pix, int64_t n_map, int W, int64_t b,
+                                   int64_t* rows_out, int64_t* count_out, void* scratch,
+                                   void* stream) {
+  GS_REQUIRE(n_map >= 0 && W > 0 && count_out && scratch, "bad arguments");
+  return gs_compact(n_map, PredActive{pix}, EmitActiveRow{pix, W, b, rows_out}, count_out, 0, -1, scratch,
+                    gs_stream(stream));
+}
+
+struct Gather3 {
+  const float* points;
+  const float* normals;
+  const float* colors;
+  float* out_pts;
+  float* out_nrm;
+  float* out_rgb;
+  __device__ void copy(int64_t src, int64_t dst) const {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      out_pts[3 * dst + k] = points[3 * src + k];
+      if (out_nrm) out_nrm[3 * dst + k] = normals[3 * src + k];
+      if (out_rgb) out_rgb[3 * dst + k] = colors[3 * src + k];
+    }
+  }
+};
+
+struct PredLattice {
+  const int32_t* pix;
+  int W, ds;
+  __device__ bool operator()(int64_t n) const {
+    const int32_t p = pix[n];
+    if (p < 0) return false;
+    return ((p / W) % ds == 0) && ((p % W) % ds == 0);
+  }
+};
+struct EmitGatherByN {
+  Gather3 g;
+  __device__ void operator()(int64_t n, int64_t pos) const { g.copy(n, pos); }
+};
+
+extern "C" int gs_select_targets_f32(const int32_t* pix, int64_t n_map, int W, int ds,
+                                     const float* points, const float* normals, const float* colors,
+                                     float* out_pts, float* out_nrm, float* out_rgb, int64_t cap,
+                                     int64_t* count_out, void* scratch, void* stream) {
+  GS_REQUIRE(n_map >= 0 && W > 0 && ds > 0 && count_out && scratch && out_pts, "bad arguments");
+  Gather3 g{points, normals, colors, out_pts, normals ? out_nrm : nullptr, colors ? out_rgb : nullptr};
+  return gs_compact(n_map, PredLattice{pix, W, ds}, EmitGatherByN{g}, count_out, 0, cap, scratch,
+                    gs_stream(stream));
+}
+
+struct PredRowLattice {
+  const int64_t* rows;
+  int ds;
+  __device__ bool operator()(int64_t r) const {
+    return (rows[4 * r + 2] % ds == 0) && (rows[4 * r + 3] % ds == 0);
+  }
+};
+struct EmitGatherByRow {
+  const int64_t* rows;
+  Gather3 g;
+  __device__ void operator()(int64_t r, int64_t pos) const { g.copy(rows[4 * r + 1], pos); }
+};
+
+extern "C" int gs_downsample_table_f32(const int64_t* rows, int64_t n_rows, int ds,
+                                       const float* points, const float* normals,
+                                       const float* colors, float* out_pts, float* out_nrm,
+                                       float* out_rgb, int64_t* count_out, void* scratch,
+                                       void* stream) {
+  GS_REQUIRE(n_rows >= 0 && ds > 0 && count_out && scratch, "bad arguments");
+  Gather3 g{points, normals, colors, out_pts, normals ? out_nrm : nullptr, colors ? out_rgb : nullptr};
+  return gs_compact(n_rows, PredRowLattice{rows, ds}, EmitGatherByRow{rows, g}, count_out, 0, -1, scratch,
+                    gs_stream(stream));
+}
+
+// valid pixels of the [::ds, ::ds] lattice, raster order (odometry/icputils.py:654-668)
+struct PredFrameLattice {
+  const float* depth;
+  int W, ds, Wl;
+  __device__ bool operator()(int64_t e) const {
+    const int64_t h = (e / Wl) * ds, w = (e % Wl) * ds;
+    return depth[h * W + w] > 0.0f;
+  }
+};
+struct EmitFrameLattice {
+  int W, ds, Wl;
+  Gather3 g;
+  __device__ void operator()(int64_t e, int64_t pos) const {
+    const int64_t h = (e / Wl) * ds, w = (e % Wl) * ds;
+    g.copy(h * W + w, pos);
+  }
+};
+
+extern "C" int gs_downsample_frame_f32(const float* gvertex, const float* gnormal, const float* rgb,
+                                       const float* depth, int H, int W, int ds, float* out_pts,
+                                       float* out_nrm, float* out_rgb, int64_t* count_out,
+                                       void* scratch, void* stream) {
+  GS_REQUIRE(H > 0 && W > 0 && ds > 0 && gvertex && depth && out_pts && count_out && scratch,
+             "bad arguments");
+  const int Hl = (H + ds - 1) / ds, Wl = (W + ds - 1) / ds;
+  Gather3 g{gvertex, gnormal, rgb, out_pts, gnormal ? out_nrm : nullptr, rgb ? out_rgb : nullptr};
+  return gs_compact((int64_t)Hl * Wl, PredFrameLattice{depth, W, ds, Wl}, EmitFrameLattice{W, ds, Wl, g},
+                    count_out, 0, -1, scratch, gs_stream(stream));
+}
+
+// ---------------------------------------------------------------- K5b: similarity ------
+// slam/fusionutils.py:396-399 for map point n against frame pixel p.
+GS_DEV bool gs_is_similar(const float* __restrict__ points, const float* __restrict__ normals,
+                          const float* __restrict__ gvertex, const float* __restrict__ gnormal,
+                          int64_t n, int64_t p, float dist_th, float dot_th) {
+  const float f0 = gvertex[3 * p], f1 = gvertex[3 * p + 1], f2 = gvertex[3 * p + 2];
+  const float q0 = points[3 * n], q1 = points[3 * n + 1], q2 = points[3 * n + 2];
+  const float dist = gs_norm3(f0 - q0, f1 - q1, f2 - q2);
+  const float dot = gs_dot3_plain(gnormal[3 * p], gnormal[3 * p + 1], gnormal[3 * p + 2], normals[3 * n],
+                                  normals[3 * n + 1], normals[3 * n + 2]);
+  return (dist < dist_th) && (dot > dot_th);
+}
+
+// slam/fusionutils.py:491-517: (1/(ccount+1e-20), |p - f|^2) packed so that unsigned order ==
+// lexicographic float order (both are >= 0).
+GS_DEV uint64_t gs_assoc_key(const float* __restrict__ points, const float* __restrict__ ccounts,
+                             const float* __restrict__ gvertex, int64_t n, int64_t p) {
+  const float inv = 1.0f / (ccounts[n] + 1e-20f);
+  const float d0 = points[3 * n] - gvertex[3 * p];
+  const float d1 = points[3 * n + 1] - gvertex[3 * p + 1];
+  const float d2 = points[3 * n + 2] - gvertex[3 * p + 2];
+  float ray = d0 * d0 + d1 * d1;
+  ray = ray + d2 * d2;
+  return ((uint64_t)__float_as_uint(inv) << 32) | (uint64_t)__float_as_uint(ray);
+}
+
+__global__ void __launch_bounds__(256) gs_similar_rows_kernel(
+    const int64_t* __restrict__ rows, int64_t n_rows, const float* __restrict__ points,
+    const float* __restrict__ normals, const float* __restrict__ gvertex,
+    const float* __restrict__ gnormal, int W, float dist_th, float dot_th, uint8_t* __restrict__ mask) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  const int64_t n = rows[4 * r + 1], p = rows[4 * r + 2] * W + rows[4 * r + 3];
+  mask[r] = gs_is_similar(points, normals, gvertex, gnormal, n, p, dist_th, dot_th) ? 1 : 0;
+}
+
+extern "C" int gs_similar_rows_f32(const int64_t* rows, int64_t n_rows, const float* points,
+                                   const float* normals, const float* gvertex, const float* gnormal,
+                                   int W, float dist_th, float dot_th, uint8_t* mask, void* stream) {
+  GS_REQUIRE(n_rows >= 0 && W > 0, "bad sizes");
+  if (n_rows == 0) return GS_OK;
+  GS_REQUIRE(rows && points && normals && gvertex && gnormal && mask, "NULL pointer");
+  hipLaunchKernelGGL(gs_similar_rows_kernel, dim3((unsigned)gs_ceil_div(n_rows, 256)), dim3(256), 0,
+                     gs_stream(stream), rows, n_rows, points, normals, gvertex, gnormal, W, dist_th,
+                     dot_th, mask);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// ---------------------------------------------------------------- K5c: best per pixel --
+// Two order-independent (hence deterministic) atomic passes replace the reference's
+// torch.unique(dim=0) sort: pass 1 takes the per-pixel minimum of the (1/cc, ray) key, pass 2
+// the minimum map index among the rows that attain it.
+__global__ void __launch_bounds__(256) gs_fill_u64_kernel(uint64_t* p, int64_t n, uint64_t v) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void __launch_bounds__(256) gs_fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ void __launch_bounds__(256) gs_rows_key_kernel(
+    const int64_t* __restrict__ rows, int64_t n_rows, const float* __restrict__ points,
+    const float* __restrict__ ccounts, const float* __restrict__ gvertex, int W,
+    uint64_t* __restrict__ key_row, unsigned long long* __restrict__ key_pix) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  const int64_t n = rows[4 * r + 1], p = rows[4 * r + 2] * W + rows[4 * r + 3];
+  const uint64_t k = gs_assoc_key(points, ccounts, gvertex, n, p);
+  key_row[r] = k;
+  atomicMin(&key_pix[p], (unsigned long long)k);
+}
+__global__ void __launch_bounds__(256) gs_rows_pick_kernel(
+    const int64_t* __restrict__ rows, int64_t n_rows, int W, const uint64_t* __restrict__ key_row,
+    const uint64_t* __restrict__ key_pix, int32_t* __restrict__ best_pix) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  const int64_t n = rows[4 * r + 1], p = rows[4 * r + 2] * W + rows[4 * r + 3];
+  // best_pix holds n | 0x80000000-free encoding: initialised to INT32_MAX, min over winners
+  if (key_row[r] == key_pix[p]) atomicMin(&best_pix[p], (int32_t)n);
+}
+__global__ void __launch_bounds__(256) gs_best_fix_kernel(int32_t* __restrict__ best_pix, int64_t P) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < P && best_pix[i] == 0x7fffffff) best_pix[i] = -1;
+}
+
+struct PredBest {
+  const int32_t* best;
+  __device__ bool operator()(int64_t p) const { return best[p] >= 0; }
+};
+struct EmitBestRow {
+  const int32_t* best;
+  int W;
+  int64_t b;
+  int64_t* rows;
+  __device__ void operator()(int64_t p, int64_t pos) const {
+    rows[4 * pos] = b;
+    rows[4 * pos + 1] = best[p];
+    rows[4 * pos + 2] = p / W;
+    rows[4 * pos + 3] = p % W;
+  }
+};
+
+extern "C" int gs_best_table_i64(const int32_t* best_pix, int H, int W, int64_t b,
+                                 int64_t* rows_out, int64_t* count_out, void* scratch, void* stream) {
+  GS_REQUIRE(H > 0 && W > 0 && best_pix && count_out && scratch, "bad arguments");
+  return gs_compact((int64_t)H * W, PredBest{best_pix}, EmitBestRow{best_pix, W, b, rows_out}, count_out, 0,
+                    -1, scratch, gs_stream(stream));
+}
+
+static inline unsigned gs_blocks(int64_t n) { return (unsigned)gs_ceil_div(n > 0 ? n : 1, 256); }
+
+extern "C" int gs_best_unique_rows_f32(const int64_t* rows, int64_t n_rows, const float* points,
+                                       const float* ccounts, const float* gvertex, int H, int W,
+                                       int64_t b, int32_t* best_pix, int64_t* rows_out,
+                                       int64_t* count_out, void* scratch, void* stream) {
+  GS_REQUIRE(n_rows >= 0 && H > 0 && W > 0 && best_pix && count_out && scratch, "bad arguments");
+  hipStream_t st = gs_stream(stream);
+  const int64_t P = (int64_t)H * W;
+  // scratch: [compaction | key_pix u64[P] | key_row u64[n_rows]]
+  char* base = reinterpret_cast<char*>(scratch) + gs_cp_scratch_bytes(P > n_rows ? P : n_rows);
+  uint64_t* key_pix = reinterpret_cast<uint64_t*>(base);
+  uint64_t* key_row = reinterpret_cast<uint64_t*>(base + gs_align(8 * (size_t)P));
+  hipLaunchKernelGGL(gs_fill_u64_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, key_pix, P, ~0ull);
+  hipLaunchKernelGGL(gs_fill_i32_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, best_pix, P, 0x7fffffff);
+  if (n_rows > 0) {
+    hipLaunchKernelGGL(gs_rows_key_kernel, dim3(gs_blocks(n_rows)), dim3(256), 0, st, rows, n_rows, points,
+                       ccounts, gvertex, W, key_row, reinterpret_cast<unsigned long long*>(key_pix));
+    hipLaunchKernelGGL(gs_rows_pick_kernel, dim3(gs_blocks(n_rows)), dim3(256), 0, st, rows, n_rows, W,
+                       key_row, key_pix, best_pix);
+  }
+  hipLaunchKernelGGL(gs_best_fix_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, best_pix, P);
+  GS_LAUNCH_CHECK();
+  if (rows_out) return gs_best_table_i64(best_pix, H, W, b, rows_out, count_out, scratch, stream);
+  return GS_OK;
+}
+
+// fused path: pix[] straight to best_pix[] (no tables)
+__global__ void __launch_bounds__(256) gs_assoc_key_kernel(
+    const int32_t* __restrict__ pix, int64_t n_map, const float* __restrict__ points,
+    const float* __restrict__ normals, const float* __restrict__ ccounts,
+    const float* __restrict__ gvertex, const float* __restrict__ gnormal, float dist_th, float dot_th,
+    uint64_t* __restrict__ key_pt, unsigned long long* __restrict__ key_pix,
+    uint8_t* __restrict__ similar) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_map) return;
+  const int32_t p = pix[n];
+  bool sim = false;
+  uint64_t k = ~0ull;
+  if (p >= 0 && gs_is_similar(points, normals, gvertex, gnormal, n, p, dist_th, dot_th)) {
+    sim = true;
+    k = gs_assoc_key(points, ccounts, gvertex, n, p);
+    atomicMin(&key_pix[p], (unsigned long long)k);
+  }
+  key_pt[n] = k;
+  if (similar) similar[n] = sim ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) gs_assoc_pick_kernel(
+    const int32_t* __restrict__ pix, int64_t n_map, const uint64_t* __restrict__ key_pt,
+    const uint64_t* __restrict__ key_pix, int32_t* __restrict__ best_pix) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_map) return;
+  const uint64_t k = key_pt[n];
+  if (k == ~0ull) return;  // not similar (a real key can never be all ones: ray is not NaN-coded)
+  const int32_t p = pix[n];
+  if (k == key_pix[p]) atomicMin(&best_pix[p], (int32_t)n);
+}
+
+extern "C" int gs_associate_f32(const int32_t* pix, int64_t n_map, const float* points,
+                                const float* normals, const float* ccounts, const float* gvertex,
+                                const float* gnormal, int H, int W, float dist_th, float dot_th,
+                                int32_t* best_pix, uint8_t* similar, void* scratch, void* stream) {
+  GS_REQUIRE(n_map >= 0 && H > 0 && W > 0 && best_pix && scratch, "bad arguments");
+  GS_REQUIRE(n_map < 0x7fffffff, "map too large for int32 indices");
+  hipStream_t st = gs_stream(stream);
+  const int64_t P = (int64_t)H * W;
+  char* base = reinterpret_cast<char*>(scratch) + gs_cp_scratch_bytes(P > n_map ? P : n_map);
+  uint64_t* key_pix = reinterpret_cast<uint64_t*>(base);
+  uint64_t* key_pt = reinterpret_cast<uint64_t*>(base + gs_align(8 * (size_t)P));
+  hipLaunchKernelGGL(gs_fill_u64_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, key_pix, P, ~0ull);
+  hipLaunchKernelGGL(gs_fill_i32_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, best_pix, P, 0x7fffffff);
+  if (n_map > 0) {
+    GS_REQUIRE(pix && points && normals && ccounts && gvertex && gnormal, "NULL pointer");
+    hipLaunchKernelGGL(gs_assoc_key_kernel, dim3(gs_blocks(n_map)), dim3(256), 0, st, pix, n_map, points,
+                       normals, ccounts, gvertex, gnormal, dist_th, dot_th, key_pt,
+                       reinterpret_cast<unsigned long long*>(key_pix), similar);
+    hipLaunchKernelGGL(gs_assoc_pick_kernel, dim3(gs_blocks(n_map)), dim3(256), 0, st, pix, n_map, key_pt,
+                       key_pix, best_pix);
+  }
+  hipLaunchKernelGGL(gs_best_fix_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, best_pix, P);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+__global__ void __launch_bounds__(256) gs_rows_to_best_kernel(const int64_t* __restrict__ rows,
+                                                              int64_t n_rows, int W,
+                                                              int32_t* __restrict__ best_pix) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  best_pix[rows[4 * r + 2] * W + rows[4 * r + 3]] = (int32_t)rows[4 * r + 1];
+}
+
+extern "C" int gs_rows_to_best_pix(const int64_t* rows, int64_t n_rows, int H, int W,
+                                   int32_t* best_pix, void* stream) {
+  GS_REQUIRE(n_rows >= 0 && H > 0 && W > 0 && best_pix, "bad arguments");
+  hipStream_t st = gs_stream(stream);
+  const int64_t P = (int64_t)H * W;
+  hipLaunchKernelGGL(gs_fill_i32_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, best_pix, P, -1);
+  if (n_rows > 0)
+    hipLaunchKernelGGL(gs_rows_to_best_kernel, dim3(gs_blocks(n_rows)), dim3(256), 0, st, rows, n_rows, W,
+                       best_pix);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}

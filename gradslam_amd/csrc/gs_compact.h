@@ -1,0 +1,91 @@
+// gs_compact.h — order-preserving stream compaction (count -> scan tiles -> scatter).
+//
+// The reference's boolean-mask gathers (tensor[mask]) keep input order; appended surfels are
+// in raster order (slam/fusionutils.py:710-713), tables are ordered by (b, n) or (b, h, w).
+// Unordered atomics would break those contracts, so compaction is a deterministic 3-launch
+// scan: every tile of 1024 consecutive elements counts its survivors, one block scans the
+// tile counts, and the scatter pass recomputes the predicate and writes survivor k of the
+// whole input to output slot k.
+#pragma once
+#include "gs_common.h"
+
+constexpr int GS_CP_BLOCK = 256;
+constexpr int GS_CP_ITEMS = 4;
+constexpr int GS_CP_TILE = GS_CP_BLOCK * GS_CP_ITEMS;
+
+static inline int64_t gs_cp_tiles(int64_t n) { return gs_ceil_div(n > 0 ? n : 1, GS_CP_TILE); }
+// scratch: int32 tile_counts[ntiles] | int64 tile_offsets[ntiles]
+static inline size_t gs_cp_scratch_bytes(int64_t n) {
+  int64_t t = gs_cp_tiles(n);
+  return gs_align(sizeof(int32_t) * t) + gs_align(sizeof(int64_t) * t);
+}
+
+template <class Pred>
+__global__ void __launch_bounds__(GS_CP_BLOCK) gs_cp_count_kernel(int64_t n, Pred pred,
+                                                                   int32_t* __restrict__ tile_counts) {
+  __shared__ int smem[GS_CP_BLOCK / GS_WAVE + 1];
+  const int64_t base = (int64_t)blockIdx.x * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < GS_CP_ITEMS; ++i) {
+    int64_t e = base + i;
+    if (e < n && pred(e)) ++c;
+  }
+  int total;
+  (void)gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &total);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+}
+
+// Single block: exclusive scan of tile counts; writes the grand total (plus `base_count`)
+// to count_out[0].  If cap >= 0 and the total exceeds it, count_out[1] is set to 1 and the
+// scatter pass clips (it never writes past cap).
+__global__ void gs_cp_scan_tiles_kernel(const int32_t* __restrict__ tile_counts, int64_t ntiles,
+                                        int64_t* __restrict__ tile_offsets,
+                                        int64_t* __restrict__ count_out, int64_t base_count);
+
+template <class Pred, class Emit>
+__global__ void __launch_bounds__(GS_CP_BLOCK) gs_cp_scatter_kernel(
+    int64_t n, Pred pred, Emit emit, const int64_t* __restrict__ tile_offsets, int64_t cap) {
+  __shared__ int smem[GS_CP_BLOCK / GS_WAVE + 1];
+  const int64_t base = (int64_t)blockIdx.x * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
+  bool keep[GS_CP_ITEMS];
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < GS_CP_ITEMS; ++i) {
+    int64_t e = base + i;
+    keep[i] = (e < n) && pred(e);
+    c += keep[i] ? 1 : 0;
+  }
+  int total;
+  int excl = gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &total);
+  int64_t pos = tile_offsets[blockIdx.x] + excl;
+#pragma unroll
+  for (int i = 0; i < GS_CP_ITEMS; ++i) {
+    if (keep[i]) {
+      if (cap < 0 || pos < cap) emit(base + i, pos);
+      ++pos;
+    }
+  }
+}
+
+// Host driver.  count_out: device int64[1] <- base_count + survivors.
+template <class Pred, class Emit>
+static int gs_compact(int64_t n, Pred pred, Emit emit, int64_t* count_out, int64_t base_count,
+                      int64_t cap, void* scratch, hipStream_t st) {
+  const int64_t ntiles = gs_cp_tiles(n);
+  int32_t* tile_counts = reinterpret_cast<int32_t*>(scratch);
+  int64_t* tile_offsets = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(scratch) +
+                                                     gs_align(sizeof(int32_t) * ntiles));
+  hipLaunchKernelGGL((gs_cp_count_kernel<Pred>), dim3((unsigned)ntiles), dim3(GS_CP_BLOCK), 0, st, n,
+                     pred, tile_counts);
+  hipLaunchKernelGGL(gs_cp_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, tile_counts, ntiles,
+                     tile_offsets, count_out, base_count);
+  hipLaunchKernelGGL((gs_cp_scatter_kernel<Pred, Emit>), dim3((unsigned)ntiles), dim3(GS_CP_BLOCK), 0,
+                     st, n, pred, emit, tile_offsets, cap);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    gs_set_error("gs_compact: %s", hipGetErrorString(e));
+    return GS_ERR_HIP;
+  }
+  return GS_OK;
+}

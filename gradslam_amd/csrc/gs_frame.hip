@@ -1,0 +1,213 @@
+// gs_frame.hip — K1: depth -> vertex / normal / alpha / valid, local -> global maps; plus the
+// library-wide plumbing (error string, ABI version, scratch sizing, tile-scan kernel).
+// HBM-bound: 4 B/px read, 32-56 B/px written; the 3x3 (really 2x2 forward-difference)
+// neighbourhood of the normal is served from an LDS depth tile with a one-pixel halo.
+#include <stdarg.h>
+#include <string.h>
+
+#include "gs_compact.h"
+
+// ------------------------------------------------------------------ plumbing -----------
+static thread_local char g_err[512] = "";
+
+void gs_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int gs_abi_version(void) { return GS_ABI_VERSION; }
+extern "C" const char* gs_last_error(void) { return g_err; }
+
+extern "C" int64_t gs_scratch_bytes(int64_t n_map, int64_t n_pix) {
+  int64_t n = n_map > n_pix ? n_map : n_pix;
+  // compaction scratch + per-pixel and per-point 64-bit association keys
+  return (int64_t)(gs_cp_scratch_bytes(n) + gs_align(8 * (size_t)(n_pix > 0 ? n_pix : 1)) +
+                   gs_align(8 * (size_t)(n_map > 0 ? n_map : 1)) + 4096);
+}
+
+__global__ void gs_cp_scan_tiles_kernel(const int32_t* __restrict__ tile_counts, int64_t ntiles,
+                                        int64_t* __restrict__ tile_offsets,
+                                        int64_t* __restrict__ count_out, int64_t base_count) {
+  __shared__ int smem[1024 / GS_WAVE + 1];
+  __shared__ int64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t t0 = 0; t0 < ntiles; t0 += 1024) {
+    int64_t t = t0 + threadIdx.x;
+    int c = (t < ntiles) ? tile_counts[t] : 0;
+    int total;
+    int excl = gs_block_excl_scan<1024>(c, smem, &total);
+    if (t < ntiles) tile_offsets[t] = carry + excl;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && count_out) count_out[0] = base_count + carry;
+}
+
+// ------------------------------------------------------------------ K1 -----------------
+constexpr int FM_TW = 64;  // tile width  (one wave per row)
+constexpr int FM_TH = 8;   // tile height (each of the 4 waves handles 2 rows)
+constexpr int FM_LW = FM_TW + 2;
+constexpr int FM_LH = FM_TH + 2;
+
+// local vertex of pixel (h, w) from its depth: einsum(Kinv, (u, v, 1)) as FMA chain, then
+// * depth, then * valid (structures/rgbdimages.py:662-679).
+GS_DEV void fm_vertex(float d, int h, int w, const GsKinv& k, float& x, float& y, float& z) {
+  float u = (float)w, v = (float)h;
+  float ax = k.k00 * u;
+  ax = gs_fma(0.0f, v, ax);
+  ax = gs_fma(k.k02, 1.0f, ax);
+  float ay = 0.0f * u;
+  ay = gs_fma(k.k11, v, ay);
+  ay = gs_fma(k.k12, 1.0f, ay);
+  float az = 0.0f * u;
+  az = gs_fma(0.0f, v, az);
+  az = gs_fma(1.0f, 1.0f, az);
+  float validf = d > 0.0f ? 1.0f : 0.0f;
+  x = (ax * d) * validf;
+  y = (ay * d) * validf;
+  z = (az * d) * validf;
+}
+
+__global__ void __launch_bounds__(256) gs_frame_maps_kernel(
+    const float* __restrict__ depth, const float* __restrict__ K16, int H, int W, float two_sigma_sq,
+    float* __restrict__ vertex, float* __restrict__ normal, float* __restrict__ alpha,
+    uint8_t* __restrict__ valid) {
+  __shared__ float tile[FM_LH][FM_LW];
+  const int w_base = blockIdx.x * FM_TW, h_base = blockIdx.y * FM_TH;
+  // stage depth tile with a one-pixel halo on every side (coordinates clamped into the image;
+  // clamped duplicates are never used for a pixel that exists)
+  for (int i = threadIdx.x; i < FM_LH * FM_LW; i += 256) {
+    int lh = i / FM_LW, lw = i - lh * FM_LW;
+    int gh = h_base + lh - 1, gw = w_base + lw - 1;
+    gh = gh < 0 ? 0 : (gh > H - 1 ? H - 1 : gh);
+    gw = gw < 0 ? 0 : (gw > W - 1 ? W - 1 : gw);
+    tile[lh][lw] = depth[(size_t)gh * W + gw];
+  }
+  __syncthreads();
+  const GsKinv k = gs_kinv(K16);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int w = w_base + lane;
+  if (w >= W) return;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int lh = wave * 2 + r;
+    const int h = h_base + lh;
+    if (h >= H) continue;
+    const size_t p = (size_t)h * W + w;
+    const float d = tile[lh + 1][lane + 1];
+    float vx, vy, vz;
+    fm_vertex(d, h, w, k, vx, vy, vz);
+    if (vertex) {
+      vertex[3 * p] = vx;
+      vertex[3 * p + 1] = vy;
+      vertex[3 * p + 2] = vz;
+    }
+    if (valid) valid[p] = d > 0.0f ? 1 : 0;
+    if (alpha) alpha[p] = gs_alpha_of(vx, vy, vz, two_sigma_sq, 1e-7f);
+    if (normal) {
+      // forward differences; the last column / row reuse the previous difference
+      // (structures/rgbdimages.py:724-731)
+      const int w0 = (w < W - 1) ? w : W - 2;
+      const int h0 = (h < H - 1) ? h : H - 2;
+      const int lw0 = w0 - w_base + 1, lh0 = h0 - h_base + 1;
+      float a0x, a0y, a0z, a1x, a1y, a1z, b0x, b0y, b0z, b1x, b1y, b1z;
+      fm_vertex(tile[lh + 1][lw0], h, w0, k, a0x, a0y, a0z);
+      fm_vertex(tile[lh + 1][lw0 + 1], h, w0 + 1, k, a1x, a1y, a1z);
+      fm_vertex(tile[lh0][lane + 1], h0, w, k, b0x, b0y, b0z);
+      fm_vertex(tile[lh0 + 1][lane + 1], h0 + 1, w, k, b1x, b1y, b1z);
+      const float dhx = a1x - a0x, dhy = a1y - a0y, dhz = a1z - a0z;
+      const float dvx = b1x - b0x, dvy = b1y - b0y, dvz = b1z - b0z;
+      // torch.cross: fma(a1, b2, -(a2*b1))
+      const float nx = gs_fma(dhy, dvz, -(dhz * dvy));
+      const float ny = gs_fma(dhz, dvx, -(dhx * dvz));
+      const float nz = gs_fma(dhx, dvy, -(dhy * dvx));
+      const float nrm = gs_norm3(nx, ny, nz);
+      const float den = (nrm == 0.0f) ? 1.0f : nrm;
+      const float validf = d > 0.0f ? 1.0f : 0.0f;
+      normal[3 * p] = (nx / den) * validf;
+      normal[3 * p + 1] = (ny / den) * validf;
+      normal[3 * p + 2] = (nz / den) * validf;
+    }
+  }
+}
+
+extern "C" int gs_frame_maps_f32(const float* depth, const float* K16, int H, int W,
+                                 float two_sigma_sq, float* vertex, float* normal, float* alpha,
+                                 uint8_t* valid, void* stream) {
+  GS_REQUIRE(depth && K16, "depth and K16 must not be NULL");
+  GS_REQUIRE(H >= 2 && W >= 2, "image must be at least 2x2");
+  dim3 grid((unsigned)gs_ceil_div(W, FM_TW), (unsigned)gs_ceil_div(H, FM_TH));
+  hipLaunchKernelGGL(gs_frame_maps_kernel, grid, dim3(256), 0, gs_stream(stream), depth, K16, H, W,
+                     two_sigma_sq, vertex, normal, alpha, valid);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// local -> global: R v + t re-masked (rgbdimages.py:700-708), R n (rgbdimages.py:760-762)
+__global__ void __launch_bounds__(256) gs_global_maps_kernel(
+    const float* __restrict__ vertex, const float* __restrict__ normal,
+    const float* __restrict__ depth, const float* __restrict__ pose16, int64_t P,
+    float* __restrict__ gvertex, float* __restrict__ gnormal) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  float T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = pose16[i];
+  if (gvertex) {
+    const float v0 = vertex[3 * p], v1 = vertex[3 * p + 1], v2 = vertex[3 * p + 2];
+    const float validf = depth[p] > 0.0f ? 1.0f : 0.0f;
+    float g0, g1, g2;
+    gs_rigid_fma(T, v0, v1, v2, g0, g1, g2);
+    gvertex[3 * p] = g0 * validf;
+    gvertex[3 * p + 1] = g1 * validf;
+    gvertex[3 * p + 2] = g2 * validf;
+  }
+  if (gnormal) {
+    const float n0 = normal[3 * p], n1 = normal[3 * p + 1], n2 = normal[3 * p + 2];
+    gnormal[3 * p] = gs_dot3_fma(T[0], T[1], T[2], n0, n1, n2);
+    gnormal[3 * p + 1] = gs_dot3_fma(T[4], T[5], T[6], n0, n1, n2);
+    gnormal[3 * p + 2] = gs_dot3_fma(T[8], T[9], T[10], n0, n1, n2);
+  }
+}
+
+extern "C" int gs_global_maps_f32(const float* vertex, const float* normal, const float* depth,
+                                  const float* pose16, int H, int W, float* gvertex,
+                                  float* gnormal, void* stream) {
+  GS_REQUIRE(H > 0 && W > 0, "empty image");
+  GS_REQUIRE(!gvertex || (vertex && depth), "gvertex needs vertex and depth");
+  GS_REQUIRE(!gnormal || normal, "gnormal needs normal");
+  const int64_t P = (int64_t)H * W;
+  hipStream_t st = gs_stream(stream);
+  if (!pose16) {  // rgbdimages.py:683-685 / :747-749: no poses -> plain copy
+    if (gvertex) GS_HIP(hipMemcpyAsync(gvertex, vertex, P * 12, hipMemcpyDeviceToDevice, st));
+    if (gnormal) GS_HIP(hipMemcpyAsync(gnormal, normal, P * 12, hipMemcpyDeviceToDevice, st));
+    return GS_OK;
+  }
+  hipLaunchKernelGGL(gs_global_maps_kernel, dim3((unsigned)gs_ceil_div(P, 256)), dim3(256), 0, st,
+                     vertex, normal, depth, pose16, P, gvertex, gnormal);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+__global__ void __launch_bounds__(256) gs_alpha_kernel(const float* __restrict__ pts, int64_t n,
+                                                       float two_sigma_sq, float eps,
+                                                       float* __restrict__ alpha) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  alpha[i] = gs_alpha_of(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], two_sigma_sq, eps);
+}
+
+extern "C" int gs_alpha_f32(const float* points, int64_t n, float two_sigma_sq, float eps,
+                            float* alpha, void* stream) {
+  GS_REQUIRE(n >= 0, "negative n");
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(points && alpha, "NULL pointer");
+  hipLaunchKernelGGL(gs_alpha_kernel, dim3((unsigned)gs_ceil_div(n, 256)), dim3(256), 0,
+                     gs_stream(stream), points, n, two_sigma_sq, eps, alpha);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}

@@ -1,0 +1,316 @@
+"""Tensor-level wrappers of the C-ABI (one sequence per call).  Each function validates
+devices, allocates outputs with torch, and enqueues the HIP kernels on torch's current stream.
+Nothing here computes with torch: arithmetic happens in libgradslam_hip.so or not at all."""
+import torch
+
+from . import _C
+from ._C import Workspace, check, lib, ptr, require_device, stream
+
+f32 = torch.float32
+
+
+def two_sigma_sq(sigma):
+    if torch.is_tensor(sigma):
+        sigma = float(sigma)
+    return float(torch.tensor(2 * (float(sigma) ** 2), dtype=torch.float64).to(torch.float32))
+
+
+def _c(t, dtype=f32):
+    if t is None:
+        return None
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _count(t):
+    """Reads a device int64 counter back (one host sync)."""
+    return int(t.item())
+
+
+# ----------------------------------------------------------------------------------- K1
+def frame_maps(depth, K, sigma=0.6, want_normal=True, want_alpha=True, want_valid=True):
+    """depth (H,W) f32, K (4,4) f32 -> vertex (H,W,3), normal (H,W,3), alpha (H,W), valid (H,W) bool."""
+    depth, K = _c(depth), _c(K)
+    dev = require_device(depth, K)
+    H, W = depth.shape
+    vertex = torch.empty((H, W, 3), dtype=f32, device=dev)
+    normal = torch.empty((H, W, 3), dtype=f32, device=dev) if want_normal else None
+    alpha = torch.empty((H, W), dtype=f32, device=dev) if want_alpha else None
+    valid = torch.empty((H, W), dtype=torch.uint8, device=dev) if want_valid else None
+    check(lib().gs_frame_maps_f32(ptr(depth), ptr(K), H, W, two_sigma_sq(sigma), ptr(vertex), ptr(normal),
+                                  ptr(alpha), ptr(valid), stream(dev)), "gs_frame_maps_f32")
+    return vertex, normal, alpha, (valid.view(torch.bool) if valid is not None else None)
+
+
+def global_maps(vertex, normal, depth, pose):
+    vertex, normal, depth, pose = _c(vertex), _c(normal), _c(depth), _c(pose)
+    dev = require_device(vertex, normal, depth, pose)
+    H, W = depth.shape[:2]
+    gv = torch.empty_like(vertex)
+    gn = torch.empty_like(normal) if normal is not None else None
+    check(lib().gs_global_maps_f32(ptr(vertex), ptr(normal), ptr(depth), ptr(pose), H, W, ptr(gv), ptr(gn),
+                                   stream(dev)), "gs_global_maps_f32")
+    return gv, gn
+
+
+def alpha_of_points(points, sigma, eps=1e-7):
+    points = _c(points)
+    dev = require_device(points)
+    out = torch.empty(points.shape[:-1], dtype=f32, device=dev)
+    check(lib().gs_alpha_f32(ptr(points), out.numel(), two_sigma_sq(sigma), float(eps), ptr(out), stream(dev)),
+          "gs_alpha_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------------- K2
+def downsample_frame(gvertex, gnormal, rgb, depth, ds):
+    gvertex, gnormal, rgb, depth = _c(gvertex), _c(gnormal), _c(rgb), _c(depth)
+    dev = require_device(gvertex, gnormal, rgb, depth)
+    H, W = depth.shape[:2]
+    cap = ((H + ds - 1) // ds) * ((W + ds - 1) // ds)
+    pts = torch.empty((cap, 3), dtype=f32, device=dev)
+    nrm = torch.empty((cap, 3), dtype=f32, device=dev) if gnormal is not None else None
+    col = torch.empty((cap, 3), dtype=f32, device=dev) if rgb is not None else None
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = Workspace.get(dev)
+    check(lib().gs_downsample_frame_f32(ptr(gvertex), ptr(gnormal), ptr(rgb), ptr(depth), H, W, ds, ptr(pts),
+                                        ptr(nrm), ptr(col), ptr(cnt), ptr(ws.scratch(0, H * W)), stream(dev)),
+          "gs_downsample_frame_f32")
+    c = _count(cnt)
+    return pts[:c], (nrm[:c] if nrm is not None else None), (col[:c] if col is not None else None)
+
+
+def project_map(points, pose, K, H, W):
+    points, pose, K = _c(points), _c(pose), _c(K)
+    dev = require_device(points, pose, K)
+    n = points.shape[0]
+    pix = torch.empty(n, dtype=torch.int32, device=dev)
+    check(lib().gs_project_map_f32(ptr(points), n, ptr(pose), ptr(K), H, W, ptr(pix), stream(dev)),
+          "gs_project_map_f32")
+    return pix
+
+
+def active_table(pix, W, b=0):
+    dev = require_device(pix)
+    n = pix.shape[0]
+    rows = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = Workspace.get(dev)
+    check(lib().gs_active_table_i64(ptr(pix), n, W, b, ptr(rows), ptr(cnt), ptr(ws.scratch(n, 0)), stream(dev)),
+          "gs_active_table_i64")
+    return rows[: _count(cnt)]
+
+
+def select_targets(pix, W, ds, points, normals, colors=None, cap=None):
+    points, normals, colors = _c(points), _c(normals), _c(colors)
+    dev = require_device(pix, points, normals, colors)
+    n = pix.shape[0]
+    cap = n if cap is None else int(cap)
+    op = torch.empty((cap, 3), dtype=f32, device=dev)
+    on = torch.empty((cap, 3), dtype=f32, device=dev) if normals is not None else None
+    oc = torch.empty((cap, 3), dtype=f32, device=dev) if colors is not None else None
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = Workspace.get(dev)
+    check(lib().gs_select_targets_f32(ptr(pix), n, W, ds, ptr(points), ptr(normals), ptr(colors), ptr(op), ptr(on),
+                                      ptr(oc), cap, ptr(cnt), ptr(ws.scratch(n, 0)), stream(dev)),
+          "gs_select_targets_f32")
+    c = _count(cnt)
+    if c > cap:
+        raise _C.HipExtensionError("gs_select_targets_f32: %d targets exceed capacity %d" % (c, cap))
+    return op[:c], (on[:c] if on is not None else None), (oc[:c] if oc is not None else None)
+
+
+def downsample_table(rows, ds, points, normals=None, colors=None):
+    rows = _c(rows, torch.int64)
+    points, normals, colors = _c(points), _c(normals), _c(colors)
+    dev = require_device(rows, points, normals, colors)
+    r = rows.shape[0]
+    op = torch.empty((r, 3), dtype=f32, device=dev)
+    on = torch.empty((r, 3), dtype=f32, device=dev) if normals is not None else None
+    oc = torch.empty((r, 3), dtype=f32, device=dev) if colors is not None else None
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = Workspace.get(dev)
+    check(lib().gs_downsample_table_f32(ptr(rows), r, ds, ptr(points), ptr(normals), ptr(colors), ptr(op), ptr(on),
+                                        ptr(oc), ptr(cnt), ptr(ws.scratch(r, 0)), stream(dev)),
+          "gs_downsample_table_f32")
+    c = _count(cnt)
+    return op[:c], (on[:c] if on is not None else None), (oc[:c] if oc is not None else None)
+
+
+# ----------------------------------------------------------------------------------- K3 / K4
+def knn1(src, tgt):
+    src, tgt = _c(src), _c(tgt)
+    dev = require_device(src, tgt)
+    ns = src.shape[0]
+    idx = torch.empty(ns, dtype=torch.int64, device=dev)
+    d2 = torch.empty(ns, dtype=f32, device=dev)
+    best = torch.empty(ns, dtype=torch.int64, device=dev)
+    check(lib().gs_knn1_f32(ptr(src), ns, ptr(tgt), tgt.shape[0], ptr(idx), ptr(d2), ptr(best), stream(dev)),
+          "gs_knn1_f32")
+    return idx, d2
+
+
+def gauss_newton_rows(src, tgt, tgt_normals, dist_thresh=None):
+    src, tgt, tn = _c(src), _c(tgt), _c(tgt_normals)
+    dev = require_device(src, tgt, tn)
+    ns = src.shape[0]
+    A = torch.empty((ns, 6), dtype=f32, device=dev)
+    b = torch.empty(ns, dtype=f32, device=dev)
+    idx = torch.empty(ns, dtype=torch.int64, device=dev)
+    keep = torch.empty(ns, dtype=torch.uint8, device=dev)
+    best = torch.empty(ns, dtype=torch.int64, device=dev)
+    check(lib().gs_gauss_newton_rows_f32(ptr(src), ns, ptr(tgt), ptr(tn), tgt.shape[0],
+                                         -1.0 if dist_thresh is None else float(dist_thresh), ptr(A), ptr(b),
+                                         ptr(idx), ptr(keep), ptr(best), stream(dev)), "gs_gauss_newton_rows_f32")
+    return A, b, idx, keep.view(torch.bool)
+
+
+def solve_normal_eq(A, b, damp=1e-8, keep=None):
+    A, b = _c(A), _c(b).reshape(-1)
+    keep = None if keep is None else _c(keep.view(torch.uint8) if keep.dtype == torch.bool else keep, torch.uint8)
+    dev = require_device(A, b, keep)
+    x = torch.empty(A.shape[1], dtype=f32, device=dev)
+    check(lib().gs_solve_normal_eq_f32(ptr(A), ptr(b), ptr(keep), A.shape[0], A.shape[1], float(damp), ptr(x),
+                                       stream(dev)), "gs_solve_normal_eq_f32")
+    return x
+
+
+def se3_exp(xi):
+    xi = _c(xi).reshape(6)
+    dev = require_device(xi)
+    T = torch.empty((4, 4), dtype=f32, device=dev)
+    check(lib().gs_se3_exp_f32(ptr(xi), ptr(T), stream(dev)), "gs_se3_exp_f32")
+    return T
+
+
+def transform_points(pts, T):
+    pts, T = _c(pts), _c(T)
+    dev = require_device(pts, T)
+    out = torch.empty_like(pts)
+    check(lib().gs_transform_points_f32(ptr(pts), pts.shape[0], ptr(T), ptr(out), stream(dev)),
+          "gs_transform_points_f32")
+    return out
+
+
+def icp(src, tgt, tgt_normals, init=None, compose=None, mode=1, numiters=20, damp=1e-8, dist_thresh=None,
+        lambda_max=2.0, B=1.0, B2=1.0, nu=200.0, return_idx=True, return_trace=False):
+    """Whole (grad)LM point-to-plane ICP on the device; returns T (4,4) [, idx (Ns,)] [, trace]."""
+    src, tgt, tn = _c(src), _c(tgt), _c(tgt_normals)
+    dev = require_device(src, tgt, tn)
+    init = torch.eye(4, dtype=f32, device=dev) if init is None else _c(init)
+    compose = _c(compose)
+    require_device(init, compose)
+    ns, nt = src.shape[0], tgt.shape[0]
+    prm = _C.IcpParams(int(mode), int(numiters), float(damp), -1.0 if dist_thresh is None else float(dist_thresh),
+                       float(lambda_max), float(B), float(B2), float(nu))
+    T = torch.empty((4, 4), dtype=f32, device=dev)
+    idx = torch.empty(ns, dtype=torch.int64, device=dev) if return_idx else None
+    ws = Workspace.get(dev)
+    scratch = ws.bytes("icp", lib().gs_icp_scratch_bytes(ns, nt))
+    check(lib().gs_icp_f32(ptr(src), ns, ptr(tgt), ptr(tn), nt, ptr(init), ptr(compose), prm, ptr(T), ptr(idx),
+                           ptr(scratch), stream(dev)), "gs_icp_f32")
+    out = [T]
+    if return_idx:
+        out.append(idx)
+    if return_trace:
+        tr = torch.empty((numiters, 12), dtype=f32, device=dev)
+        check(lib().gs_icp_trace_f32(ptr(scratch), numiters, ptr(tr), stream(dev)), "gs_icp_trace_f32")
+        out.append(tr)
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+# ----------------------------------------------------------------------------------- K5
+def similar_rows(rows, points, normals, gvertex, gnormal, dist_th, dot_th):
+    rows = _c(rows, torch.int64)
+    points, normals, gvertex, gnormal = _c(points), _c(normals), _c(gvertex), _c(gnormal)
+    dev = require_device(rows, points, normals, gvertex, gnormal)
+    W = gvertex.shape[1]
+    mask = torch.empty(rows.shape[0], dtype=torch.uint8, device=dev)
+    check(lib().gs_similar_rows_f32(ptr(rows), rows.shape[0], ptr(points), ptr(normals), ptr(gvertex), ptr(gnormal),
+                                    W, float(dist_th), float(dot_th), ptr(mask), stream(dev)), "gs_similar_rows_f32")
+    return mask.view(torch.bool)
+
+
+def best_unique_rows(rows, points, ccounts, gvertex, b=0):
+    rows = _c(rows, torch.int64)
+    points, ccounts, gvertex = _c(points), _c(ccounts), _c(gvertex)
+    dev = require_device(rows, points, ccounts, gvertex)
+    H, W = gvertex.shape[:2]
+    r = rows.shape[0]
+    best = torch.empty(H * W, dtype=torch.int32, device=dev)
+    out = torch.empty((H * W, 4), dtype=torch.int64, device=dev)
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = Workspace.get(dev)
+    check(lib().gs_best_unique_rows_f32(ptr(rows), r, ptr(points), ptr(ccounts), ptr(gvertex), H, W, b, ptr(best),
+                                        ptr(out), ptr(cnt), ptr(ws.scratch(r, H * W)), stream(dev)),
+          "gs_best_unique_rows_f32")
+    return out[: _count(cnt)], best
+
+
+def associate(pix, points, normals, ccounts, gvertex, gnormal, dist_th, dot_th, want_similar=False):
+    points, normals, ccounts, gvertex, gnormal = _c(points), _c(normals), _c(ccounts), _c(gvertex), _c(gnormal)
+    dev = require_device(pix, points, normals, ccounts, gvertex, gnormal)
+    H, W = gvertex.shape[:2]
+    n = pix.shape[0]
+    best = torch.empty(H * W, dtype=torch.int32, device=dev)
+    sim = torch.empty(n, dtype=torch.uint8, device=dev) if want_similar else None
+    ws = Workspace.get(dev)
+    check(lib().gs_associate_f32(ptr(pix), n, ptr(points), ptr(normals), ptr(ccounts), ptr(gvertex), ptr(gnormal),
+                                 H, W, float(dist_th), float(dot_th), ptr(best), ptr(sim),
+                                 ptr(ws.scratch(n, H * W)), stream(dev)), "gs_associate_f32")
+    return (best, sim.view(torch.bool)) if want_similar else best
+
+
+def best_table(best_pix, H, W, b=0):
+    dev = require_device(best_pix)
+    out = torch.empty((H * W, 4), dtype=torch.int64, device=dev)
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = Workspace.get(dev)
+    check(lib().gs_best_table_i64(ptr(best_pix), H, W, b, ptr(out), ptr(cnt), ptr(ws.scratch(0, H * W)),
+                                  stream(dev)), "gs_best_table_i64")
+    return out[: _count(cnt)]
+
+
+def rows_to_best_pix(rows, H, W):
+    rows = _c(rows, torch.int64)
+    dev = require_device(rows)
+    best = torch.empty(H * W, dtype=torch.int32, device=dev)
+    check(lib().gs_rows_to_best_pix(ptr(rows), rows.shape[0], H, W, ptr(best), stream(dev)), "gs_rows_to_best_pix")
+    return best
+
+
+# ----------------------------------------------------------------------------------- K6
+def fuse_append_(points, normals, colors, ccounts, n_map, best_pix, gvertex, gnormal, rgb, alpha, depth,
+                 renorm_all=True):
+    """In-place on capacity-backed buffers (rows >= n_map are free space).  Returns the new count."""
+    gvertex, gnormal, rgb, alpha, depth = _c(gvertex), _c(gnormal), _c(rgb), _c(alpha), _c(depth)
+    dev = require_device(points, normals, colors, ccounts, best_pix, gvertex, gnormal, rgb, alpha, depth)
+    H, W = depth.shape[:2]
+    cap = points.shape[0]
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = Workspace.get(dev)
+    check(lib().gs_fuse_append_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map), cap,
+                                   ptr(best_pix), ptr(gvertex), ptr(gnormal), ptr(rgb), ptr(alpha), ptr(depth), H, W,
+                                   1 if renorm_all else 0, ptr(cnt), ptr(ws.scratch(n_map, H * W)), stream(dev)),
+          "gs_fuse_append_f32")
+    c = _count(cnt)
+    if c > cap:
+        raise _C.HipExtensionError("gs_fuse_append_f32: surfel store overflow (%d > %d)" % (c, cap))
+    return c
+
+
+def append_valid_(points, normals, colors, ccounts, n_map, gvertex, gnormal, rgb, alpha, depth):
+    gvertex, gnormal, rgb, alpha, depth = _c(gvertex), _c(gnormal), _c(rgb), _c(alpha), _c(depth)
+    dev = require_device(points, normals, colors, ccounts, gvertex, gnormal, rgb, alpha, depth)
+    H, W = depth.shape[:2]
+    cap = points.shape[0]
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = Workspace.get(dev)
+    check(lib().gs_append_valid_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map), cap,
+                                    ptr(gvertex), ptr(gnormal), ptr(rgb), ptr(alpha), ptr(depth), H, W, ptr(cnt),
+                                    ptr(ws.scratch(n_map, H * W)), stream(dev)), "gs_append_valid_f32")
+    c = _count(cnt)
+    if c > cap:
+        raise _C.HipExtensionError("gs_append_valid_f32: surfel store overflow (%d > %d)" % (c, cap))
+    return c

@@ -32,18 +32,21 @@
 extern "C" {
 #endif
 
+/* exported from libgradslam_hip.so (the library is built with -fvisibility=hidden) */
+#define GS_API __attribute__((visibility("default")))
+
 #define GS_OK 0
 #define GS_ERR_INVALID 1 /* bad argument (null pointer, non-positive size, ...) */
 #define GS_ERR_HIP 2     /* a HIP runtime call failed; see gs_last_error() */
 #define GS_ERR_CAPACITY 3 /* an output would exceed the caller-provided capacity */
 
 /* ABI version; bumped on any signature change. */
-int gs_abi_version(void);
+GS_API int gs_abi_version(void);
 /* Message of the last non-OK return on this thread (never NULL). */
-const char* gs_last_error(void);
+GS_API const char* gs_last_error(void);
 /* Bytes of device scratch the functions below need for a map of `n_map` points and an
  * image of `n_pix` pixels (caller allocates once, reuses every frame). */
-int64_t gs_scratch_bytes(int64_t n_map, int64_t n_pix);
+GS_API int64_t gs_scratch_bytes(int64_t n_map, int64_t n_pix);
 
 /* ---------------------------------------------------------------- K1: frame maps ------
  * depth -> local vertex map, local normal map, confidence alpha, validity mask.
@@ -53,19 +56,19 @@ int64_t gs_scratch_bytes(int64_t n_map, int64_t n_pix);
  * RGBDImages.valid_depth_mask (:320-332) and get_alpha as called by fuse_with_map
  * (slam/fusionutils.py:69-72, :657).  Any of vertex/normal/alpha/valid may be NULL.
  * two_sigma_sq = (float)(2*sigma*sigma) evaluated in double by the caller. */
-int gs_frame_maps_f32(const float* depth, const float* K16, int H, int W, float two_sigma_sq,
+GS_API int gs_frame_maps_f32(const float* depth, const float* K16, int H, int W, float two_sigma_sq,
                       float* vertex, float* normal, float* alpha, uint8_t* valid, void* stream);
 
 /* local maps + pose -> global vertex / normal maps.
  * Replaces RGBDImages._compute_global_vertex_map (structures/rgbdimages.py:681-708) and
  * _compute_global_normal_map (:745-762).  gnormal may be NULL.  pose16 == NULL means the
  * reference's "no poses" branch (plain copy). */
-int gs_global_maps_f32(const float* vertex, const float* normal, const float* depth,
+GS_API int gs_global_maps_f32(const float* vertex, const float* normal, const float* depth,
                        const float* pose16, int H, int W, float* gvertex, float* gnormal,
                        void* stream);
 
 /* get_alpha on an arbitrary (n,3) point array (slam/fusionutils.py:16-73). */
-int gs_alpha_f32(const float* points, int64_t n, float two_sigma_sq, float eps, float* alpha,
+GS_API int gs_alpha_f32(const float* points, int64_t n, float two_sigma_sq, float eps, float* alpha,
                  void* stream);
 
 /* ------------------------------------------------------- K2: ICP source / target sets --
@@ -73,7 +76,7 @@ int gs_alpha_f32(const float* points, int64_t n, float two_sigma_sq, float eps, 
  * Replaces downsample_rgbdimages (odometry/icputils.py:623-669).  out_* have room for
  * ceil(H/ds)*ceil(W/ds) rows; out_nrm/out_rgb (and gnormal/rgb) may be NULL.
  * count_out: device int64[1]. */
-int gs_downsample_frame_f32(const float* gvertex, const float* gnormal, const float* rgb,
+GS_API int gs_downsample_frame_f32(const float* gvertex, const float* gnormal, const float* rgb,
                             const float* depth, int H, int W, int ds, float* out_pts,
                             float* out_nrm, float* out_rgb, int64_t* count_out, void* scratch,
                             void* stream);
@@ -83,26 +86,27 @@ int gs_downsample_frame_f32(const float* gvertex, const float* gnormal, const fl
  * (slam/fusionutils.py:249-274): inverse_transformation, Pointclouds.transform
  * (structures/pointclouds.py:466-573), pinhole_projection_ (:575-614, geometry/projutils.py
  * :225-238), the in-frame test and round/clamp.  pose16 is camera-to-world. */
-int gs_project_map_f32(const float* points, int64_t n_map, const float* pose16,
+GS_API int gs_project_map_f32(const float* points, int64_t n_map, const float* pose16,
                        const float* K16, int H, int W, int32_t* pix, void* stream);
 
 /* pix[] -> ordered table rows [b, n, h, w] (find_active_map_points' return value,
  * slam/fusionutils.py:276-282).  rows_out has room for n_map rows; count_out device int64. */
-int gs_active_table_i64(const int32_t* pix, int64_t n_map, int W, int64_t b, int64_t* rows_out,
+GS_API int gs_active_table_i64(const int32_t* pix, int64_t n_map, int W, int64_t b, int64_t* rows_out,
                         int64_t* count_out, void* scratch, void* stream);
 
 /* Active map points whose pixel lies on the [::ds, ::ds] lattice, in map order, gathered.
  * Replaces downsample_pointclouds (odometry/icputils.py:596-620) fed by
- * find_active_map_points.  out_* have room for `cap` rows (GS_ERR_CAPACITY is reported
- * through count_out[1] != 0, the kernel never writes past cap). normals/colors optional. */
-int gs_select_targets_f32(const int32_t* pix, int64_t n_map, int W, int ds, const float* points,
+ * find_active_map_points.  out_* have room for `cap` rows: the kernels never write past cap, count_out[0]
+ * always receives the TRUE number of selected points (the caller compares it with cap).
+ * normals/colors optional. */
+GS_API int gs_select_targets_f32(const int32_t* pix, int64_t n_map, int W, int ds, const float* points,
                           const float* normals, const float* colors, float* out_pts,
                           float* out_nrm, float* out_rgb, int64_t cap, int64_t* count_out,
                           void* scratch, void* stream);
 
 /* downsample_pointclouds on an explicit table (rows of one sequence): keeps rows with
  * h % ds == 0 and w % ds == 0, gathers map attributes by n.  (odometry/icputils.py:596-620) */
-int gs_downsample_table_f32(const int64_t* rows, int64_t n_rows, int ds, const float* points,
+GS_API int gs_downsample_table_f32(const int64_t* rows, int64_t n_rows, int ds, const float* points,
                             const float* normals, const float* colors, float* out_pts,
                             float* out_nrm, float* out_rgb, int64_t* count_out, void* scratch,
                             void* stream);
@@ -112,28 +116,29 @@ int gs_downsample_table_f32(const int64_t* rows, int64_t n_rows, int ds, const f
  * ties) and that squared distance.  Replaces chamferdist.chamfer.knn_points as called at
  * odometry/icputils.py:200 (third-party, chamferdist==1.0.0, requirements.txt:2).
  * best_scratch: device uint64[n_src].  out_idx int64[n_src], out_d2 float[n_src] (may be NULL). */
-int gs_knn1_f32(const float* src, int64_t n_src, const float* tgt, int64_t n_tgt,
+GS_API int gs_knn1_f32(const float* src, int64_t n_src, const float* tgt, int64_t n_tgt,
                 int64_t* out_idx, float* out_d2, uint64_t* best_scratch, void* stream);
 
 /* --------------------------------------------------------- K4: Gauss-Newton system -----
  * gauss_newton_solve (odometry/icputils.py:93-232): KNN + rows A_i = [n, s x n],
  * b_i = n.(d - s).  A (n_src,6) and b (n_src) are written densely for ALL src rows plus a
  * keep mask (dist filter, :203-208); idx int64[n_src].  dist_thresh < 0 means None. */
-int gs_gauss_newton_rows_f32(const float* src, int64_t n_src, const float* tgt,
+GS_API int gs_gauss_newton_rows_f32(const float* src, int64_t n_src, const float* tgt,
                              const float* tgt_normals, int64_t n_tgt, float dist_thresh,
                              float* A, float* b, int64_t* idx, uint8_t* keep,
                              uint64_t* best_scratch, void* stream);
 
-/* solve_linear_system (odometry/icputils.py:22-90): x = (A^T A + damp I)^-1 A^T b.
- * keep may be NULL.  x: device float[6]. */
-int gs_solve_normal_eq_f32(const float* A, const float* b, const uint8_t* keep, int64_t n_rows,
-                           float damp, float* x6, void* scratch, void* stream);
+/* solve_linear_system (odometry/icputils.py:22-90): x = (A^T A + damp I)^-1 A^T b for
+ * A (n_rows, ncols), 1 <= ncols <= 8 (the SLAM path uses 6).  keep may be NULL.
+ * x: device float[ncols]. */
+GS_API int gs_solve_normal_eq_f32(const float* A, const float* b, const uint8_t* keep, int64_t n_rows,
+                           int ncols, float damp, float* x, void* stream);
 
 /* se3_exp (geometry/se3utils.py:77-115): xi(6) -> T(4x4). */
-int gs_se3_exp_f32(const float* xi6, float* T16, void* stream);
+GS_API int gs_se3_exp_f32(const float* xi6, float* T16, void* stream);
 
 /* transform_pointcloud (geometry/geometryutils.py:737-794): out = R p + t. */
-int gs_transform_points_f32(const float* pts, int64_t n, const float* T16, float* out,
+GS_API int gs_transform_points_f32(const float* pts, int64_t n, const float* T16, float* out,
                             void* stream);
 
 /* Whole LM loop on the device, no host sync.
@@ -155,27 +160,27 @@ typedef struct gs_icp_params {
   float nu;          /* gradICP, default 200.0 */
 } gs_icp_params;
 
-int64_t gs_icp_scratch_bytes(int64_t n_src, int64_t n_tgt);
-int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, const float* tgt_normals,
+GS_API int64_t gs_icp_scratch_bytes(int64_t n_src, int64_t n_tgt);
+GS_API int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, const float* tgt_normals,
                int64_t n_tgt, const float* init16, const float* compose16,
                const gs_icp_params* params_host, float* out_T16, int64_t* out_idx,
                void* icp_scratch, void* stream);
 
 /* Per-iteration record kept in icp_scratch for the backward pass / diagnostics:
  * gs_icp_trace_f32 copies (numiters, 12) floats = [err, new_err, damp_after, sigmoid, xi(6), pad(2)]. */
-int gs_icp_trace_f32(const void* icp_scratch, int numiters, float* trace_out, void* stream);
+GS_API int gs_icp_trace_f32(const void* icp_scratch, int numiters, float* trace_out, void* stream);
 
 /* ------------------------------------------------- K5: surfel association (PointFusion) -
  * find_similar_map_points on an explicit table (slam/fusionutils.py:381-401):
  * mask[r] = |f - p| < dist_th  &&  f_n . p_n > dot_th  for row r = [b, n, h, w]. */
-int gs_similar_rows_f32(const int64_t* rows, int64_t n_rows, const float* points,
+GS_API int gs_similar_rows_f32(const int64_t* rows, int64_t n_rows, const float* points,
                         const float* normals, const float* gvertex, const float* gnormal, int W,
                         float dist_th, float dot_th, uint8_t* mask, void* stream);
 
 /* find_best_unique_correspondences on an explicit table (slam/fusionutils.py:489-544):
  * per pixel the row minimising (1/(ccount+1e-20), |p-f|^2, n); output rows sorted by (h, w)
  * as [b, n, h, w].  best_pix: device int32[H*W] work array (also returned: winner n or -1). */
-int gs_best_unique_rows_f32(const int64_t* rows, int64_t n_rows, const float* points,
+GS_API int gs_best_unique_rows_f32(const int64_t* rows, int64_t n_rows, const float* points,
                             const float* ccounts, const float* gvertex, int H, int W, int64_t b,
                             int32_t* best_pix, int64_t* rows_out, int64_t* count_out,
                             void* scratch, void* stream);
@@ -183,16 +188,16 @@ int gs_best_unique_rows_f32(const int64_t* rows, int64_t n_rows, const float* po
 /* Fused find_correspondences (slam/fusionutils.py:549-577) without tables:
  * pix[] (from gs_project_map_f32) + map + frame -> best_pix[H*W] = winning map index or -1.
  * similar (may be NULL): uint8[n_map] = is_similar_mask scattered by map index. */
-int gs_associate_f32(const int32_t* pix, int64_t n_map, const float* points,
+GS_API int gs_associate_f32(const int32_t* pix, int64_t n_map, const float* points,
                      const float* normals, const float* ccounts, const float* gvertex,
                      const float* gnormal, int H, int W, float dist_th, float dot_th,
                      int32_t* best_pix, uint8_t* similar, void* scratch, void* stream);
 
 /* best_pix[] -> ordered table rows [b, n, h, w] sorted by (h, w). */
-int gs_best_table_i64(const int32_t* best_pix, int H, int W, int64_t b, int64_t* rows_out,
+GS_API int gs_best_table_i64(const int32_t* best_pix, int H, int W, int64_t b, int64_t* rows_out,
                       int64_t* count_out, void* scratch, void* stream);
 /* table rows -> best_pix[] (for fuse_with_map called with an explicit table). */
-int gs_rows_to_best_pix(const int64_t* rows, int64_t n_rows, int H, int W, int32_t* best_pix,
+GS_API int gs_rows_to_best_pix(const int64_t* rows, int64_t n_rows, int H, int W, int32_t* best_pix,
                         void* stream);
 
 /* ------------------------------------------------------ K6: merge + append (PointFusion) -
@@ -204,7 +209,7 @@ int gs_rows_to_best_pix(const int64_t* rows, int64_t n_rows, int H, int W, int32
  *   unmatched valid pixels are appended in raster order at rows n_map .. n_map+n_new-1.
  * The arrays must have room for n_map + H*W rows.  n_map_host is the current size;
  * new_count_out: device int64[1] receives n_map + n_new. */
-int gs_fuse_append_f32(float* points, float* normals, float* colors, float* ccounts,
+GS_API int gs_fuse_append_f32(float* points, float* normals, float* colors, float* ccounts,
                        int64_t n_map_host, int64_t capacity, const int32_t* best_pix,
                        const float* gvertex, const float* gnormal, const float* rgb,
                        const float* alpha, const float* depth, int H, int W, int renorm_all,
@@ -213,7 +218,7 @@ int gs_fuse_append_f32(float* points, float* normals, float* colors, float* ccou
 /* update_map_aggregate (slam/fusionutils.py:725-758) / pointclouds_from_rgbdimages
  * (structures/utils.py:7-57): append every valid pixel, raster order.  normals / colors /
  * ccounts (with gnormal / rgb / alpha) may be NULL. */
-int gs_append_valid_f32(float* points, float* normals, float* colors, float* ccounts,
+GS_API int gs_append_valid_f32(float* points, float* normals, float* colors, float* ccounts,
                         int64_t n_map_host, int64_t capacity, const float* gvertex,
                         const float* gnormal, const float* rgb, const float* alpha,
                         const float* depth, int H, int W, int64_t* new_count_out, void* scratch,

@@ -446,11 +446,54 @@ static void normal_eq_f64(const float* A, const float* b, const uint8_t* keep, i
   if (err) *err = (float)e;
 }
 
+/* general ncols <= 8 (the reference's own KAT uses 4 columns, tests/odometry/test_icputils.py:18-49) */
+static void inv_n_f64(const double* M, double* Minv, int n) {
+  double a[8][16];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) { a[i][j] = M[n * i + j]; a[i][n + j] = (i == j) ? 1.0 : 0.0; }
+  for (int c = 0; c < n; ++c) {
+    int piv = c; double best = fabs(a[c][c]);
+    for (int r = c + 1; r < n; ++r) if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
+    if (piv != c) for (int j = 0; j < 2 * n; ++j) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+    double inv = 1.0 / a[c][c];
+    for (int j = 0; j < 2 * n; ++j) a[c][j] *= inv;
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      double f = a[r][c];
+      for (int j = 0; j < 2 * n; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Minv[n * i + j] = a[i][n + j];
+}
+
 EXPORT void gs_or_solve_normal_eq(const float* A, const float* b, const uint8_t* keep,
-                                  int64_t n_rows, float damp, float* x6) {
-  float AtA[36], Atb[6];
-  normal_eq_f64(A, b, keep, n_rows, AtA, Atb, NULL);
-  solve_from_normal_eq(AtA, Atb, damp, x6);
+                                  int64_t n_rows, int ncols, float damp, float* x) {
+  double S[64] = {0}, v[8] = {0}, M[64], Mi[64];
+  float AtA[64], Atb[8];
+  for (int64_t i = 0; i < n_rows; ++i) {
+    if (keep && !keep[i]) continue;
+    const float* a = A + ncols * i;
+    for (int r = 0; r < ncols; ++r) {
+      for (int c = r; c < ncols; ++c) S[ncols * r + c] += (double)a[r] * (double)a[c];
+      v[r] += (double)a[r] * (double)b[i];
+    }
+  }
+  for (int r = 0; r < ncols; ++r) {
+    for (int c = r; c < ncols; ++c) AtA[ncols * r + c] = AtA[ncols * c + r] = (float)S[ncols * r + c];
+    Atb[r] = (float)v[r];
+  }
+  for (int i = 0; i < ncols; ++i)
+    for (int j = 0; j < ncols; ++j) {
+      float e = (i == j) ? 1.0f : 0.0f;
+      float m = AtA[ncols * i + j] + e * damp;
+      M[ncols * i + j] = (double)m;
+    }
+  inv_n_f64(M, Mi, ncols);
+  for (int i = 0; i < ncols; ++i) {
+    float acc = (float)Mi[ncols * i] * Atb[0];
+    for (int k = 1; k < ncols; ++k) acc = acc + (float)Mi[ncols * i + k] * Atb[k];
+    x[i] = acc;
+  }
 }
 
 /* geometry/se3utils.py:77-115, evaluated in double from the float32 xi and rounded once. */

@@ -178,10 +178,10 @@ def gauss_newton_rows(src, tgt, tgt_normals, dist_thresh=None):
 def solve_normal_eq(A, b, damp=1e-8, keep=None):
     A = _c(A, np.float32)
     b = _c(b, np.float32).reshape(-1)
-    x = np.empty(6, np.float32)
+    x = np.empty(A.shape[1], np.float32)
     k = None if keep is None else _c(keep, np.uint8)
     lib().gs_or_solve_normal_eq(_f(A), _f(b), None if k is None else k.ctypes.data_as(u8p),
-                                C.c_int64(A.shape[0]), C.c_float(damp), _f(x))
+                                C.c_int64(A.shape[0]), A.shape[1], C.c_float(damp), _f(x))
     return x
 
 

@@ -1,0 +1,328 @@
+"""GPU parity tests proper: every C-ABI entry point (through gradslam_amd.ops) against the CPU
+oracle on the same inputs, plus the golden vectors recorded from the real reference.
+
+Bars: index tables / masks / counts BIT-EXACT; frame maps, alpha and fused
+surfels bit-exact against the oracle (same operation sequence by construction); ICP transforms
+within 1e-6 of the oracle and 2e-5 of the reference (float64-accumulated normal equations vs
+the reference's float32 sgemm)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from gradslam_amd.datasets.synthetic import make_sequence
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+DIST_TH, DOT_TH, SIGMA = 0.05, math.cos(20 * math.pi / 180), 0.6
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from gradslam_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.dtype == np.float32:
+        # +0 / -0 compare equal on purpose; NaNs are not expected
+        assert np.array_equal(a, b), "mismatches: %d of %d (max abs %g)" % (
+            (a != b).sum(), a.size, np.abs(a.astype(np.float64) - b.astype(np.float64)).max())
+    else:
+        assert np.array_equal(a, b), "mismatches: %d of %d" % ((a != b).sum(), a.size)
+
+
+# ------------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize("case", ["msrd", "synth640", "tiny", "neg_fy_ragged"])
+def test_frame_and_global_maps(ops, golden, case):
+    if case == "msrd":
+        g = golden("msrd_b0")
+        depth, K, pose = g["depths"][1, ..., 0], g["intrinsics"], g["poses"][1]
+    elif case == "synth640":
+        s = make_sequence(2, 480, 640, seed=5)
+        depth, K, pose = s["depths"][1, ..., 0], s["intrinsics"][0], s["poses"][1]
+    elif case == "tiny":
+        depth = np.array([[1.0, 0.0], [2.0, 3.0]], np.float32)
+        K, pose = np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)
+        K[0, 0] = K[1, 1] = 2.0
+    else:  # odd sizes that do not divide the 64x8 tile, negative fy, invalid borders
+        rng = np.random.default_rng(3)
+        depth = (rng.random((67, 131)) * 3).astype(np.float32)
+        depth[rng.random(depth.shape) < 0.2] = 0
+        depth[:, -1] = 0
+        depth[-1, :5] = -1.0
+        K = np.array([[120.3, 0, 65.2, 0], [0, -120.0, 33.1, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+        pose = o.se3_exp(np.array([0.1, -0.2, 0.05, 0.02, -0.01, 0.03], np.float32))
+    v, n, a, valid = ops.frame_maps(dev(depth), dev(K), SIGMA)
+    gv, gn = ops.global_maps(v, n, dev(depth), dev(pose))
+    ov, on, oa, ovalid = o.frame_maps(depth, K, SIGMA)
+    ogv, ogn = o.global_maps(ov, on, depth, pose)
+    same_bits(host(v), ov)
+    same_bits(host(n), on)
+    same_bits(host(a), oa)
+    assert np.array_equal(host(valid), ovalid)
+    same_bits(host(gv), ogv)
+    same_bits(host(gn), ogn)
+    if case == "msrd":  # and against the reference's own golden maps
+        same_bits(host(v), g["vertex_map"][1])
+        same_bits(host(n), g["normal_map"][1])
+        same_bits(host(gv), g["global_vertex_map"][1])
+        same_bits(host(gn), g["global_normal_map"][1])
+        np.testing.assert_allclose(host(a), g["alpha"][1], rtol=2e-7)
+
+
+def test_global_maps_without_pose_is_a_copy(ops):
+    s = make_sequence(1, 32, 48, seed=1)
+    depth = dev(s["depths"][0, ..., 0])
+    v, n, _, _ = ops.frame_maps(depth, dev(s["intrinsics"][0]))
+    gv, gn = ops.global_maps(v, n, depth, None)
+    assert torch.equal(gv, v) and torch.equal(gn, n)
+
+
+def test_alpha_of_points(ops):
+    rng = np.random.default_rng(0)
+    pts = (rng.standard_normal((1000, 3)) * 2).astype(np.float32)
+    pts[0] = 0
+    pts[1] = 100.0
+    same_bits(host(ops.alpha_of_points(dev(pts), SIGMA)), o.alpha(pts, SIGMA))
+
+
+# ------------------------------------------------------------------------------------ K2/K5/K6
+def _fusion_case(name, golden):
+    if name == "msrd":
+        g = golden("msrd_b0")
+        return dict(P=g["map0_points"], N=g["map0_normals"], C=g["map0_colors"], F=g["map0_ccounts"],
+                    depth=g["depths"][1, ..., 0], rgb=g["colors"][1], K=g["intrinsics"], pose=g["poses"][1], g=g)
+    H, W = (480, 640) if name == "synth640" else (96, 128)
+    s = make_sequence(2, H, W, seed=11)
+    K = s["intrinsics"][0]
+    d0 = s["depths"][0, ..., 0]
+    v, n, a, _ = o.frame_maps(d0, K, SIGMA)
+    gv, gn = o.global_maps(v, n, d0, s["poses"][0])
+    e3, e1 = np.zeros((0, 3), np.float32), np.zeros((0, 1), np.float32)
+    P, N, C, F = o.fuse_append(e3, e3, e3, e1, np.full(H * W, -1, np.int32), gv, gn, s["colors"][0], a, d0)
+    return dict(P=P, N=N, C=C, F=F, depth=s["depths"][1, ..., 0], rgb=s["colors"][1], K=K, pose=s["poses"][1], g=None)
+
+
+@pytest.mark.parametrize("name", ["msrd", "synth128", "synth640"])
+def test_association_and_fusion_bit_exact(ops, golden, name):
+    c = _fusion_case(name, golden)
+    H, W = c["depth"].shape
+    P, N, C, F = (dev(c[k]) for k in "PNCF")
+    depth, rgb, K, pose = dev(c["depth"]), dev(c["rgb"]), dev(c["K"]), dev(c["pose"])
+    v, n, a, _ = ops.frame_maps(depth, K, SIGMA)
+    gv, gn = ops.global_maps(v, n, depth, pose)
+    ov, on, oa, _ = o.frame_maps(c["depth"], c["K"], SIGMA)
+    ogv, ogn = o.global_maps(ov, on, c["depth"], c["pose"])
+
+    pix = ops.project_map(P, pose, K, H, W)
+    opix = o.project_map(c["P"], c["pose"], c["K"], H, W)
+    same_bits(host(pix), opix)
+    act = ops.active_table(pix, W)
+    oact = o.active_table(opix, W)
+    same_bits(host(act), oact)
+    mask = ops.similar_rows(act, P, N, gv, gn, DIST_TH, DOT_TH)
+    omask = o.similar_rows(oact, c["P"], c["N"], ogv, ogn, DIST_TH, DOT_TH)
+    same_bits(host(mask), omask)
+    uq, best_from_rows = ops.best_unique_rows(act[mask], P, F, gv)
+    ouq = o.best_unique_rows(oact[omask], c["P"], c["F"], ogv)
+    same_bits(host(uq), ouq)
+    best, sim = ops.associate(pix, P, N, F, gv, gn, DIST_TH, DOT_TH, want_similar=True)
+    obest, osim = o.associate(opix, c["P"], c["N"], c["F"], ogv, ogn, DIST_TH, DOT_TH)
+    same_bits(host(best), obest)
+    same_bits(host(best_from_rows), obest)
+    same_bits(host(sim), osim)
+    same_bits(host(ops.best_table(best, H, W)), ouq)
+    same_bits(host(ops.rows_to_best_pix(uq, H, W)), obest)
+
+    # K2 down-samplers
+    tp, tn, _ = ops.select_targets(pix, W, 4, P, N)
+    otp, otn, _ = o.select_targets(opix, W, 4, c["P"], c["N"])
+    same_bits(host(tp), otp)
+    same_bits(host(tn), otn)
+    tp2, tn2, _ = ops.downsample_table(act, 4, P, N)
+    same_bits(host(tp2), otp)
+    fp, fn, fc = ops.downsample_frame(gv, gn, rgb, depth, 4)
+    ofp, ofn, ofc = o.downsample_frame(ogv, ogn, c["rgb"], c["depth"], 4)
+    same_bits(host(fp), ofp)
+    same_bits(host(fn), ofn)
+    same_bits(host(fc), ofc)
+
+    # K6 fuse + append, parity mode and fast mode
+    for renorm in (True, False):
+        n0 = c["P"].shape[0]
+        cap = n0 + H * W
+        bufs = [torch.zeros((cap, k), dtype=torch.float32, device="cuda") for k in (3, 3, 3, 1)]
+        for b_, src in zip(bufs, (P, N, C, F)):
+            b_[:n0] = src.reshape(n0, -1)
+        cnt = ops.fuse_append_(bufs[0], bufs[1], bufs[2], bufs[3], n0, best, gv, gn, rgb, a, depth, renorm)
+        oP, oN, oC, oF = o.fuse_append(c["P"], c["N"], c["C"], c["F"], obest, ogv, ogn, c["rgb"], oa, c["depth"], renorm)
+        assert cnt == oP.shape[0]
+        for b_, ref in zip(bufs, (oP, oN, oC, oF)):
+            same_bits(host(b_[:cnt]), ref)
+    if c["g"] is not None:  # tables against the reference's own output
+        g = c["g"]
+        same_bits(host(act), g["active"])
+        same_bits(host(mask), g["similar_mask"])
+        same_bits(host(uq), g["unique"])
+
+
+def test_empty_map_and_all_invalid_frame(ops):
+    H, W = 16, 24
+    depth = np.zeros((H, W), np.float32)
+    K = np.eye(4, dtype=np.float32)
+    K[0, 0] = K[1, 1] = 20
+    d = dev(depth)
+    v, n, a, valid = ops.frame_maps(d, dev(K))
+    assert not host(valid).any() and not host(v).any()
+    gv, gn = ops.global_maps(v, n, d, dev(np.eye(4, dtype=np.float32)))
+    e3 = torch.zeros((0, 3), device="cuda")
+    pix = ops.project_map(e3, dev(np.eye(4, dtype=np.float32)), dev(K), H, W)
+    assert pix.numel() == 0
+    best = ops.associate(pix, e3, e3, torch.zeros((0, 1), device="cuda"), gv, gn, DIST_TH, DOT_TH)
+    assert (host(best) == -1).all()
+    bufs = [torch.zeros((H * W, k), device="cuda") for k in (3, 3, 3, 1)]
+    rgb = torch.zeros((H, W, 3), device="cuda")
+    assert ops.fuse_append_(*bufs, 0, best, gv, gn, rgb, a, d) == 0       # nothing valid to append
+    depth[3, 5] = 1.5
+    d = dev(depth)
+    v, n, a, valid = ops.frame_maps(d, dev(K))
+    gv, gn = ops.global_maps(v, n, d, dev(np.eye(4, dtype=np.float32)))
+    assert ops.fuse_append_(*bufs, 0, best, gv, gn, rgb, a, d) == 1
+    same_bits(host(bufs[0][:1]), host(gv)[3, 5][None])
+    pts, _, _ = ops.downsample_frame(gv, gn, rgb, d, 4)
+    assert pts.shape[0] == 0  # (3,5) is off the ds=4 lattice
+
+
+def test_store_overflow_is_reported(ops):
+    s = make_sequence(1, 32, 32, seed=2)
+    d = dev(s["depths"][0, ..., 0])
+    v, n, a, _ = ops.frame_maps(d, dev(s["intrinsics"][0]))
+    gv, gn = ops.global_maps(v, n, d, dev(s["poses"][0]))
+    bufs = [torch.zeros((10, k), device="cuda") for k in (3, 3, 3, 1)]
+    best = torch.full((32 * 32,), -1, dtype=torch.int32, device="cuda")
+    from gradslam_amd._C import HipExtensionError
+    with pytest.raises(HipExtensionError, match="overflow"):
+        ops.fuse_append_(*bufs, 0, best, gv, gn, dev(s["colors"][0]), a, d)
+    assert torch.isfinite(bufs[0]).all()
+
+
+# ------------------------------------------------------------------------------------ K3
+@pytest.mark.parametrize("ns,nt", [(1, 1), (5, 3), (257, 513), (1024, 512), (5000, 7001), (19200, 23000)])
+def test_knn_exact(ops, ns, nt):
+    rng = np.random.default_rng(ns * 31 + nt)
+    tgt = rng.standard_normal((nt, 3)).astype(np.float32)
+    src = (tgt[rng.integers(0, nt, ns)] + 0.01 * rng.standard_normal((ns, 3))).astype(np.float32)
+    if nt > 10:  # exact duplicates: ties must resolve to the lowest index
+        tgt[nt // 2:nt // 2 + 5] = tgt[3]
+        src[0] = tgt[3]
+    idx, d2 = ops.knn1(dev(src), dev(tgt))
+    oidx, od2 = o.knn1(src, tgt)
+    same_bits(host(idx), oidx)
+    same_bits(host(d2), od2)
+
+
+def test_knn_ties_on_a_lattice(ops):
+    """Integer lattice: many exactly equidistant targets; the lowest index must win."""
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3)
+    tgt = g.astype(np.float32)
+    src = (g[::3] + 0.5).astype(np.float32)
+    idx, _ = ops.knn1(dev(src), dev(tgt))
+    oidx, _ = o.knn1(src, tgt)
+    same_bits(host(idx), oidx)
+    d = ((src[:, None] - tgt[None]) ** 2).sum(-1)
+    assert np.array_equal(oidx, d.argmin(1))
+
+
+# ------------------------------------------------------------------------------------ K4
+def test_gauss_newton_rows_and_solve(ops, golden):
+    g = golden("icp_unit")
+    src, tgt, tn = g["src"], g["tgt"], g["tgt_normals"]
+    for thr in (None, float(g["gn_thr"])):
+        A, b, idx, keep = ops.gauss_newton_rows(dev(src), dev(tgt), dev(tn), thr)
+        oA, ob, oidx, okeep = o.gauss_newton_rows(src, tgt, tn, thr)
+        same_bits(host(idx), oidx)
+        same_bits(host(keep), okeep)
+        same_bits(host(A), oA)
+        same_bits(host(b), ob)
+        x = ops.solve_normal_eq(A, b, 1e-8, keep)
+        ox = o.solve_normal_eq(oA, ob, 1e-8, okeep)
+        np.testing.assert_allclose(host(x), ox, rtol=1e-6, atol=1e-9)
+    same_bits(host(ops.gauss_newton_rows(dev(src), dev(tgt), dev(tn))[0]), g["gn_A"])
+    np.testing.assert_allclose(host(ops.solve_normal_eq(dev(g["gn_A"]), dev(g["gn_b"]), 1e-8)), g["solve_x"][:, 0],
+                               rtol=2e-3, atol=2e-6)
+    # the reference's own KAT (4 unknowns): A x ~ b (tests/odometry/test_icputils.py:18-49)
+    x = host(ops.solve_normal_eq(dev(g["kat_A"]), dev(g["kat_b"]), 1e-8))
+    np.testing.assert_allclose(x, g["kat_x"][:, 0], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(g["kat_A"] @ x, g["kat_b"][:, 0], rtol=1.3e-6 * 50, atol=1e-4)
+
+
+def test_se3_exp_and_transform(ops, golden):
+    g = golden("icp_unit")
+    for xi, T in zip(g["se3_xi"], g["se3_T"]):
+        t = host(ops.se3_exp(dev(xi)))
+        np.testing.assert_allclose(t, o.se3_exp(xi), rtol=0, atol=1e-7)
+        np.testing.assert_allclose(t, T, rtol=1e-5, atol=1e-6)
+    T = o.se3_exp(g["se3_xi"][1])
+    same_bits(host(ops.transform_points(dev(g["src"]), dev(T))), o.transform_points(g["src"], T))
+
+
+@pytest.mark.parametrize("mode,key", [(0, "icp"), (1, "gradicp")])
+@pytest.mark.parametrize("iters", [3, 20])
+def test_icp_against_oracle_and_reference(ops, golden, mode, key, iters):
+    g = golden("icp_unit")
+    src, tgt, tn = g["src"], g["tgt"], g["tgt_normals"]
+    T, idx, tr = ops.icp(dev(src), dev(tgt), dev(tn), mode=mode, numiters=iters, return_trace=True)
+    oT, oidx, otr = o.icp(src, tgt, tn, mode=mode, numiters=iters, return_trace=True)
+    np.testing.assert_allclose(host(T), oT, rtol=0, atol=1e-6)
+    assert (host(idx) == oidx).mean() >= 0.999
+    np.testing.assert_allclose(host(tr)[:, :2], otr[:, :2], rtol=1e-4, atol=1e-9)   # err, new_err
+    np.testing.assert_allclose(host(tr)[:, 4:10], otr[:, 4:10], rtol=1e-3, atol=1e-7)  # xi
+    np.testing.assert_allclose(host(T), g["%s%d_T" % (key, iters)], rtol=0, atol=2e-5)
+    assert (host(idx) == g["%s%d_idx" % (key, iters)]).mean() > 0.995
+
+
+def test_icp_compose_and_dist_thresh(ops, golden):
+    g = golden("icp_unit")
+    src, tgt, tn = g["src"], g["tgt"], g["tgt_normals"]
+    comp = o.se3_exp(np.array([0.3, 0.1, -0.2, 0.05, 0.02, -0.04], np.float32))
+    init = o.se3_exp(np.array([0.001, 0.0, 0.002, 0.0, 0.001, 0.0], np.float32))
+    T = ops.icp(dev(src), dev(tgt), dev(tn), init=dev(init), compose=dev(comp), mode=1, numiters=5, dist_thresh=0.01,
+                return_idx=False)
+    oT, _ = o.icp(src, tgt, tn, init=init, compose=comp, mode=1, numiters=5, dist_thresh=0.01)
+    np.testing.assert_allclose(host(T), oT, rtol=0, atol=1e-6)
+
+
+def test_icp_full_size_properties(ops):
+    """BASELINE size (640x480 / ds4: ~18k x ~18k points): the oracle would take minutes, so check
+    size-independent properties: ICP recovers a known small rigid motion, and applying the
+    recovered transform strictly reduces the mean NN distance."""
+    s = make_sequence(2, 480, 640, seed=4)
+    K = s["intrinsics"][0]
+    pts = []
+    for f in range(2):
+        d = dev(s["depths"][f, ..., 0])
+        v, n, _, _ = ops.frame_maps(d, dev(K))
+        gv, gn = ops.global_maps(v, n, d, dev(s["poses"][0]))  # both under pose 0: frame 1 is misplaced
+        p, nn, _ = ops.downsample_frame(gv, gn, None, d, 4)
+        pts.append((p, nn))
+    (tgt, tn), (src, _) = pts
+    T = ops.icp(src, tgt, tn, mode=1, numiters=20, return_idx=False)
+    true_T = np.linalg.inv(s["poses"][0].astype(np.float64)) @ s["poses"][1].astype(np.float64)
+    assert np.abs(host(T) - true_T).max() < 2e-3
+    _, d_before = ops.knn1(src, tgt)
+    _, d_after = ops.knn1(ops.transform_points(src, T), tgt)
+    assert float(d_after.mean()) < 0.5 * float(d_before.mean())
