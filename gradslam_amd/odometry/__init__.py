@@ -1,0 +1,4 @@
+from .base import *  # noqa: F401,F403
+from .gradicp import *  # noqa: F401,F403
+from .icp import *  # noqa: F401,F403
+from . import icputils  # noqa: F401

@@ -1,0 +1,359 @@
+"""Function-level mirror of the reference's slam/fusionutils.py (same names, arguments, table
+layouts, ordering contracts and error messages); the bodies are HIP kernels.
+
+    get_alpha                          -> gs_alpha_f32 / fused in gs_frame_maps_f32   (fusionutils.py:16-73)
+    are_points_close / are_normals_similar -> gs_similar_rows_f32                      (:76-195)
+    find_active_map_points             -> gs_project_map_f32 + gs_active_table_i64    (:198-287)
+    find_similar_map_points            -> gs_similar_rows_f32                         (:290-411)
+    find_best_unique_correspondences   -> gs_best_unique_rows_f32                     (:414-546)
+    find_correspondences               -> gs_project_map_f32 + gs_associate_f32       (:549-577)
+    fuse_with_map                      -> gs_rows_to_best_pix + gs_fuse_append_f32    (:580-722)
+    update_map_aggregate               -> gs_append_valid_f32                         (:725-758)
+    update_map_fusion                  -> project + associate + fuse, no tables       (:761-789)
+
+`pc2im_bnhw` tables are int64 (rows, 4) = [b, n, h, w] exactly as in the reference.
+"""
+import warnings
+from typing import Union
+
+import torch
+
+from ..structures.pointclouds import Pointclouds
+from ..structures.rgbdimages import RGBDImages
+
+__all__ = ["update_map_fusion", "update_map_aggregate"]
+
+# parity mode (default): rewrite every map row as (cc*x)*(1/cc) each frame exactly like the
+# reference's full-map weighted average (fusionutils.py:678-699).  False leaves unmatched
+# surfels untouched (saves 72 B/surfel/frame of HBM traffic, results differ by <= 1 ulp/frame).
+RENORMALIZE_UNMATCHED = True
+
+
+# --------------------------------------------------------------------------- small helpers
+def get_alpha(points: torch.Tensor, sigma: Union[torch.Tensor, float, int], dim: int = -1, keepdim: bool = False,
+              eps: float = 1e-7) -> torch.Tensor:
+    if not torch.is_tensor(points):
+        raise TypeError("Expected input points to be of type torch.Tensor. Got {0} instead.".format(type(points)))
+    if not (torch.is_tensor(sigma) or isinstance(sigma, float) or isinstance(sigma, int)):
+        raise TypeError("Expected input sigma to be of type torch.Tensor or float or int. Got {0} instead.".format(
+            type(sigma)))
+    if not isinstance(eps, float):
+        raise TypeError("Expected input eps to be of type float. Got {0} instead.".format(type(eps)))
+    if points.shape[dim] != 3:
+        raise ValueError("Expected length of dim-th ({0}th) dimension to be 3. Got {1} instead.".format(
+            dim, points.shape[dim]))
+    if torch.is_tensor(sigma) and sigma.ndim != 0:
+        raise ValueError("Expected sigma.ndim to be 0 (scalar). Got {0}.".format(sigma.ndim))
+    from .. import ops
+    moved = points.movedim(dim, -1)
+    alpha = ops.alpha_of_points(moved.reshape(-1, 3), float(sigma), eps).view(moved.shape[:-1])
+    return alpha.unsqueeze(dim) if keepdim else alpha
+
+
+def _pairwise_checks(tensor1, tensor2, th, th_name, dim):
+    if not torch.is_tensor(tensor1):
+        raise TypeError("Expected input tensor1 to be of type torch.Tensor. Got {0} instead.".format(type(tensor1)))
+    if not torch.is_tensor(tensor2):
+        raise TypeError("Expected input tensor2 to be of type torch.Tensor. Got {0} instead.".format(type(tensor2)))
+    if not (isinstance(th, float) or isinstance(th, int)):
+        raise TypeError("Expected input {0} to be of type float or int. Got {1} instead.".format(th_name, type(th)))
+    if tensor1.shape != tensor2.shape:
+        raise ValueError("tensor1 and tensor2 should have the same shape, but had shapes {0} and {1} respectively."
+                         .format(tensor1.shape, tensor2.shape))
+    if tensor1.shape[dim] != 3:
+        raise ValueError("Expected length of input tensors' dim-th ({0}th) dimension to be 3. Got {1} instead."
+                         .format(dim, tensor1.shape[dim]))
+
+
+def _pairwise(tensor1, tensor2, dim, dist_th, dot_th, use_points):
+    """Runs gs_similar_rows_f32 on row i of tensor1 against row i of tensor2 with the unused half
+    of the test neutralised."""
+    from .. import ops
+    a = tensor1.movedim(dim, -1)
+    out_shape = a.shape[:-1]
+    a = a.reshape(-1, 3).contiguous().float()
+    b = tensor2.movedim(dim, -1).reshape(-1, 3).contiguous().float()
+    n = a.shape[0]
+    ar = torch.arange(n, device=a.device)
+    rows = torch.stack([torch.zeros_like(ar), ar, torch.zeros_like(ar), ar], 1)
+    zero = torch.zeros_like(a)
+    if use_points:   # |t1 - t2| < dist_th; normals (1,0,0).(1,0,0) = 1 > -inf
+        ex = torch.zeros_like(a)
+        ex[:, 0] = 1
+        mask = ops.similar_rows(rows, b, ex, a.view(1, n, 3), ex.view(1, n, 3), dist_th, float("-inf"))
+    else:            # t1 . t2 > dot_th; points 0 - 0 = 0 < +inf
+        mask = ops.similar_rows(rows, zero, b, zero.view(1, n, 3), a.view(1, n, 3), float("inf"), dot_th)
+    return mask.view(out_shape)
+
+
+def are_points_close(tensor1: torch.Tensor, tensor2: torch.Tensor, dist_th: Union[float, int], dim: int = -1):
+    _pairwise_checks(tensor1, tensor2, dist_th, "dist_th", dim)
+    return _pairwise(tensor1, tensor2, dim, float(dist_th), 0.0, True)
+
+
+def are_normals_similar(tensor1: torch.Tensor, tensor2: torch.Tensor, dot_th: Union[float, int], dim: int = -1):
+    _pairwise_checks(tensor1, tensor2, dot_th, "dot_th", dim)
+    return _pairwise(tensor1, tensor2, dim, 0.0, float(dot_th), False)
+
+
+def _check_pc(pointclouds):
+    if not isinstance(pointclouds, Pointclouds):
+        raise TypeError("Expected pointclouds to be of type gradslam.Pointclouds. Got {0}.".format(type(pointclouds)))
+
+
+def _check_rgbd(rgbdimages):
+    if not isinstance(rgbdimages, RGBDImages):
+        raise TypeError("Expected rgbdimages to be of type gradslam.RGBDImages. Got {0}.".format(type(rgbdimages)))
+
+
+def _check_table(pc2im_bnhw):
+    if not torch.is_tensor(pc2im_bnhw):
+        raise TypeError("Expected input pc2im_bnhw to be of type torch.Tensor. Got {0} instead.".format(
+            type(pc2im_bnhw)))
+    if pc2im_bnhw.dtype != torch.int64:
+        raise TypeError("Expected input pc2im_bnhw to have dtype of torch.int64 (torch.long), not {0}.".format(
+            pc2im_bnhw.dtype))
+
+
+def _check_table_shape(pc2im_bnhw):
+    if pc2im_bnhw.ndim != 2:
+        raise ValueError("Expected pc2im_bnhw.ndim of 2. Got {0}.".format(pc2im_bnhw.ndim))
+    if pc2im_bnhw.shape[1] != 4:
+        raise ValueError("Expected pc2im_bnhw.shape[1] to be 4. Got {0}.".format(pc2im_bnhw.shape[1]))
+
+
+def _check_seq1(rgbdimages):
+    if rgbdimages.shape[1] != 1:
+        raise ValueError("Expected rgbdimages to have sequence length of 1. Got {0}.".format(rgbdimages.shape[1]))
+
+
+def _check_batch(pointclouds, rgbdimages):
+    if len(rgbdimages) != len(pointclouds):
+        raise ValueError("Expected equal batch sizes for pointclouds and rgbdimages. Got {0} and {1} respectively."
+                         .format(len(pointclouds), len(rgbdimages)))
+
+
+def _rows_of(pc2im_bnhw, b, B):
+    """(rows of sequence b, their positions in the table)"""
+    if B == 1:
+        return pc2im_bnhw, None
+    sel = (pc2im_bnhw[:, 0] == b).nonzero().flatten()
+    return pc2im_bnhw[sel], sel
+
+
+def _frame(rgbdimages):
+    """channels-last float32 views the kernels consume: K (B,4,4), poses (B,4,4), depth (B,H,W)."""
+    fr = rgbdimages.to_channels_last()
+    return fr, fr.intrinsics[:, 0].contiguous().float(), fr.poses[:, 0].contiguous().float()
+
+
+# --------------------------------------------------------------------------- tables
+def find_active_map_points(pointclouds: Pointclouds, rgbdimages: RGBDImages) -> torch.Tensor:
+    _check_pc(pointclouds)
+    _check_rgbd(rgbdimages)
+    _check_seq1(rgbdimages)
+    device = pointclouds.device
+    if not pointclouds.has_points:
+        return torch.empty((0, 4), dtype=torch.int64, device=device)
+    _check_batch(pointclouds, rgbdimages)
+    from .. import ops
+    fr, K, poses = _frame(rgbdimages)
+    _, _, H, W = fr.shape
+    tables = []
+    for b in range(len(pointclouds)):
+        pix = ops.project_map(pointclouds.points_list[b], poses[b], K[b], H, W)
+        tables.append(ops.active_table(pix, W, b))
+    pc2im_bnhw = tables[0] if len(tables) == 1 else torch.cat(tables, 0)
+    if pc2im_bnhw.shape[0] == 0:
+        warnings.warn("No active map points were found")
+    return pc2im_bnhw
+
+
+def find_similar_map_points(pointclouds: Pointclouds, rgbdimages: RGBDImages, pc2im_bnhw: torch.Tensor,
+                            dist_th: Union[float, int], dot_th: Union[float, int]):
+    _check_pc(pointclouds)
+    _check_rgbd(rgbdimages)
+    _check_table(pc2im_bnhw)
+    _check_seq1(rgbdimages)
+    _check_table_shape(pc2im_bnhw)
+    device = pointclouds.device
+    if not pointclouds.has_points or pc2im_bnhw.shape[0] == 0:
+        return torch.empty((0, 4), dtype=torch.int64, device=device), torch.empty(0, dtype=torch.bool, device=device)
+    _check_batch(pointclouds, rgbdimages)
+    if not pointclouds.has_normals:
+        raise ValueError("Pointclouds must have normals for finding similar map points, but did not.")
+    from .. import ops
+    fr = rgbdimages.to_channels_last()
+    B = len(pointclouds)
+    mask = torch.zeros(pc2im_bnhw.shape[0], dtype=torch.bool, device=device)
+    for b in range(B):
+        rows, sel = _rows_of(pc2im_bnhw, b, B)
+        if rows.shape[0] == 0:
+            continue
+        m = ops.similar_rows(rows, pointclouds.points_list[b], pointclouds.normals_list[b],
+                             fr.global_vertex_map[b, 0], fr.global_normal_map[b, 0], dist_th, dot_th)
+        if sel is None:
+            mask = m
+        else:
+            mask[sel] = m
+    pc2im_bnhw_similar = pc2im_bnhw[mask]
+    if len(pc2im_bnhw_similar) == 0:
+        warnings.warn("No similar map points were found (despite total {0} active points across the batch)".format(
+            pc2im_bnhw.shape[0]), RuntimeWarning)
+    return pc2im_bnhw_similar, mask
+
+
+def find_best_unique_correspondences(pointclouds: Pointclouds, rgbdimages: RGBDImages,
+                                     pc2im_bnhw: torch.Tensor) -> torch.Tensor:
+    _check_pc(pointclouds)
+    _check_table(pc2im_bnhw)
+    _check_seq1(rgbdimages)
+    _check_table_shape(pc2im_bnhw)
+    device = pointclouds.device
+    if not pointclouds.has_points or pc2im_bnhw.shape[0] == 0:
+        return torch.empty((0, 4), dtype=torch.int64, device=device)
+    _check_batch(pointclouds, rgbdimages)
+    if not pointclouds.has_features:
+        raise ValueError("Pointclouds must have features for finding best unique correspondences, but did not.")
+    from .. import ops
+    fr = rgbdimages.to_channels_last()
+    B = len(pointclouds)
+    out = []
+    for b in range(B):
+        rows, _ = _rows_of(pc2im_bnhw, b, B)
+        if rows.shape[0] == 0:
+            continue
+        uq, _ = ops.best_unique_rows(rows, pointclouds.points_list[b], pointclouds.features_list[b][:, :1],
+                                     fr.global_vertex_map[b, 0], b)
+        out.append(uq)
+    return out[0] if len(out) == 1 else torch.cat(out, 0)
+
+
+def _best_pix_per_sequence(pointclouds, rgbdimages, dist_th, dot_th):
+    """Fused find_correspondences: per sequence the (H*W,) int32 winner table (no pc2im rows)."""
+    from .. import ops
+    fr, K, poses = _frame(rgbdimages)
+    _, _, H, W = fr.shape
+    best = []
+    for b in range(len(rgbdimages)):
+        if not pointclouds.has_points or pointclouds._n[b] == 0:
+            best.append(torch.full((H * W,), -1, dtype=torch.int32, device=fr.device))
+            continue
+        P, N, F = pointclouds.points_list[b], pointclouds.normals_list[b], pointclouds.features_list[b]
+        pix = ops.project_map(P, poses[b], K[b], H, W)
+        best.append(ops.associate(pix, P, N, F[:, :1], fr.global_vertex_map[b, 0], fr.global_normal_map[b, 0],
+                                  dist_th, dot_th))
+    return best
+
+
+def find_correspondences(pointclouds: Pointclouds, rgbdimages: RGBDImages, dist_th: Union[float, int],
+                         dot_th: Union[float, int]) -> torch.Tensor:
+    _check_pc(pointclouds)
+    _check_rgbd(rgbdimages)
+    _check_seq1(rgbdimages)
+    if not pointclouds.has_points:
+        return torch.empty((0, 4), dtype=torch.int64, device=pointclouds.device)
+    _check_batch(pointclouds, rgbdimages)
+    if not pointclouds.has_normals:
+        raise ValueError("Pointclouds must have normals for finding similar map points, but did not.")
+    if not pointclouds.has_features:
+        raise ValueError("Pointclouds must have features for finding best unique correspondences, but did not.")
+    from .. import ops
+    _, _, H, W = rgbdimages.shape
+    best = _best_pix_per_sequence(pointclouds, rgbdimages, dist_th, dot_th)
+    tables = [ops.best_table(bp, H, W, b) for b, bp in enumerate(best)]
+    return tables[0] if len(tables) == 1 else torch.cat(tables, 0)
+
+
+# --------------------------------------------------------------------------- map updates
+def _fuse(pointclouds, rgbdimages, best_pix, sigma, inplace):
+    from .. import ops
+    fr = rgbdimages.to_channels_last()
+    B, _, H, W = fr.shape
+    if pointclouds.device != fr.device:
+        raise ValueError("Device of pointclouds to append and to be appended must match: ({0} != {1})".format(
+            fr.device, pointclouds.device))
+    alpha = fr._alpha_map(sigma)
+    gv, gn = fr.global_vertex_map, fr.global_normal_map
+    rgb, depth = fr.rgb_image.contiguous().float(), fr.depth_image.contiguous().float()
+    if len(pointclouds) == 0:
+        if not inplace:  # nothing to merge into: build the result in a fresh store
+            pointclouds, inplace = Pointclouds(device=pointclouds.device), True
+        pointclouds._init_empty_batch(B, 1)
+    out = pointclouds if inplace else Pointclouds(device=pointclouds.device)
+    if not inplace:
+        out._init_empty_batch(B, pointclouds._buf["features"][0].shape[-1])
+    for b in range(B):
+        n0 = pointclouds._n[b]
+        P, N, C, F = pointclouds._reserve(b, H * W)
+        if P.dtype != torch.float32 or F.shape[-1] != 1:
+            raise ValueError("map fusion needs float32 surfels with one feature column (the confidence count)")
+        n1 = ops.fuse_append_(P, N, C, F, n0, best_pix[b], gv[b, 0], gn[b, 0], rgb[b, 0], alpha[b, 0, ..., 0],
+                              depth[b, 0, ..., 0], RENORMALIZE_UNMATCHED)
+        if inplace:
+            pointclouds._set_count(b, n1)
+        else:
+            # the reference merges into its argument before cloning (fusionutils.py:696-719): the
+            # input keeps the merged rows (count unchanged), the appended rows exist only in the copy
+            for k, src in zip(("points", "normals", "colors", "features"), (P, N, C, F)):
+                out._buf[k][b] = src[:n1].clone()
+            out._set_count(b, n1)
+    return out
+
+
+def fuse_with_map(pointclouds: Pointclouds, rgbdimages: RGBDImages, pc2im_bnhw: torch.Tensor,
+                  sigma: Union[torch.Tensor, float, int], inplace: bool = False) -> Pointclouds:
+    _check_pc(pointclouds)
+    _check_rgbd(rgbdimages)
+    _check_table(pc2im_bnhw)
+    _check_table_shape(pc2im_bnhw)
+    if pointclouds.has_points:
+        if not pointclouds.has_normals:
+            raise ValueError("Pointclouds must have normals for map fusion, but did not.")
+        if not pointclouds.has_colors:
+            raise ValueError("Pointclouds must have colors for map fusion, but did not.")
+        if not pointclouds.has_features:
+            raise ValueError("Pointclouds must have features (ccounts) for map fusion, but did not.")
+    from .. import ops
+    B, _, H, W = rgbdimages.shape
+    best = []
+    for b in range(B):
+        rows, _ = _rows_of(pc2im_bnhw.to(rgbdimages.device), b, B)
+        best.append(ops.rows_to_best_pix(rows, H, W))
+    return _fuse(pointclouds, rgbdimages, best, sigma, inplace)
+
+
+def update_map_aggregate(pointclouds: Pointclouds, rgbdimages: RGBDImages, inplace: bool = False) -> Pointclouds:
+    _check_pc(pointclouds)
+    _check_rgbd(rgbdimages)
+    _check_seq1(rgbdimages)
+    from .. import ops
+    fr = rgbdimages.to_channels_last()
+    B, _, H, W = fr.shape
+    if not inplace:
+        pointclouds = pointclouds.clone()
+    if len(pointclouds) == 0:
+        pointclouds._init_empty_batch(B, 0)
+    gv, gn = fr.global_vertex_map, fr.global_normal_map
+    rgb, depth = fr.rgb_image.contiguous().float(), fr.depth_image.contiguous().float()
+    if pointclouds.has_features:
+        raise ValueError("pointclouds to append and to be appended must either both have or not have features: "
+                         "(False != True)")
+    for b in range(B):
+        P, N, C, _ = pointclouds._reserve(b, H * W)
+        n1 = ops.append_valid_(P, N, C, None, pointclouds._n[b], gv[b, 0], gn[b, 0], rgb[b, 0], None,
+                               depth[b, 0, ..., 0])
+        pointclouds._set_count(b, n1)
+    return pointclouds
+
+
+def update_map_fusion(pointclouds: Pointclouds, rgbdimages: RGBDImages, dist_th: Union[float, int],
+                      dot_th: Union[float, int], sigma: Union[torch.Tensor, float, int],
+                      inplace: bool = False) -> Pointclouds:
+    _check_pc(pointclouds)
+    _check_rgbd(rgbdimages)
+    _check_seq1(rgbdimages)
+    if pointclouds.has_points:
+        _check_batch(pointclouds, rgbdimages)
+    best = _best_pix_per_sequence(pointclouds, rgbdimages, dist_th, dot_th)
+    return _fuse(pointclouds, rgbdimages, best, sigma, inplace)

@@ -1,0 +1,457 @@
+"""Batched variable-length pointcloud / surfel map with the interface of the reference's
+`gradslam.Pointclouds` (structures/pointclouds.py:13-1467), re-designed around growth:
+
+  * every sequence b owns CAPACITY-BACKED buffers points/normals/colors (cap, 3) and features
+    (cap, F); the HIP fuse/append kernels write new surfels in place and only the count
+    changes.  Capacity grows geometrically, so a 500-frame sequence reallocates O(log N) times
+    instead of re-concatenating and re-padding every attribute every frame
+    (reference: pointclouds.py:1203-1228, :948-995);
+  * `*_list` are zero-copy views buf[:n]; `*_padded` is a zero-copy view when the batch has
+    one sequence (the one-sequence-per-GPU layout) and is materialised lazily otherwise.
+
+Only the container logic lives here (torch as memory plumbing); the arithmetic of the SLAM path
+is in libgradslam_hip.so.
+"""
+from typing import List, Optional, Union
+
+import torch
+
+__all__ = ["Pointclouds"]
+
+_ATTRS = ("points", "normals", "colors", "features")
+
+
+def _canon_device(device):
+    return torch.Tensor().to(device).device
+
+
+class Pointclouds(object):
+    r"""Batch of pointclouds (with varying numbers of points).
+
+    Args:
+        points (list of (N_b, 3) tensors, or (B, N, 3) tensor, or None)
+        normals, colors: same container type and shapes as `points`, or None
+        features: list of (N_b, F) tensors or (B, N, F) tensor, or None
+        device: device of the internal tensors (default: that of `points`, or cpu when empty)
+    """
+
+    def __init__(
+        self,
+        points: Union[List[torch.Tensor], torch.Tensor, None] = None,
+        normals: Union[List[torch.Tensor], torch.Tensor, None] = None,
+        colors: Union[List[torch.Tensor], torch.Tensor, None] = None,
+        features: Union[List[torch.Tensor], torch.Tensor, None] = None,
+        device: Union[torch.device, str, None] = None,
+    ):
+        if not (points is None or isinstance(points, list) or torch.is_tensor(points)):
+            raise TypeError("Expected points to be of type list or tensor or None; got %r" % type(points))
+        for name, val in (("normals", normals), ("colors", colors), ("features", features)):
+            if not (val is None or isinstance(val, type(points))):
+                raise TypeError("Expected %s to be of same type as points (%r); got %r"
+                                % (name, type(points), type(val)))
+        if points is not None and len(points) == 0:
+            raise ValueError("len(points) (= 0) should be > 0")
+
+        self._buf = {k: None for k in _ATTRS}   # per attribute: list of (cap_b, C) tensors or None
+        self._n: List[int] = []                 # points per sequence
+        self._padded_cache = {}
+        self.equisized = None
+
+        if isinstance(points, list):
+            shapes = [p.shape for p in points]
+            if any(p.ndim != 2 for p in points):
+                raise ValueError("ndim of all tensors in points list should be 2")
+            if any(s[-1] != 3 for s in shapes):
+                raise ValueError("last dim of all tensors in points should have shape 3 (X, Y, Z)")
+            self.device = _canon_device(device) if device is not None else points[0].device
+            if not (normals is None or [n.shape for n in normals] == shapes):
+                raise ValueError("normals tensors should have same shape as points tensors, but didn't")
+            if not (colors is None or [c.shape for c in colors] == shapes):
+                raise ValueError("colors tensors should have same shape as points tensors, but didn't")
+            if not (features is None or all(f.ndim == 2 for f in features)):
+                raise ValueError("ndim of all tensors in features list should be 2")
+            if not (features is None or [len(f) for f in features] == [s[0] for s in shapes]):
+                raise ValueError("number of features per pointcloud has to be equal to number of points")
+            if not (features is None or len(set(f.shape[-1] for f in features)) == 1):
+                raise ValueError("number of features per pointcloud has to be the same")
+            self._n = [int(s[0]) for s in shapes]
+            for k, val in zip(_ATTRS, (points, normals, colors, features)):
+                self._buf[k] = None if val is None else [v.to(self.device) for v in val]
+            self.equisized = len(set(self._n)) == 1
+        elif torch.is_tensor(points):
+            self.device = _canon_device(device) if device is not None else points.device
+            if points.ndim != 3:
+                raise ValueError("points should have ndim=3, but had ndim={}".format(points.ndim))
+            if points.shape[-1] != 3:
+                raise ValueError("last dim of points should have shape 3 (X, Y, Z) but had shape %r"
+                                 % (points.shape[-1]))
+            if points.shape[0] == 0:
+                raise ValueError("Batch size of 0 not supported yet. Got input points shape {}.".format(points.shape))
+            if not (normals is None or normals.shape == points.shape):
+                raise ValueError("normals tensor should have same shape as points tensor, but didn't: %r != %r"
+                                 % (normals.shape, points.shape))
+            if not (colors is None or colors.shape == points.shape):
+                raise ValueError("colors tensor should have same shape as points tensor, but didn't: %r != %r"
+                                 % (colors.shape, points.shape))
+            if not (features is None or features.ndim == 3):
+                raise ValueError("features should have ndim=3, but had ndim={}".format(features.ndim))
+            if not (features is None or features.shape[:-1] == points.shape[:-1]):
+                raise ValueError("first 2 dims of features tensor and points tensor should have same shape, "
+                                 "but didn't: %r != %r" % (features.shape[:-1], points.shape[:-1]))
+            B, N = points.shape[:2]
+            self._n = [int(N)] * B
+            for k, val in zip(_ATTRS, (points, normals, colors, features)):
+                self._buf[k] = None if val is None else [val[b].to(self.device) for b in range(B)]
+            self.equisized = True
+        else:
+            self.device = _canon_device(device) if device is not None else torch.device("cpu")
+
+    # ------------------------------------------------------------------ basic protocol
+    def __len__(self):
+        return len(self._n)
+
+    @property
+    def _B(self):
+        return len(self._n)
+
+    @property
+    def _N(self):
+        return max(self._n) if self._n else 0
+
+    def __getitem__(self, index):
+        if not self.has_points:
+            raise IndexError("cannot index an empty Pointclouds")
+        if isinstance(index, int):
+            ids = [index]
+        elif isinstance(index, slice):
+            ids = list(range(len(self)))[index]
+        elif isinstance(index, list):
+            ids = index
+        elif torch.is_tensor(index):
+            if index.dim() != 1 or index.dtype.is_floating_point:
+                raise IndexError(index)
+            ids = index.nonzero().flatten().tolist() if index.dtype == torch.bool else index.tolist()
+        else:
+            raise IndexError(index)
+        if len(ids) == 0:
+            raise IndexError("Incorrect indexing at dimension 0, make sure range is within 0 and %d" % len(self))
+        lists = {k: (None if self._buf[k] is None else [self._buf[k][i][: self._n[i]] for i in ids]) for k in _ATTRS}
+        return Pointclouds(lists["points"], lists["normals"], lists["colors"], lists["features"])
+
+    # ------------------------------------------------------------------ has_*
+    @property
+    def has_points(self):
+        return self._buf["points"] is not None and any(n > 0 for n in self._n)
+
+    @property
+    def has_normals(self):
+        return self._buf["normals"] is not None
+
+    @property
+    def has_colors(self):
+        return self._buf["colors"] is not None
+
+    @property
+    def has_features(self):
+        return self._buf["features"] is not None
+
+    @property
+    def num_features(self):
+        return None if not self.has_features else self._buf["features"][0].shape[-1]
+
+    @property
+    def num_points_per_pointcloud(self):
+        return torch.tensor(self._n if self._n else [0], device=self.device)
+
+    # ------------------------------------------------------------------ list / padded views
+    def _list(self, k):
+        if self._buf[k] is None:
+            return None
+        return [t[:n] for t, n in zip(self._buf[k], self._n)]
+
+    def _padded(self, k):
+        if self._buf[k] is None:
+            return None
+        if len(self._n) == 1:  # zero-copy: the one-sequence-per-GPU layout
+            return self._buf[k][0][: self._n[0]].unsqueeze(0)
+        key = (k, tuple(self._n))
+        hit = self._padded_cache.get(k)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        N, C = self._N, self._buf[k][0].shape[-1]
+        out = torch.zeros((len(self._n), N, C), dtype=self._buf[k][0].dtype, device=self.device)
+        for b, (t, n) in enumerate(zip(self._buf[k], self._n)):
+            out[b, :n] = t[:n]
+        self._padded_cache[k] = (key, out)
+        return out
+
+    points_list = property(lambda self: self._list("points"))
+    normals_list = property(lambda self: self._list("normals"))
+    colors_list = property(lambda self: self._list("colors"))
+    features_list = property(lambda self: self._list("features"))
+
+    @property
+    def points_padded(self):
+        return self._padded("points")
+
+    @property
+    def normals_padded(self):
+        return self._padded("normals")
+
+    @property
+    def colors_padded(self):
+        return self._padded("colors")
+
+    @property
+    def features_padded(self):
+        return self._padded("features")
+
+    @property
+    def nonpad_mask(self):
+        if not self._n:
+            return None
+        ar = torch.arange(self._N, device=self.device).unsqueeze(0)
+        return ar < torch.tensor(self._n, device=self.device).unsqueeze(1)
+
+    def _set_padded(self, k, value, channels=None):
+        if value is None:
+            self._buf[k] = None
+            return
+        if not torch.is_tensor(value):
+            raise TypeError("value must be torch.Tensor. Got {}".format(type(value)))
+        if not self._n:
+            raise ValueError("cannot set padded representation for an empty pointclouds object")
+        C = channels if channels is not None else value.shape[-1]
+        if value.ndim != 3 or tuple(value.shape) != (len(self._n), self._N, C):
+            raise ValueError("value must have shape {}, but had shape {}".format((len(self._n), self._N, C),
+                                                                                 tuple(value.shape)))
+        if value.device != self.device:
+            raise ValueError("value must have the same device as pointclouds object: {} != {}".format(
+                value.device, self.device))
+        self._buf[k] = [value[b, :n].clone() for b, n in enumerate(self._n)]
+        self._padded_cache.pop(k, None)
+
+    @points_padded.setter
+    def points_padded(self, value):
+        self._set_padded("points", value, 3)
+
+    @normals_padded.setter
+    def normals_padded(self, value):
+        self._set_padded("normals", value, 3)
+
+    @colors_padded.setter
+    def colors_padded(self, value):
+        self._set_padded("colors", value, 3)
+
+    @features_padded.setter
+    def features_padded(self, value):
+        self._set_padded("features", value)
+
+    # ------------------------------------------------------------------ surfel-store interface
+    # (used by gradslam_amd.slam.fusionutils; not part of the reference API)
+    def _invalidate(self):
+        self._padded_cache.clear()
+        self.equisized = (len(set(self._n)) == 1) if self._n else None
+
+    def _init_empty_batch(self, B, num_features, with_normals=True, with_colors=True):
+        """Turns an empty map into B empty sequences with the given attribute set."""
+        assert not self._n
+        self._n = [0] * B
+        mk = lambda c: [torch.empty((0, c), dtype=torch.float32, device=self.device) for _ in range(B)]  # noqa: E731
+        self._buf["points"] = mk(3)
+        self._buf["normals"] = mk(3) if with_normals else None
+        self._buf["colors"] = mk(3) if with_colors else None
+        self._buf["features"] = mk(num_features) if num_features else None
+
+    def _reserve(self, b, extra):
+        """Guarantees room for `extra` more rows in sequence b (geometric growth) and returns the
+        capacity-backed buffers (points, normals, colors, features)."""
+        need = self._n[b] + int(extra)
+        cap = self._buf["points"][b].shape[0]
+        if need > cap:
+            new_cap = max(need, int(cap * 2), 1024)
+            for k in _ATTRS:
+                if self._buf[k] is None:
+                    continue
+                old = self._buf[k][b]
+                new = torch.empty((new_cap, old.shape[-1]), dtype=old.dtype, device=self.device)
+                new[: self._n[b]] = old[: self._n[b]]
+                self._buf[k][b] = new
+            self._padded_cache.clear()
+        return tuple(None if self._buf[k] is None else self._buf[k][b] for k in _ATTRS)
+
+    def _set_count(self, b, n):
+        self._n[b] = int(n)
+        self._invalidate()
+
+    # ------------------------------------------------------------------ copies / moves
+    def clone(self):
+        other = Pointclouds(device=self.device)
+        other._n = list(self._n)
+        for k in _ATTRS:
+            other._buf[k] = None if self._buf[k] is None else [t[:n].clone() for t, n in zip(self._buf[k], self._n)]
+        other.equisized = self.equisized
+        return other
+
+    def detach(self):
+        other = Pointclouds(device=self.device)
+        other._n = list(self._n)
+        for k in _ATTRS:
+            other._buf[k] = None if self._buf[k] is None else [t.detach() for t in self._buf[k]]
+        other.equisized = self.equisized
+        return other
+
+    def to(self, device, copy: bool = False):
+        device = _canon_device(device)
+        if not copy and self.device == device:
+            return self
+        other = self.clone()
+        if self.device != device:
+            other.device = device
+            for k in _ATTRS:
+                if other._buf[k] is not None:
+                    other._buf[k] = [t.to(device) for t in other._buf[k]]
+        return other
+
+    def cpu(self):
+        return self.to(torch.device("cpu"))
+
+    def cuda(self):
+        return self.to(torch.device("cuda"))
+
+    # ------------------------------------------------------------------ append
+    def append_points(self, pointclouds: "Pointclouds"):
+        r"""Appends the points of `pointclouds` sequence-wise, in place
+        (reference: structures/pointclouds.py:1117-1237)."""
+        if not isinstance(pointclouds, type(self)):
+            raise TypeError("Append object must be of type gradslam.Pointclouds, but was of type {}.".format(
+                type(pointclouds)))
+        if not (pointclouds.device == self.device):
+            raise ValueError("Device of pointclouds to append and to be appended must match: ({0} != {1})".format(
+                pointclouds.device, self.device))
+        if not pointclouds.has_points:
+            return self
+        if self.has_points:
+            if len(pointclouds) != len(self):
+                raise ValueError("Batch size of pointclouds to append and to be appended must match: ({0} != {1})"
+                                 .format(len(pointclouds), len(self)))
+            for name in ("normals", "colors", "features"):
+                if (self._buf[name] is not None) != (pointclouds._buf[name] is not None):
+                    raise ValueError("pointclouds to append and to be appended must either both have or not have "
+                                     "{0}: ({1} != {2})".format(name, pointclouds._buf[name] is not None,
+                                                                self._buf[name] is not None))
+            if self.has_features and self.num_features != pointclouds.num_features:
+                raise ValueError("pointclouds to append and to be appended must have the same number of features: "
+                                 "({0} != {1})".format(pointclouds.num_features, self.num_features))
+            for b in range(len(self)):
+                m = pointclouds._n[b]
+                if m == 0:
+                    continue
+                self._reserve(b, m)
+                n0 = self._n[b]
+                for k in _ATTRS:
+                    if self._buf[k] is not None:
+                        self._buf[k][b][n0:n0 + m] = pointclouds._buf[k][b][:m]
+                self._n[b] = n0 + m
+        else:
+            self._n = list(pointclouds._n)
+            for k in _ATTRS:
+                src = pointclouds._buf[k]
+                self._buf[k] = None if src is None else [t[:n].clone() for t, n in zip(src, pointclouds._n)]
+        self._invalidate()
+        return self
+
+    # ------------------------------------------------------------------ rigid-body helpers
+    # Container algebra of the reference API (pointclouds.py:399-614).  The SLAM hot path does
+    # NOT go through these (projection/association is fused in the HIP kernels).
+    def _apply(self, k, fn):
+        if self._buf[k] is not None:
+            self._buf[k] = [fn(b, t[:n]) for b, (t, n) in enumerate(zip(self._buf[k], self._n))]
+            self._padded_cache.pop(k, None)
+
+    def offset_(self, offset):
+        if not (torch.is_tensor(offset) or isinstance(offset, (float, int))):
+            raise TypeError("Operand should be tensor, float or int but was %r instead" % type(offset))
+        if not self.has_points:
+            return self
+        if torch.is_tensor(offset) and offset.ndim == 3:
+            self._apply("points", lambda b, t: t + offset[b if offset.shape[0] > 1 else 0, : t.shape[0] if offset.shape[1] > 1 else 1])
+        else:
+            self._apply("points", lambda b, t: t + offset)
+        return self
+
+    def scale_(self, scale):
+        if not (torch.is_tensor(scale) or isinstance(scale, (float, int))):
+            raise TypeError("Operand should be tensor, float or int but was %r instead" % type(scale))
+        if self.has_points:
+            self._apply("points", lambda b, t: t * scale)
+        return self
+
+    def rotate_(self, rmat: torch.Tensor, *, pre_multiplication=True):
+        if not torch.is_tensor(rmat):
+            raise TypeError("Rotation matrix should be tensor, but was %r instead" % type(rmat))
+        if not ((rmat.ndim == 2 or rmat.ndim == 3) and rmat.shape[-2:] == (3, 3)):
+            raise ValueError("Rotation matrix should be of shape (3, 3) or (B, 3, 3), but was {} instead.".format(
+                rmat.shape))
+        if rmat.ndim == 3 and rmat.shape[0] != len(self):
+            raise ValueError("Rotation matrix batch size ({}) != Pointclouds batch size ({})".format(
+                rmat.shape[0], len(self)))
+        if not self.has_points:
+            return self
+        if pre_multiplication:
+            rmat = rmat.transpose(-1, -2)
+        pick = (lambda b: rmat[b]) if rmat.ndim == 3 else (lambda b: rmat)
+        self._apply("points", lambda b, t: t @ pick(b))
+        self._apply("normals", lambda b, t: t @ pick(b))
+        return self
+
+    def transform_(self, transform: torch.Tensor, *, pre_multiplication=True):
+        if not torch.is_tensor(transform):
+            raise TypeError("transform should be tensor, but was %r instead" % type(transform))
+        if not ((transform.ndim == 2 or transform.ndim == 3) and transform.shape[-2:] == (4, 4)):
+            raise ValueError("transform should be of shape (4, 4) or (B, 4, 4), but was {} instead.".format(
+                transform.shape))
+        if transform.ndim == 3 and transform.shape[0] != len(self):
+            raise ValueError("transform batch size ({}) != Pointclouds batch size ({})".format(
+                transform.shape[0], len(self)))
+        if not self.has_points:
+            return self
+        rmat, tvec = transform[..., :3, :3], transform[..., :3, 3]
+        self.rotate_(rmat, pre_multiplication=pre_multiplication)
+        pick = (lambda b: tvec[b]) if tvec.ndim == 2 else (lambda b: tvec)
+        self._apply("points", lambda b, t: t + pick(b))
+        return self
+
+    def pinhole_projection_(self, intrinsics: torch.Tensor):
+        if not torch.is_tensor(intrinsics):
+            raise TypeError("intrinsics should be tensor, but was {} instead".format(type(intrinsics)))
+        if not ((intrinsics.ndim == 2 or intrinsics.ndim == 3) and intrinsics.shape[-2:] == (4, 4)):
+            raise ValueError("intrinsics should be of shape (4, 4) or (B, 4, 4), but was {} instead.".format(
+                intrinsics.shape))
+        if not self.has_points:
+            return self
+        pick = (lambda b: intrinsics[b]) if intrinsics.ndim == 3 else (lambda b: intrinsics)
+
+        def proj(b, t):
+            K = pick(b)
+            h = torch.cat([t, torch.ones_like(t[:, :1])], -1) @ K.transpose(0, 1)
+            z = torch.where(h[:, 2:3] != 0, h[:, 2:3], torch.ones_like(h[:, 2:3]))
+            return torch.cat([h[:, :2] / z, torch.ones_like(z)], -1)
+
+        self._apply("points", proj)
+        return self
+
+    def offset(self, offset):
+        return self.clone().offset_(offset)
+
+    def scale(self, scale):
+        return self.clone().scale_(scale)
+
+    def rotate(self, rmat, *, pre_multiplication=True):
+        return self.clone().rotate_(rmat, pre_multiplication=pre_multiplication)
+
+    def transform(self, transform, *, pre_multiplication=True):
+        return self.clone().transform_(transform, pre_multiplication=pre_multiplication)
+
+    def pinhole_projection(self, intrinsics):
+        return self.clone().pinhole_projection_(intrinsics)

@@ -1,0 +1,349 @@
+"""RGB-D frame container with the interface of the reference's `gradslam.RGBDImages`
+(structures/rgbdimages.py:13-915).  The lazily evaluated maps (`vertex_map`, `normal_map`,
+`global_vertex_map`, `global_normal_map`, `valid_depth_mask`) are produced by the HIP kernels
+gs_frame_maps_f32 / gs_global_maps_f32 instead of the reference's einsum / cross / norm chains
+(rgbdimages.py:643-762); there is no PyTorch fallback for them.
+
+Layout: the kernels work on channels-last (H, W, C) frames; a channels-first container is
+converted at the kernel boundary, exactly like the reference converts before the SLAM path
+(structures/utils.py:39)."""
+from typing import Optional, Union
+
+import torch
+
+__all__ = ["RGBDImages"]
+
+
+class RGBDImages(object):
+    r"""Batch of RGB-D sequences: rgb (B, L, H, W, 3), depth (B, L, H, W, 1), intrinsics (B, 1, 4, 4)
+    and optional poses (B, L, 4, 4) (channels-first variants supported through `channels_first`)."""
+
+    _INTERNAL_TENSORS = ["_rgb_image", "_depth_image", "_intrinsics", "_poses", "_pixel_pos", "_vertex_map",
+                         "_normal_map", "_global_vertex_map", "_global_normal_map"]
+
+    def __init__(
+        self,
+        rgb_image: torch.Tensor,
+        depth_image: torch.Tensor,
+        intrinsics: torch.Tensor,
+        poses: Optional[torch.Tensor] = None,
+        channels_first: bool = False,
+        device: Union[torch.device, str, None] = None,
+        *,
+        pixel_pos: Optional[torch.Tensor] = None,
+    ):
+        if not torch.is_tensor(rgb_image):
+            raise TypeError("Expected rgb_image to be of type tensor; got {}".format(type(rgb_image)))
+        if not torch.is_tensor(depth_image):
+            raise TypeError("Expected depth_image to be of type tensor; got {}".format(type(depth_image)))
+        if not torch.is_tensor(intrinsics):
+            raise TypeError("Expected intrinsics to be of type tensor; got {}".format(type(intrinsics)))
+        if not (poses is None or torch.is_tensor(poses)):
+            raise TypeError("Expected poses to be of type tensor or None; got {}".format(type(poses)))
+        if not isinstance(channels_first, bool):
+            raise TypeError("Expected channels_first to be of type bool; got {}".format(type(channels_first)))
+        if not (pixel_pos is None or torch.is_tensor(pixel_pos)):
+            raise TypeError("Expected pixel_pos to be of type tensor or None; got {}".format(type(pixel_pos)))
+        self._channels_first = channels_first
+
+        if rgb_image.ndim != 5:
+            raise ValueError("rgb_image should have ndim=5, but had ndim={}".format(rgb_image.ndim))
+        if depth_image.ndim != 5:
+            raise ValueError("depth_image should have ndim=5, but had ndim={}".format(depth_image.ndim))
+        if intrinsics.ndim != 4:
+            raise ValueError("intrinsics should have ndim=4, but had ndim={}".format(intrinsics.ndim))
+        if poses is not None and poses.ndim != 4:
+            raise ValueError("poses should have ndim=4, but had ndim={}".format(poses.ndim))
+
+        self._rgb_image_shape = rgb_image.shape
+        self._depth_shape = tuple(v if i != self.cdim else 1 for i, v in enumerate(rgb_image.shape))
+        self._depth_image_shape = self._depth_shape
+        self._intrinsics_shape = (rgb_image.shape[0], 1, 4, 4)
+        self._poses_shape = (*rgb_image.shape[:2], 4, 4)
+        self._pixel_pos_shape = (*rgb_image.shape[: self.cdim], *rgb_image.shape[self.cdim + 1:], 3)
+
+        if rgb_image.shape[self.cdim] != 3:
+            raise ValueError("Expected rgb_image to have 3 channels on dimension {0}. Got {1} instead".format(
+                self.cdim, rgb_image.shape[self.cdim]))
+        if depth_image.shape != self._depth_shape:
+            raise ValueError("Expected depth_image to have shape {0}. Got {1} instead".format(
+                self._depth_shape, depth_image.shape))
+        if intrinsics.shape != self._intrinsics_shape:
+            raise ValueError("Expected intrinsics to have shape {0}. Got {1} instead".format(
+                self._intrinsics_shape, intrinsics.shape))
+        if poses is not None and (poses.shape != self._poses_shape):
+            raise ValueError("Expected poses to have shape {0}. Got {1} instead".format(self._poses_shape, poses.shape))
+        if pixel_pos is not None and (pixel_pos.shape != self._pixel_pos_shape):
+            raise ValueError("Expected pixel_pos to have shape {0}. Got {1} instead".format(
+                self._pixel_pos_shape, pixel_pos.shape))
+
+        devices = [x.device for x in (rgb_image, depth_image, intrinsics, poses, pixel_pos) if x is not None]
+        if len(set(devices)) != 1:
+            raise ValueError("All inputs must be on same device, but got more than 1 device: {}".format(set(devices)))
+
+        self._rgb_image = rgb_image if device is None else rgb_image.to(device)
+        self.device = self._rgb_image.device
+        self._depth_image = depth_image.to(self.device)
+        self._intrinsics = intrinsics.to(self.device)
+        self._poses = poses.to(self.device) if poses is not None else None
+        self._pixel_pos = pixel_pos.to(self.device) if pixel_pos is not None else None
+
+        self._vertex_map = None
+        self._global_vertex_map = None
+        self._normal_map = None
+        self._global_normal_map = None
+        self._valid_depth_mask = None
+        self._alpha_cache = None  # (sigma, alpha map) computed by the same kernel as the vertex map
+
+        self._B, self._L = self._rgb_image.shape[:2]
+        self.h = self._rgb_image.shape[3] if self._channels_first else self._rgb_image.shape[2]
+        self.w = self._rgb_image.shape[4] if self._channels_first else self._rgb_image.shape[3]
+        self.shape = (self._B, self._L, self.h, self.w)
+
+    # ------------------------------------------------------------------ indexing
+    def __getitem__(self, index):
+        if isinstance(index, tuple) or isinstance(index, int):
+            slices = ()
+            if isinstance(index, int):
+                slices += (slice(index, index + 1),) + (slice(None, None),)
+            elif len(index) > 2:
+                raise IndexError("Only batch and sequences can be indexed")
+            else:
+                for x in index:
+                    slices += (slice(x, x + 1),) if isinstance(x, int) else (x,)
+                if len(slices) == 1:
+                    slices += (slice(None, None),)
+            new_rgb = self._rgb_image[slices[0], slices[1]]
+            if new_rgb.shape[0] == 0:
+                raise IndexError("Incorrect indexing at dimension 0, make sure range is within 0 and {0}".format(self._B))
+            if new_rgb.shape[1] == 0:
+                raise IndexError("Incorrect indexing at dimension 1, make sure range is within 0 and {0}".format(self._L))
+            other = RGBDImages(new_rgb, self._depth_image[slices[0], slices[1]], self._intrinsics[slices[0], :],
+                               channels_first=self.channels_first)
+            for k in self._INTERNAL_TENSORS:
+                if k in ["_rgb_image", "_depth_image", "_intrinsics"]:
+                    continue
+                v = getattr(self, k)
+                if torch.is_tensor(v):
+                    setattr(other, k, v[slices[0], slices[1]])
+            return other
+        raise IndexError(index)
+
+    def __len__(self):
+        return self._B
+
+    # ------------------------------------------------------------------ plain properties
+    @property
+    def channels_first(self):
+        return self._channels_first
+
+    @property
+    def cdim(self):
+        return 2 if self.channels_first else 4
+
+    rgb_image = property(lambda self: self._rgb_image)
+    depth_image = property(lambda self: self._depth_image)
+    intrinsics = property(lambda self: self._intrinsics)
+    poses = property(lambda self: self._poses)
+    pixel_pos = property(lambda self: self._pixel_pos)
+
+    @property
+    def has_poses(self):
+        return self._poses is not None
+
+    @property
+    def valid_depth_mask(self):
+        if self._valid_depth_mask is None:
+            self._valid_depth_mask = self._depth_image > 0
+        return self._valid_depth_mask
+
+    # ------------------------------------------------------------------ HIP-backed lazy maps
+    def _cl(self, t):
+        """channels-last contiguous float32 view/copy of a (B, L, ...) image tensor."""
+        if self.channels_first:
+            t = t.permute(0, 1, 3, 4, 2)
+        return t.contiguous().float()
+
+    def _from_cl(self, t):
+        return t.permute(0, 1, 4, 2, 3).contiguous() if self.channels_first else t
+
+    def _compute_local_maps(self, sigma=None):
+        """vertex + normal (+ alpha when sigma is given) for every (b, l) frame: one kernel each."""
+        from .. import ops
+        B, L, H, W = self.shape
+        depth = self._cl(self._depth_image)
+        K = self._intrinsics.contiguous().float()
+        vm = torch.empty((B, L, H, W, 3), dtype=torch.float32, device=self.device)
+        nm = torch.empty_like(vm)
+        am = torch.empty((B, L, H, W, 1), dtype=torch.float32, device=self.device) if sigma is not None else None
+        for b in range(B):
+            for s in range(L):
+                v, n, a, _ = ops.frame_maps(depth[b, s, ..., 0], K[b, 0], 0.6 if sigma is None else sigma,
+                                            want_alpha=sigma is not None, want_valid=False)
+                vm[b, s], nm[b, s] = v, n
+                if am is not None:
+                    am[b, s, ..., 0] = a
+        self._vertex_map, self._normal_map = self._from_cl(vm), self._from_cl(nm)
+        if am is not None:
+            self._alpha_cache = (float(sigma), am)
+
+    def _alpha_map(self, sigma):
+        """(B, L, H, W, 1) sample confidence exp(-|v|^2 / 2 sigma^2) of the local vertex map
+        (slam/fusionutils.py:657), channels-last."""
+        sigma = float(sigma)
+        if self._alpha_cache is None or self._alpha_cache[0] != sigma or self._vertex_map is None:
+            self._compute_local_maps(sigma)
+        return self._alpha_cache[1]
+
+    @property
+    def vertex_map(self):
+        if self._vertex_map is None:
+            self._compute_local_maps()
+        return self._vertex_map
+
+    @property
+    def normal_map(self):
+        if self._normal_map is None:
+            self._compute_local_maps()
+        return self._normal_map
+
+    def _compute_global_maps(self):
+        from .. import ops
+        B, L, H, W = self.shape
+        vm, nm = self._cl(self.vertex_map), self._cl(self.normal_map)
+        if self._poses is None:
+            self._global_vertex_map, self._global_normal_map = self.vertex_map.clone(), self.normal_map.clone()
+            return
+        depth = self._cl(self._depth_image)
+        poses = self._poses.contiguous().float()
+        gv, gn = torch.empty_like(vm), torch.empty_like(nm)
+        for b in range(B):
+            for s in range(L):
+                gv[b, s], gn[b, s] = ops.global_maps(vm[b, s], nm[b, s], depth[b, s, ..., 0], poses[b, s])
+        self._global_vertex_map, self._global_normal_map = self._from_cl(gv), self._from_cl(gn)
+
+    @property
+    def global_vertex_map(self):
+        if self._global_vertex_map is None:
+            self._compute_global_maps()
+        return self._global_vertex_map
+
+    @property
+    def global_normal_map(self):
+        if self._global_normal_map is None:
+            self._compute_global_maps()
+        return self._global_normal_map
+
+    # ------------------------------------------------------------------ setters (cache rules of
+    # the reference: rgbdimages.py:399-463)
+    @staticmethod
+    def _assert_shape(value, shape):
+        if not torch.is_tensor(value):
+            raise TypeError("value must be torch.Tensor. Got {}".format(type(value)))
+        if tuple(value.shape) != tuple(shape):
+            raise ValueError("value must have shape {0}. Got {1} instead".format(tuple(shape), tuple(value.shape)))
+
+    @rgb_image.setter
+    def rgb_image(self, value):
+        if value is not None:
+            self._assert_shape(value, self._rgb_image_shape)
+        self._rgb_image = value
+
+    def _drop_local(self):
+        self._vertex_map = self._normal_map = self._alpha_cache = None
+        self._global_vertex_map = self._global_normal_map = None
+
+    @depth_image.setter
+    def depth_image(self, value):
+        if value is not None:
+            self._assert_shape(value, self._depth_image_shape)
+        self._depth_image = value
+        self._valid_depth_mask = None
+        self._drop_local()
+
+    @intrinsics.setter
+    def intrinsics(self, value):
+        if value is not None:
+            self._assert_shape(value, self._intrinsics_shape)
+        self._intrinsics = value
+        self._drop_local()
+
+    @poses.setter
+    def poses(self, value):
+        if value is not None:
+            self._assert_shape(value, self._poses_shape)
+        self._poses = value
+        self._global_vertex_map = None
+        self._global_normal_map = None
+
+    # ------------------------------------------------------------------ copies / moves / layout
+    def detach(self):
+        other = self.clone()
+        for k in self._INTERNAL_TENSORS:
+            v = getattr(self, k)
+            if torch.is_tensor(v):
+                setattr(other, k, v.detach())
+        return other
+
+    def clone(self):
+        other = RGBDImages(self._rgb_image.clone(), self._depth_image.clone(), self._intrinsics.clone(),
+                           channels_first=self.channels_first)
+        for k in self._INTERNAL_TENSORS:
+            if k in ["_rgb_image", "_depth_image", "_intrinsics"]:
+                continue
+            v = getattr(self, k)
+            if torch.is_tensor(v):
+                setattr(other, k, v.clone())
+        return other
+
+    def to(self, device, copy: bool = False):
+        device = torch.Tensor().to(device).device
+        if not copy and self.device == device:
+            return self
+        other = self.clone()
+        other.device = device
+        for k in self._INTERNAL_TENSORS:
+            v = getattr(self, k)
+            if torch.is_tensor(v):
+                setattr(other, k, v.to(device))
+        return other
+
+    def cpu(self):
+        return self.to(torch.device("cpu"))
+
+    def cuda(self):
+        return self.to(torch.device("cuda"))
+
+    def to_channels_last(self, copy: bool = False):
+        if not (copy or self.channels_first):
+            return self
+        return self.clone().to_channels_last_()
+
+    def to_channels_first(self, copy: bool = False):
+        if not copy and self.channels_first:
+            return self
+        return self.clone().to_channels_first_()
+
+    def _permute_all(self, ordering):
+        for k in ("_rgb_image", "_depth_image", "_vertex_map", "_global_vertex_map", "_normal_map",
+                  "_global_normal_map"):
+            v = getattr(self, k)
+            if v is not None:
+                setattr(self, k, v.permute(*ordering).contiguous())
+        self._valid_depth_mask = None
+        self._rgb_image_shape = tuple(self._rgb_image.shape)
+        self._depth_image_shape = tuple(self._depth_image.shape)
+
+    def to_channels_last_(self):
+        if not self.channels_first:
+            return self
+        self._permute_all((0, 1, 3, 4, 2))
+        self._channels_first = False
+        return self
+
+    def to_channels_first_(self):
+        if self.channels_first:
+            return self
+        self._permute_all((0, 1, 4, 2, 3))
+        self._channels_first = True
+        return self

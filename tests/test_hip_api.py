@@ -1,0 +1,228 @@
+"""GPU tests of the drop-in Python API (gradslam_amd.RGBDImages / Pointclouds / slam.*): the
+same calls a gradslam user makes, checked against the golden vectors recorded from the real
+reference and against the oracle's frame loop."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from gradslam_amd.datasets.synthetic import make_sequence
+from oracle import oracle as o
+from oracle import slam as oslam
+from tests.conftest import ate
+
+pytestmark = pytest.mark.gpu
+
+DIST_TH, DOT_TH, SIGMA = 0.05, math.cos(20 * math.pi / 180), 0.6
+T = torch.from_numpy
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def gs():
+    assert torch.cuda.is_available()
+    import gradslam_amd
+    return gradslam_amd
+
+
+def msrd_frames(gs, g, channels_first=False):
+    colors, depths = T(g["colors"][None]).cuda(), T(g["depths"][None]).cuda()
+    if channels_first:
+        colors, depths = colors.permute(0, 1, 4, 2, 3).contiguous(), depths.permute(0, 1, 4, 2, 3).contiguous()
+    return gs.RGBDImages(colors, depths, T(g["intrinsics"][None, None]).cuda(), T(g["poses"][None]).cuda(),
+                         channels_first=channels_first)
+
+
+@pytest.mark.parametrize("channels_first", [False, True])
+def test_rgbdimages_lazy_maps_match_reference(gs, golden, channels_first):
+    g = golden("msrd_b0")
+    r = msrd_frames(gs, g, channels_first)
+    perm = (lambda t: t.permute(0, 1, 3, 4, 2)) if channels_first else (lambda t: t)
+    for prop, key in (("vertex_map", "vertex_map"), ("normal_map", "normal_map"),
+                      ("global_vertex_map", "global_vertex_map"), ("global_normal_map", "global_normal_map")):
+        assert np.array_equal(host(perm(getattr(r, prop)))[0], g[key]), prop
+    assert np.array_equal(host(perm(r.valid_depth_mask))[0], g["depths"] > 0)
+    # cache rules: new poses drop only the global maps
+    v_before = r.vertex_map
+    r.poses = r.poses.clone()
+    assert r._global_vertex_map is None and r.vertex_map is v_before
+    # slicing keeps cached maps
+    sub = r[:, 1]
+    assert sub.shape[1] == 1 and np.array_equal(host(perm(sub.vertex_map))[0, 0], g["vertex_map"][1])
+
+
+def test_fusionutils_tables_match_reference(gs, golden):
+    from gradslam_amd.slam import fusionutils as fu
+    g = golden("msrd_b0")
+    r = msrd_frames(gs, g)
+    f0, f1 = r[:, 0], r[:, 1]
+    pc0 = fu.update_map_fusion(gs.Pointclouds(device="cuda"), f0, DIST_TH, DOT_TH, SIGMA)
+    assert np.array_equal(host(pc0.points_list[0]), g["map0_points"])
+    assert np.array_equal(host(pc0.normals_list[0]), g["map0_normals"])
+    assert np.array_equal(host(pc0.colors_list[0]), g["map0_colors"])
+    np.testing.assert_allclose(host(pc0.features_list[0]), g["map0_ccounts"], rtol=2e-7)
+    # use the reference's own map (its ccounts differ from ours by <= 1 ulp through exp) for exact tables
+    pc = gs.Pointclouds(points=[T(g["map0_points"]).cuda()], normals=[T(g["map0_normals"]).cuda()],
+                        colors=[T(g["map0_colors"]).cuda()], features=[T(g["map0_ccounts"]).cuda()])
+    act = fu.find_active_map_points(pc, f1)
+    assert act.dtype == torch.int64 and np.array_equal(host(act), g["active"])
+    sim, mask = fu.find_similar_map_points(pc, f1, act, DIST_TH, DOT_TH)
+    assert np.array_equal(host(mask), g["similar_mask"]) and np.array_equal(host(sim), g["similar"])
+    uq = fu.find_best_unique_correspondences(pc, f1, sim)
+    assert np.array_equal(host(uq), g["unique"])
+    assert np.array_equal(host(fu.find_correspondences(pc, f1, DIST_TH, DOT_TH)), g["unique"])
+    # fuse_with_map: alpha of frame 1 comes from our exp -> 1-ulp tolerance on merged values
+    fused = fu.fuse_with_map(pc, f1, uq, SIGMA)
+    assert fused.points_list[0].shape[0] == g["map1_points"].shape[0]
+    np.testing.assert_allclose(host(fused.points_list[0]), g["map1_points"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(host(fused.normals_list[0]), g["map1_normals"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(host(fused.colors_list[0]), g["map1_colors"], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(host(fused.features_list[0]), g["map1_ccounts"], rtol=1e-6)
+    # reference quirk kept: the input map is merged in place even with inplace=False, but not grown
+    assert pc.points_list[0].shape[0] == g["map0_points"].shape[0]
+    np.testing.assert_allclose(host(pc.points_list[0]), g["map1_points"][: g["map0_points"].shape[0]], rtol=1e-6,
+                               atol=1e-7)
+    # down-samplers (odometry/icputils.py)
+    from gradslam_amd.odometry import icputils
+    pc_ref = gs.Pointclouds(points=[T(g["map0_points"]).cuda()], normals=[T(g["map0_normals"]).cuda()])
+    ds = icputils.downsample_pointclouds(pc_ref, act, 4)
+    assert np.array_equal(host(ds.points_list[0]), g["ds4_map_points"])
+    dsf = icputils.downsample_rgbdimages(f1, 4)
+    assert np.array_equal(host(dsf.points_list[0]), g["ds4_frame_points"])
+    assert np.array_equal(host(dsf.normals_list[0]), g["ds4_frame_normals"])
+
+
+def test_fusion_kat_through_the_api(gs, golden):
+    """Mirror of tests/slam/test_fusionutils.py:672-750 / :918-986 of the reference."""
+    from gradslam_amd.slam import fusionutils as fu
+    g = golden("fusion_kat")
+    pcs = gs.Pointclouds(points=T(g["points"])[None].cuda(), normals=T(g["normals"])[None].cuda(),
+                         colors=T(g["colors"])[None].cuda(), features=T(g["ccounts"])[None].cuda())
+    fr = gs.RGBDImages(T(g["rgb"])[None, None].cuda(), T(g["depth"])[None, None].cuda(),
+                       T(g["intrinsics"])[None, None].cuda(), T(g["pose"])[None, None].cuda())
+    uq = fu.find_best_unique_correspondences(pcs, fr, T(g["rows"]).cuda())
+    assert np.array_equal(host(uq), g["unique"])
+    fused = fu.fuse_with_map(pcs.clone(), fr, uq, float(g["sigma"]))
+    np.testing.assert_allclose(host(fused.points_list[0]), g["fused_points"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(host(fused.features_list[0]), g["fused_ccounts"], rtol=1e-6, atol=1e-9)
+    fused0 = fu.fuse_with_map(pcs.clone(), fr, torch.empty((0, 4), dtype=torch.int64, device="cuda"), float(g["sigma"]))
+    np.testing.assert_allclose(host(fused0.points_list[0]), g["fused0_points"], rtol=1e-6, atol=1e-6)
+    a = fu.get_alpha(T(g["points"]).cuda()[None], float(g["sigma"]), keepdim=True)
+    assert a.shape == (1, 8, 1)
+    pts = T(g["points"]).cuda()
+    close = fu.are_points_close(pts, pts + 0.01, 0.05)
+    assert close.all() and not fu.are_points_close(pts, pts + 1.0, 0.05).any()
+    nr = T(g["normals"]).cuda()
+    assert fu.are_normals_similar(nr, nr, 0.9).all() and not fu.are_normals_similar(nr, -nr, 0.9).any()
+
+
+def test_icputils_api(gs, golden):
+    from gradslam_amd.odometry import icputils
+    from gradslam_amd.odometry.icp import GradICPOdometryProvider, ICPOdometryProvider
+    g = golden("icp_unit")
+    src, tgt, tn = (T(g[k]).cuda() for k in ("src", "tgt", "tgt_normals"))
+    A, b, idx = icputils.gauss_newton_solve(src[None], tgt[None], tn[None])
+    assert np.array_equal(host(A), g["gn_A"]) and np.array_equal(host(b), g["gn_b"]) and np.array_equal(host(idx), g["gn_idx"])
+    A2, b2, idx2 = icputils.gauss_newton_solve(src[None], tgt[None], tn[None], float(g["gn_thr"]))
+    assert np.array_equal(host(A2), g["gn_thr_A"]) and np.array_equal(host(idx2), g["gn_thr_idx"])
+    x = icputils.solve_linear_system(T(g["kat_A"]).cuda(), T(g["kat_b"]).cuda(), 1e-8)
+    assert x.shape == (4, 1)
+    np.testing.assert_allclose(g["kat_A"] @ host(x), g["kat_b"], rtol=1e-4, atol=1e-4)
+    eye = torch.eye(4, device="cuda")
+    Ti, _ = icputils.point_to_plane_ICP(src[None], tgt[None], tn[None], eye, numiters=20)
+    Tg, _ = icputils.point_to_plane_gradICP(src[None], tgt[None], tn[None], eye, numiters=20)
+    np.testing.assert_allclose(host(Ti), g["icp20_T"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(host(Tg), g["gradicp20_T"], atol=2e-5, rtol=0)
+    with pytest.raises(AttributeError):  # the reference's documented-but-broken None default (icputils.py:298)
+        icputils.point_to_plane_ICP(src[None], tgt[None], tn[None], None)
+    maps_pc, frames_pc = gs.Pointclouds(points=[tgt], normals=[tn]), gs.Pointclouds(points=[src])
+    for prov, key in ((ICPOdometryProvider(20), "icp20_T"), (GradICPOdometryProvider(20), "gradicp20_T")):
+        out = prov.provide(maps_pc, frames_pc)
+        assert out.shape == (1, 1, 4, 4)
+        np.testing.assert_allclose(host(out[0, 0]), g[key], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("key,cls,odom", [("pf_gradicp", "PointFusion", "gradicp"), ("pf_icp", "PointFusion", "icp"),
+                                          ("pf_gt", "PointFusion", "gt"), ("icpslam_gradicp", "ICPSLAM", "gradicp")])
+def test_slam_sequences_vs_reference_and_oracle(gs, golden, key, cls, odom):
+    """Config C1 (64x64x3): poses within ATE 1e-4 m of the reference, same map size, coordinates
+    within 1e-5; and against the oracle's loop on the same inputs."""
+    g = golden("synth64")
+    poses = g["poses"].copy()
+    if odom != "gt":
+        poses[1:] = poses[:1]
+    frames = gs.RGBDImages(T(g["colors"][None]).cuda(), T(g["depths"][None]).cuda(),
+                           T(g["intrinsics"][None, None]).cuda(), T(poses[None]).cuda())
+    slam = getattr(gs.slam, cls)(odom=odom, device="cuda")
+    pc, rp = slam(frames)
+    rp = host(rp)[0]
+    assert rp.shape == (3, 4, 4)
+    assert ate(rp, g[key + "_poses"]) <= 1e-4
+    np.testing.assert_allclose(rp, g[key + "_poses"], rtol=0, atol=2e-5)
+    assert pc.points_list[0].shape[0] == g[key + "_points"].shape[0]
+    np.testing.assert_allclose(host(pc.points_list[0]), g[key + "_points"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(pc.normals_list[0]), g[key + "_normals"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(pc.colors_list[0]), g[key + "_colors"], rtol=1e-4, atol=1e-2)
+    m, op = oslam.run_sequence(g["colors"], g["depths"], g["intrinsics"], poses,
+                               slam="pointfusion" if cls == "PointFusion" else "icpslam", odom=odom)
+    np.testing.assert_allclose(rp, op, rtol=0, atol=2e-6)
+    assert len(m) == pc.points_list[0].shape[0]
+    if odom == "gt":  # no ICP in the loop: the whole map must be bit-identical to the oracle's
+        assert np.array_equal(host(pc.points_list[0]), m.points)
+        assert np.array_equal(host(pc.features_list[0]), m.ccounts)
+
+
+def test_batch_of_two_sequences(gs):
+    """B=2 on one GPU: sequences are independent; each must equal its own single-sequence run."""
+    seqs = [make_sequence(3, 48, 64, seed=s) for s in (21, 22)]
+    stack = lambda k: T(np.stack([s[k] for s in seqs])).cuda()  # noqa: E731
+    poses = stack("poses")
+    poses[:, 1:] = poses[:, :1]
+    frames = gs.RGBDImages(stack("colors"), stack("depths"), stack("intrinsics")[:, None][:, :, 0], poses)
+    pc, rp = gs.slam.PointFusion(odom="gradicp", device="cuda")(frames)
+    assert len(pc) == 2 and rp.shape == (2, 3, 4, 4)
+    for b, s in enumerate(seqs):
+        p = s["poses"].copy()
+        p[1:] = p[:1]
+        m, op = oslam.run_sequence(s["colors"], s["depths"], s["intrinsics"][0], p)
+        np.testing.assert_allclose(host(rp[b]), op, rtol=0, atol=2e-6)
+        assert pc.points_list[b].shape[0] == len(m)
+        np.testing.assert_allclose(host(pc.points_list[b]), m.points, rtol=1e-5, atol=1e-5)
+    pad = pc.points_padded
+    assert pad.shape[0] == 2 and pad.shape[1] == max(pc._n)
+    assert bool((pad[pc.nonpad_mask.logical_not()] == 0).all())
+
+
+def test_sequence_120_vs_reference(gs, golden):
+    g = golden("synth120")
+    s = make_sequence(4, 120, 160, seed=int(g["colors_seed"]))
+    poses = g["poses"].copy()
+    poses[1:] = poses[:1]
+    frames = gs.RGBDImages(T(s["colors"][None]).cuda(), T(g["depths"][None]).cuda(),
+                           T(g["intrinsics"][None, None]).cuda(), T(poses[None]).cuda())
+    pc, rp = gs.slam.PointFusion(device="cuda")(frames)
+    assert ate(host(rp)[0], g["pf_gradicp_poses"]) <= 1e-4
+    assert pc.points_list[0].shape[0] == int(g["pf_gradicp_count"])
+    np.testing.assert_allclose(host(pc.points_list[0]).astype(np.float64).sum(0), g["pf_gradicp_points_sum"], rtol=1e-5)
+
+
+def test_step_api_and_growth(gs):
+    """ICPSLAM.step as documented (slam/icpslam.py:140-178) + geometric capacity growth."""
+    s = make_sequence(6, 48, 64, seed=9)
+    frames = gs.RGBDImages(T(s["colors"][None]).cuda(), T(s["depths"][None]).cuda(),
+                           T(s["intrinsics"][None]).cuda(), T(s["poses"][None]).cuda())
+    slam = gs.slam.PointFusion(odom="gt", device="cuda")
+    pc = gs.Pointclouds(device="cuda")
+    counts = []
+    for t in range(6):
+        pc, poses = slam.step(pc, frames[:, t], None, inplace=True)
+        assert poses.shape == (1, 1, 4, 4)
+        counts.append(pc.points_list[0].shape[0])
+    assert all(b >= a for a, b in zip(counts, counts[1:])) and counts[-1] > counts[0]
+    pc2 = pc.clone()
+    assert torch.equal(pc2.points_padded, pc.points_padded) and pc2.points_list[0].data_ptr() != pc.points_list[0].data_ptr()
+    assert pc.cpu().device.type == "cpu"
