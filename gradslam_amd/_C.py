@@ -29,6 +29,9 @@ _PROTOS = {
     "gs_abi_version": [],
     "gs_last_error": [],
     "gs_scratch_bytes": [_i64, _i64],
+    "gs_profile_begin": [_i32],
+    "gs_profile_end": [],
+    "gs_profile_read": [_i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)],
     "gs_frame_maps_f32": [_vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp],
     "gs_global_maps_f32": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gs_alpha_f32": [_vp, _i64, _f, _f, _vp, _vp],

@@ -71,6 +71,7 @@ extern "C" int gs_project_map_f32(const float* points, int64_t n_map, const floa
   GS_REQUIRE(points && pose16 && K16 && pix, "NULL pointer");
   GS_REQUIRE((int64_t)H * W < (1ll << 31), "image too large for int32 pixel ids");
   const float u_hi = (float)((double)W - 0.999), v_hi = (float)((double)H - 0.999);
+  GsProf prof(GS_PROF_PROJECT, 16.0 * (double)n_map, gs_stream(stream));  // 12 B point read + 4 B pix write
   hipLaunchKernelGGL(gs_project_map_kernel, dim3((unsigned)gs_ceil_div(n_map, 256)), dim3(256), 0,
                      gs_stream(stream), points, n_map, pose16, K16, H, W, u_hi, v_hi, pix);
   GS_LAUNCH_CHECK();
@@ -379,6 +380,9 @@ extern "C" int gs_associate_f32(const int32_t* pix, int64_t n_map, const float* 
   char* base = reinterpret_cast<char*>(scratch) + gs_cp_scratch_bytes(P > n_map ? P : n_map);
   uint64_t* key_pix = reinterpret_cast<uint64_t*>(base);
   uint64_t* key_pt = reinterpret_cast<uint64_t*>(base + gs_align(8 * (size_t)P));
+  // 4 launches: map rows 4+12+12+4 B read, 8 B key write, 4+8 B re-read; frame gathers 24 B per
+  // active point (counted as all points); per pixel 12 B init + 8 B key + 8 B winner traffic
+  GsProf prof(GS_PROF_ASSOC, 76.0 * (double)n_map + 28.0 * (double)P, st);
   hipLaunchKernelGGL(gs_fill_u64_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, key_pix, P, ~0ull);
   hipLaunchKernelGGL(gs_fill_i32_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, best_pix, P, 0x7fffffff);
   if (n_map > 0) {

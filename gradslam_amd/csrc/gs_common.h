@@ -40,6 +40,25 @@ static inline hipStream_t gs_stream(void* s) { return reinterpret_cast<hipStream
 static inline int64_t gs_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t gs_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// ---------------------------------------------------------------- in-library timing ----
+// Optional HIP-event timing of kernel launches on the stream they are launched on (bench.py's
+// roofline line).  Disabled by default: a GsProf scope is then two predictable branches.
+enum GsProfKind { GS_PROF_KNN = 0, GS_PROF_LINEARIZE = 1, GS_PROF_FRAME = 2, GS_PROF_PROJECT = 3,
+                  GS_PROF_ASSOC = 4, GS_PROF_FUSE = 5, GS_PROF_COMPACT = 6, GS_PROF_SOLVE = 7, GS_PROF_KINDS = 8 };
+extern bool g_gs_prof_on;
+int gs_prof_open(int kind, double work, hipStream_t st);
+void gs_prof_close(int slot, hipStream_t st);
+struct GsProf {
+  int slot;
+  hipStream_t st;
+  GsProf(int kind, double work, hipStream_t s) : slot(-1), st(s) {
+    if (g_gs_prof_on) slot = gs_prof_open(kind, work, s);
+  }
+  ~GsProf() {
+    if (slot >= 0) gs_prof_close(slot, st);
+  }
+};
+
 // ---------------------------------------------------------------- device math ----------
 #define GS_DEV __device__ __forceinline__
 

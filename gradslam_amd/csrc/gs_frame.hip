@@ -17,6 +17,60 @@ void gs_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- optional kernel timing (see gs_common.h) ----
+#include <vector>
+bool g_gs_prof_on = false;
+namespace {
+struct ProfRec { hipEvent_t a, b; int kind; double work; bool closed; };
+std::vector<ProfRec> g_prof;
+size_t g_prof_used = 0;
+double g_prof_ms[GS_PROF_KINDS], g_prof_work[GS_PROF_KINDS];
+int64_t g_prof_n[GS_PROF_KINDS];
+}  // namespace
+
+int gs_prof_open(int kind, double work, hipStream_t st) {
+  if (g_prof_used >= g_prof.size()) return -1;
+  ProfRec& r = g_prof[g_prof_used];
+  r.kind = kind; r.work = work; r.closed = false;
+  if (hipEventRecord(r.a, st) != hipSuccess) return -1;
+  return (int)g_prof_used++;
+}
+void gs_prof_close(int slot, hipStream_t st) {
+  if (hipEventRecord(g_prof[slot].b, st) == hipSuccess) g_prof[slot].closed = true;
+}
+
+extern "C" int gs_profile_begin(int max_records) {
+  GS_REQUIRE(max_records > 0 && max_records <= (1 << 20), "max_records out of range");
+  while (g_prof.size() < (size_t)max_records) {
+    ProfRec r;
+    GS_HIP(hipEventCreate(&r.a));
+    GS_HIP(hipEventCreate(&r.b));
+    r.kind = 0; r.work = 0; r.closed = false;
+    g_prof.push_back(r);
+  }
+  g_prof_used = 0;
+  for (int k = 0; k < GS_PROF_KINDS; ++k) { g_prof_ms[k] = 0; g_prof_work[k] = 0; g_prof_n[k] = 0; }
+  g_gs_prof_on = true;
+  return GS_OK;
+}
+extern "C" int gs_profile_end(void) {
+  g_gs_prof_on = false;
+  GS_HIP(hipDeviceSynchronize());
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    const ProfRec& r = g_prof[i];
+    if (!r.closed) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    g_prof_ms[r.kind] += ms; g_prof_work[r.kind] += r.work; g_prof_n[r.kind] += 1;
+  }
+  return GS_OK;
+}
+extern "C" int gs_profile_read(int kind, double* ms_total, int64_t* launches, double* work_total) {
+  GS_REQUIRE(kind >= 0 && kind < GS_PROF_KINDS && ms_total && launches && work_total, "bad arguments");
+  *ms_total = g_prof_ms[kind]; *launches = g_prof_n[kind]; *work_total = g_prof_work[kind];
+  return GS_OK;
+}
+
 extern "C" int gs_abi_version(void) { return GS_ABI_VERSION; }
 extern "C" const char* gs_last_error(void) { return g_err; }
 
@@ -141,6 +195,8 @@ extern "C" int gs_frame_maps_f32(const float* depth, const float* K16, int H, in
   GS_REQUIRE(depth && K16, "depth and K16 must not be NULL");
   GS_REQUIRE(H >= 2 && W >= 2, "image must be at least 2x2");
   dim3 grid((unsigned)gs_ceil_div(W, FM_TW), (unsigned)gs_ceil_div(H, FM_TH));
+  const double bytes = (double)H * W * (4.0 + (vertex ? 12 : 0) + (normal ? 12 : 0) + (alpha ? 4 : 0) + (valid ? 1 : 0));
+  GsProf prof(GS_PROF_FRAME, bytes, gs_stream(stream));
   hipLaunchKernelGGL(gs_frame_maps_kernel, grid, dim3(256), 0, gs_stream(stream), depth, K16, H, W,
                      two_sigma_sq, vertex, normal, alpha, valid);
   GS_LAUNCH_CHECK();
@@ -187,6 +243,7 @@ extern "C" int gs_global_maps_f32(const float* vertex, const float* normal, cons
     if (gnormal) GS_HIP(hipMemcpyAsync(gnormal, normal, P * 12, hipMemcpyDeviceToDevice, st));
     return GS_OK;
   }
+  GsProf prof(GS_PROF_FRAME, (double)P * (4.0 + (gvertex ? 24 : 0) + (gnormal ? 24 : 0)), st);
   hipLaunchKernelGGL(gs_global_maps_kernel, dim3((unsigned)gs_ceil_div(P, 256)), dim3(256), 0, st,
                      vertex, normal, depth, pose16, P, gvertex, gnormal);
   GS_LAUNCH_CHECK();

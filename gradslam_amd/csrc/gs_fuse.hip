@@ -97,6 +97,8 @@ extern "C" int gs_fuse_append_f32(float* points, float* normals, float* colors, 
   char* base = reinterpret_cast<char*>(scratch) + gs_cp_scratch_bytes(P > n_map ? P : n_map);
   int32_t* any_flag = reinterpret_cast<int32_t*>(base);
   int32_t* pix_of = reinterpret_cast<int32_t*>(base + 256);
+  // parity mode rewrites every row (2 x 40 B) + 8 B pix_of traffic; appended pixels 40 B + 40 B
+  GsProf prof(GS_PROF_FUSE, 88.0 * (double)n_map + 45.0 * (double)P, st);
   if (n_map > 0) {
     GS_HIP(hipMemsetAsync(any_flag, 0, 4, st));
     hipLaunchKernelGGL(gs_fill_i32_kernel2, dim3((unsigned)gs_ceil_div(n_map, 256)), dim3(256), 0, st,

@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) gs_knn1_kernel(
 static int knn_launch(const float* src_in, const float* Tapply, float* src_out, int64_t n_src,
                       const float* tgt, int64_t n_tgt, unsigned long long* best, hipStream_t st) {
   dim3 grid((unsigned)gs_ceil_div(n_src, KNN_STILE), (unsigned)gs_ceil_div(n_tgt, KNN_TCHUNK));
+  GsProf prof(GS_PROF_KNN, (double)n_src * (double)n_tgt, st);  // work unit: pair distances
   hipLaunchKernelGGL(gs_knn1_kernel, grid, dim3(KNN_BLOCK), 0, st, src_in, Tapply, src_out, n_src, tgt,
                      n_tgt, best);
   return GS_OK;
@@ -611,15 +612,27 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
   for (int it = 0; it < prm->numiters; ++it) {
     // apply the pending transform (initial transform or last T_step) while searching
     knn_launch(cur_in, sc.state->T_step, cur, n_src, tgt, n_tgt, sc.best, st);
-    hipLaunchKernelGGL((gs_icp_linearize_kernel<true>), dim3(nblk), dim3(LIN_BLOCK), 0, st, cur, nullptr, n_src,
-                       tgt, tgt_normals, sc.best, prm->dist_thresh, sc.partials, out_idx);
-    hipLaunchKernelGGL(gs_icp_solve_kernel, dim3(1), dim3(64), 0, st, sc.partials, nblk, sc.state);
+    {
+      GsProf prof(GS_PROF_LINEARIZE, 44.0 * (double)n_src, st);  // 8 B best + 12 B src + 24 B gather
+      hipLaunchKernelGGL((gs_icp_linearize_kernel<true>), dim3(nblk), dim3(LIN_BLOCK), 0, st, cur, nullptr, n_src,
+                         tgt, tgt_normals, sc.best, prm->dist_thresh, sc.partials, out_idx);
+    }
+    {
+      GsProf prof(GS_PROF_SOLVE, 1.0, st);
+      hipLaunchKernelGGL(gs_icp_solve_kernel, dim3(1), dim3(64), 0, st, sc.partials, nblk, sc.state);
+    }
     // look-ahead: one_step = Tr * cur, searched and reduced without materialising it
     knn_launch(cur, sc.state->Tr, nullptr, n_src, tgt, n_tgt, sc.best, st);
-    hipLaunchKernelGGL((gs_icp_linearize_kernel<false>), dim3(nblk), dim3(LIN_BLOCK), 0, st, cur,
-                       sc.state->Tr, n_src, tgt, tgt_normals, sc.best, prm->dist_thresh, sc.partials, nullptr);
-    hipLaunchKernelGGL(gs_icp_update_kernel, dim3(1), dim3(64), 0, st, sc.partials, nblk, sc.state, *prm, it,
-                       compose16, out_T16);
+    {
+      GsProf prof(GS_PROF_LINEARIZE, 44.0 * (double)n_src, st);
+      hipLaunchKernelGGL((gs_icp_linearize_kernel<false>), dim3(nblk), dim3(LIN_BLOCK), 0, st, cur,
+                         sc.state->Tr, n_src, tgt, tgt_normals, sc.best, prm->dist_thresh, sc.partials, nullptr);
+    }
+    {
+      GsProf prof(GS_PROF_SOLVE, 1.0, st);
+      hipLaunchKernelGGL(gs_icp_update_kernel, dim3(1), dim3(64), 0, st, sc.partials, nblk, sc.state, *prm, it,
+                         compose16, out_T16);
+    }
     cur_in = cur;
     float* t = cur; cur = other; other = t;
   }

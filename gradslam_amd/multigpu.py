@@ -1,0 +1,91 @@
+"""One process per GPU: independent RGB-D sequences shard across ranks.
+
+Sequences of a batch never exchange data (the reference loops `for b in range(B)`,
+odometry/icp.py:84), so the data path needs NO collective: rank r runs the sequences
+`shard_sequences(B, world, r)` on its own MI355X.  The only exchange is the final gather of the
+recovered poses (64 B per frame) and, optionally, the maps (~40 B per surfel), done once with
+torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests):
+an all_gather of per-rank counts followed by one padded all_gather per attribute.
+"""
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .structures.pointclouds import Pointclouds
+
+__all__ = ["init_from_env", "shard_sequences", "gather_poses", "gather_maps"]
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Initialises torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
+    Returns (rank, world, local_rank); a no-op single-process setup when WORLD_SIZE is unset."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_sequences(num_sequences: int, world: int, rank: int) -> List[int]:
+    """Indices of the sequences rank `rank` owns: contiguous blocks, sizes differ by at most one."""
+    if num_sequences < 0 or world < 1 or not (0 <= rank < world):
+        raise ValueError("bad shard request: B={} world={} rank={}".format(num_sequences, world, rank))
+    base, rem = divmod(num_sequences, world)
+    start = rank * base + min(rank, rem)
+    return list(range(start, start + base + (1 if rank < rem else 0)))
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _gather_rows(t: torch.Tensor) -> List[torch.Tensor]:
+    """all_gather of a (n_r, ...) tensor whose first dimension differs per rank."""
+    world = _world()
+    if world == 1:
+        return [t]
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    padded = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    padded[: t.shape[0]] = t
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded)
+    return [o[:c] for o, c in zip(out, counts)]
+
+
+def gather_poses(local_poses: torch.Tensor) -> torch.Tensor:
+    """(B_local, L, 4, 4) on every rank -> (B_total, L, 4, 4) in rank order on every rank."""
+    return torch.cat(_gather_rows(local_poses.contiguous()), 0)
+
+
+def gather_maps(pointclouds: Pointclouds) -> Pointclouds:
+    """Every rank's local maps -> one Pointclouds holding all sequences (rank order), on every rank.
+    Variable sizes are handled by flattening each attribute to (sum_b n_b, C) plus a count vector."""
+    dev = pointclouds.device
+    counts = torch.tensor(pointclouds._n, dtype=torch.int64, device=dev).reshape(-1)
+    all_counts = torch.cat(_gather_rows(counts), 0).tolist()
+    lists = {}
+    for k in ("points", "normals", "colors", "features"):
+        src = getattr(pointclouds, k + "_list")
+        has = torch.tensor([0 if src is None else src[0].shape[-1]], dtype=torch.int64, device=dev)
+        width = max(int(w.item()) for w in _gather_rows(has))
+        if width == 0:
+            lists[k] = None
+            continue
+        flat = (torch.cat(src, 0) if src is not None and len(src) else
+                torch.zeros((0, width), dtype=torch.float32, device=dev))
+        flat_all = torch.cat(_gather_rows(flat.contiguous()), 0)
+        lists[k] = list(torch.split(flat_all, all_counts, 0))
+    if not all_counts:
+        return Pointclouds(device=dev)
+    return Pointclouds(lists["points"], lists["normals"], lists["colors"], lists["features"])
