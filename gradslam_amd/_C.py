@@ -41,6 +41,8 @@ _PROTOS = {
     "gs_select_targets_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "gs_downsample_table_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gs_knn1_f32": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
+    "gs_knn1_grid_scratch_bytes": [_i64, _i64],
+    "gs_knn1_grid_f32": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, C.POINTER(C.c_int64), _vp],
     "gs_gauss_newton_rows_f32": [_vp, _i64, _vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "gs_solve_normal_eq_f32": [_vp, _vp, _vp, _i64, _i32, _f, _vp, _vp],
     "gs_se3_exp_f32": [_vp, _vp, _vp],
@@ -57,7 +59,8 @@ _PROTOS = {
                            _vp, _vp, _vp],
     "gs_append_valid_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
 }
-_RESTYPE = {"gs_last_error": C.c_char_p, "gs_scratch_bytes": _i64, "gs_icp_scratch_bytes": _i64}
+_RESTYPE = {"gs_last_error": C.c_char_p, "gs_scratch_bytes": _i64, "gs_icp_scratch_bytes": _i64,
+            "gs_knn1_grid_scratch_bytes": _i64}
 EXPORTS = tuple(_PROTOS)
 
 

@@ -1,23 +1,14 @@
-// gs_icp.hip — K3 (exact brute-force 1-NN) and K4 (Gauss-Newton system, 6x6 solve, SE(3)
-// exponential, LM / gradLM update) with the whole 20-iteration loop enqueued without a host
-// sync.
-//
-// K3 is fp32-VALU bound (Ns x Nt pair distances, 6 VALU ops + 3 for the running arg-min per
-// pair); the target chunk of a block lives in LDS and is read with wave-uniform (broadcast)
-// ds_read_b128, every lane keeps KNN_SPT source points in registers.  (src tile, tgt chunk)
-// pairs are spread over a 2-D grid so that >= 1000 workgroups fill the 256 CUs; chunk results
-// meet in a 64-bit atomicMin on (distance bits << 32 | index), which is order independent and
-// resolves ties to the lowest index exactly like a sequential scan.
+// gs_icp.hip — K4: Gauss-Newton system, 6x6 solve, SE(3) exponential, LM / gradLM update, with
+// the whole 20-iteration loop (2 exact 1-NN searches per iteration, gs_knn.hip) enqueued without
+// a host sync.
 //
 // K4 accumulates J^T J / J^T r / r^T r in float64 from float32 products (order-independent to
 // ~1e-16, so HIP and oracle agree after the single rounding to float32) with fixed-order
 // wave -> block -> grid reduction, then one lane solves and updates on the device.
-#include "gs_common.h"
+#include <stdlib.h>
+#include <string.h>
 
-constexpr int KNN_BLOCK = 256;
-constexpr int KNN_SPT = 4;
-constexpr int KNN_STILE = KNN_BLOCK * KNN_SPT;
-constexpr int KNN_TCHUNK = 512;
+#include "gs_knn.h"
 
 // Device-resident state of one ICP solve (floats unless noted), lives in icp_scratch.
 struct GsIcpState {
@@ -30,106 +21,6 @@ struct GsIcpState {
   float pad[6];
   float trace[64 * 12];  // up to 64 iterations
 };
-
-GS_DEV unsigned long long knn_pack(float d, uint32_t idx) {
-  return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)idx;
-}
-
-__global__ void __launch_bounds__(KNN_BLOCK) gs_knn1_kernel(
-    const float* __restrict__ src_in, const float* __restrict__ Tapply, float* __restrict__ src_out,
-    int64_t n_src, const float* __restrict__ tgt, int64_t n_tgt, unsigned long long* __restrict__ best) {
-  __shared__ float4 tl[KNN_TCHUNK];
-  const int64_t j0 = (int64_t)blockIdx.y * KNN_TCHUNK;
-  const int cnt = (int)((n_tgt - j0) < KNN_TCHUNK ? (n_tgt - j0) : KNN_TCHUNK);
-  for (int i = threadIdx.x; i < cnt; i += KNN_BLOCK) {
-    const float* t = tgt + 3 * (j0 + i);
-    tl[i] = make_float4(t[0], t[1], t[2], 0.0f);
-  }
-  float sx[KNN_SPT], sy[KNN_SPT], sz[KNN_SPT], bd[KNN_SPT];
-  int bi[KNN_SPT];
-  float T[12];
-  if (Tapply) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = Tapply[i];
-  }
-#pragma unroll
-  for (int k = 0; k < KNN_SPT; ++k) {
-    const int64_t s = (int64_t)blockIdx.x * KNN_STILE + k * KNN_BLOCK + threadIdx.x;
-    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
-    if (s < n_src) {
-      p0 = src_in[3 * s];
-      p1 = src_in[3 * s + 1];
-      p2 = src_in[3 * s + 2];
-      if (Tapply) {
-        float q0, q1, q2;
-        gs_rigid_fma(T, p0, p1, p2, q0, q1, q2);
-        p0 = q0; p1 = q1; p2 = q2;
-      }
-      if (src_out && blockIdx.y == 0) {
-        src_out[3 * s] = p0;
-        src_out[3 * s + 1] = p1;
-        src_out[3 * s + 2] = p2;
-      }
-    }
-    sx[k] = p0; sy[k] = p1; sz[k] = p2;
-    bd[k] = __builtin_inff();
-    bi[k] = 0;
-  }
-  __syncthreads();
-#pragma unroll 4
-  for (int j = 0; j < cnt; ++j) {
-    const float4 t = tl[j];
-#pragma unroll
-    for (int k = 0; k < KNN_SPT; ++k) {
-      const float dx = sx[k] - t.x, dy = sy[k] - t.y, dz = sz[k] - t.z;
-      float d = dx * dx;
-      d = gs_fma(dy, dy, d);
-      d = gs_fma(dz, dz, d);
-      const bool lt = d < bd[k];
-      bd[k] = lt ? d : bd[k];
-      bi[k] = lt ? j : bi[k];
-    }
-  }
-  if (cnt <= 0) return;
-#pragma unroll
-  for (int k = 0; k < KNN_SPT; ++k) {
-    const int64_t s = (int64_t)blockIdx.x * KNN_STILE + k * KNN_BLOCK + threadIdx.x;
-    if (s < n_src) atomicMin(&best[s], knn_pack(bd[k], (uint32_t)(j0 + bi[k])));
-  }
-}
-
-static int knn_launch(const float* src_in, const float* Tapply, float* src_out, int64_t n_src,
-                      const float* tgt, int64_t n_tgt, unsigned long long* best, hipStream_t st) {
-  dim3 grid((unsigned)gs_ceil_div(n_src, KNN_STILE), (unsigned)gs_ceil_div(n_tgt, KNN_TCHUNK));
-  GsProf prof(GS_PROF_KNN, (double)n_src * (double)n_tgt, st);  // work unit: pair distances
-  hipLaunchKernelGGL(gs_knn1_kernel, grid, dim3(KNN_BLOCK), 0, st, src_in, Tapply, src_out, n_src, tgt,
-                     n_tgt, best);
-  return GS_OK;
-}
-
-__global__ void __launch_bounds__(256) gs_knn_unpack_kernel(const unsigned long long* __restrict__ best,
-                                                            int64_t n, int64_t* __restrict__ idx,
-                                                            float* __restrict__ d2) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long b = best[i];
-  idx[i] = (int64_t)(b & 0xffffffffull);
-  if (d2) d2[i] = __uint_as_float((uint32_t)(b >> 32));
-}
-
-extern "C" int gs_knn1_f32(const float* src, int64_t n_src, const float* tgt, int64_t n_tgt,
-                           int64_t* out_idx, float* out_d2, uint64_t* best_scratch, void* stream) {
-  GS_REQUIRE(n_src > 0 && n_tgt > 0, "empty point set");
-  GS_REQUIRE(n_tgt < 0xffffffffll, "too many targets");
-  GS_REQUIRE(src && tgt && out_idx && best_scratch, "NULL pointer");
-  hipStream_t st = gs_stream(stream);
-  GS_HIP(hipMemsetAsync(best_scratch, 0xff, 8 * (size_t)n_src, st));
-  knn_launch(src, nullptr, nullptr, n_src, tgt, n_tgt, reinterpret_cast<unsigned long long*>(best_scratch), st);
-  hipLaunchKernelGGL(gs_knn_unpack_kernel, dim3((unsigned)gs_ceil_div(n_src, 256)), dim3(256), 0, st,
-                     reinterpret_cast<const unsigned long long*>(best_scratch), n_src, out_idx, out_d2);
-  GS_LAUNCH_CHECK();
-  return GS_OK;
-}
 
 // ---------------------------------------------------------------- K4: rows -------------
 // odometry/icputils.py:210-230 for one source point and its associated target.
@@ -147,12 +38,13 @@ GS_DEV void gn_row(float sx, float sy, float sz, const float* __restrict__ tgt,
 
 __global__ void __launch_bounds__(256) gs_gn_rows_kernel(
     const float* __restrict__ src, int64_t n_src, const float* __restrict__ tgt,
-    const float* __restrict__ tn, const unsigned long long* __restrict__ best, float dist_thresh,
+    const float* __restrict__ tn, int64_t n_tgt, const unsigned long long* __restrict__ best, float dist_thresh,
     float* __restrict__ A, float* __restrict__ b, int64_t* __restrict__ idx, uint8_t* __restrict__ keep) {
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= n_src) return;
   const unsigned long long bb = best[s];
-  const int64_t j = (int64_t)(bb & 0xffffffffull);
+  int64_t j = (int64_t)(bb & 0xffffffffull);
+  if (j >= n_tgt) j = 0;  // only when every distance was NaN
   const float d2 = __uint_as_float((uint32_t)(bb >> 32));
   float a[6], r;
   gn_row(src[3 * s], src[3 * s + 1], src[3 * s + 2], tgt, tn, j, a, r);
@@ -171,57 +63,60 @@ extern "C" int gs_gauss_newton_rows_f32(const float* src, int64_t n_src, const f
   GS_REQUIRE(src && tgt && tgt_normals && A && b && idx && best_scratch, "NULL pointer");
   hipStream_t st = gs_stream(stream);
   GS_HIP(hipMemsetAsync(best_scratch, 0xff, 8 * (size_t)n_src, st));
-  knn_launch(src, nullptr, nullptr, n_src, tgt, n_tgt, reinterpret_cast<unsigned long long*>(best_scratch), st);
+  gs_knn_brute_launch(src, nullptr, nullptr, n_src, tgt, n_tgt, reinterpret_cast<unsigned long long*>(best_scratch), st);
   hipLaunchKernelGGL(gs_gn_rows_kernel, dim3((unsigned)gs_ceil_div(n_src, 256)), dim3(256), 0, st, src,
-                     n_src, tgt, tgt_normals, reinterpret_cast<const unsigned long long*>(best_scratch),
+                     n_src, tgt, tgt_normals, n_tgt, reinterpret_cast<const unsigned long long*>(best_scratch),
                      dist_thresh, A, b, idx, keep);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }
 
 // ---------------------------------------------------------------- small dense algebra ---
-// n x n inverse, Gauss-Jordan with partial pivoting in double; same operation order as
-// oracle/gs_oracle.c:inv6_f64 (n <= 8).
-GS_DEV void gs_inv_f64(const double* M, double* Minv, int n) {
-  double a[8][16];
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) {
-      a[i][j] = M[n * i + j];
-      a[i][n + j] = (i == j) ? 1.0 : 0.0;
+// Solve (AtA + damp I) x = Atb (odometry/icputils.py:85-90; the reference inverts in float32 with
+// LAPACK and multiplies).  The system is symmetric positive definite, so it is solved directly by
+// un-pivoted Gauss-Jordan elimination in double on the augmented matrix and rounded once; N is a
+// template parameter so that the whole elimination lives in registers (no scratch memory).
+// Operation order is identical to oracle/gs_oracle.c:solve_spd_f64.
+template <int N>
+GS_DEV void gs_solve_spd(const float* AtA, const float* Atb, float damp, float* x) {
+  double a[N][N + 1];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float e = (i == j) ? 1.0f : 0.0f;
+      const float m = AtA[N * i + j] + e * damp;  // At_A + damp_matrix * damp, in float32
+      a[i][j] = (double)m;
     }
-  for (int c = 0; c < n; ++c) {
-    int piv = c;
-    double bestv = fabs(a[c][c]);
-    for (int r = c + 1; r < n; ++r)
-      if (fabs(a[r][c]) > bestv) { bestv = fabs(a[r][c]); piv = r; }
-    if (piv != c)
-      for (int j = 0; j < 2 * n; ++j) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+    a[i][N] = (double)Atb[i];
+  }
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
     const double inv = 1.0 / a[c][c];
-    for (int j = 0; j < 2 * n; ++j) a[c][j] *= inv;
-    for (int r = 0; r < n; ++r) {
+#pragma unroll
+    for (int j = c; j <= N; ++j) a[c][j] *= inv;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
       if (r == c) continue;
       const double f = a[r][c];
-      for (int j = 0; j < 2 * n; ++j) a[r][j] -= f * a[c][j];
+#pragma unroll
+      for (int j = c; j <= N; ++j) a[r][j] -= f * a[c][j];
     }
   }
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) Minv[n * i + j] = a[i][n + j];
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = (float)a[i][N];
 }
 
-// (AtA + damp I)^-1 Atb from float32 normal equations (odometry/icputils.py:85-90).
 GS_DEV void gs_solve_normal(const float* AtA, const float* Atb, float damp, int n, float* x) {
-  double M[64], Mi[64];
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) {
-      const float e = (i == j) ? 1.0f : 0.0f;
-      const float m = AtA[n * i + j] + e * damp;
-      M[n * i + j] = (double)m;
-    }
-  gs_inv_f64(M, Mi, n);
-  for (int i = 0; i < n; ++i) {
-    float acc = (float)Mi[n * i] * Atb[0];
-    for (int k = 1; k < n; ++k) acc = acc + (float)Mi[n * i + k] * Atb[k];
-    x[i] = acc;
+  switch (n) {
+    case 1: gs_solve_spd<1>(AtA, Atb, damp, x); break;
+    case 2: gs_solve_spd<2>(AtA, Atb, damp, x); break;
+    case 3: gs_solve_spd<3>(AtA, Atb, damp, x); break;
+    case 4: gs_solve_spd<4>(AtA, Atb, damp, x); break;
+    case 5: gs_solve_spd<5>(AtA, Atb, damp, x); break;
+    case 6: gs_solve_spd<6>(AtA, Atb, damp, x); break;
+    case 7: gs_solve_spd<7>(AtA, Atb, damp, x); break;
+    default: gs_solve_spd<8>(AtA, Atb, damp, x); break;
   }
 }
 
@@ -393,8 +288,9 @@ constexpr int LIN_NV = 28;  // 21 upper-triangular JtJ + 6 Jtr + 1 rtr
 template <bool FULL>
 __global__ void __launch_bounds__(LIN_BLOCK) gs_icp_linearize_kernel(
     const float* __restrict__ src, const float* __restrict__ Tapply, int64_t n_src,
-    const float* __restrict__ tgt, const float* __restrict__ tn, unsigned long long* __restrict__ best,
-    float dist_thresh, double* __restrict__ partials, int64_t* __restrict__ out_idx) {
+    const float* __restrict__ tgt, const float* __restrict__ tn, int64_t n_tgt,
+    unsigned long long* __restrict__ best, float dist_thresh, double* __restrict__ partials,
+    int64_t* __restrict__ out_idx) {
   __shared__ double red[LIN_BLOCK / GS_WAVE][LIN_NV];
   const int64_t s = (int64_t)blockIdx.x * LIN_BLOCK + threadIdx.x;
   double v[LIN_NV];
@@ -403,7 +299,8 @@ __global__ void __launch_bounds__(LIN_BLOCK) gs_icp_linearize_kernel(
   if (s < n_src) {
     const unsigned long long bb = best[s];
     best[s] = ~0ull;
-    const int64_t j = (int64_t)(bb & 0xffffffffull);
+    int64_t j = (int64_t)(bb & 0xffffffffull);
+    if (j >= n_tgt) j = 0;  // only when every distance was NaN
     const float d2 = __uint_as_float((uint32_t)(bb >> 32));
     const bool keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
     float p0 = src[3 * s], p1 = src[3 * s + 1], p2 = src[3 * s + 2];
@@ -465,7 +362,7 @@ __global__ void gs_icp_solve_kernel(const double* __restrict__ partials, int nbl
     }
   for (int i = 0; i < 6; ++i) Atb[i] = (float)S[21 + i];
   st->err = (float)S[27];
-  gs_solve_normal(AtA, Atb, st->damp, 6, xi);
+  gs_solve_spd<6>(AtA, Atb, st->damp, xi);
   gs_se3_exp_dev(xi, Tr);
   for (int i = 0; i < 6; ++i) st->xi[i] = xi[i];
   for (int i = 0; i < 16; ++i) st->Tr[i] = Tr[i];
@@ -566,6 +463,7 @@ struct IcpScratch {
   float* srcB;
   double* partials;
   GsIcpState* state;
+  void* grid;
 };
 static IcpScratch icp_carve(void* scratch, int64_t n_src) {
   char* p = reinterpret_cast<char*>(scratch);
@@ -579,15 +477,26 @@ static IcpScratch icp_carve(void* scratch, int64_t n_src) {
   s.srcB = reinterpret_cast<float*>(p);
   p += gs_align(12 * (size_t)n_src);
   s.partials = reinterpret_cast<double*>(p);
+  p += gs_align(sizeof(double) * LIN_NV * (size_t)gs_ceil_div(n_src, LIN_BLOCK));
+  s.grid = p;
   return s;
 }
 
+// GRADSLAM_HIP_KNN=brute forces the brute-force engine (A/B runs; results are identical).
+static bool icp_grid_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GRADSLAM_HIP_KNN");
+    v = (e && strcmp(e, "brute") == 0) ? 0 : 1;
+  }
+  return v == 1;
+}
+
 extern "C" int64_t gs_icp_scratch_bytes(int64_t n_src, int64_t n_tgt) {
-  (void)n_tgt;
   if (n_src < 1) n_src = 1;
   const int64_t nblk = gs_ceil_div(n_src, LIN_BLOCK);
   return (int64_t)(gs_align(sizeof(GsIcpState)) + gs_align(8 * (size_t)n_src) + 2 * gs_align(12 * (size_t)n_src) +
-                   gs_align(sizeof(double) * LIN_NV * (size_t)nblk) + 4096);
+                   gs_align(sizeof(double) * LIN_NV * (size_t)nblk) + gs_knn_grid_scratch_bytes(n_src, n_tgt) + 4096);
 }
 
 extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, const float* tgt_normals,
@@ -606,27 +515,38 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
   GS_HIP(hipMemsetAsync(sc.best, 0xff, 8 * (size_t)n_src, st));
   hipLaunchKernelGGL(gs_icp_init_kernel, dim3(1), dim3(64), 0, st, sc.state, init16, prm->damp, prm->numiters,
                      compose16, out_T16);
+  // the target set is fixed for all 2*numiters searches of this solve: bin it once
+  const bool use_grid = icp_grid_enabled() && gs_knn_use_grid(n_src, n_tgt) && prm->numiters > 0;
+  if (use_grid) {
+    int rc = gs_knn_grid_build(tgt, n_tgt, n_src, sc.grid, st);
+    if (rc != GS_OK) return rc;
+  }
+  auto knn = [&](const float* s_in, const float* Tapply, float* s_out) {
+    if (use_grid) gs_knn_grid_query(s_in, Tapply, s_out, n_src, tgt, n_tgt, sc.best, sc.grid, st);
+    else gs_knn_brute_launch(s_in, Tapply, s_out, n_src, tgt, n_tgt, sc.best, st);
+  };
   const float* cur_in = src;   // source cloud before this iteration's pending transform
   float* cur = sc.srcA;        // where the transformed cloud of this iteration is written
   float* other = sc.srcB;
   for (int it = 0; it < prm->numiters; ++it) {
     // apply the pending transform (initial transform or last T_step) while searching
-    knn_launch(cur_in, sc.state->T_step, cur, n_src, tgt, n_tgt, sc.best, st);
+    knn(cur_in, sc.state->T_step, cur);
     {
       GsProf prof(GS_PROF_LINEARIZE, 44.0 * (double)n_src, st);  // 8 B best + 12 B src + 24 B gather
       hipLaunchKernelGGL((gs_icp_linearize_kernel<true>), dim3(nblk), dim3(LIN_BLOCK), 0, st, cur, nullptr, n_src,
-                         tgt, tgt_normals, sc.best, prm->dist_thresh, sc.partials, out_idx);
+                         tgt, tgt_normals, n_tgt, sc.best, prm->dist_thresh, sc.partials, out_idx);
     }
     {
       GsProf prof(GS_PROF_SOLVE, 1.0, st);
       hipLaunchKernelGGL(gs_icp_solve_kernel, dim3(1), dim3(64), 0, st, sc.partials, nblk, sc.state);
     }
     // look-ahead: one_step = Tr * cur, searched and reduced without materialising it
-    knn_launch(cur, sc.state->Tr, nullptr, n_src, tgt, n_tgt, sc.best, st);
+    knn(cur, sc.state->Tr, nullptr);
     {
       GsProf prof(GS_PROF_LINEARIZE, 44.0 * (double)n_src, st);
       hipLaunchKernelGGL((gs_icp_linearize_kernel<false>), dim3(nblk), dim3(LIN_BLOCK), 0, st, cur,
-                         sc.state->Tr, n_src, tgt, tgt_normals, sc.best, prm->dist_thresh, sc.partials, nullptr);
+                         sc.state->Tr, n_src, tgt, tgt_normals, n_tgt, sc.best, prm->dist_thresh, sc.partials,
+                         nullptr);
     }
     {
       GsProf prof(GS_PROF_SOLVE, 1.0, st);

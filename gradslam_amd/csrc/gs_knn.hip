@@ -1,0 +1,476 @@
+// gs_knn.hip — K3: exact 1-nearest-neighbour search (replaces chamferdist.knn_points as called at
+// odometry/icputils.py:200; squared L2 d = fma(dz,dz,fma(dy,dy,dx*dx)), lowest index on ties).
+//
+// Two engines with bit-identical results:
+//
+//  * brute force: fp32-VALU bound (Ns x Nt pair distances, 6 VALU ops + 3 for the running arg-min
+//    per pair).  A block stages its target chunk in LDS and reads it with wave-uniform (broadcast)
+//    ds_read_b128; every lane keeps KNN_SPT source points in registers.  (src tile, tgt chunk)
+//    pairs are spread over a 2-D grid; chunk results meet in a 64-bit atomicMin on
+//    (distance bits << 32 | index): order independent, ties resolve to the lowest index exactly
+//    like a sequential scan.
+//
+//  * uniform grid (used by the ICP loop, where the SAME target set is searched 40 times per
+//    frame): targets are counting-sorted into cells of a 3-D grid once; a query visits Chebyshev
+//    shells of cells around its own cell and stops as soon as the best distance found is provably
+//    smaller than anything an unvisited cell can hold.  Every candidate goes through the same
+//    distance arithmetic and the same (distance, index) ordering as the brute-force scan, so the
+//    result is the brute-force result, not an approximation.  Queries that are not resolved
+//    within GS_GRID_RINGS shells (points far from every target) are collected and finished by the
+//    brute-force kernel.  Work drops from Ns*Nt pair distances to ~10^2 per query.
+#include "gs_knn.h"
+
+constexpr int KNN_BLOCK = 256;
+constexpr int KNN_SPT = 4;
+constexpr int KNN_STILE = KNN_BLOCK * KNN_SPT;
+constexpr int KNN_TCHUNK = 512;
+
+// ---------------------------------------------------------------- brute force ----------
+// LISTED: source indices come from list[0 .. *count) (the grid engine's unresolved queries) and
+// source tiles are strided over gridDim.x; otherwise tile = blockIdx.x over all n_src points.
+template <bool LISTED>
+__global__ void __launch_bounds__(KNN_BLOCK) gs_knn1_kernel(
+    const float* __restrict__ src_in, const float* __restrict__ Tapply, float* __restrict__ src_out,
+    int64_t n_src, const float* __restrict__ tgt, int64_t n_tgt, unsigned long long* __restrict__ best,
+    const int* __restrict__ list, const int* __restrict__ count) {
+  __shared__ float4 tl[KNN_TCHUNK];
+  const int64_t n_q = LISTED ? (int64_t)(*count) : n_src;
+  if (LISTED && n_q == 0) return;
+  const int64_t j0 = (int64_t)blockIdx.y * KNN_TCHUNK;
+  const int cnt = (int)((n_tgt - j0) < KNN_TCHUNK ? (n_tgt - j0) : KNN_TCHUNK);
+  if (cnt <= 0) return;
+  for (int i = threadIdx.x; i < cnt; i += KNN_BLOCK) {
+    const float* t = tgt + 3 * (j0 + i);
+    tl[i] = make_float4(t[0], t[1], t[2], 0.0f);
+  }
+  float T[12];
+  if (Tapply) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = Tapply[i];
+  }
+  __syncthreads();
+  for (int64_t tile = blockIdx.x; tile * KNN_STILE < n_q; tile += gridDim.x) {
+    float sx[KNN_SPT], sy[KNN_SPT], sz[KNN_SPT], bd[KNN_SPT];
+    int bi[KNN_SPT];
+    int64_t sidx[KNN_SPT];
+#pragma unroll
+    for (int k = 0; k < KNN_SPT; ++k) {
+      const int64_t q = tile * KNN_STILE + k * KNN_BLOCK + threadIdx.x;
+      int64_t s = -1;
+      if (q < n_q) s = LISTED ? (int64_t)list[q] : q;
+      float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
+      if (s >= 0) {
+        p0 = src_in[3 * s];
+        p1 = src_in[3 * s + 1];
+        p2 = src_in[3 * s + 2];
+        if (Tapply) {
+          float q0, q1, q2;
+          gs_rigid_fma(T, p0, p1, p2, q0, q1, q2);
+          p0 = q0; p1 = q1; p2 = q2;
+        }
+        if (!LISTED && src_out && blockIdx.y == 0) {
+          src_out[3 * s] = p0;
+          src_out[3 * s + 1] = p1;
+          src_out[3 * s + 2] = p2;
+        }
+      }
+      sidx[k] = s;
+      sx[k] = p0; sy[k] = p1; sz[k] = p2;
+      bd[k] = __builtin_inff();
+      bi[k] = 0;
+    }
+#pragma unroll 4
+    for (int j = 0; j < cnt; ++j) {
+      const float4 t = tl[j];
+#pragma unroll
+      for (int k = 0; k < KNN_SPT; ++k) {
+        const float dx = sx[k] - t.x, dy = sy[k] - t.y, dz = sz[k] - t.z;
+        float d = dx * dx;
+        d = gs_fma(dy, dy, d);
+        d = gs_fma(dz, dz, d);
+        const bool lt = d < bd[k];
+        bd[k] = lt ? d : bd[k];
+        bi[k] = lt ? j : bi[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KNN_SPT; ++k)
+      if (sidx[k] >= 0) atomicMin(&best[sidx[k]], knn_pack(bd[k], (uint32_t)(j0 + bi[k])));
+    if (!LISTED) break;
+  }
+}
+
+int gs_knn_brute_launch(const float* src_in, const float* Tapply, float* src_out, int64_t n_src,
+                        const float* tgt, int64_t n_tgt, unsigned long long* best, hipStream_t st) {
+  dim3 grid((unsigned)gs_ceil_div(n_src, KNN_STILE), (unsigned)gs_ceil_div(n_tgt, KNN_TCHUNK));
+  GsProf prof(GS_PROF_KNN, (double)n_src * (double)n_tgt, st);  // work unit: pair distances
+  hipLaunchKernelGGL((gs_knn1_kernel<false>), grid, dim3(KNN_BLOCK), 0, st, src_in, Tapply, src_out, n_src, tgt,
+                     n_tgt, best, nullptr, nullptr);
+  return GS_OK;
+}
+
+// ---------------------------------------------------------------- uniform grid ---------
+struct GsGrid {
+  float ox, oy, oz;  // bounding box of the (finite) targets
+  float mx, my, mz;
+  float c, inv_c;    // cell edge
+  int nx, ny, nz, ncell;
+};
+
+struct GridMem {
+  GsGrid* g;
+  int* unres_count;  // [2], ping-pong between consecutive queries
+  int* cell_count;   // [MAXCELL + 1]
+  int* cell_start;   // [MAXCELL + 1]
+  int* tile_sums;    // [MAXCELL / 1024 + 1]
+  float4* sorted;    // [n_tgt] (x, y, z, original index bits), grouped by cell
+  int* unres_list;   // [n_src]
+};
+constexpr int GRID_TILE = 1024;
+
+static GridMem grid_carve(void* scratch, int64_t n_src, int64_t n_tgt) {
+  char* p = reinterpret_cast<char*>(scratch);
+  GridMem m;
+  m.g = reinterpret_cast<GsGrid*>(p); p += 256;
+  m.unres_count = reinterpret_cast<int*>(p); p += 256;
+  m.cell_count = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1));
+  m.cell_start = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1));
+  m.tile_sums = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL / GRID_TILE + 2));
+  m.sorted = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1));
+  m.unres_list = reinterpret_cast<int*>(p);
+  (void)n_src;
+  return m;
+}
+
+size_t gs_knn_grid_scratch_bytes(int64_t n_src, int64_t n_tgt) {
+  return 512 + 2 * gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1)) + gs_align(4 * (size_t)(GS_GRID_MAXCELL / GRID_TILE + 2)) +
+         gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1)) + gs_align(4 * (size_t)(n_src > 0 ? n_src : 1)) + 256;
+}
+
+GS_DEV int grid_axis(float v, float o, float inv_c, int n) {
+  const float f = (v - o) * inv_c;
+  // NaN fails both comparisons and lands in cell 0
+  return f >= 0.0f ? (f < (float)n ? (int)f : n - 1) : 0;
+}
+GS_DEV int grid_cell(const GsGrid& g, float x, float y, float z) {
+  const int ix = grid_axis(x, g.ox, g.inv_c, g.nx);
+  const int iy = grid_axis(y, g.oy, g.inv_c, g.ny);
+  const int iz = grid_axis(z, g.oz, g.inv_c, g.nz);
+  return (iz * g.ny + iy) * g.nx + ix;
+}
+
+// One block: bounding box of the finite targets, then the cell size.  Heuristic: targets are a
+// sampled surface (spacing ~ sqrt(area / n)) or, failing that, a volume (spacing ~ cbrt(V / n));
+// the cell edge is the larger of 2 surface spacings and 1 volume spacing, grown until the grid
+// fits GS_GRID_MAXCELL cells.  Any positive cell size is CORRECT; the choice only affects speed.
+__global__ void __launch_bounds__(1024) gs_grid_bbox_kernel(const float* __restrict__ tgt, int64_t n_tgt,
+                                                            GsGrid* __restrict__ g, int* __restrict__ unres_count) {
+  __shared__ float red[6][1024 / GS_WAVE];
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int64_t i = threadIdx.x; i < n_tgt; i += 1024) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float v = tgt[3 * i + k];
+      if (v > -3.0e38f && v < 3.0e38f) {  // finite
+        lo[k] = v < lo[k] ? v : lo[k];
+        hi[k] = v > hi[k] ? v : hi[k];
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float a = lo[k], b = hi[k];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const float a2 = __shfl_down(a, d, GS_WAVE), b2 = __shfl_down(b, d, GS_WAVE);
+      a = a2 < a ? a2 : a;
+      b = b2 > b ? b2 : b;
+    }
+    if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float o[3], m[3];
+    for (int k = 0; k < 3; ++k) {
+      float a = red[k][0], b = red[3 + k][0];
+      for (int w = 1; w < 1024 / GS_WAVE; ++w) {
+        a = red[k][w] < a ? red[k][w] : a;
+        b = red[3 + k][w] > b ? red[3 + k][w] : b;
+      }
+      if (!(a <= b)) { a = 0.0f; b = 0.0f; }  // no finite coordinate on this axis
+      o[k] = a; m[k] = b;
+    }
+    const float tiny = 1e-6f;
+    const float ex = (m[0] - o[0]) + tiny, ey = (m[1] - o[1]) + tiny, ez = (m[2] - o[2]) + tiny;
+    const float n = (float)(n_tgt > 0 ? n_tgt : 1);
+    const float area = ex * ey + ey * ez + ex * ez;
+    float c = 2.0f * sqrtf(area / n);
+    const float cv = cbrtf((ex * ey * ez) / n);
+    c = cv > c ? cv : c;
+    const float emax = ex > ey ? (ex > ez ? ex : ez) : (ey > ez ? ey : ez);
+    c = c > emax * (1.0f / 1024.0f) ? c : emax * (1.0f / 1024.0f);
+    c = c > 1e-6f ? c : 1e-6f;
+    int nx, ny, nz;
+    for (;;) {
+      nx = (int)(ex / c) + 1; ny = (int)(ey / c) + 1; nz = (int)(ez / c) + 1;
+      if ((double)nx * (double)ny * (double)nz <= (double)GS_GRID_MAXCELL) break;
+      c *= 1.26f;
+    }
+    g->ox = o[0]; g->oy = o[1]; g->oz = o[2];
+    g->mx = m[0]; g->my = m[1]; g->mz = m[2];
+    g->c = c; g->inv_c = 1.0f / c;
+    g->nx = nx; g->ny = ny; g->nz = nz; g->ncell = nx * ny * nz;
+    unres_count[0] = 0;
+    unres_count[1] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256) gs_grid_count_kernel(const float* __restrict__ tgt, int64_t n_tgt,
+                                                            const GsGrid* __restrict__ gp,
+                                                            int* __restrict__ cell_count) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_tgt) return;
+  const GsGrid g = *gp;
+  atomicAdd(&cell_count[grid_cell(g, tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2])], 1);
+}
+
+// exclusive scan of cell_count[0 .. ncell] (ncell + 1 entries, the last one is the end sentinel)
+__global__ void __launch_bounds__(256) gs_grid_tile_sum_kernel(const int* __restrict__ cell_count,
+                                                               const GsGrid* __restrict__ gp,
+                                                               int* __restrict__ tile_sums) {
+  __shared__ int smem[256 / GS_WAVE + 1];
+  const int n = gp->ncell + 1;
+  const int base = blockIdx.x * GRID_TILE + threadIdx.x * 4;
+  if (blockIdx.x * GRID_TILE >= n) return;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c += (base + i < n) ? cell_count[base + i] : 0;
+  int total;
+  (void)gs_block_excl_scan<256>(c, smem, &total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(256) gs_grid_scan_kernel(const int* __restrict__ cell_count,
+                                                           const GsGrid* __restrict__ gp,
+                                                           const int* __restrict__ tile_sums,
+                                                           int* __restrict__ cell_start) {
+  __shared__ int smem[256 / GS_WAVE + 1];
+  const int n = gp->ncell + 1;
+  if (blockIdx.x * GRID_TILE >= n) return;
+  // prefix of the tiles before this one
+  int pre = 0;
+  for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) pre += tile_sums[t];
+  int tile_prefix;
+  (void)gs_block_excl_scan<256>(pre, smem, &tile_prefix);
+  const int base = blockIdx.x * GRID_TILE + threadIdx.x * 4;
+  int v[4], c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = (base + i < n) ? cell_count[base + i] : 0;
+    c += v[i];
+  }
+  int total;
+  int run = tile_prefix + gs_block_excl_scan<256>(c, smem, &total);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (base + i < n) cell_start[base + i] = run;
+    run += v[i];
+  }
+}
+
+__global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __restrict__ tgt, int64_t n_tgt,
+                                                              const GsGrid* __restrict__ gp,
+                                                              const int* __restrict__ cell_start,
+                                                              int* __restrict__ cell_count,
+                                                              float4* __restrict__ sorted) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_tgt) return;
+  const GsGrid g = *gp;
+  const float x = tgt[3 * i], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
+  const int cid = grid_cell(g, x, y, z);
+  // slots of a cell are handed out back to front; the order inside a cell is irrelevant because
+  // queries order candidates by (distance, original index).  Leaves cell_count all zero again.
+  const int slot = cell_start[cid] + atomicSub(&cell_count[cid], 1) - 1;
+  sorted[slot] = make_float4(x, y, z, __int_as_float((int)i));
+}
+
+int gs_knn_grid_build(const float* tgt, int64_t n_tgt, int64_t n_src, void* grid_scratch, hipStream_t st) {
+  GridMem m = grid_carve(grid_scratch, n_src, n_tgt);
+  GsProf prof(GS_PROF_COMPACT, 28.0 * (double)n_tgt + 8.0 * GS_GRID_MAXCELL, st);
+  hipError_t e = hipMemsetAsync(m.cell_count, 0, 4 * (size_t)(GS_GRID_MAXCELL + 1), st);
+  if (e != hipSuccess) { gs_set_error("gs_knn_grid_build: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
+  hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3(1), dim3(1024), 0, st, tgt, n_tgt, m.g, m.unres_count);
+  hipLaunchKernelGGL(gs_grid_count_kernel, dim3((unsigned)gs_ceil_div(n_tgt, 256)), dim3(256), 0, st, tgt, n_tgt,
+                     m.g, m.cell_count);
+  const unsigned ntile = (unsigned)gs_ceil_div(GS_GRID_MAXCELL + 1, GRID_TILE);
+  hipLaunchKernelGGL(gs_grid_tile_sum_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums);
+  hipLaunchKernelGGL(gs_grid_scan_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums,
+                     m.cell_start);
+  hipLaunchKernelGGL(gs_grid_scatter_kernel, dim3((unsigned)gs_ceil_div(n_tgt, 256)), dim3(256), 0, st, tgt,
+                     n_tgt, m.g, m.cell_start, m.cell_count, m.sorted);
+  return GS_OK;
+}
+
+// candidate ordering identical to the packed 64-bit minimum of the brute-force engine
+GS_DEV void grid_consider(float qx, float qy, float qz, const float4 p, float& bd, uint32_t& bi) {
+  const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+  float d = dx * dx;
+  d = gs_fma(dy, dy, d);
+  d = gs_fma(dz, dz, d);
+  const uint32_t idx = (uint32_t)__float_as_int(p.w);
+  if (d < bd || (d == bd && idx < bi)) {
+    bd = d;
+    bi = idx;
+  }
+}
+
+constexpr int GQ_BLOCK = 64;
+
+__global__ void __launch_bounds__(GQ_BLOCK) gs_grid_query_kernel(
+    const float* __restrict__ src_in, const float* __restrict__ Tapply, float* __restrict__ src_out,
+    int64_t n_src, const GsGrid* __restrict__ gp, const int* __restrict__ cell_start,
+    const float4* __restrict__ sorted, unsigned long long* __restrict__ best, int* __restrict__ unres_count,
+    int* __restrict__ unres_next, int* __restrict__ unres_list) {
+  const int64_t s = (int64_t)blockIdx.x * GQ_BLOCK + threadIdx.x;
+  if (s == 0) *unres_next = 0;  // arm the counter of the NEXT query (ping-pong)
+  if (s >= n_src) return;
+  const GsGrid g = *gp;
+  float qx = src_in[3 * s], qy = src_in[3 * s + 1], qz = src_in[3 * s + 2];
+  if (Tapply) {
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = Tapply[i];
+    float t0, t1, t2;
+    gs_rigid_fma(T, qx, qy, qz, t0, t1, t2);
+    qx = t0; qy = t1; qz = t2;
+  }
+  if (src_out) {
+    src_out[3 * s] = qx;
+    src_out[3 * s + 1] = qy;
+    src_out[3 * s + 2] = qz;
+  }
+  // cell of the query's projection onto the bounding box (the projection onto a convex set never
+  // increases the distance to points inside it, so shell bounds around it stay valid)
+  const float px = fminf(fmaxf(qx, g.ox), g.mx), py = fminf(fmaxf(qy, g.oy), g.my), pz = fminf(fmaxf(qz, g.oz), g.mz);
+  const int cx = grid_axis(px, g.ox, g.inv_c, g.nx), cy = grid_axis(py, g.oy, g.inv_c, g.ny),
+            cz = grid_axis(pz, g.oz, g.inv_c, g.nz);
+  float bd = __builtin_inff();
+  uint32_t bi = 0xffffffffu;
+  bool done = false;
+  for (int k = 0; k <= GS_GRID_RINGS && !done; ++k) {
+    for (int dz = -k; dz <= k; ++dz) {
+      const int zz = cz + dz;
+      if (zz < 0 || zz >= g.nz) continue;
+      for (int dy = -k; dy <= k; ++dy) {
+        const int yy = cy + dy;
+        if (yy < 0 || yy >= g.ny) continue;
+        const int row = (zz * g.ny + yy) * g.nx;
+        const bool full_row = (dz == -k || dz == k || dy == -k || dy == k);
+        if (full_row) {
+          const int x0 = cx - k < 0 ? 0 : cx - k, x1 = cx + k >= g.nx ? g.nx - 1 : cx + k;
+          const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
+          for (int i = b; i < e; ++i) grid_consider(qx, qy, qz, sorted[i], bd, bi);
+        } else {  // interior row of the shell: only its two end cells belong to shell k
+          const int xa = cx - k, xb = cx + k;
+          if (xa >= 0) {
+            const int b = cell_start[row + xa], e = cell_start[row + xa + 1];
+            for (int i = b; i < e; ++i) grid_consider(qx, qy, qz, sorted[i], bd, bi);
+          }
+          if (xb < g.nx) {
+            const int b = cell_start[row + xb], e = cell_start[row + xb + 1];
+            for (int i = b; i < e; ++i) grid_consider(qx, qy, qz, sorted[i], bd, bi);
+          }
+        }
+      }
+    }
+    // every unvisited target is farther than k cells from the projected query; 0.1 % of a cell is
+    // orders of magnitude above the float rounding of the cell assignment
+    const float rb = (float)k * g.c * 0.999f;
+    done = bd <= rb * rb;
+  }
+  if (done) {
+    best[s] = knn_pack(bd, bi);
+  } else {
+    best[s] = ~0ull;  // finished by the brute-force pass
+    unres_list[atomicAdd(unres_count, 1)] = (int)s;
+  }
+}
+
+int gs_knn_grid_query(const float* src_in, const float* Tapply, float* src_out, int64_t n_src,
+                      const float* tgt, int64_t n_tgt, unsigned long long* best, void* grid_scratch,
+                      hipStream_t st) {
+  static unsigned seq = 0;  // ping-pong index of the unresolved counter (one host thread per GPU)
+  GridMem m = grid_carve(grid_scratch, n_src, n_tgt);
+  int* cnt = m.unres_count + (seq & 1);
+  int* nxt = m.unres_count + ((seq + 1) & 1);
+  ++seq;
+  GsProf prof(GS_PROF_KNN, (double)n_src * (double)n_tgt, st);  // brute-force-equivalent pairs
+  hipLaunchKernelGGL(gs_grid_query_kernel, dim3((unsigned)gs_ceil_div(n_src, GQ_BLOCK)), dim3(GQ_BLOCK), 0, st,
+                     src_in, Tapply, src_out, n_src, m.g, m.cell_start, m.sorted, best, cnt, nxt, m.unres_list);
+  // unresolved queries (device-side count; blocks exit at once when it is zero)
+  unsigned gx = (unsigned)gs_ceil_div(n_src, KNN_STILE);
+  gx = gx > 4 ? 4 : gx;
+  dim3 grid(gx, (unsigned)gs_ceil_div(n_tgt, KNN_TCHUNK));
+  hipLaunchKernelGGL((gs_knn1_kernel<true>), grid, dim3(KNN_BLOCK), 0, st, src_in, Tapply, nullptr, n_src, tgt,
+                     n_tgt, best, m.unres_list, cnt);
+  return GS_OK;
+}
+
+// ---------------------------------------------------------------- C-ABI ----------------
+__global__ void __launch_bounds__(256) gs_knn_unpack_kernel(const unsigned long long* __restrict__ best,
+                                                            int64_t n, int64_t n_tgt, int64_t* __restrict__ idx,
+                                                            float* __restrict__ d2) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long b = best[i];
+  int64_t j = (int64_t)(b & 0xffffffffull);
+  if (j >= n_tgt) j = 0;  // only when every distance was NaN
+  idx[i] = j;
+  if (d2) d2[i] = __uint_as_float((uint32_t)(b >> 32));
+}
+
+extern "C" int gs_knn1_f32(const float* src, int64_t n_src, const float* tgt, int64_t n_tgt,
+                           int64_t* out_idx, float* out_d2, uint64_t* best_scratch, void* stream) {
+  GS_REQUIRE(n_src > 0 && n_tgt > 0, "empty point set");
+  GS_REQUIRE(n_tgt < 0x7fffffffll && n_src < 0x7fffffffll, "too many points");
+  GS_REQUIRE(src && tgt && out_idx && best_scratch, "NULL pointer");
+  hipStream_t st = gs_stream(stream);
+  GS_HIP(hipMemsetAsync(best_scratch, 0xff, 8 * (size_t)n_src, st));
+  gs_knn_brute_launch(src, nullptr, nullptr, n_src, tgt, n_tgt, reinterpret_cast<unsigned long long*>(best_scratch), st);
+  hipLaunchKernelGGL(gs_knn_unpack_kernel, dim3((unsigned)gs_ceil_div(n_src, 256)), dim3(256), 0, st,
+                     reinterpret_cast<const unsigned long long*>(best_scratch), n_src, n_tgt, out_idx, out_d2);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int64_t gs_knn1_grid_scratch_bytes(int64_t n_src, int64_t n_tgt) {
+  return (int64_t)(gs_align(8 * (size_t)(n_src > 0 ? n_src : 1)) + gs_knn_grid_scratch_bytes(n_src, n_tgt));
+}
+
+extern "C" int gs_knn1_grid_f32(const float* src, int64_t n_src, const float* tgt, int64_t n_tgt,
+                                int64_t* out_idx, float* out_d2, void* scratch, int64_t* unresolved_out,
+                                void* stream) {
+  GS_REQUIRE(n_src > 0 && n_tgt > 0, "empty point set");
+  GS_REQUIRE(n_tgt < 0x7fffffffll && n_src < 0x7fffffffll, "too many points");
+  GS_REQUIRE(src && tgt && out_idx && scratch, "NULL pointer");
+  hipStream_t st = gs_stream(stream);
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(scratch);
+  void* gscratch = reinterpret_cast<char*>(scratch) + gs_align(8 * (size_t)n_src);
+  GS_HIP(hipMemsetAsync(best, 0xff, 8 * (size_t)n_src, st));
+  int rc = gs_knn_grid_build(tgt, n_tgt, n_src, gscratch, st);
+  if (rc != GS_OK) return rc;
+  GridMem m = grid_carve(gscratch, n_src, n_tgt);
+  rc = gs_knn_grid_query(src, nullptr, nullptr, n_src, tgt, n_tgt, best, gscratch, st);
+  if (rc != GS_OK) return rc;
+  hipLaunchKernelGGL(gs_knn_unpack_kernel, dim3((unsigned)gs_ceil_div(n_src, 256)), dim3(256), 0, st, best, n_src,
+                     n_tgt, out_idx, out_d2);
+  if (unresolved_out) {  // diagnostic: how many queries needed the brute-force pass (sum of both counters:
+    // exactly one of them was used by this query, the other one is zero)
+    int h[2] = {0, 0};
+    GS_HIP(hipMemcpyAsync(h, m.unres_count, 8, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    *unresolved_out = (int64_t)h[0] + (int64_t)h[1];
+  }
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}

@@ -151,6 +151,21 @@ def knn1(src, tgt):
     return idx, d2
 
 
+def knn1_grid(src, tgt, return_unresolved=False):
+    """Same as knn1 through the uniform-grid engine used inside the ICP loop (bit-identical)."""
+    import ctypes
+    src, tgt = _c(src), _c(tgt)
+    dev = require_device(src, tgt)
+    ns, nt = src.shape[0], tgt.shape[0]
+    idx = torch.empty(ns, dtype=torch.int64, device=dev)
+    d2 = torch.empty(ns, dtype=f32, device=dev)
+    scratch = Workspace.get(dev).bytes("knn_grid", lib().gs_knn1_grid_scratch_bytes(ns, nt))
+    unres = ctypes.c_int64(0)
+    check(lib().gs_knn1_grid_f32(ptr(src), ns, ptr(tgt), nt, ptr(idx), ptr(d2), ptr(scratch),
+                                 ctypes.byref(unres) if return_unresolved else None, stream(dev)), "gs_knn1_grid_f32")
+    return (idx, d2, unres.value) if return_unresolved else (idx, d2)
+
+
 def gauss_newton_rows(src, tgt, tgt_normals, dist_thresh=None):
     src, tgt, tn = _c(src), _c(tgt), _c(tgt_normals)
     dev = require_device(src, tgt, tn)

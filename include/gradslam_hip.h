@@ -130,6 +130,15 @@ GS_API int gs_downsample_table_f32(const int64_t* rows, int64_t n_rows, int ds, 
 GS_API int gs_knn1_f32(const float* src, int64_t n_src, const float* tgt, int64_t n_tgt,
                 int64_t* out_idx, float* out_d2, uint64_t* best_scratch, void* stream);
 
+/* Same result through the uniform-grid engine the ICP loop uses (targets counting-sorted into
+ * cells once, Chebyshev-shell search with an exactness bound, brute-force pass for queries it
+ * cannot resolve): bit-identical to gs_knn1_f32.  scratch: gs_knn1_grid_scratch_bytes().
+ * unresolved_out (HOST pointer, may be NULL; forces a stream sync): queries finished by brute force. */
+GS_API int64_t gs_knn1_grid_scratch_bytes(int64_t n_src, int64_t n_tgt);
+GS_API int gs_knn1_grid_f32(const float* src, int64_t n_src, const float* tgt, int64_t n_tgt,
+                            int64_t* out_idx, float* out_d2, void* scratch, int64_t* unresolved_out_host,
+                            void* stream);
+
 /* --------------------------------------------------------- K4: Gauss-Newton system -----
  * gauss_newton_solve (odometry/icputils.py:93-232): KNN + rows A_i = [n, s x n],
  * b_i = n.(d - s).  A (n_src,6) and b (n_src) are written densely for ALL src rows plus a

@@ -386,44 +386,35 @@ EXPORT void gs_or_gauss_newton_rows(const float* src, int64_t ns, const float* t
   free(d2);
 }
 
-/* 6x6 inverse by Gauss-Jordan with partial pivoting in double (torch.inverse at
- * odometry/icputils.py:90 is LAPACK LU in float32; double here keeps HIP and oracle within
- * one rounding of each other and is closer to the exact inverse than the reference). */
-static void inv6_f64(const double* M, double* Minv) {
-  double a[6][12];
-  for (int i = 0; i < 6; ++i)
-    for (int j = 0; j < 6; ++j) { a[i][j] = M[6 * i + j]; a[i][6 + j] = (i == j) ? 1.0 : 0.0; }
-  for (int c = 0; c < 6; ++c) {
-    int piv = c; double best = fabs(a[c][c]);
-    for (int r = c + 1; r < 6; ++r) if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
-    if (piv != c) for (int j = 0; j < 12; ++j) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+/* Solve (AtA + damp*I) x = Atb, odometry/icputils.py:85-90.  The reference inverts in float32
+ * (torch.inverse = LAPACK LU) and multiplies; the system is symmetric positive definite, so here
+ * (and, operation for operation, in the HIP kernel gs_solve_spd) it is solved directly by
+ * un-pivoted Gauss-Jordan elimination in double and rounded once.  That is closer to the exact
+ * solution than the reference and keeps HIP and oracle within one rounding of each other. */
+static void solve_spd_f64(const float* AtA, const float* Atb, float damp, int n, float* x) {
+  double a[8][9];
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) {
+      float e = (i == j) ? 1.0f : 0.0f;
+      float m = AtA[n * i + j] + e * damp; /* At_A + damp_matrix * damp in float32 */
+      a[i][j] = (double)m;
+    }
+    a[i][n] = (double)Atb[i];
+  }
+  for (int c = 0; c < n; ++c) {
     double inv = 1.0 / a[c][c];
-    for (int j = 0; j < 12; ++j) a[c][j] *= inv;
-    for (int r = 0; r < 6; ++r) {
+    for (int j = c; j <= n; ++j) a[c][j] *= inv;
+    for (int r = 0; r < n; ++r) {
       if (r == c) continue;
       double f = a[r][c];
-      for (int j = 0; j < 12; ++j) a[r][j] -= f * a[c][j];
+      for (int j = c; j <= n; ++j) a[r][j] -= f * a[c][j];
     }
   }
-  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Minv[6 * i + j] = a[i][6 + j];
+  for (int i = 0; i < n; ++i) x[i] = (float)a[i][n];
 }
 
-/* solve from float32 normal equations: (AtA + damp*I)^-1 Atb, odometry/icputils.py:85-90. */
 static void solve_from_normal_eq(const float* AtA, const float* Atb, float damp, float* x6) {
-  double M[36], Mi[36];
-  for (int i = 0; i < 6; ++i)
-    for (int j = 0; j < 6; ++j) {
-      float e = (i == j) ? 1.0f : 0.0f;
-      float m = AtA[6 * i + j] + e * damp; /* At_A + damp_matrix * damp in float32 */
-      M[6 * i + j] = (double)m;
-    }
-  inv6_f64(M, Mi);
-  for (int i = 0; i < 6; ++i) {
-    /* matmul(inverse, Atb): tiny matmul, plain, ascending k, float32 */
-    float acc = (float)Mi[6 * i] * Atb[0];
-    for (int k = 1; k < 6; ++k) acc = acc + (float)Mi[6 * i + k] * Atb[k];
-    x6[i] = acc;
-  }
+  solve_spd_f64(AtA, Atb, damp, 6, x6);
 }
 
 /* A^T A, A^T b and b.b accumulated in double from float32 products, rounded once. */
@@ -447,28 +438,9 @@ static void normal_eq_f64(const float* A, const float* b, const uint8_t* keep, i
 }
 
 /* general ncols <= 8 (the reference's own KAT uses 4 columns, tests/odometry/test_icputils.py:18-49) */
-static void inv_n_f64(const double* M, double* Minv, int n) {
-  double a[8][16];
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) { a[i][j] = M[n * i + j]; a[i][n + j] = (i == j) ? 1.0 : 0.0; }
-  for (int c = 0; c < n; ++c) {
-    int piv = c; double best = fabs(a[c][c]);
-    for (int r = c + 1; r < n; ++r) if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
-    if (piv != c) for (int j = 0; j < 2 * n; ++j) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
-    double inv = 1.0 / a[c][c];
-    for (int j = 0; j < 2 * n; ++j) a[c][j] *= inv;
-    for (int r = 0; r < n; ++r) {
-      if (r == c) continue;
-      double f = a[r][c];
-      for (int j = 0; j < 2 * n; ++j) a[r][j] -= f * a[c][j];
-    }
-  }
-  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Minv[n * i + j] = a[i][n + j];
-}
-
 EXPORT void gs_or_solve_normal_eq(const float* A, const float* b, const uint8_t* keep,
                                   int64_t n_rows, int ncols, float damp, float* x) {
-  double S[64] = {0}, v[8] = {0}, M[64], Mi[64];
+  double S[64] = {0}, v[8] = {0};
   float AtA[64], Atb[8];
   for (int64_t i = 0; i < n_rows; ++i) {
     if (keep && !keep[i]) continue;
@@ -482,18 +454,7 @@ EXPORT void gs_or_solve_normal_eq(const float* A, const float* b, const uint8_t*
     for (int c = r; c < ncols; ++c) AtA[ncols * r + c] = AtA[ncols * c + r] = (float)S[ncols * r + c];
     Atb[r] = (float)v[r];
   }
-  for (int i = 0; i < ncols; ++i)
-    for (int j = 0; j < ncols; ++j) {
-      float e = (i == j) ? 1.0f : 0.0f;
-      float m = AtA[ncols * i + j] + e * damp;
-      M[ncols * i + j] = (double)m;
-    }
-  inv_n_f64(M, Mi, ncols);
-  for (int i = 0; i < ncols; ++i) {
-    float acc = (float)Mi[ncols * i] * Atb[0];
-    for (int k = 1; k < ncols; ++k) acc = acc + (float)Mi[ncols * i + k] * Atb[k];
-    x[i] = acc;
-  }
+  solve_spd_f64(AtA, Atb, damp, ncols, x);
 }
 
 /* geometry/se3utils.py:77-115, evaluated in double from the float32 xi and rounded once. */

@@ -1,0 +1,155 @@
+"""The uniform-grid 1-NN engine used inside the ICP loop must return EXACTLY what the brute-force
+engine (and the CPU oracle) returns: same indices (lowest index on ties), same squared distances
+bit for bit — on surfaces, volumes, clusters with far outliers, duplicates, degenerate boxes and
+non-finite input.  Also checks that the whole ICP solve is identical with either engine."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from gradslam_amd.datasets.synthetic import make_sequence
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from gradslam_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def check_same(ops, src, tgt, max_unresolved_frac=None):
+    bi, bd = ops.knn1(dev(src), dev(tgt))
+    gi, gd, unres = ops.knn1_grid(dev(src), dev(tgt), return_unresolved=True)
+    assert np.array_equal(host(gi), host(bi)), "grid index != brute-force index at %d queries" % (
+        (host(gi) != host(bi)).sum())
+    assert np.array_equal(host(gd).view(np.int32), host(bd).view(np.int32))
+    if max_unresolved_frac is not None:
+        assert unres <= max_unresolved_frac * src.shape[0], (unres, src.shape[0])
+    return unres
+
+
+def surface(rng, n, noise=0.0):
+    u, v = rng.random(n) * 2.4 - 1.2, rng.random(n) * 1.8 - 0.9
+    z = 2.0 + 0.3 * np.sin(3 * u) * np.cos(2.5 * v)
+    p = np.stack([u, v, z], -1)
+    return (p + noise * rng.standard_normal(p.shape)).astype(np.float32)
+
+
+def test_surface_like_icp_case(ops):
+    rng = np.random.default_rng(0)
+    tgt = surface(rng, 26000)
+    src = surface(rng, 19000, noise=0.003)
+    unres = check_same(ops, src, tgt, max_unresolved_frac=0.02)
+    oi, od = o.knn1(src[:2000], tgt)
+    gi, gd = ops.knn1_grid(dev(src[:2000]), dev(tgt))
+    assert np.array_equal(host(gi), oi) and np.array_equal(host(gd), od)
+    assert unres >= 0
+
+
+@pytest.mark.parametrize("ns,nt", [(256, 2048), (3000, 2500), (19200, 23000), (5000, 100000)])
+def test_uniform_volume(ops, ns, nt):
+    rng = np.random.default_rng(ns + nt)
+    tgt = rng.random((nt, 3)).astype(np.float32)
+    src = rng.random((ns, 3)).astype(np.float32)
+    check_same(ops, src, tgt)
+
+
+def test_far_outliers_fall_back_to_brute_force(ops):
+    rng = np.random.default_rng(5)
+    tgt = surface(rng, 20000)
+    src = surface(rng, 4000, noise=0.002)
+    src[::7] += np.array([5.0, -3.0, 8.0], np.float32)      # far outside the bounding box
+    src[3::11] += np.array([0.0, 0.0, 0.4], np.float32)     # inside the box but far from the surface
+    unres = check_same(ops, src, tgt)
+    assert unres > 0  # the fallback path was actually exercised
+
+
+def test_duplicates_and_lattice_ties(ops):
+    g = np.stack(np.meshgrid(np.arange(24), np.arange(24), np.arange(6), indexing="ij"), -1).reshape(-1, 3)
+    tgt = np.concatenate([g, g[::5]]).astype(np.float32)      # exact duplicates with higher indices
+    src = (g[::3] + 0.5).astype(np.float32)                   # 8 equidistant lattice neighbours each
+    src = np.concatenate([src, tgt[100:400]])                  # and exact hits (distance 0)
+    check_same(ops, src, tgt)
+    oi, _ = o.knn1(src, tgt)
+    gi, _ = ops.knn1_grid(dev(src), dev(tgt))
+    assert np.array_equal(host(gi), oi)
+
+
+def test_degenerate_boxes(ops):
+    rng = np.random.default_rng(9)
+    plane = rng.random((5000, 3)).astype(np.float32)
+    plane[:, 2] = 1.25                                        # zero extent along z
+    check_same(ops, (plane[:700] + np.float32(0.01)), plane)
+    line = np.zeros((3000, 3), np.float32)
+    line[:, 0] = np.linspace(0, 1, 3000)
+    check_same(ops, rng.random((500, 3)).astype(np.float32), line)
+    same = np.tile(np.array([[0.3, -0.2, 1.0]], np.float32), (2100, 1))   # every target identical
+    check_same(ops, rng.random((300, 3)).astype(np.float32), same)
+
+
+def test_clusters_with_empty_space(ops):
+    rng = np.random.default_rng(11)
+    a = (rng.standard_normal((15000, 3)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal((15000, 3)) * 0.05 + np.array([4.0, 0, 0])).astype(np.float32)
+    tgt = np.concatenate([a, b])
+    src = np.concatenate([a[:2000] + 0.01, b[:2000] - 0.01, np.array([[2.0, 0, 0]] * 64, np.float32)])
+    check_same(ops, src.astype(np.float32), tgt)
+
+
+def test_non_finite_targets_are_ignored_like_brute_force(ops):
+    rng = np.random.default_rng(13)
+    tgt = surface(rng, 6000)
+    tgt[10] = np.nan
+    tgt[20, 1] = np.inf
+    src = surface(rng, 1500, noise=0.002)
+    check_same(ops, src, tgt)
+
+
+_AB_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from gradslam_amd import ops
+from gradslam_amd.datasets.synthetic import make_sequence
+s = make_sequence(2, 240, 320, seed=6)
+K = torch.from_numpy(s["intrinsics"][0]).cuda()
+pts = []
+for f in range(2):
+    d = torch.from_numpy(s["depths"][f, ..., 0]).cuda()
+    v, n, _, _ = ops.frame_maps(d, K)
+    gv, gn = ops.global_maps(v, n, d, torch.from_numpy(s["poses"][0]).cuda())
+    pts.append(ops.downsample_frame(gv, gn, None, d, 2)[:2])
+(tgt, tn), (src, _) = pts
+T, idx, tr = ops.icp(src, tgt, tn, mode=1, numiters=20, return_trace=True)
+np.savez(sys.argv[1], T=T.cpu().numpy(), idx=idx.cpu().numpy(), tr=tr.cpu().numpy(), n=np.array([src.shape[0], tgt.shape[0]]))
+"""
+
+
+def test_icp_identical_with_grid_and_brute_engines(tmp_path):
+    """Whole 20-iteration gradICP solve (19k x 19k points) run in two fresh processes, one per
+    engine: transforms, neighbour indices and the per-iteration trace must be bit-identical."""
+    outs = []
+    for mode in ("grid", "brute"):
+        out = str(tmp_path / (mode + ".npz"))
+        env = dict(os.environ, GRADSLAM_HIP_KNN=mode)
+        subprocess.run([sys.executable, "-c", _AB_SCRIPT % REPO, out], check=True, env=env, timeout=600)
+        outs.append(np.load(out))
+    a, b = outs
+    assert a["n"][0] > 15000 and a["n"][1] > 15000
+    assert np.array_equal(a["idx"], b["idx"])
+    assert np.array_equal(a["T"].view(np.int32), b["T"].view(np.int32))
+    assert np.array_equal(a["tr"].view(np.int32), b["tr"].view(np.int32))
