@@ -161,8 +161,8 @@ GS_DEV int grid_cell(const GsGrid& g, float x, float y, float z) {
 
 // One block: bounding box of the finite targets, then the cell size.  Heuristic: targets are a
 // sampled surface (spacing ~ sqrt(area / n)) or, failing that, a volume (spacing ~ cbrt(V / n));
-// the cell edge is the larger of 2 surface spacings and 1 volume spacing, grown until the grid
-// fits GS_GRID_MAXCELL cells.  Any positive cell size is CORRECT; the choice only affects speed.
+// the cell edge is the larger of 1.5 surface spacings and 0.5 volume spacings (3 shells then
+// still reach 1.75 volume spacings), grown until the grid fits GS_GRID_MAXCELL cells.  Any positive cell size is CORRECT; the choice only affects speed.
 __global__ void __launch_bounds__(1024) gs_grid_bbox_kernel(const float* __restrict__ tgt, int64_t n_tgt,
                                                             GsGrid* __restrict__ g, int* __restrict__ unres_count) {
   __shared__ float red[6][1024 / GS_WAVE];
@@ -205,8 +205,8 @@ __global__ void __launch_bounds__(1024) gs_grid_bbox_kernel(const float* __restr
     const float ex = (m[0] - o[0]) + tiny, ey = (m[1] - o[1]) + tiny, ez = (m[2] - o[2]) + tiny;
     const float n = (float)(n_tgt > 0 ? n_tgt : 1);
     const float area = ex * ey + ey * ez + ex * ez;
-    float c = 2.0f * sqrtf(area / n);
-    const float cv = cbrtf((ex * ey * ez) / n);
+    float c = 1.5f * sqrtf(area / n);
+    const float cv = 0.5f * cbrtf((ex * ey * ez) / n);
     c = cv > c ? cv : c;
     const float emax = ex > ey ? (ex > ez ? ex : ez) : (ey > ez ? ey : ez);
     c = c > emax * (1.0f / 1024.0f) ? c : emax * (1.0f / 1024.0f);
@@ -311,29 +311,54 @@ int gs_knn_grid_build(const float* tgt, int64_t n_tgt, int64_t n_src, void* grid
   return GS_OK;
 }
 
-// candidate ordering identical to the packed 64-bit minimum of the brute-force engine
-GS_DEV void grid_consider(float qx, float qy, float qz, const float4 p, float& bd, uint32_t& bi) {
+// A query is served by a group of GQ_G = 16 lanes (4 queries per wave): the lanes first fetch the
+// [begin, end) bounds of the row segments of a shell in parallel, then stride together over every
+// segment, and finally min-reduce their packed (distance bits << 32 | index) keys -- the same
+// ordering as the brute-force engine's 64-bit atomicMin.  This turns ~100 serial dependent
+// gathers per query into ~15 wave-wide ones (the search is latency-, not bandwidth-bound).
+constexpr int GQ_G = 16;
+constexpr int GQ_BLOCK = 256;
+
+GS_DEV unsigned long long grid_key(float qx, float qy, float qz, const float4 p) {
   const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
   float d = dx * dx;
   d = gs_fma(dy, dy, d);
   d = gs_fma(dz, dz, d);
-  const uint32_t idx = (uint32_t)__float_as_int(p.w);
-  if (d < bd || (d == bd && idx < bi)) {
-    bd = d;
-    bi = idx;
-  }
+  // a NaN distance never wins (brute force: `d < best` is false for NaN)
+  return d == d ? knn_pack(d, (uint32_t)__float_as_int(p.w)) : ~0ull;
 }
 
-constexpr int GQ_BLOCK = 64;
+// cooperative scan of one segment list: lane `lane` holds (sb, se) of slot `lane` (se <= sb: empty)
+GS_DEV unsigned long long grid_scan_slots(int sb, int se, int nslots, int lane, float qx, float qy, float qz,
+                                          const float4* __restrict__ sorted, unsigned long long key) {
+  for (int j = 0; j < nslots; ++j) {
+    const int b = __shfl(sb, j, GQ_G), e = __shfl(se, j, GQ_G);
+    for (int i = b + lane; i < e; i += GQ_G) {
+      const unsigned long long k2 = grid_key(qx, qy, qz, sorted[i]);
+      key = k2 < key ? k2 : key;
+    }
+  }
+  return key;
+}
+
+GS_DEV unsigned long long grid_group_min(unsigned long long key) {
+#pragma unroll
+  for (int d = GQ_G / 2; d > 0; d >>= 1) {
+    const unsigned long long o = __shfl_xor(key, d, GQ_G);
+    key = o < key ? o : key;
+  }
+  return key;
+}
 
 __global__ void __launch_bounds__(GQ_BLOCK) gs_grid_query_kernel(
     const float* __restrict__ src_in, const float* __restrict__ Tapply, float* __restrict__ src_out,
     int64_t n_src, const GsGrid* __restrict__ gp, const int* __restrict__ cell_start,
     const float4* __restrict__ sorted, unsigned long long* __restrict__ best, int* __restrict__ unres_count,
     int* __restrict__ unres_next, int* __restrict__ unres_list) {
-  const int64_t s = (int64_t)blockIdx.x * GQ_BLOCK + threadIdx.x;
-  if (s == 0) *unres_next = 0;  // arm the counter of the NEXT query (ping-pong)
-  if (s >= n_src) return;
+  const int lane = threadIdx.x & (GQ_G - 1);
+  const int64_t s = ((int64_t)blockIdx.x * GQ_BLOCK + threadIdx.x) / GQ_G;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *unres_next = 0;  // arm the counter of the NEXT query (ping-pong)
+  if (s >= n_src) return;  // whole 16-lane groups leave together
   const GsGrid g = *gp;
   float qx = src_in[3 * s], qy = src_in[3 * s + 1], qz = src_in[3 * s + 2];
   if (Tapply) {
@@ -344,7 +369,7 @@ __global__ void __launch_bounds__(GQ_BLOCK) gs_grid_query_kernel(
     gs_rigid_fma(T, qx, qy, qz, t0, t1, t2);
     qx = t0; qy = t1; qz = t2;
   }
-  if (src_out) {
+  if (src_out && lane == 0) {
     src_out[3 * s] = qx;
     src_out[3 * s + 1] = qy;
     src_out[3 * s + 2] = qz;
@@ -354,45 +379,54 @@ __global__ void __launch_bounds__(GQ_BLOCK) gs_grid_query_kernel(
   const float px = fminf(fmaxf(qx, g.ox), g.mx), py = fminf(fmaxf(qy, g.oy), g.my), pz = fminf(fmaxf(qz, g.oz), g.mz);
   const int cx = grid_axis(px, g.ox, g.inv_c, g.nx), cy = grid_axis(py, g.oy, g.inv_c, g.ny),
             cz = grid_axis(pz, g.oz, g.inv_c, g.nz);
-  float bd = __builtin_inff();
-  uint32_t bi = 0xffffffffu;
+  unsigned long long key = ~0ull;
   bool done = false;
-  for (int k = 0; k <= GS_GRID_RINGS && !done; ++k) {
-    for (int dz = -k; dz <= k; ++dz) {
-      const int zz = cz + dz;
-      if (zz < 0 || zz >= g.nz) continue;
-      for (int dy = -k; dy <= k; ++dy) {
-        const int yy = cy + dy;
-        if (yy < 0 || yy >= g.ny) continue;
-        const int row = (zz * g.ny + yy) * g.nx;
-        const bool full_row = (dz == -k || dz == k || dy == -k || dy == k);
-        if (full_row) {
-          const int x0 = cx - k < 0 ? 0 : cx - k, x1 = cx + k >= g.nx ? g.nx - 1 : cx + k;
-          const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
-          for (int i = b; i < e; ++i) grid_consider(qx, qy, qz, sorted[i], bd, bi);
-        } else {  // interior row of the shell: only its two end cells belong to shell k
-          const int xa = cx - k, xb = cx + k;
-          if (xa >= 0) {
-            const int b = cell_start[row + xa], e = cell_start[row + xa + 1];
-            for (int i = b; i < e; ++i) grid_consider(qx, qy, qz, sorted[i], bd, bi);
+  for (int k = 1; k <= GS_GRID_RINGS && !done; ++k) {
+    // k == 1: the full 3x3x3 block (shells 0 and 1) as 9 rows of up to 3 cells;
+    // k >= 2: shell k only -- border rows are one run of 2k+1 cells, interior rows contribute
+    // their two end cells.  Two slots per row, GQ_G slots per pass.
+    const int side = 2 * k + 1, nslot = 2 * side * side;
+    for (int s0 = 0; s0 < nslot; s0 += GQ_G) {
+      const int slot = s0 + lane;
+      int sb = 0, se = 0;
+      if (slot < nslot) {
+        const int rowi = slot >> 1, second = slot & 1;
+        const int dz = rowi / side - k, dy = rowi % side - k;
+        const int zz = cz + dz, yy = cy + dy;
+        if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
+          const int row = (zz * g.ny + yy) * g.nx;
+          const bool full_row = (k == 1) || dz == -k || dz == k || dy == -k || dy == k;
+          int x0, x1;
+          if (full_row) {
+            x0 = second ? 1 : (cx - k < 0 ? 0 : cx - k);
+            x1 = second ? 0 : (cx + k >= g.nx ? g.nx - 1 : cx + k);
+          } else {
+            x0 = x1 = second ? cx + k : cx - k;
+            if (x0 < 0 || x0 >= g.nx) { x0 = 1; x1 = 0; }
           }
-          if (xb < g.nx) {
-            const int b = cell_start[row + xb], e = cell_start[row + xb + 1];
-            for (int i = b; i < e; ++i) grid_consider(qx, qy, qz, sorted[i], bd, bi);
+          if (x0 <= x1) {
+            sb = cell_start[row + x0];
+            se = cell_start[row + x1 + 1];
           }
         }
       }
+      const int rem = nslot - s0;
+      key = grid_scan_slots(sb, se, rem < GQ_G ? rem : GQ_G, lane, qx, qy, qz, sorted, key);
     }
+    key = grid_group_min(key);
     // every unvisited target is farther than k cells from the projected query; 0.1 % of a cell is
     // orders of magnitude above the float rounding of the cell assignment
     const float rb = (float)k * g.c * 0.999f;
+    const float bd = __uint_as_float((uint32_t)(key >> 32));  // NaN while nothing was found
     done = bd <= rb * rb;
   }
-  if (done) {
-    best[s] = knn_pack(bd, bi);
-  } else {
-    best[s] = ~0ull;  // finished by the brute-force pass
-    unres_list[atomicAdd(unres_count, 1)] = (int)s;
+  if (lane == 0) {
+    if (done) {
+      best[s] = key;
+    } else {
+      best[s] = ~0ull;  // finished by the brute-force pass
+      unres_list[atomicAdd(unres_count, 1)] = (int)s;
+    }
   }
 }
 
@@ -405,7 +439,7 @@ int gs_knn_grid_query(const float* src_in, const float* Tapply, float* src_out, 
   int* nxt = m.unres_count + ((seq + 1) & 1);
   ++seq;
   GsProf prof(GS_PROF_KNN, (double)n_src * (double)n_tgt, st);  // brute-force-equivalent pairs
-  hipLaunchKernelGGL(gs_grid_query_kernel, dim3((unsigned)gs_ceil_div(n_src, GQ_BLOCK)), dim3(GQ_BLOCK), 0, st,
+  hipLaunchKernelGGL(gs_grid_query_kernel, dim3((unsigned)gs_ceil_div(n_src * GQ_G, GQ_BLOCK)), dim3(GQ_BLOCK), 0, st,
                      src_in, Tapply, src_out, n_src, m.g, m.cell_start, m.sorted, best, cnt, nxt, m.unres_list);
   // unresolved queries (device-side count; blocks exit at once when it is zero)
   unsigned gx = (unsigned)gs_ceil_div(n_src, KNN_STILE);
