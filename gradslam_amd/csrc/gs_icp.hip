@@ -341,17 +341,122 @@ __global__ void __launch_bounds__(LIN_BLOCK) gs_icp_linearize_kernel(
   }
 }
 
-GS_DEV double icp_sum_partials(const double* __restrict__ partials, int nblk, int i) {
+// ---------------------------------------------------------------- fused search + linearise
+// One kernel per half-iteration when the grid engine is active: a 512-thread block serves 32
+// source points (one per 16-lane group), finishes the rare unresolved queries itself by a
+// whole-block brute-force scan, then wave 0 builds the 32 rows and reduces them to ONE partial
+// row.  No neighbour table round-trips through HBM, no separate fallback / linearise launches.
+constexpr int FS_BLOCK = 512;            // 8 waves; 2-3 blocks per CU keep every block of a 640x480 solve resident
+constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 32 queries per block, their rows are built by wave 0
+
+template <bool FULL>
+__global__ void __launch_bounds__(FS_BLOCK) gs_icp_search_linearize_kernel(
+    const float* __restrict__ src_in, const float* __restrict__ Tapply, float* __restrict__ src_out, int64_t n_src,
+    const float* __restrict__ tgt, const float* __restrict__ tn, int64_t n_tgt, const GsGrid* __restrict__ gp,
+    const int* __restrict__ cell_start, const float4* __restrict__ sorted, float dist_thresh,
+    double* __restrict__ partials, int64_t* __restrict__ out_idx) {
+  __shared__ unsigned long long keys_s[FS_QPB];
+  __shared__ float qs[FS_QPB][3];
+  __shared__ int unres_q[FS_QPB];
+  __shared__ int unres_n;
+  __shared__ unsigned long long red[FS_BLOCK / GS_WAVE];
+  const int lane = threadIdx.x & (GQ_G - 1), slot = threadIdx.x / GQ_G;
+  const int64_t s = (int64_t)blockIdx.x * FS_QPB + slot;
+  if (threadIdx.x == 0) unres_n = 0;
+  __syncthreads();
+  if (s < n_src) {
+    const GsGrid g = *gp;
+    float qx = src_in[3 * s], qy = src_in[3 * s + 1], qz = src_in[3 * s + 2];
+    if (Tapply) {
+      float T[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) T[i] = Tapply[i];
+      float t0, t1, t2;
+      gs_rigid_fma(T, qx, qy, qz, t0, t1, t2);
+      qx = t0; qy = t1; qz = t2;
+    }
+    bool done;
+    const unsigned long long key = grid_search16(g, cell_start, sorted, qx, qy, qz, lane, &done);
+    if (lane == 0) {
+      if (src_out) {
+        src_out[3 * s] = qx;
+        src_out[3 * s + 1] = qy;
+        src_out[3 * s + 2] = qz;
+      }
+      qs[slot][0] = qx; qs[slot][1] = qy; qs[slot][2] = qz;
+      keys_s[slot] = key;
+      if (!done) unres_q[atomicAdd(&unres_n, 1)] = slot;
+    }
+  }
+  __syncthreads();
+  const int nun = unres_n;  // block-uniform
+  for (int u = 0; u < nun; ++u) {
+    const int us = unres_q[u];
+    const unsigned long long key = block_brute_min<FS_BLOCK>(qs[us][0], qs[us][1], qs[us][2], tgt, n_tgt, red);
+    if (threadIdx.x == 0) keys_s[us] = key;
+  }
+  __syncthreads();
+  if (threadIdx.x >= GS_WAVE) return;  // wave 0: one row per lane
+  const int64_t r = (int64_t)blockIdx.x * FS_QPB + threadIdx.x;
+  double v[LIN_NV];
+#pragma unroll
+  for (int i = 0; i < LIN_NV; ++i) v[i] = 0.0;
+  if (r < n_src && threadIdx.x < FS_QPB) {
+    const unsigned long long bb = keys_s[threadIdx.x];
+    int64_t j = (int64_t)(bb & 0xffffffffull);
+    if (j >= n_tgt) j = 0;  // only when every distance was NaN
+    const float d2 = __uint_as_float((uint32_t)(bb >> 32));
+    const bool keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
+    float a[6], res;
+    gn_row(qs[threadIdx.x][0], qs[threadIdx.x][1], qs[threadIdx.x][2], tgt, tn, j, a, res);
+    if (FULL && out_idx) out_idx[r] = j;
+    if (keep) {
+      if (FULL) {
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int k = i; k < 6; ++k) v[q++] = (double)a[i] * (double)a[k];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[21 + i] = (double)a[i] * (double)res;
+      }
+      v[27] = (double)res * (double)res;
+    }
+  }
+#pragma unroll
+  for (int i = FULL ? 0 : 27; i < LIN_NV; ++i) {
+    const double sum = gs_wave_sum_f64(v[i]);
+    if (threadIdx.x == 0) partials[(int64_t)blockIdx.x * LIN_NV + i] = sum;
+  }
+}
+
+// Fixed-order, block-parallel sum of the per-block partial rows (SUM_BLOCK threads): thread t adds
+// rows t/32, t/32 + SUM_BLOCK/32, ... of value t%32, then value i is finished by adding the
+// SUM_BLOCK/32 sub-sums in index order.  (A single lane walking all rows was latency-bound:
+// one dependent global load per row.)  Values [first, LIN_NV) are produced in S[].
+constexpr int SUM_BLOCK = 1024;
+GS_DEV void icp_sum_partials(const double* __restrict__ partials, int nblk, int first, double* S,
+                             double (*sub)[32]) {
+  const int i = threadIdx.x & 31, j = threadIdx.x >> 5;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += partials[(int64_t)b * LIN_NV + i];
-  return s;
+  if (i >= first && i < LIN_NV)
+    for (int b = j; b < nblk; b += SUM_BLOCK / 32) s += partials[(int64_t)b * LIN_NV + i];
+  sub[j][i] = s;
+  __syncthreads();
+  if (threadIdx.x >= first && threadIdx.x < LIN_NV) {
+    double t = 0.0;
+    for (int k = 0; k < SUM_BLOCK / 32; ++k) t += sub[k][threadIdx.x];
+    S[threadIdx.x] = t;
+  }
+  __syncthreads();
 }
 
 // After the first linearisation of an iteration: solve for xi, Tr = se3_exp(xi).
-__global__ void gs_icp_solve_kernel(const double* __restrict__ partials, int nblk, GsIcpState* __restrict__ st) {
-  __shared__ double S[LIN_NV];
-  if (threadIdx.x < LIN_NV) S[threadIdx.x] = icp_sum_partials(partials, nblk, threadIdx.x);
-  __syncthreads();
+__global__ void __launch_bounds__(SUM_BLOCK) gs_icp_solve_kernel(const double* __restrict__ partials, int nblk,
+                                                                 GsIcpState* __restrict__ st) {
+  __shared__ double S[32];
+  __shared__ double sub[SUM_BLOCK / 32][32];
+  icp_sum_partials(partials, nblk, 0, S, sub);
   if (threadIdx.x != 0) return;
   float AtA[36], Atb[6], xi[6], Tr[16];
   int q = 0;
@@ -370,14 +475,15 @@ __global__ void gs_icp_solve_kernel(const double* __restrict__ partials, int nbl
 
 // After the look-ahead residual: LM accept/reject (mode 0, odometry/icputils.py:356-365) or
 // the gradLM soft update (mode 1, :527-543).  On the last iteration writes the result.
-__global__ void gs_icp_update_kernel(const double* __restrict__ partials, int nblk, GsIcpState* __restrict__ st,
-                                     gs_icp_params prm, int it, const float* __restrict__ compose16,
-                                     float* __restrict__ out_T16) {
-  __shared__ double Snew;
-  if (threadIdx.x == 0) Snew = icp_sum_partials(partials, nblk, 27);
-  __syncthreads();
+__global__ void __launch_bounds__(SUM_BLOCK) gs_icp_update_kernel(const double* __restrict__ partials, int nblk,
+                                                                  GsIcpState* __restrict__ st, gs_icp_params prm,
+                                                                  int it, const float* __restrict__ compose16,
+                                                                  float* __restrict__ out_T16) {
+  __shared__ double S[32];
+  __shared__ double sub[SUM_BLOCK / 32][32];
+  icp_sum_partials(partials, nblk, 27, S, sub);
   if (threadIdx.x != 0) return;
-  const float new_err = (float)Snew;
+  const float new_err = (float)S[27];
   const float err = st->err;
   float damp = st->damp;
   float Tstep[16], Ttot[16];
@@ -477,7 +583,7 @@ static IcpScratch icp_carve(void* scratch, int64_t n_src) {
   s.srcB = reinterpret_cast<float*>(p);
   p += gs_align(12 * (size_t)n_src);
   s.partials = reinterpret_cast<double*>(p);
-  p += gs_align(sizeof(double) * LIN_NV * (size_t)gs_ceil_div(n_src, LIN_BLOCK));
+  p += gs_align(sizeof(double) * LIN_NV * (size_t)gs_ceil_div(n_src, FS_QPB));
   s.grid = p;
   return s;
 }
@@ -494,7 +600,7 @@ static bool icp_grid_enabled() {
 
 extern "C" int64_t gs_icp_scratch_bytes(int64_t n_src, int64_t n_tgt) {
   if (n_src < 1) n_src = 1;
-  const int64_t nblk = gs_ceil_div(n_src, LIN_BLOCK);
+  const int64_t nblk = gs_ceil_div(n_src, FS_QPB);  // the fused kernels emit one partial row per 32 points
   return (int64_t)(gs_align(sizeof(GsIcpState)) + gs_align(8 * (size_t)n_src) + 2 * gs_align(12 * (size_t)n_src) +
                    gs_align(sizeof(double) * LIN_NV * (size_t)nblk) + gs_knn_grid_scratch_bytes(n_src, n_tgt) + 4096);
 }
@@ -512,45 +618,59 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
   hipStream_t st = gs_stream(stream);
   IcpScratch sc = icp_carve(icp_scratch, n_src);
   const int nblk = (int)gs_ceil_div(n_src, LIN_BLOCK);
-  GS_HIP(hipMemsetAsync(sc.best, 0xff, 8 * (size_t)n_src, st));
   hipLaunchKernelGGL(gs_icp_init_kernel, dim3(1), dim3(64), 0, st, sc.state, init16, prm->damp, prm->numiters,
                      compose16, out_T16);
   // the target set is fixed for all 2*numiters searches of this solve: bin it once
   const bool use_grid = icp_grid_enabled() && gs_knn_use_grid(n_src, n_tgt) && prm->numiters > 0;
+  GridMem gm = grid_carve(sc.grid, n_src, n_tgt);
   if (use_grid) {
     int rc = gs_knn_grid_build(tgt, n_tgt, n_src, sc.grid, st);
     if (rc != GS_OK) return rc;
+  } else {
+    GS_HIP(hipMemsetAsync(sc.best, 0xff, 8 * (size_t)n_src, st));
   }
-  auto knn = [&](const float* s_in, const float* Tapply, float* s_out) {
-    if (use_grid) gs_knn_grid_query(s_in, Tapply, s_out, n_src, tgt, n_tgt, sc.best, sc.grid, st);
-    else gs_knn_brute_launch(s_in, Tapply, s_out, n_src, tgt, n_tgt, sc.best, st);
+  const int nfs = (int)gs_ceil_div(n_src, FS_QPB);
+  const int nrows = use_grid ? nfs : nblk;  // partial rows the solve / update kernels add up
+  // one half-iteration: search (with the pending transform applied on load) + rows + partial sums
+  auto half = [&](bool full, const float* s_in, const float* Tapply, float* s_out) {
+    if (use_grid) {
+      GsProf prof(GS_PROF_KNN, (double)n_src * (double)n_tgt, st);  // brute-force-equivalent pairs
+      if (full)
+        hipLaunchKernelGGL((gs_icp_search_linearize_kernel<true>), dim3(nfs), dim3(FS_BLOCK), 0, st, s_in, Tapply,
+                           s_out, n_src, tgt, tgt_normals, n_tgt, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
+                           sc.partials, out_idx);
+      else
+        hipLaunchKernelGGL((gs_icp_search_linearize_kernel<false>), dim3(nfs), dim3(FS_BLOCK), 0, st, s_in, Tapply,
+                           s_out, n_src, tgt, tgt_normals, n_tgt, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
+                           sc.partials, nullptr);
+      return;
+    }
+    gs_knn_brute_launch(s_in, Tapply, s_out, n_src, tgt, n_tgt, sc.best, st);
+    GsProf prof(GS_PROF_LINEARIZE, 44.0 * (double)n_src, st);  // 8 B best + 12 B src + 24 B gather
+    // the brute-force kernel wrote the transformed cloud to s_out (first search of an iteration)
+    // or nothing (look-ahead: the row kernel re-applies Tr)
+    if (full)
+      hipLaunchKernelGGL((gs_icp_linearize_kernel<true>), dim3(nblk), dim3(LIN_BLOCK), 0, st, s_out, nullptr, n_src,
+                         tgt, tgt_normals, n_tgt, sc.best, prm->dist_thresh, sc.partials, out_idx);
+    else
+      hipLaunchKernelGGL((gs_icp_linearize_kernel<false>), dim3(nblk), dim3(LIN_BLOCK), 0, st, s_in, Tapply, n_src,
+                         tgt, tgt_normals, n_tgt, sc.best, prm->dist_thresh, sc.partials, nullptr);
   };
   const float* cur_in = src;   // source cloud before this iteration's pending transform
   float* cur = sc.srcA;        // where the transformed cloud of this iteration is written
   float* other = sc.srcB;
   for (int it = 0; it < prm->numiters; ++it) {
     // apply the pending transform (initial transform or last T_step) while searching
-    knn(cur_in, sc.state->T_step, cur);
-    {
-      GsProf prof(GS_PROF_LINEARIZE, 44.0 * (double)n_src, st);  // 8 B best + 12 B src + 24 B gather
-      hipLaunchKernelGGL((gs_icp_linearize_kernel<true>), dim3(nblk), dim3(LIN_BLOCK), 0, st, cur, nullptr, n_src,
-                         tgt, tgt_normals, n_tgt, sc.best, prm->dist_thresh, sc.partials, out_idx);
-    }
+    half(true, cur_in, sc.state->T_step, cur);
     {
       GsProf prof(GS_PROF_SOLVE, 1.0, st);
-      hipLaunchKernelGGL(gs_icp_solve_kernel, dim3(1), dim3(64), 0, st, sc.partials, nblk, sc.state);
+      hipLaunchKernelGGL(gs_icp_solve_kernel, dim3(1), dim3(SUM_BLOCK), 0, st, sc.partials, nrows, sc.state);
     }
     // look-ahead: one_step = Tr * cur, searched and reduced without materialising it
-    knn(cur, sc.state->Tr, nullptr);
-    {
-      GsProf prof(GS_PROF_LINEARIZE, 44.0 * (double)n_src, st);
-      hipLaunchKernelGGL((gs_icp_linearize_kernel<false>), dim3(nblk), dim3(LIN_BLOCK), 0, st, cur,
-                         sc.state->Tr, n_src, tgt, tgt_normals, n_tgt, sc.best, prm->dist_thresh, sc.partials,
-                         nullptr);
-    }
+    half(false, cur, sc.state->Tr, nullptr);
     {
       GsProf prof(GS_PROF_SOLVE, 1.0, st);
-      hipLaunchKernelGGL(gs_icp_update_kernel, dim3(1), dim3(64), 0, st, sc.partials, nblk, sc.state, *prm, it,
+      hipLaunchKernelGGL(gs_icp_update_kernel, dim3(1), dim3(SUM_BLOCK), 0, st, sc.partials, nrows, sc.state, *prm, it,
                          compose16, out_T16);
     }
     cur_in = cur;

@@ -110,53 +110,9 @@ int gs_knn_brute_launch(const float* src_in, const float* Tapply, float* src_out
 }
 
 // ---------------------------------------------------------------- uniform grid ---------
-struct GsGrid {
-  float ox, oy, oz;  // bounding box of the (finite) targets
-  float mx, my, mz;
-  float c, inv_c;    // cell edge
-  int nx, ny, nz, ncell;
-};
-
-struct GridMem {
-  GsGrid* g;
-  int* unres_count;  // [2], ping-pong between consecutive queries
-  int* cell_count;   // [MAXCELL + 1]
-  int* cell_start;   // [MAXCELL + 1]
-  int* tile_sums;    // [MAXCELL / 1024 + 1]
-  float4* sorted;    // [n_tgt] (x, y, z, original index bits), grouped by cell
-  int* unres_list;   // [n_src]
-};
-constexpr int GRID_TILE = 1024;
-
-static GridMem grid_carve(void* scratch, int64_t n_src, int64_t n_tgt) {
-  char* p = reinterpret_cast<char*>(scratch);
-  GridMem m;
-  m.g = reinterpret_cast<GsGrid*>(p); p += 256;
-  m.unres_count = reinterpret_cast<int*>(p); p += 256;
-  m.cell_count = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1));
-  m.cell_start = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1));
-  m.tile_sums = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL / GRID_TILE + 2));
-  m.sorted = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1));
-  m.unres_list = reinterpret_cast<int*>(p);
-  (void)n_src;
-  return m;
-}
-
 size_t gs_knn_grid_scratch_bytes(int64_t n_src, int64_t n_tgt) {
-  return 512 + 2 * gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1)) + gs_align(4 * (size_t)(GS_GRID_MAXCELL / GRID_TILE + 2)) +
+  return 512 + 2 * gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1)) + gs_align(4 * (size_t)(GS_GRID_MAXCELL / GS_GRID_TILE + 2)) +
          gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1)) + gs_align(4 * (size_t)(n_src > 0 ? n_src : 1)) + 256;
-}
-
-GS_DEV int grid_axis(float v, float o, float inv_c, int n) {
-  const float f = (v - o) * inv_c;
-  // NaN fails both comparisons and lands in cell 0
-  return f >= 0.0f ? (f < (float)n ? (int)f : n - 1) : 0;
-}
-GS_DEV int grid_cell(const GsGrid& g, float x, float y, float z) {
-  const int ix = grid_axis(x, g.ox, g.inv_c, g.nx);
-  const int iy = grid_axis(y, g.oy, g.inv_c, g.ny);
-  const int iz = grid_axis(z, g.oz, g.inv_c, g.nz);
-  return (iz * g.ny + iy) * g.nx + ix;
 }
 
 // One block: bounding box of the finite targets, then the cell size.  Heuristic: targets are a
@@ -241,8 +197,8 @@ __global__ void __launch_bounds__(256) gs_grid_tile_sum_kernel(const int* __rest
                                                                int* __restrict__ tile_sums) {
   __shared__ int smem[256 / GS_WAVE + 1];
   const int n = gp->ncell + 1;
-  const int base = blockIdx.x * GRID_TILE + threadIdx.x * 4;
-  if (blockIdx.x * GRID_TILE >= n) return;
+  const int base = blockIdx.x * GS_GRID_TILE + threadIdx.x * 4;
+  if (blockIdx.x * GS_GRID_TILE >= n) return;
   int c = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) c += (base + i < n) ? cell_count[base + i] : 0;
@@ -256,13 +212,13 @@ __global__ void __launch_bounds__(256) gs_grid_scan_kernel(const int* __restrict
                                                            int* __restrict__ cell_start) {
   __shared__ int smem[256 / GS_WAVE + 1];
   const int n = gp->ncell + 1;
-  if (blockIdx.x * GRID_TILE >= n) return;
+  if (blockIdx.x * GS_GRID_TILE >= n) return;
   // prefix of the tiles before this one
   int pre = 0;
   for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) pre += tile_sums[t];
   int tile_prefix;
   (void)gs_block_excl_scan<256>(pre, smem, &tile_prefix);
-  const int base = blockIdx.x * GRID_TILE + threadIdx.x * 4;
+  const int base = blockIdx.x * GS_GRID_TILE + threadIdx.x * 4;
   int v[4], c = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -302,7 +258,7 @@ int gs_knn_grid_build(const float* tgt, int64_t n_tgt, int64_t n_src, void* grid
   hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3(1), dim3(1024), 0, st, tgt, n_tgt, m.g, m.unres_count);
   hipLaunchKernelGGL(gs_grid_count_kernel, dim3((unsigned)gs_ceil_div(n_tgt, 256)), dim3(256), 0, st, tgt, n_tgt,
                      m.g, m.cell_count);
-  const unsigned ntile = (unsigned)gs_ceil_div(GS_GRID_MAXCELL + 1, GRID_TILE);
+  const unsigned ntile = (unsigned)gs_ceil_div(GS_GRID_MAXCELL + 1, GS_GRID_TILE);
   hipLaunchKernelGGL(gs_grid_tile_sum_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums);
   hipLaunchKernelGGL(gs_grid_scan_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums,
                      m.cell_start);
@@ -311,44 +267,7 @@ int gs_knn_grid_build(const float* tgt, int64_t n_tgt, int64_t n_src, void* grid
   return GS_OK;
 }
 
-// A query is served by a group of GQ_G = 16 lanes (4 queries per wave): the lanes first fetch the
-// [begin, end) bounds of the row segments of a shell in parallel, then stride together over every
-// segment, and finally min-reduce their packed (distance bits << 32 | index) keys -- the same
-// ordering as the brute-force engine's 64-bit atomicMin.  This turns ~100 serial dependent
-// gathers per query into ~15 wave-wide ones (the search is latency-, not bandwidth-bound).
-constexpr int GQ_G = 16;
 constexpr int GQ_BLOCK = 256;
-
-GS_DEV unsigned long long grid_key(float qx, float qy, float qz, const float4 p) {
-  const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-  float d = dx * dx;
-  d = gs_fma(dy, dy, d);
-  d = gs_fma(dz, dz, d);
-  // a NaN distance never wins (brute force: `d < best` is false for NaN)
-  return d == d ? knn_pack(d, (uint32_t)__float_as_int(p.w)) : ~0ull;
-}
-
-// cooperative scan of one segment list: lane `lane` holds (sb, se) of slot `lane` (se <= sb: empty)
-GS_DEV unsigned long long grid_scan_slots(int sb, int se, int nslots, int lane, float qx, float qy, float qz,
-                                          const float4* __restrict__ sorted, unsigned long long key) {
-  for (int j = 0; j < nslots; ++j) {
-    const int b = __shfl(sb, j, GQ_G), e = __shfl(se, j, GQ_G);
-    for (int i = b + lane; i < e; i += GQ_G) {
-      const unsigned long long k2 = grid_key(qx, qy, qz, sorted[i]);
-      key = k2 < key ? k2 : key;
-    }
-  }
-  return key;
-}
-
-GS_DEV unsigned long long grid_group_min(unsigned long long key) {
-#pragma unroll
-  for (int d = GQ_G / 2; d > 0; d >>= 1) {
-    const unsigned long long o = __shfl_xor(key, d, GQ_G);
-    key = o < key ? o : key;
-  }
-  return key;
-}
 
 __global__ void __launch_bounds__(GQ_BLOCK) gs_grid_query_kernel(
     const float* __restrict__ src_in, const float* __restrict__ Tapply, float* __restrict__ src_out,
@@ -374,52 +293,8 @@ __global__ void __launch_bounds__(GQ_BLOCK) gs_grid_query_kernel(
     src_out[3 * s + 1] = qy;
     src_out[3 * s + 2] = qz;
   }
-  // cell of the query's projection onto the bounding box (the projection onto a convex set never
-  // increases the distance to points inside it, so shell bounds around it stay valid)
-  const float px = fminf(fmaxf(qx, g.ox), g.mx), py = fminf(fmaxf(qy, g.oy), g.my), pz = fminf(fmaxf(qz, g.oz), g.mz);
-  const int cx = grid_axis(px, g.ox, g.inv_c, g.nx), cy = grid_axis(py, g.oy, g.inv_c, g.ny),
-            cz = grid_axis(pz, g.oz, g.inv_c, g.nz);
-  unsigned long long key = ~0ull;
-  bool done = false;
-  for (int k = 1; k <= GS_GRID_RINGS && !done; ++k) {
-    // k == 1: the full 3x3x3 block (shells 0 and 1) as 9 rows of up to 3 cells;
-    // k >= 2: shell k only -- border rows are one run of 2k+1 cells, interior rows contribute
-    // their two end cells.  Two slots per row, GQ_G slots per pass.
-    const int side = 2 * k + 1, nslot = 2 * side * side;
-    for (int s0 = 0; s0 < nslot; s0 += GQ_G) {
-      const int slot = s0 + lane;
-      int sb = 0, se = 0;
-      if (slot < nslot) {
-        const int rowi = slot >> 1, second = slot & 1;
-        const int dz = rowi / side - k, dy = rowi % side - k;
-        const int zz = cz + dz, yy = cy + dy;
-        if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
-          const int row = (zz * g.ny + yy) * g.nx;
-          const bool full_row = (k == 1) || dz == -k || dz == k || dy == -k || dy == k;
-          int x0, x1;
-          if (full_row) {
-            x0 = second ? 1 : (cx - k < 0 ? 0 : cx - k);
-            x1 = second ? 0 : (cx + k >= g.nx ? g.nx - 1 : cx + k);
-          } else {
-            x0 = x1 = second ? cx + k : cx - k;
-            if (x0 < 0 || x0 >= g.nx) { x0 = 1; x1 = 0; }
-          }
-          if (x0 <= x1) {
-            sb = cell_start[row + x0];
-            se = cell_start[row + x1 + 1];
-          }
-        }
-      }
-      const int rem = nslot - s0;
-      key = grid_scan_slots(sb, se, rem < GQ_G ? rem : GQ_G, lane, qx, qy, qz, sorted, key);
-    }
-    key = grid_group_min(key);
-    // every unvisited target is farther than k cells from the projected query; 0.1 % of a cell is
-    // orders of magnitude above the float rounding of the cell assignment
-    const float rb = (float)k * g.c * 0.999f;
-    const float bd = __uint_as_float((uint32_t)(key >> 32));  // NaN while nothing was found
-    done = bd <= rb * rb;
-  }
+  bool done;
+  const unsigned long long key = grid_search16(g, cell_start, sorted, qx, qy, qz, lane, &done);
   if (lane == 0) {
     if (done) {
       best[s] = key;
