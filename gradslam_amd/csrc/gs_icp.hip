@@ -396,12 +396,12 @@ __global__ void __launch_bounds__(FS_BLOCK) gs_icp_search_linearize_kernel(
     if (threadIdx.x == 0) keys_s[us] = key;
   }
   __syncthreads();
-  if (threadIdx.x >= GS_WAVE) return;  // wave 0: one row per lane
-  const int64_t r = (int64_t)blockIdx.x * FS_QPB + threadIdx.x;
+  // rows: lane t < 32 of wave 0 builds the row of query t
   double v[LIN_NV];
 #pragma unroll
   for (int i = 0; i < LIN_NV; ++i) v[i] = 0.0;
-  if (r < n_src && threadIdx.x < FS_QPB) {
+  const int64_t r = (int64_t)blockIdx.x * FS_QPB + threadIdx.x;
+  if (threadIdx.x < FS_QPB && r < n_src) {
     const unsigned long long bb = keys_s[threadIdx.x];
     int64_t j = (int64_t)(bb & 0xffffffffull);
     if (j >= n_tgt) j = 0;  // only when every distance was NaN
@@ -423,10 +423,37 @@ __global__ void __launch_bounds__(FS_BLOCK) gs_icp_search_linearize_kernel(
       v[27] = (double)res * (double)res;
     }
   }
+  if (!FULL) {  // residual only: one value, a plain wave reduction is enough
+    if (threadIdx.x < GS_WAVE) {
+      const double sum = gs_wave_sum_f64(v[27]);
+      if (threadIdx.x == 0) partials[(int64_t)blockIdx.x * LIN_NV + 27] = sum;
+    }
+    return;
+  }
+  // 32 rows x 28 values through LDS (a 28-fold wave shuffle reduction costs ~6 us of dependent
+  // cross-lane traffic in one wave): 8 groups of 28 threads add 4 rows each, then 28 threads add
+  // the 8 sub-sums, always in index order.
+  __shared__ double rows_s[FS_QPB][LIN_NV + 1];
+  __shared__ double sub_s[8][LIN_NV];
+  if (threadIdx.x < FS_QPB) {
 #pragma unroll
-  for (int i = FULL ? 0 : 27; i < LIN_NV; ++i) {
-    const double sum = gs_wave_sum_f64(v[i]);
-    if (threadIdx.x == 0) partials[(int64_t)blockIdx.x * LIN_NV + i] = sum;
+    for (int i = 0; i < LIN_NV; ++i) rows_s[threadIdx.x][i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 * LIN_NV) {
+    const int i = threadIdx.x % LIN_NV, part = threadIdx.x / LIN_NV;
+    double t = rows_s[4 * part][i];
+    t += rows_s[4 * part + 1][i];
+    t += rows_s[4 * part + 2][i];
+    t += rows_s[4 * part + 3][i];
+    sub_s[part][i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < LIN_NV) {
+    double t = sub_s[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += sub_s[k][threadIdx.x];
+    partials[(int64_t)blockIdx.x * LIN_NV + threadIdx.x] = t;
   }
 }
 
@@ -439,8 +466,16 @@ GS_DEV void icp_sum_partials(const double* __restrict__ partials, int nblk, int 
                              double (*sub)[32]) {
   const int i = threadIdx.x & 31, j = threadIdx.x >> 5;
   double s = 0.0;
-  if (i >= first && i < LIN_NV)
-    for (int b = j; b < nblk; b += SUM_BLOCK / 32) s += partials[(int64_t)b * LIN_NV + i];
+  if (i >= first && i < LIN_NV) {
+    constexpr int STEP = SUM_BLOCK / 32;
+    for (int b = j; b < nblk; b += 8 * STEP) {  // 8 independent loads in flight, added in row order
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = (b + u * STEP < nblk) ? partials[(int64_t)(b + u * STEP) * LIN_NV + i] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += a[u];
+    }
+  }
   sub[j][i] = s;
   __syncthreads();
   if (threadIdx.x >= first && threadIdx.x < LIN_NV) {

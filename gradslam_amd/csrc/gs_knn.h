@@ -91,14 +91,41 @@ GS_DEV unsigned long long grid_key(float qx, float qy, float qz, const float4 p)
 }
 
 // cooperative scan of one segment list: lane `lane` holds (sb, se) of slot `lane` (se <= sb: empty)
-GS_DEV unsigned long long grid_scan_slots(int sb, int se, int nslots, int lane, float qx, float qy, float qz,
+// The candidates of all 16 slots are treated as ONE flat list (prefix sum of the slot lengths over
+// the group); lane l takes flat positions l, l+16, ... and finds (slot, offset) of each by a
+// 4-step binary search on the prefix with shuffles.  Gather addresses therefore depend on
+// registers only, so the two gathers of a pass are in flight together instead of one dependent
+// global load per slot.  Every lane runs the same number of passes (shuffles need all 16 lanes).
+GS_DEV int grid_flat_index(int t, int sb, int excl) {
+  int j = 0;
+#pragma unroll
+  for (int step = GQ_G / 2; step > 0; step >>= 1) {
+    const int e = __shfl(excl, j + step, GQ_G);
+    j = (e <= t) ? j + step : j;
+  }
+  return __shfl(sb, j, GQ_G) + (t - __shfl(excl, j, GQ_G));
+}
+
+GS_DEV unsigned long long grid_scan_slots(int sb, int se, int lane, float qx, float qy, float qz,
                                           const float4* __restrict__ sorted, unsigned long long key) {
-  for (int j = 0; j < nslots; ++j) {
-    const int b = __shfl(sb, j, GQ_G), e = __shfl(se, j, GQ_G);
-    for (int i = b + lane; i < e; i += GQ_G) {
-      const unsigned long long k2 = grid_key(qx, qy, qz, sorted[i]);
-      key = k2 < key ? k2 : key;
-    }
+  const int len = se > sb ? se - sb : 0;
+  int incl = len;
+#pragma unroll
+  for (int d = 1; d < GQ_G; d <<= 1) {
+    const int t = __shfl_up(incl, d, GQ_G);
+    if (lane >= d) incl += t;
+  }
+  const int excl = incl - len;
+  const int total = __shfl(incl, GQ_G - 1, GQ_G);
+  for (int t0 = 0; t0 < total; t0 += 2 * GQ_G) {
+    const int ta = t0 + lane, tb = t0 + GQ_G + lane;
+    const int ia = grid_flat_index(ta < total ? ta : 0, sb, excl);
+    const int ib = grid_flat_index(tb < total ? tb : 0, sb, excl);
+    const float4 pa = sorted[ia], pb = sorted[ib];  // total > 0: index 0 of the list is always valid
+    const unsigned long long ka = ta < total ? grid_key(qx, qy, qz, pa) : ~0ull;
+    const unsigned long long kb = tb < total ? grid_key(qx, qy, qz, pb) : ~0ull;
+    key = ka < key ? ka : key;
+    key = kb < key ? kb : key;
   }
   return key;
 }
@@ -129,12 +156,12 @@ GS_DEV unsigned long long grid_search16(const GsGrid& g, const int* __restrict__
     // k == 1: the full 3x3x3 block (shells 0 and 1) as 9 rows of up to 3 cells;
     // k >= 2: shell k only -- border rows are one run of 2k+1 cells, interior rows contribute
     // their two end cells.  Two slots per row, GQ_G slots per pass.
-    const int side = 2 * k + 1, nslot = 2 * side * side;
+    const int side = 2 * k + 1, per_row = (k == 1) ? 1 : 2, nslot = per_row * side * side;
     for (int s0 = 0; s0 < nslot; s0 += GQ_G) {
       const int slot = s0 + lane;
       int sb = 0, se = 0;
       if (slot < nslot) {
-        const int rowi = slot >> 1, second = slot & 1;
+        const int rowi = (k == 1) ? slot : (slot >> 1), second = (k == 1) ? 0 : (slot & 1);
         const int dz = rowi / side - k, dy = rowi % side - k;
         const int zz = cz + dz, yy = cy + dy;
         if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
@@ -154,8 +181,7 @@ GS_DEV unsigned long long grid_search16(const GsGrid& g, const int* __restrict__
           }
         }
       }
-      const int rem = nslot - s0;
-      key = grid_scan_slots(sb, se, rem < GQ_G ? rem : GQ_G, lane, qx, qy, qz, sorted, key);
+      key = grid_scan_slots(sb, se, lane, qx, qy, qz, sorted, key);
     }
     key = grid_group_min(key);
     // every unvisited target is farther than k cells from the projected query; 0.1 % of a cell is
