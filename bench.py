@@ -12,11 +12,12 @@ Frames are resident in HBM before the timed region.  Weak scaling: per-GPU work 
 (one sequence per GPU), value = total frames of all ranks / max-over-ranks time.
 
 The JSON line also carries
-  roofline      the dominant kernel (exact brute-force 1-NN, fp32-VALU bound): algorithmic flop
-                (8 per pair distance) / its mean launch duration measured with HIP
-                events on the launch stream inside the library, in a second pass over the SAME
-                frames from the same map state (so event overhead never touches `value`);
+  roofline      the dominant kernel (fused exact grid 1-NN + Gauss-Newton linearisation): compulsory
+                bytes / its mean launch duration measured with HIP events on the launch stream
+                inside the library, in a second pass over the SAME frames from the same map state
+                (so event overhead never touches `value`);
   roofline_hbm  the HBM-bound kernel groups (K1 frame maps, K5 projection+association, K6 fuse);
+  roofline_bruteforce  the brute-force 1-NN engine (fp32-VALU bound, 8 flop per pair distance);
   cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/) on the host cores
                 for a bounded sample of the same workload, rank 0, N=1 only.
 """
@@ -155,23 +156,25 @@ def main():
     assert all_poses.shape[0] == world and len(all_maps) == world
 
     # ---------------- roofline pass: same frames from the same map state, HIP events inside the library
-    roofline, roofline_hbm = None, None
+    roofline, roofline_hbm, roofline_brute = None, None, None
     if snapshot is not None and rank == 0:
         pc2, prev2 = snapshot
         _C.check(lib.gs_profile_begin(64 * K + 1024), "gs_profile_begin")
         run_steps(slam, pc2, frames, prev2, Wm, L)
         _C.check(lib.gs_profile_end(), "gs_profile_end")
-        ms, n, pairs = read_profile(lib, 0)
-        if n > 0:
-            achieved = KNN_FLOP_PER_PAIR * pairs / (ms * 1e-3) / 1e12
-            roofline = {"kernel": "gs_knn1_kernel (exact brute-force 1-NN, K3)", "bound": "valu_fp32",
-                        "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                        "launches": n, "avg_launch_us": ms * 1e3 / n, "pairs_per_launch": pairs / n,
-                        "flop_per_pair": KNN_FLOP_PER_PAIR,
-                        "note": "fp32 VALU-bound, not MFMA (K=3 inner product; MFMA would change rounding and "
-                                "the exact indices). peak = fp32 vector = f32-MFMA rate 157.3 TFLOP/s; traffic: "
-                                "see profiles/ (PMC pass), not measurable inside bench.py"}
+        ms, n, nbytes = read_profile(lib, 8)
+        if n > 0:  # dominant kernel by GPU time: the fused exact-NN search + Gauss-Newton linearisation
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            roofline = {"kernel": "gs_icp_search_linearize_kernel (K3+K4 fused: exact grid 1-NN + GN rows + partial "
+                                  "sums), %d launches per frame" % (n // K),
+                        "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                        "launches": n, "avg_launch_us": ms * 1e3 / n, "alg_bytes_per_launch": nbytes / n,
+                        "note": "latency-bound, not bandwidth-bound: ~19k queries x ~60 dependent L2 gathers per "
+                                "launch; compulsory bytes = Ns*(24 src io + 216 cell bounds + 24 match gather + 7 "
+                                "partials) + 16*Nt. PMC traffic per launch: profiles/r01_c_pmc_hbm_traffic.txt "
+                                "(6.9 MB fetched, 0.34 MB written). The same search as brute force is the "
+                                "fp32-VALU-bound kernel in roofline_bruteforce."}
         groups = {}
         for kind, name in ((2, "K1 frame maps"), (3, "K5a map projection"), (4, "K5 association"),
                            (5, "K6 fuse+append"), (1, "K4 linearise")):
@@ -183,8 +186,28 @@ def main():
         roofline_hbm = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "groups": groups}
         tot = {k: read_profile(lib, k)[0] for k in range(8)}
         roofline_hbm["gpu_ms_per_frame_by_group"] = {
-            n_: tot[k] / K for k, n_ in ((0, "knn"), (1, "linearise"), (7, "solve_update"), (2, "frame_maps"),
-                                         (3, "project"), (4, "associate"), (5, "fuse"))}
+            n_: tot[k] / K for k, n_ in ((8, "icp_search_linearise"), (7, "icp_solve_update"), (6, "grid_build"),
+                                         (2, "frame_maps"), (3, "project"), (4, "associate"), (5, "fuse"))}
+        # the brute-force engine (API-level knn_points, fallback of the grid): fp32-VALU roofline on the
+        # ICP point sets of the last frame
+        from gradslam_amd import ops
+        lastf = frames[:, L - 1].to_channels_last()
+        lastf.poses = recovered[-1][:, None]
+        src, _, _ = ops.downsample_frame(lastf.global_vertex_map[0, 0], None, None, lastf.depth_image[0, 0, ..., 0], 4)
+        pix = ops.project_map(pc.points_list[0], recovered[-1][0], lastf.intrinsics[0, 0], args.height, args.width)
+        tgt, _, _ = ops.select_targets(pix, args.width, 4, pc.points_list[0], pc.normals_list[0])
+        ops.knn1(src, tgt)
+        _C.check(lib.gs_profile_begin(64), "gs_profile_begin")
+        for _ in range(10):
+            ops.knn1(src, tgt)
+        _C.check(lib.gs_profile_end(), "gs_profile_end")
+        bms, bn, pairs = read_profile(lib, 0)
+        tf = KNN_FLOP_PER_PAIR * pairs / (bms * 1e-3) / 1e12
+        roofline_brute = {"kernel": "gs_knn1_kernel (brute-force exact 1-NN)", "bound": "valu_fp32",
+                          "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
+                          "avg_launch_us": bms * 1e3 / bn, "pairs_per_launch": pairs / bn,
+                          "flop_per_pair": KNN_FLOP_PER_PAIR,
+                          "grid_engine_speedup_vs_this": (bms / bn) / (ms / n) if n else None}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -204,7 +227,8 @@ def main():
                        "parity_mode": "renormalize_unmatched=True (reference-identical merge)",
                        "final_gather_ms": gather_ms, "api": "gradslam_amd.slam.PointFusion.step",
                        "ate_vs_ground_truth_m_rank0": ate_gt},
-            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "roofline_bruteforce": roofline_brute,
+            "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:

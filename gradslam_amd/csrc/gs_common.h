@@ -44,7 +44,8 @@ static inline size_t gs_align(size_t x, size_t a = 256) { return (x + a - 1) / a
 // Optional HIP-event timing of kernel launches on the stream they are launched on (bench.py's
 // roofline line).  Disabled by default: a GsProf scope is then two predictable branches.
 enum GsProfKind { GS_PROF_KNN = 0, GS_PROF_LINEARIZE = 1, GS_PROF_FRAME = 2, GS_PROF_PROJECT = 3,
-                  GS_PROF_ASSOC = 4, GS_PROF_FUSE = 5, GS_PROF_COMPACT = 6, GS_PROF_SOLVE = 7, GS_PROF_KINDS = 8 };
+                  GS_PROF_ASSOC = 4, GS_PROF_FUSE = 5, GS_PROF_COMPACT = 6, GS_PROF_SOLVE = 7, GS_PROF_ICP_FUSED = 8,
+                  GS_PROF_KINDS = 9 };
 extern bool g_gs_prof_on;
 int gs_prof_open(int kind, double work, hipStream_t st);
 void gs_prof_close(int slot, hipStream_t st);

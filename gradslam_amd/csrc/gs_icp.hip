@@ -669,7 +669,9 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
   // one half-iteration: search (with the pending transform applied on load) + rows + partial sums
   auto half = [&](bool full, const float* s_in, const float* Tapply, float* s_out) {
     if (use_grid) {
-      GsProf prof(GS_PROF_KNN, (double)n_src * (double)n_tgt, st);  // brute-force-equivalent pairs
+      // compulsory bytes of one fused half-iteration: source in (+out on the first half), 27 cell bounds
+      // (8 B) per query, matched target + normal gather, partial rows, one pass over the binned targets
+      GsProf prof(GS_PROF_ICP_FUSED, (double)n_src * (full ? 271.0 : 259.0) + 16.0 * (double)n_tgt, st);
       if (full)
         hipLaunchKernelGGL((gs_icp_search_linearize_kernel<true>), dim3(nfs), dim3(FS_BLOCK), 0, st, s_in, Tapply,
                            s_out, n_src, tgt, tgt_normals, n_tgt, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,

@@ -52,9 +52,9 @@ GS_API int64_t gs_scratch_bytes(int64_t n_map, int64_t n_pix);
  * bench.py for the roofline line; off by default).  gs_profile_begin arms up to max_records
  * timed launches, gs_profile_end synchronises the device and aggregates,
  * gs_profile_read returns per kernel group: total milliseconds, launches, and work units
- * (kind 0 KNN: pair distances; kinds 1-6: algorithmic bytes).
- * kinds: 0 KNN, 1 ICP linearise, 2 frame maps, 3 map projection, 4 association, 5 fuse/append,
- * 6 compaction, 7 ICP solve/update. */
+ * (kind 0 brute-force KNN: pair distances; other kinds: algorithmic bytes).
+ * kinds: 0 brute-force KNN, 1 ICP linearise, 2 frame maps, 3 map projection, 4 association,
+ * 5 fuse/append, 6 compaction / grid build, 7 ICP solve/update, 8 fused ICP search+linearise. */
 GS_API int gs_profile_begin(int max_records);
 GS_API int gs_profile_end(void);
 GS_API int gs_profile_read(int kind, double* ms_total, int64_t* launches, double* work_total);

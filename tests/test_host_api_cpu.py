@@ -1,0 +1,216 @@
+"""CPU-only tests of the host layer: container logic of Pointclouds / RGBDImages and the
+reference's error behaviour (type / shape checks run before any HIP call, with the reference's
+messages: tests/slam/test_fusionutils.py:369-398, :543-669 style)."""
+import pytest
+import torch
+
+import gradslam_amd as gs
+from gradslam_amd._C import HipExtensionError
+from gradslam_amd.odometry import icputils
+from gradslam_amd.slam import fusionutils as fu
+
+
+def rgbd(B=1, L=2, H=4, W=5, poses=True):
+    return gs.RGBDImages(torch.rand(B, L, H, W, 3), torch.rand(B, L, H, W, 1), torch.eye(4).repeat(B, 1, 1, 1),
+                         torch.eye(4).repeat(B, L, 1, 1) if poses else None)
+
+
+# ------------------------------------------------------------------ Pointclouds
+def test_pointclouds_list_and_padded_construction():
+    p = [torch.rand(5, 3), torch.rand(3, 3)]
+    f = [torch.rand(5, 2), torch.rand(3, 2)]
+    pc = gs.Pointclouds(points=p, normals=[x + 1 for x in p], features=f)
+    assert len(pc) == 2 and pc.has_points and pc.has_normals and not pc.has_colors and pc.has_features
+    assert pc.num_points_per_pointcloud.tolist() == [5, 3] and pc.equisized is False
+    assert pc.points_padded.shape == (2, 5, 3) and torch.equal(pc.points_padded[1, :3], p[1])
+    assert bool((pc.points_padded[1, 3:] == 0).all())
+    assert pc.nonpad_mask.tolist() == [[True] * 5, [True] * 3 + [False] * 2]
+    assert pc.features_padded.shape == (2, 5, 2)
+    pad = gs.Pointclouds(points=torch.rand(2, 4, 3), colors=torch.rand(2, 4, 3))
+    assert pad.equisized and [t.shape[0] for t in pad.points_list] == [4, 4]
+    one = gs.Pointclouds(points=[p[0]])
+    assert one.points_padded.data_ptr() == one.points_list[0].data_ptr()  # zero-copy for one sequence
+    empty = gs.Pointclouds()
+    assert len(empty) == 0 and not empty.has_points and empty.points_list is None and empty.device.type == "cpu"
+
+
+def test_pointclouds_constructor_errors():
+    with pytest.raises(TypeError, match="Expected points to be of type list or tensor or None"):
+        gs.Pointclouds(points=3)
+    with pytest.raises(TypeError, match="Expected normals to be of same type as points"):
+        gs.Pointclouds(points=[torch.rand(2, 3)], normals=torch.rand(1, 2, 3))
+    with pytest.raises(ValueError, match="should be > 0"):
+        gs.Pointclouds(points=[])
+    with pytest.raises(ValueError, match="ndim of all tensors in points list should be 2"):
+        gs.Pointclouds(points=[torch.rand(3)])
+    with pytest.raises(ValueError, match="last dim of all tensors in points should have shape 3"):
+        gs.Pointclouds(points=[torch.rand(3, 4)])
+    with pytest.raises(ValueError, match="normals tensors should have same shape"):
+        gs.Pointclouds(points=[torch.rand(3, 3)], normals=[torch.rand(2, 3)])
+    with pytest.raises(ValueError, match="number of features per pointcloud has to be equal"):
+        gs.Pointclouds(points=[torch.rand(3, 3)], features=[torch.rand(2, 1)])
+    with pytest.raises(ValueError, match="points should have ndim=3"):
+        gs.Pointclouds(points=torch.rand(3, 3))
+    with pytest.raises(ValueError, match="first 2 dims of features tensor"):
+        gs.Pointclouds(points=torch.rand(1, 3, 3), features=torch.rand(1, 2, 1))
+
+
+def test_append_clone_getitem_and_growth():
+    a = gs.Pointclouds(points=[torch.rand(4, 3), torch.rand(2, 3)], colors=[torch.rand(4, 3), torch.rand(2, 3)])
+    b = gs.Pointclouds(points=[torch.rand(1, 3), torch.rand(6, 3)], colors=[torch.rand(1, 3), torch.rand(6, 3)])
+    before = [t.clone() for t in a.points_list]
+    c = a.clone()
+    a.append_points(b)
+    assert a.num_points_per_pointcloud.tolist() == [5, 8]
+    assert torch.equal(a.points_list[1][:2], before[1]) and torch.equal(a.points_list[1][2:], b.points_list[1])
+    assert c.num_points_per_pointcloud.tolist() == [4, 2]  # the clone is independent
+    assert a.points_padded.shape == (2, 8, 3)
+    for _ in range(12):  # geometric growth keeps the prefix intact
+        a.append_points(b)
+    assert a.num_points_per_pointcloud.tolist() == [17, 80] and torch.equal(a.points_list[0][:4], before[0])
+    sub = a[1]
+    assert len(sub) == 1 and sub.points_list[0].shape[0] == 80
+    e = gs.Pointclouds()
+    e.append_points(b)
+    assert e.num_points_per_pointcloud.tolist() == [1, 6] and e.has_colors
+    with pytest.raises(TypeError, match="Append object must be of type gradslam.Pointclouds"):
+        a.append_points(torch.rand(2, 3))
+    with pytest.raises(ValueError, match="Batch size of pointclouds to append"):
+        a.append_points(gs.Pointclouds(points=[torch.rand(1, 3)], colors=[torch.rand(1, 3)]))
+    with pytest.raises(ValueError, match="must either both have or not have normals"):
+        a.append_points(gs.Pointclouds(points=[torch.rand(1, 3)] * 2, colors=[torch.rand(1, 3)] * 2,
+                                       normals=[torch.rand(1, 3)] * 2))
+
+
+def test_padded_setters_and_rigid_helpers():
+    pc = gs.Pointclouds(points=[torch.rand(4, 3), torch.rand(2, 3)], normals=[torch.rand(4, 3), torch.rand(2, 3)])
+    new = torch.zeros(2, 4, 3)
+    new[0] = 1.0
+    new[1, :2] = 2.0
+    pc.points_padded = new
+    assert torch.equal(pc.points_list[1], torch.full((2, 3), 2.0))
+    with pytest.raises(ValueError, match="value must have shape"):
+        pc.points_padded = torch.zeros(2, 5, 3)
+    T = torch.eye(4)
+    T[:3, 3] = torch.tensor([1.0, 2.0, 3.0])
+    moved = pc.transform(T)
+    assert torch.allclose(moved.points_list[0], torch.ones(4, 3) + T[:3, 3]) and torch.equal(pc.points_list[0], torch.ones(4, 3))
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 2.0
+    proj = gs.Pointclouds(points=[torch.tensor([[1.0, 2.0, 4.0]])]).pinhole_projection(K)
+    assert torch.allclose(proj.points_list[0], torch.tensor([[0.5, 1.0, 1.0]]))
+    with pytest.raises(ValueError, match="transform should be of shape"):
+        pc.transform_(torch.eye(3))
+
+
+# ------------------------------------------------------------------ RGBDImages
+def test_rgbdimages_container():
+    r = rgbd(B=2, L=3)
+    assert r.shape == (2, 3, 4, 5) and len(r) == 2 and r.has_poses and r.cdim == 4
+    s = r[:, 1]
+    assert s.shape == (2, 1, 4, 5) and torch.equal(s.depth_image, r.depth_image[:, 1:2]) and s.poses.shape == (2, 1, 4, 4)
+    assert r[1].shape == (1, 3, 4, 5) and r[0, 2].shape == (1, 1, 4, 5)
+    with pytest.raises(IndexError):
+        r[:, 5]
+    cf = r.to_channels_first()
+    assert cf.channels_first and cf.rgb_image.shape == (2, 3, 3, 4, 5) and cf.cdim == 2
+    assert torch.equal(cf.to_channels_last().rgb_image, r.rgb_image)
+    assert torch.equal(r.valid_depth_mask, r.depth_image > 0)
+    r.poses = torch.eye(4).repeat(2, 3, 1, 1) * 2
+    with pytest.raises(ValueError, match="value must have shape"):
+        r.poses = torch.eye(4)
+    c = r.clone()
+    c.depth_image.zero_()
+    assert r.depth_image.abs().sum() > 0
+
+
+def test_rgbdimages_constructor_errors():
+    rgb, d, K = torch.rand(1, 1, 4, 5, 3), torch.rand(1, 1, 4, 5, 1), torch.eye(4).view(1, 1, 4, 4)
+    with pytest.raises(TypeError, match="Expected rgb_image to be of type tensor"):
+        gs.RGBDImages(None, d, K)
+    with pytest.raises(TypeError, match="Expected channels_first to be of type bool"):
+        gs.RGBDImages(rgb, d, K, channels_first=1)
+    with pytest.raises(ValueError, match="rgb_image should have ndim=5"):
+        gs.RGBDImages(rgb[0], d, K)
+    with pytest.raises(ValueError, match="Expected rgb_image to have 3 channels"):
+        gs.RGBDImages(torch.rand(1, 1, 4, 5, 4), d, K)
+    with pytest.raises(ValueError, match="Expected depth_image to have shape"):
+        gs.RGBDImages(rgb, torch.rand(1, 1, 4, 4, 1), K)
+    with pytest.raises(ValueError, match="Expected intrinsics to have shape"):
+        gs.RGBDImages(rgb, d, torch.eye(4).view(1, 4, 4, 1))
+    with pytest.raises(ValueError, match="Expected poses to have shape"):
+        gs.RGBDImages(rgb, d, K, torch.eye(4).repeat(1, 2, 1, 1))
+
+
+def test_lazy_maps_need_the_gpu_and_say_so():
+    with pytest.raises(HipExtensionError, match="no CPU fallback"):
+        rgbd().vertex_map
+
+
+# ------------------------------------------------------------------ function-level error behaviour
+def test_fusionutils_validation_messages():
+    pc, fr = gs.Pointclouds(points=[torch.rand(3, 3)]), rgbd(L=1)
+    tab = torch.zeros((2, 4), dtype=torch.int64)
+    with pytest.raises(TypeError, match="Expected pointclouds to be of type gradslam.Pointclouds"):
+        fu.find_active_map_points(torch.rand(3), fr)
+    with pytest.raises(TypeError, match="Expected rgbdimages to be of type gradslam.RGBDImages"):
+        fu.find_active_map_points(pc, torch.rand(3))
+    with pytest.raises(ValueError, match="Expected rgbdimages to have sequence length of 1"):
+        fu.find_active_map_points(pc, rgbd(L=2))
+    with pytest.raises(ValueError, match="Expected equal batch sizes"):
+        fu.find_active_map_points(pc, rgbd(B=2, L=1))
+    with pytest.raises(TypeError, match="Expected input pc2im_bnhw to have dtype of torch.int64"):
+        fu.find_similar_map_points(pc, fr, tab.int(), 0.1, 0.9)
+    with pytest.raises(ValueError, match=r"Expected pc2im_bnhw.shape\[1\] to be 4"):
+        fu.find_similar_map_points(pc, fr, tab[:, :3], 0.1, 0.9)
+    with pytest.raises(ValueError, match="Pointclouds must have normals for finding similar map points"):
+        fu.find_similar_map_points(pc, fr, tab, 0.1, 0.9)
+    with pytest.raises(ValueError, match="Pointclouds must have features for finding best unique"):
+        fu.find_best_unique_correspondences(pc, fr, tab)
+    with pytest.raises(ValueError, match="Pointclouds must have normals for map fusion"):
+        fu.fuse_with_map(pc, fr, tab, 0.6)
+    with pytest.raises(TypeError, match="Expected input sigma to be of type torch.Tensor or float or int"):
+        fu.get_alpha(torch.rand(4, 3), "x")
+    with pytest.raises(ValueError, match="Expected length of dim-th"):
+        fu.get_alpha(torch.rand(4, 2), 0.6)
+    with pytest.raises(ValueError, match="tensor1 and tensor2 should have the same shape"):
+        fu.are_points_close(torch.rand(4, 3), torch.rand(5, 3), 0.1)
+    # empty inputs return empty tables without touching the GPU (fusionutils.py:237-238, :365-368, :475-476)
+    e = gs.Pointclouds()
+    assert fu.find_active_map_points(e, fr).shape == (0, 4)
+    sim, mask = fu.find_similar_map_points(e, fr, tab, 0.1, 0.9)
+    assert sim.shape == (0, 4) and mask.shape == (0,) and mask.dtype == torch.bool
+    assert fu.find_best_unique_correspondences(e, fr, tab).dtype == torch.int64
+
+
+def test_icputils_and_slam_validation_messages():
+    a = torch.rand(1, 5, 3)
+    with pytest.raises(TypeError, match="Expected A to be of type torch.Tensor"):
+        icputils.solve_linear_system(None, torch.rand(3, 1))
+    with pytest.raises(ValueError, match=r"b.shape\[1\] should 1"):
+        icputils.solve_linear_system(torch.rand(3, 6), torch.rand(3, 2))
+    with pytest.raises(ValueError, match="src_pc should have ndim=3"):
+        icputils.gauss_newton_solve(a[0], a, a)
+    with pytest.raises(ValueError, match=r"tgt_pc.shape\[1\] and tgt_normals.shape\[1\] must be equal"):
+        icputils.gauss_newton_solve(a, a, torch.rand(1, 4, 3))
+    with pytest.raises(TypeError, match="Expected numiters to be of type int"):
+        icputils.point_to_plane_ICP(a, a, a, torch.eye(4), numiters=2.0)
+    with pytest.raises(ValueError, match="Expected initial_transform.shape to be"):
+        icputils.point_to_plane_gradICP(a, a, a, torch.eye(3))
+    with pytest.raises(TypeError, match="Expected lambda_max to be of type float or int"):
+        icputils.point_to_plane_gradICP(a, a, a, torch.eye(4), lambda_max="2")
+    with pytest.raises(TypeError, match="Expected ds_ratio to be of type int"):
+        icputils.downsample_rgbdimages(rgbd(L=1), 2.0)
+    with pytest.raises(ValueError, match="odometry method"):
+        gs.slam.ICPSLAM(odom="orb")
+    with pytest.raises(TypeError, match="Distance threshold must be of type float or int"):
+        gs.slam.PointFusion(dist_th="a")
+    slam = gs.slam.PointFusion(odom="gradicp")
+    assert abs(slam.dot_th - 0.9396926207859084) < 1e-12 and slam.dsratio == 4 and slam.device.type == "cpu"
+    with pytest.raises(TypeError, match="Expected frames to be of type gradslam.RGBDImages"):
+        slam(torch.rand(3))
+    with pytest.raises(ValueError, match="`live_frame` must have poses"):
+        slam.step(gs.Pointclouds(), rgbd(L=1, poses=False), None)
+    from gradslam_amd.odometry.icp import ICPOdometryProvider
+    with pytest.raises(ValueError, match="maps_pointclouds missing normals"):
+        ICPOdometryProvider().provide(gs.Pointclouds(points=[a[0]]), gs.Pointclouds(points=[a[0]]))
