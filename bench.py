@@ -184,7 +184,7 @@ def main():
                 groups[name] = {"achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "launch_groups": gn,
                                 "avg_us": gms * 1e3 / gn, "alg_bytes_per_group": gbytes / gn}
         roofline_hbm = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "groups": groups}
-        tot = {k: read_profile(lib, k)[0] for k in range(8)}
+        tot = {k: read_profile(lib, k)[0] for k in range(9)}
         roofline_hbm["gpu_ms_per_frame_by_group"] = {
             n_: tot[k] / K for k, n_ in ((8, "icp_search_linearise"), (7, "icp_solve_update"), (6, "grid_build"),
                                          (2, "frame_maps"), (3, "project"), (4, "associate"), (5, "fuse"))}
