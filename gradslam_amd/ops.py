@@ -29,26 +29,33 @@ def _count(t):
 
 
 # ----------------------------------------------------------------------------------- K1
-def frame_maps(depth, K, sigma=0.6, want_normal=True, want_alpha=True, want_valid=True):
-    """depth (H,W) f32, K (4,4) f32 -> vertex (H,W,3), normal (H,W,3), alpha (H,W), valid (H,W) bool."""
+def frame_maps(depth, K, sigma=0.6, want_normal=True, want_alpha=True, want_valid=True, out=None):
+    """depth (H,W) f32, K (4,4) f32 -> vertex (H,W,3), normal (H,W,3), alpha (H,W), valid (H,W) bool.
+    out: optional (vertex, normal, alpha) contiguous float32 buffers to write into (None entries are
+    allocated / skipped according to the want_* flags)."""
     depth, K = _c(depth), _c(K)
     dev = require_device(depth, K)
     H, W = depth.shape
-    vertex = torch.empty((H, W, 3), dtype=f32, device=dev)
-    normal = torch.empty((H, W, 3), dtype=f32, device=dev) if want_normal else None
-    alpha = torch.empty((H, W), dtype=f32, device=dev) if want_alpha else None
+    ov, on, oa = out if out is not None else (None, None, None)
+    vertex = ov if ov is not None else torch.empty((H, W, 3), dtype=f32, device=dev)
+    normal = on if on is not None else (torch.empty((H, W, 3), dtype=f32, device=dev) if want_normal else None)
+    alpha = oa if oa is not None else (torch.empty((H, W), dtype=f32, device=dev) if want_alpha else None)
     valid = torch.empty((H, W), dtype=torch.uint8, device=dev) if want_valid else None
+    require_device(vertex, normal, alpha)
     check(lib().gs_frame_maps_f32(ptr(depth), ptr(K), H, W, two_sigma_sq(sigma), ptr(vertex), ptr(normal),
                                   ptr(alpha), ptr(valid), stream(dev)), "gs_frame_maps_f32")
     return vertex, normal, alpha, (valid.view(torch.bool) if valid is not None else None)
 
 
-def global_maps(vertex, normal, depth, pose):
+def global_maps(vertex, normal, depth, pose, out=None):
+    """out: optional (gvertex, gnormal) contiguous float32 buffers to write into."""
     vertex, normal, depth, pose = _c(vertex), _c(normal), _c(depth), _c(pose)
     dev = require_device(vertex, normal, depth, pose)
     H, W = depth.shape[:2]
-    gv = torch.empty_like(vertex)
-    gn = torch.empty_like(normal) if normal is not None else None
+    og, on = out if out is not None else (None, None)
+    gv = og if og is not None else torch.empty_like(vertex)
+    gn = on if on is not None else (torch.empty_like(normal) if normal is not None else None)
+    require_device(gv, gn)
     check(lib().gs_global_maps_f32(ptr(vertex), ptr(normal), ptr(depth), ptr(pose), H, W, ptr(gv), ptr(gn),
                                    stream(dev)), "gs_global_maps_f32")
     return gv, gn

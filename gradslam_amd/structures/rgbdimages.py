@@ -178,11 +178,9 @@ class RGBDImages(object):
         am = torch.empty((B, L, H, W, 1), dtype=torch.float32, device=self.device) if sigma is not None else None
         for b in range(B):
             for s in range(L):
-                v, n, a, _ = ops.frame_maps(depth[b, s, ..., 0], K[b, 0], 0.6 if sigma is None else sigma,
-                                            want_alpha=sigma is not None, want_valid=False)
-                vm[b, s], nm[b, s] = v, n
-                if am is not None:
-                    am[b, s, ..., 0] = a
+                ops.frame_maps(depth[b, s, ..., 0], K[b, 0], 0.6 if sigma is None else sigma,
+                               want_alpha=sigma is not None, want_valid=False,
+                               out=(vm[b, s], nm[b, s], None if am is None else am[b, s, ..., 0]))
         self._vertex_map, self._normal_map = self._from_cl(vm), self._from_cl(nm)
         if am is not None:
             self._alpha_cache = (float(sigma), am)
@@ -219,7 +217,7 @@ class RGBDImages(object):
         gv, gn = torch.empty_like(vm), torch.empty_like(nm)
         for b in range(B):
             for s in range(L):
-                gv[b, s], gn[b, s] = ops.global_maps(vm[b, s], nm[b, s], depth[b, s, ..., 0], poses[b, s])
+                ops.global_maps(vm[b, s], nm[b, s], depth[b, s, ..., 0], poses[b, s], out=(gv[b, s], gn[b, s]))
         self._global_vertex_map, self._global_normal_map = self._from_cl(gv), self._from_cl(gn)
 
     @property

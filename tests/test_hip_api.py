@@ -228,3 +228,27 @@ def test_step_api_and_growth(gs):
     pc2 = pc.clone()
     assert torch.equal(pc2.points_padded, pc.points_padded) and pc2.points_list[0].data_ptr() != pc.points_list[0].data_ptr()
     assert pc.cpu().device.type == "cpu"
+
+
+def test_scannet_resolution_map_growth(gs):
+    """Config C5 shape (1296x968, ScanNet-like): dynamic map growth across capacity doublings with
+    gradICP odometry at 78k x ~80k ICP points per frame; poses must track the ground truth."""
+    L, H, W = 6, 968, 1296
+    s = make_sequence(L, H, W, seed=3)
+    poses = s["poses"].copy()
+    poses[1:] = poses[:1]
+    frames = gs.RGBDImages(T(s["colors"][None]).cuda(), T(s["depths"][None]).cuda(),
+                           T(s["intrinsics"][None]).cuda(), T(poses[None]).cuda())
+    slam = gs.slam.PointFusion(odom="gradicp", device="cuda")
+    pc, prev, counts = gs.Pointclouds(device="cuda"), None, []
+    for t in range(L):
+        live = frames[:, t]
+        pc, _ = slam.step(pc, live, prev, inplace=True)
+        prev = live
+        counts.append(pc.points_list[0].shape[0])
+    assert counts[0] > 1_000_000 and all(b > a for a, b in zip(counts, counts[1:]))
+    assert pc._buf["points"][0].shape[0] >= counts[-1]          # capacity-backed store
+    assert torch.isfinite(pc.points_list[0]).all() and bool((pc.features_list[0] > 0).all())
+    rec = torch.stack([frames[:, 0].poses[0, 0]] + [prev.poses[0, 0]])  # first and last
+    assert ate(host(prev.poses[0]), s["poses"][L - 1:L]) < 5e-3
+    assert rec.shape == (2, 4, 4)
