@@ -1,0 +1,469 @@
+// gs_icp_loop.hip — the device-resident LM loop of point_to_plane_ICP / point_to_plane_gradICP
+// (odometry/icputils.py:235-367, :370-545): 2 exact 1-NN searches, one Gauss-Newton linearisation,
+// one 6x6 solve, two SE(3) exponentials per iteration, 20 iterations, no host sync.
+//
+// Normal equations are accumulated in float64 from float32 products (order-independent to ~1e-16,
+// so HIP and oracle agree after the single rounding to float32) with fixed-order reductions.
+//
+// Grid path (large target sets; the SLAM loop): ONE kernel per half-iteration.  Its prologue lets
+// every block redundantly finish the PREVIOUS half-iteration (add up the partial rows the previous
+// kernel left, then the scalar stage: solve + se3_exp, or LM / gradLM update) so that no separate
+// single-block kernels sit on the critical path; block 0 records the state.  Then 16 lanes per
+// source point run the grid search (gs_knn.h), the block finishes unresolved queries by brute
+// force, builds the Gauss-Newton rows and emits one partial row.  State and partial rows are
+// double-buffered between consecutive kernels.  2 x numiters + 1 launches per solve.
+//
+// Brute-force path (small problems, GRADSLAM_HIP_KNN=brute): search / linearise / solve / update
+// as separate kernels.
+#include <stdlib.h>
+#include <string.h>
+
+#include "gs_icp_math.h"
+#include "gs_knn.h"
+
+struct GsIcpState {
+  IcpSmall s[2];          // double-buffered by the grid path; the brute-force path uses s[0]
+  float trace[64 * 12];   // up to 64 iterations
+};
+
+// ---------------------------------------------------------------- fixed-order sums ------
+// Adds up partial rows (nrows x LIN_NV doubles).  Thread t works on value t%32 and row subset
+// t/32; 16 loads are in flight per thread; the sub-sums are then added in index order.  Every
+// block that runs this on the same rows gets bit-identical sums.
+template <int BLOCK>
+GS_DEV void icp_sum_rows(const double* __restrict__ partials, int nrows, double* S, double (*sub)[32]) {
+  constexpr int STEP = BLOCK / 32;
+  const int i = threadIdx.x & 31, j = threadIdx.x >> 5;
+  double s = 0.0;
+  if (i < LIN_NV) {
+    for (int b = j; b < nrows; b += 16 * STEP) {
+      double a[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a[u] = (b + u * STEP < nrows) ? partials[(int64_t)(b + u * STEP) * LIN_NV + i] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += a[u];
+    }
+  }
+  sub[j][i] = s;
+  __syncthreads();
+  if (threadIdx.x < LIN_NV) {
+    double t = 0.0;
+    for (int k = 0; k < STEP; ++k) t += sub[k][threadIdx.x];
+    S[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// Same for the single residual column (value 27): all threads share the rows.
+template <int BLOCK>
+GS_DEV double icp_sum_col27(const double* __restrict__ partials, int nrows, double* red) {
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nrows; b += BLOCK) s += partials[(int64_t)b * LIN_NV + 27];
+  s = gs_wave_sum_f64(s);
+  if ((threadIdx.x & (GS_WAVE - 1)) == 0) red[threadIdx.x / GS_WAVE] = s;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < BLOCK / GS_WAVE; ++w) t += red[w];
+  __syncthreads();
+  return t;
+}
+
+// ---------------------------------------------------------------- grid path -------------
+constexpr int FS_BLOCK = 512;            // 8 waves; 2-3 blocks per CU keep every block of a 640x480 solve resident
+constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 32 queries per block, their rows are built by wave 0
+
+// FULL = true : first half of iteration `it`  (prologue: LM update of iteration it-1, then search
+//               with T_step applied, full normal equations)
+// FULL = false: look-ahead half              (prologue: solve + se3_exp, then search with Tr
+//               applied, residual only)
+template <bool FULL>
+__global__ void __launch_bounds__(FS_BLOCK) gs_icp_half_kernel(
+    const float* __restrict__ src_in, float* __restrict__ src_out, int64_t n_src, const float* __restrict__ tgt,
+    const float* __restrict__ tn, int64_t n_tgt, const GsGrid* __restrict__ gp, const int* __restrict__ cell_start,
+    const float4* __restrict__ sorted, float dist_thresh, const double* __restrict__ partials_in, int nrows_in,
+    double* __restrict__ partials_out, const IcpSmall* __restrict__ st_in, IcpSmall* __restrict__ st_out,
+    float* __restrict__ trace, gs_icp_params prm, int it, int64_t* __restrict__ out_idx) {
+  __shared__ IcpSmall sm;
+  __shared__ double S[32];
+  __shared__ double sub[FS_BLOCK / 32][32];
+  __shared__ unsigned long long keys_s[FS_QPB];
+  __shared__ float qs[FS_QPB][3];
+  __shared__ int unres_q[FS_QPB];
+  __shared__ int unres_n;
+  __shared__ unsigned long long red[FS_BLOCK / GS_WAVE];
+
+  // ---- prologue: finish the previous half-iteration (identical in every block)
+  if (FULL) {
+    double e1 = 0.0;
+    if (it > 0) e1 = icp_sum_col27<FS_BLOCK>(partials_in, nrows_in, reinterpret_cast<double*>(red));
+    if (threadIdx.x == 0) {
+      IcpSmall loc = *st_in;  // scalar stage in registers, published through LDS
+      if (it > 0) icp_update_math((float)e1, loc, prm, (blockIdx.x == 0 && it - 1 < 64) ? trace + 12 * (it - 1) : nullptr);
+      sm = loc;
+      unres_n = 0;
+    }
+  } else {
+    icp_sum_rows<FS_BLOCK>(partials_in, nrows_in, S, sub);
+    if (threadIdx.x == 0) {
+      IcpSmall loc = *st_in;
+      icp_solve_math(S, loc);
+      sm = loc;
+      unres_n = 0;
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(IcpSmall) / 4))
+    reinterpret_cast<float*>(st_out)[threadIdx.x] = reinterpret_cast<const float*>(&sm)[threadIdx.x];
+
+  // ---- search: one source point per 16-lane group, pending transform applied on load
+  const int lane = threadIdx.x & (GQ_G - 1), slot = threadIdx.x / GQ_G;
+  const int64_t s = (int64_t)blockIdx.x * FS_QPB + slot;
+  if (s < n_src) {
+    const GsGrid g = *gp;
+    const float* T = FULL ? sm.T_step : sm.Tr;
+    float qx, qy, qz;
+    gs_rigid_fma(T, src_in[3 * s], src_in[3 * s + 1], src_in[3 * s + 2], qx, qy, qz);
+    bool done;
+    const unsigned long long key = grid_search16(g, cell_start, sorted, qx, qy, qz, lane, &done);
+    if (lane == 0) {
+      if (FULL) {  // the transformed cloud of this iteration
+        src_out[3 * s] = qx;
+        src_out[3 * s + 1] = qy;
+        src_out[3 * s + 2] = qz;
+      }
+      qs[slot][0] = qx; qs[slot][1] = qy; qs[slot][2] = qz;
+      keys_s[slot] = key;
+      if (!done) unres_q[atomicAdd(&unres_n, 1)] = slot;
+    }
+  }
+  __syncthreads();
+  const int nun = unres_n;  // block-uniform
+  for (int u = 0; u < nun; ++u) {
+    const int us = unres_q[u];
+    const unsigned long long key = block_brute_min<FS_BLOCK>(qs[us][0], qs[us][1], qs[us][2], tgt, n_tgt, red);
+    if (threadIdx.x == 0) keys_s[us] = key;
+  }
+  __syncthreads();
+
+  // ---- rows: lane t < 32 of wave 0 builds the row of query t
+  double v[LIN_NV];
+#pragma unroll
+  for (int i = 0; i < LIN_NV; ++i) v[i] = 0.0;
+  const int64_t r = (int64_t)blockIdx.x * FS_QPB + threadIdx.x;
+  if (threadIdx.x < FS_QPB && r < n_src) {
+    const unsigned long long bb = keys_s[threadIdx.x];
+    int64_t j = (int64_t)(bb & 0xffffffffull);
+    if (j >= n_tgt) j = 0;  // only when every distance was NaN
+    const float d2 = __uint_as_float((uint32_t)(bb >> 32));
+    const bool keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
+    float a[6], res;
+    gn_row(qs[threadIdx.x][0], qs[threadIdx.x][1], qs[threadIdx.x][2], tgt, tn, j, a, res);
+    if (FULL && out_idx) out_idx[r] = j;
+    if (keep) {
+      if (FULL) {
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int k = i; k < 6; ++k) v[q++] = (double)a[i] * (double)a[k];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[21 + i] = (double)a[i] * (double)res;
+      }
+      v[27] = (double)res * (double)res;
+    }
+  }
+  if (!FULL) {  // residual only: one value, a plain wave reduction is enough
+    if (threadIdx.x < GS_WAVE) {
+      const double sum = gs_wave_sum_f64(v[27]);
+      if (threadIdx.x == 0) partials_out[(int64_t)blockIdx.x * LIN_NV + 27] = sum;
+    }
+    return;
+  }
+  // 32 rows x 28 values through LDS (a 28-fold wave shuffle reduction costs ~6 us of dependent
+  // cross-lane traffic in one wave): 8 groups of 28 threads add 4 rows each, then 28 threads add
+  // the 8 sub-sums, always in index order.
+  __shared__ double rows_s[FS_QPB][LIN_NV + 1];
+  __shared__ double sub_s[8][LIN_NV];
+  if (threadIdx.x < FS_QPB) {
+#pragma unroll
+    for (int i = 0; i < LIN_NV; ++i) rows_s[threadIdx.x][i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 * LIN_NV) {
+    const int i = threadIdx.x % LIN_NV, part = threadIdx.x / LIN_NV;
+    double t = rows_s[4 * part][i];
+    t += rows_s[4 * part + 1][i];
+    t += rows_s[4 * part + 2][i];
+    t += rows_s[4 * part + 3][i];
+    sub_s[part][i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < LIN_NV) {
+    double t = sub_s[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += sub_s[k][threadIdx.x];
+    partials_out[(int64_t)blockIdx.x * LIN_NV + threadIdx.x] = t;
+  }
+}
+
+// After the last look-ahead: final LM / gradLM update and the (composed) result.
+__global__ void __launch_bounds__(FS_BLOCK) gs_icp_finish_kernel(const double* __restrict__ partials_in, int nrows_in,
+                                                                 GsIcpState* __restrict__ st, int buf,
+                                                                 gs_icp_params prm, const float* __restrict__ compose16,
+                                                                 float* __restrict__ out_T16) {
+  __shared__ double red[FS_BLOCK / GS_WAVE];
+  const double e1 = icp_sum_col27<FS_BLOCK>(partials_in, nrows_in, red);
+  if (threadIdx.x != 0) return;
+  IcpSmall sm = st->s[buf];
+  const int it = prm.numiters - 1;
+  icp_update_math((float)e1, sm, prm, it < 64 ? st->trace + 12 * it : nullptr);
+  st->s[buf ^ 1] = sm;
+  icp_write_result(sm, compose16, out_T16);
+}
+
+// ---------------------------------------------------------------- brute-force path ------
+constexpr int LIN_BLOCK = 256;
+constexpr int SUM_BLOCK = 1024;
+
+// Reads the KNN result of every source point (and re-arms best[] for the next search), builds
+// its row and reduces the normal equations.  FULL = false: residual only (look-ahead).
+template <bool FULL>
+__global__ void __launch_bounds__(LIN_BLOCK) gs_icp_linearize_kernel(
+    const float* __restrict__ src, const float* __restrict__ Tapply, int64_t n_src,
+    const float* __restrict__ tgt, const float* __restrict__ tn, int64_t n_tgt,
+    unsigned long long* __restrict__ best, float dist_thresh, double* __restrict__ partials,
+    int64_t* __restrict__ out_idx) {
+  __shared__ double red[LIN_BLOCK / GS_WAVE][LIN_NV];
+  const int64_t s = (int64_t)blockIdx.x * LIN_BLOCK + threadIdx.x;
+  double v[LIN_NV];
+#pragma unroll
+  for (int i = 0; i < LIN_NV; ++i) v[i] = 0.0;
+  if (s < n_src) {
+    const unsigned long long bb = best[s];
+    best[s] = ~0ull;
+    int64_t j = (int64_t)(bb & 0xffffffffull);
+    if (j >= n_tgt) j = 0;  // only when every distance was NaN
+    const float d2 = __uint_as_float((uint32_t)(bb >> 32));
+    const bool keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
+    float p0 = src[3 * s], p1 = src[3 * s + 1], p2 = src[3 * s + 2];
+    if (Tapply) {
+      float T[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) T[i] = Tapply[i];
+      float q0, q1, q2;
+      gs_rigid_fma(T, p0, p1, p2, q0, q1, q2);
+      p0 = q0; p1 = q1; p2 = q2;
+    }
+    float a[6], r;
+    gn_row(p0, p1, p2, tgt, tn, j, a, r);
+    if (FULL && out_idx) out_idx[s] = j;
+    if (keep) {
+      if (FULL) {
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int k = i; k < 6; ++k) v[q++] = (double)a[i] * (double)a[k];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[21 + i] = (double)a[i] * (double)r;
+      }
+      v[27] = (double)r * (double)r;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = FULL ? 0 : 27; i < LIN_NV; ++i) {
+    const double sum = gs_wave_sum_f64(v[i]);
+    if (lane == 0) red[wave][i] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x < LIN_NV && (FULL || threadIdx.x == 27)) {
+    const int i = threadIdx.x;
+    partials[(int64_t)blockIdx.x * LIN_NV + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+  }
+}
+
+__global__ void __launch_bounds__(SUM_BLOCK) gs_icp_solve_kernel(const double* __restrict__ partials, int nrows,
+                                                                 GsIcpState* __restrict__ st) {
+  __shared__ double S[32];
+  __shared__ double sub[SUM_BLOCK / 32][32];
+  icp_sum_rows<SUM_BLOCK>(partials, nrows, S, sub);
+  if (threadIdx.x != 0) return;
+  IcpSmall sm = st->s[0];
+  icp_solve_math(S, sm);
+  st->s[0] = sm;
+}
+
+__global__ void __launch_bounds__(SUM_BLOCK) gs_icp_update_kernel(const double* __restrict__ partials, int nrows,
+                                                                  GsIcpState* __restrict__ st, gs_icp_params prm,
+                                                                  int it, const float* __restrict__ compose16,
+                                                                  float* __restrict__ out_T16) {
+  __shared__ double red[SUM_BLOCK / GS_WAVE];
+  const double e1 = icp_sum_col27<SUM_BLOCK>(partials, nrows, red);
+  if (threadIdx.x != 0) return;
+  IcpSmall sm = st->s[0];
+  icp_update_math((float)e1, sm, prm, it < 64 ? st->trace + 12 * it : nullptr);
+  st->s[0] = sm;
+  if (it == prm.numiters - 1) icp_write_result(sm, compose16, out_T16);
+}
+
+// ---------------------------------------------------------------- host side ------------
+__global__ void gs_icp_init_kernel(GsIcpState* __restrict__ st, const float* __restrict__ init16, float damp,
+                                   int numiters, const float* __restrict__ compose16, float* __restrict__ out_T16) {
+  if (threadIdx.x != 0) return;
+  IcpSmall sm;
+  for (int i = 0; i < 16; ++i) {
+    sm.T_total[i] = init16[i];
+    sm.T_step[i] = init16[i];  // the first search applies the initial transform
+    sm.Tr[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  }
+  for (int i = 0; i < 8; ++i) sm.xi[i] = 0.0f;
+  sm.damp = damp;
+  sm.err = 0.0f;
+  sm.pad[0] = sm.pad[1] = 0.0f;
+  st->s[0] = sm;
+  st->s[1] = sm;
+  if (numiters == 0) icp_write_result(sm, compose16, out_T16);  // degenerate: the (composed) initial transform
+}
+
+struct IcpScratch {
+  GsIcpState* state;
+  unsigned long long* best;
+  float* srcA;
+  float* srcB;
+  double* partials[2];
+  void* grid;
+};
+static size_t icp_rows(int64_t n_src) { return (size_t)gs_ceil_div(n_src, FS_QPB); }  // >= ceil(n_src / LIN_BLOCK)
+static IcpScratch icp_carve(void* scratch, int64_t n_src) {
+  char* p = reinterpret_cast<char*>(scratch);
+  IcpScratch s;
+  s.state = reinterpret_cast<GsIcpState*>(p); p += gs_align(sizeof(GsIcpState));
+  s.best = reinterpret_cast<unsigned long long*>(p); p += gs_align(8 * (size_t)n_src);
+  s.srcA = reinterpret_cast<float*>(p); p += gs_align(12 * (size_t)n_src);
+  s.srcB = reinterpret_cast<float*>(p); p += gs_align(12 * (size_t)n_src);
+  for (int k = 0; k < 2; ++k) {
+    s.partials[k] = reinterpret_cast<double*>(p);
+    p += gs_align(sizeof(double) * LIN_NV * icp_rows(n_src));
+  }
+  s.grid = p;
+  return s;
+}
+
+// GRADSLAM_HIP_KNN=brute forces the brute-force engine (A/B runs; results are identical).
+static bool icp_grid_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GRADSLAM_HIP_KNN");
+    v = (e && strcmp(e, "brute") == 0) ? 0 : 1;
+  }
+  return v == 1;
+}
+
+extern "C" int64_t gs_icp_scratch_bytes(int64_t n_src, int64_t n_tgt) {
+  if (n_src < 1) n_src = 1;
+  return (int64_t)(gs_align(sizeof(GsIcpState)) + gs_align(8 * (size_t)n_src) + 2 * gs_align(12 * (size_t)n_src) +
+                   2 * gs_align(sizeof(double) * LIN_NV * icp_rows(n_src)) + gs_knn_grid_scratch_bytes(n_src, n_tgt) +
+                   4096);
+}
+
+extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, const float* tgt_normals,
+                          int64_t n_tgt, const float* init16, const float* compose16,
+                          const gs_icp_params* prm, float* out_T16, int64_t* out_idx, void* icp_scratch,
+                          void* stream) {
+  GS_REQUIRE(prm, "params_host must not be NULL");
+  GS_REQUIRE(n_src > 0 && n_tgt > 0, "empty point set");
+  GS_REQUIRE(n_tgt < 0x7fffffffll && n_src < 0x7fffffffll, "too many points");
+  GS_REQUIRE(src && tgt && tgt_normals && init16 && out_T16 && icp_scratch, "NULL pointer");
+  GS_REQUIRE(prm->numiters >= 0 && prm->numiters <= 64, "numiters must be in [0, 64]");
+  GS_REQUIRE(prm->mode == 0 || prm->mode == 1, "mode must be 0 (ICP) or 1 (gradICP)");
+  hipStream_t st = gs_stream(stream);
+  IcpScratch sc = icp_carve(icp_scratch, n_src);
+  hipLaunchKernelGGL(gs_icp_init_kernel, dim3(1), dim3(64), 0, st, sc.state, init16, prm->damp, prm->numiters,
+                     compose16, out_T16);
+  const bool use_grid = icp_grid_enabled() && gs_knn_use_grid(n_src, n_tgt) && prm->numiters > 0;
+  float* bufs[2] = {sc.srcA, sc.srcB};
+
+  if (use_grid) {
+    // the target set is fixed for all 2*numiters searches of this solve: bin it once
+    int rc = gs_knn_grid_build(tgt, n_tgt, n_src, sc.grid, st);
+    if (rc != GS_OK) return rc;
+    GridMem gm = grid_carve(sc.grid, n_src, n_tgt);
+    const int nfs = (int)icp_rows(n_src);
+    const float* cur_in = src;  // cloud before the pending transform of the half-iteration
+    int h = 0;                  // half-iteration index: kernel h reads s[h&1] / partials[(h+1)&1], writes the others
+    for (int it = 0; it < prm->numiters; ++it) {
+      float* cur = bufs[it & 1];
+      {
+        // compulsory bytes of one fused half-iteration: source in (+out), 27 cell bounds (8 B) per
+        // query, matched target + normal gather, partial rows, one pass over the binned targets
+        GsProf prof(GS_PROF_ICP_FUSED, (double)n_src * 271.0 + 16.0 * (double)n_tgt, st);
+        hipLaunchKernelGGL((gs_icp_half_kernel<true>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur_in, cur, n_src, tgt,
+                           tgt_normals, n_tgt, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
+                           sc.partials[(h + 1) & 1], nfs, sc.partials[h & 1], &sc.state->s[h & 1],
+                           &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, out_idx);
+      }
+      ++h;
+      {
+        GsProf prof(GS_PROF_ICP_FUSED, (double)n_src * 259.0 + 16.0 * (double)n_tgt, st);
+        hipLaunchKernelGGL((gs_icp_half_kernel<false>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur, nullptr, n_src, tgt,
+                           tgt_normals, n_tgt, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
+                           sc.partials[(h + 1) & 1], nfs, sc.partials[h & 1], &sc.state->s[h & 1],
+                           &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, nullptr);
+      }
+      ++h;
+      cur_in = cur;
+    }
+    if (prm->numiters > 0) {
+      GsProf prof(GS_PROF_SOLVE, 1.0, st);
+      hipLaunchKernelGGL(gs_icp_finish_kernel, dim3(1), dim3(FS_BLOCK), 0, st, sc.partials[(h + 1) & 1], nfs, sc.state,
+                         h & 1, *prm, compose16, out_T16);
+    }
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+  }
+
+  // ---- brute-force path
+  GS_HIP(hipMemsetAsync(sc.best, 0xff, 8 * (size_t)n_src, st));
+  const int nblk = (int)gs_ceil_div(n_src, LIN_BLOCK);
+  double* partials = sc.partials[0];
+  const float* cur_in = src;
+  for (int it = 0; it < prm->numiters; ++it) {
+    float* cur = bufs[it & 1];
+    // apply the pending transform (initial transform or last T_step) while searching
+    gs_knn_brute_launch(cur_in, sc.state->s[0].T_step, cur, n_src, tgt, n_tgt, sc.best, st);
+    {
+      GsProf prof(GS_PROF_LINEARIZE, 44.0 * (double)n_src, st);  // 8 B best + 12 B src + 24 B gather
+      hipLaunchKernelGGL((gs_icp_linearize_kernel<true>), dim3(nblk), dim3(LIN_BLOCK), 0, st, cur, nullptr, n_src,
+                         tgt, tgt_normals, n_tgt, sc.best, prm->dist_thresh, partials, out_idx);
+    }
+    {
+      GsProf prof(GS_PROF_SOLVE, 1.0, st);
+      hipLaunchKernelGGL(gs_icp_solve_kernel, dim3(1), dim3(SUM_BLOCK), 0, st, partials, nblk, sc.state);
+    }
+    // look-ahead: one_step = Tr * cur, searched and reduced without materialising it
+    gs_knn_brute_launch(cur, sc.state->s[0].Tr, nullptr, n_src, tgt, n_tgt, sc.best, st);
+    {
+      GsProf prof(GS_PROF_LINEARIZE, 44.0 * (double)n_src, st);
+      hipLaunchKernelGGL((gs_icp_linearize_kernel<false>), dim3(nblk), dim3(LIN_BLOCK), 0, st, cur,
+                         sc.state->s[0].Tr, n_src, tgt, tgt_normals, n_tgt, sc.best, prm->dist_thresh, partials,
+                         nullptr);
+    }
+    {
+      GsProf prof(GS_PROF_SOLVE, 1.0, st);
+      hipLaunchKernelGGL(gs_icp_update_kernel, dim3(1), dim3(SUM_BLOCK), 0, st, partials, nblk, sc.state, *prm, it,
+                         compose16, out_T16);
+    }
+    cur_in = cur;
+  }
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_icp_trace_f32(const void* icp_scratch, int numiters, float* trace_out, void* stream) {
+  GS_REQUIRE(icp_scratch && trace_out && numiters >= 0 && numiters <= 64, "bad arguments");
+  const GsIcpState* st = reinterpret_cast<const GsIcpState*>(icp_scratch);
+  GS_HIP(hipMemcpyAsync(trace_out, st->trace, sizeof(float) * 12 * (size_t)numiters, hipMemcpyDeviceToDevice,
+                        gs_stream(stream)));
+  return GS_OK;
+}

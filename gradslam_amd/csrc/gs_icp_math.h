@@ -1,0 +1,234 @@
+// gs_icp_math.h — device-side pieces shared by the API-level ICP kernels (gs_icp.hip) and the
+// device-resident LM loop (gs_icp_loop.hip): Gauss-Newton row, SPD solve, SE(3) exponential, 4x4
+// algebra, and the two scalar stages of an LM iteration.
+#pragma once
+#include "gs_common.h"
+
+constexpr int LIN_NV = 28;  // 21 upper-triangular JtJ + 6 Jtr + 1 rtr
+
+// ---------------------------------------------------------------- K4: rows -------------
+// odometry/icputils.py:210-230 for one source point and its associated target.
+GS_DEV void gn_row(float sx, float sy, float sz, const float* __restrict__ tgt,
+                   const float* __restrict__ tn, int64_t j, float* a, float& b) {
+  const float dx = tgt[3 * j], dy = tgt[3 * j + 1], dz = tgt[3 * j + 2];
+  const float nx = tn[3 * j], ny = tn[3 * j + 1], nz = tn[3 * j + 2];
+  a[0] = nx; a[1] = ny; a[2] = nz;
+  a[3] = nz * sy - ny * sz;
+  a[4] = nx * sz - nz * sx;
+  a[5] = ny * sx - nx * sy;
+  const float t = nx * (dx - sx) + ny * (dy - sy);
+  b = t + nz * (dz - sz);
+}
+
+// ---------------------------------------------------------------- small dense algebra ---
+// Solve (AtA + damp I) x = Atb (odometry/icputils.py:85-90; the reference inverts in float32 with
+// LAPACK and multiplies).  The system is symmetric positive definite, so it is solved directly by
+// un-pivoted Gauss-Jordan elimination in double on the augmented matrix and rounded once; N is a
+// template parameter so that the whole elimination lives in registers (no scratch memory).
+// Operation order is identical to oracle/gs_oracle.c:solve_spd_f64.
+template <int N>
+GS_DEV void gs_solve_spd(const float* AtA, const float* Atb, float damp, float* x) {
+  double a[N][N + 1];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float e = (i == j) ? 1.0f : 0.0f;
+      const float m = AtA[N * i + j] + e * damp;  // At_A + damp_matrix * damp, in float32
+      a[i][j] = (double)m;
+    }
+    a[i][N] = (double)Atb[i];
+  }
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    const double inv = 1.0 / a[c][c];
+#pragma unroll
+    for (int j = c; j <= N; ++j) a[c][j] *= inv;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      if (r == c) continue;
+      const double f = a[r][c];
+#pragma unroll
+      for (int j = c; j <= N; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = (float)a[i][N];
+}
+
+GS_DEV void gs_solve_normal(const float* AtA, const float* Atb, float damp, int n, float* x) {
+  switch (n) {
+    case 1: gs_solve_spd<1>(AtA, Atb, damp, x); break;
+    case 2: gs_solve_spd<2>(AtA, Atb, damp, x); break;
+    case 3: gs_solve_spd<3>(AtA, Atb, damp, x); break;
+    case 4: gs_solve_spd<4>(AtA, Atb, damp, x); break;
+    case 5: gs_solve_spd<5>(AtA, Atb, damp, x); break;
+    case 6: gs_solve_spd<6>(AtA, Atb, damp, x); break;
+    case 7: gs_solve_spd<7>(AtA, Atb, damp, x); break;
+    default: gs_solve_spd<8>(AtA, Atb, damp, x); break;
+  }
+}
+
+// geometry/se3utils.py:77-115 in double, rounded once (same order as the oracle).
+GS_DEV void gs_se3_exp_dev(const float* xi6, float* T16) {
+  const double v[3] = {xi6[0], xi6[1], xi6[2]}, w[3] = {xi6[3], xi6[4], xi6[5]};
+  const double wh[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  double R[9], V[9];
+  const double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  if ((float)theta < 1e-6f) {
+    for (int i = 0; i < 9; ++i) {
+      R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + wh[i];
+      V[i] = R[i];
+    }
+  } else {
+    double wh2[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += wh[3 * i + k] * wh[3 * k + j];
+        wh2[3 * i + j] = s;
+      }
+    const double s = sin(theta), c = cos(theta);
+    const double Ac = s / theta, Bc = (1 - c) / (theta * theta), Cc = (theta - s) / (theta * theta * theta);
+    for (int i = 0; i < 9; ++i) {
+      const double I = (i % 4 == 0) ? 1.0 : 0.0;
+      R[i] = I + Ac * wh[i] + Bc * wh2[i];
+      V[i] = I + Bc * wh[i] + Cc * wh2[i];
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T16[4 * i + j] = (float)R[3 * i + j];
+    T16[4 * i + 3] = (float)(V[3 * i] * v[0] + V[3 * i + 1] * v[1] + V[3 * i + 2] * v[2]);
+  }
+  T16[12] = 0; T16[13] = 0; T16[14] = 0; T16[15] = 1;
+}
+
+// torch.mm of two 4x4 (odometry/icputils.py:362,543): tiny matmul, plain, ascending k.
+GS_DEV void gs_mm4(const float* A, const float* B, float* C) {
+  float t[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float acc = A[4 * i] * B[j];
+      for (int k = 1; k < 4; ++k) acc = acc + A[4 * i + k] * B[4 * k + j];
+      t[4 * i + j] = acc;
+    }
+  for (int i = 0; i < 16; ++i) C[i] = t[i];
+}
+// kornia compose_transformations (slam/icpslam.py:245-247).
+GS_DEV void gs_compose_rigid(const float* A, const float* B, float* C) {
+  float t[16];
+  for (int i = 0; i < 16; ++i) t[i] = 0.0f;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      float acc = A[4 * i] * B[j];
+      for (int k = 1; k < 3; ++k) acc = acc + A[4 * i + k] * B[4 * k + j];
+      t[4 * i + j] = acc;
+    }
+    float acc = A[4 * i] * B[3];
+    for (int k = 1; k < 3; ++k) acc = acc + A[4 * i + k] * B[4 * k + 3];
+    t[4 * i + 3] = acc + A[4 * i + 3];
+  }
+  t[15] = 1.0f;
+  for (int i = 0; i < 16; ++i) C[i] = t[i];
+}
+
+// ---------------------------------------------------------------- LM iteration, scalar stages
+// State carried between the kernels of one ICP solve.
+struct IcpSmall {
+  float T_total[16];
+  float Tr[16];      // residual transform of the current iteration: se3_exp(xi)
+  float T_step[16];  // transform applied to the source cloud at the end of the iteration
+  float xi[8];
+  float damp;
+  float err;
+  float pad[2];
+};
+
+// After the first linearisation of an iteration (S = the 28 normal-equation sums, float64):
+// err = r.r, xi = (AtA + damp I)^-1 Atb, Tr = se3_exp(xi)   (odometry/icputils.py:328-337 / :498-507)
+GS_DEV void icp_solve_math(const double* S, IcpSmall& s) {
+  float AtA[36], Atb[6], xi[6];
+  int q = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int k = i; k < 6; ++k) {
+      AtA[6 * i + k] = AtA[6 * k + i] = (float)S[q];
+      ++q;
+    }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Atb[i] = (float)S[21 + i];
+  s.err = (float)S[27];
+  gs_solve_spd<6>(AtA, Atb, s.damp, xi);
+  gs_se3_exp_dev(xi, s.Tr);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) s.xi[i] = xi[i];
+}
+
+// After the look-ahead residual (new_err = r'.r'): LM accept / reject (mode 0,
+// odometry/icputils.py:356-365) or the gradLM soft update (mode 1, :527-543).  Sets T_step,
+// T_total, damp; trace_row (12 floats, may be NULL) = [err, new_err, damp, sigmoid, xi(6), 0, 0].
+GS_DEV void icp_update_math(float new_err, IcpSmall& s, const gs_icp_params& prm, float* trace_row) {
+  const float err = s.err;
+  float damp = s.damp;
+  float Tstep[16], Ttot[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) Ttot[i] = s.T_total[i];
+  float sig = 1.0f;
+  if (prm.mode == 0) {
+    if (new_err < err) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Tstep[i] = s.Tr[i];
+      damp = damp / 2;
+      gs_mm4(Tstep, Ttot, Ttot);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Tstep[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+      damp = damp * 2;
+    }
+  } else {
+    const float lmin = (float)(1.0 / (double)prm.lambda_max);
+    const float lrange = (float)((double)prm.lambda_max - 1.0 / (double)prm.lambda_max);
+    float errdiff = new_err - err;
+    errdiff = errdiff < -70.0f ? -70.0f : (errdiff > 70.0f ? 70.0f : errdiff);
+    const float e_b = (float)exp((double)((float)(-(double)prm.B) * errdiff));
+    const float damp_new = lmin + lrange / (1.0f + e_b);
+    damp = damp * damp_new;
+    const float e_b2 = (float)exp((double)((float)(-(double)prm.B2) * errdiff));
+    const float pw = (float)pow((double)(1.0f + e_b2), (double)(float)(1.0 / (double)prm.nu));
+    sig = 1.0f / pw;
+    float xs[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xs[k] = sig * s.xi[k];
+    gs_se3_exp_dev(xs, Tstep);
+    gs_mm4(Tstep, Ttot, Ttot);
+  }
+  s.damp = damp;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    s.T_step[i] = Tstep[i];
+    s.T_total[i] = Ttot[i];
+  }
+  if (trace_row) {
+    trace_row[0] = err; trace_row[1] = new_err; trace_row[2] = damp; trace_row[3] = sig;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) trace_row[4 + k] = s.xi[k];
+    trace_row[10] = 0; trace_row[11] = 0;
+  }
+}
+
+// final result: T_total, optionally composed with the caller's pose (slam/icpslam.py:245-247)
+GS_DEV void icp_write_result(const IcpSmall& s, const float* __restrict__ compose16, float* __restrict__ out_T16) {
+  float out[16];
+  if (compose16) {
+    float Cm[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Cm[i] = compose16[i];
+    gs_compose_rigid(s.T_total, Cm, out);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[i] = s.T_total[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) out_T16[i] = out[i];
+}
