@@ -50,6 +50,11 @@ _PROTOS = {
     "gs_icp_scratch_bytes": [_i64, _i64],
     "gs_icp_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, C.POINTER(IcpParams), _vp, _vp, _vp, _vp],
     "gs_icp_trace_f32": [_vp, _i32, _vp, _vp],
+    "gs_icp_tape_bytes": [_i64, _i32],
+    "gs_icp_tape_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, C.POINTER(IcpParams), _vp, _vp, _vp, _vp, _vp],
+    "gs_icp_backward_scratch_bytes": [_i64, _i64],
+    "gs_icp_backward_f32": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, C.POINTER(IcpParams), _vp, _vp, _vp, _vp, _vp, _vp,
+                            _vp],
     "gs_similar_rows_f32": [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f, _f, _vp, _vp],
     "gs_best_unique_rows_f32": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
     "gs_associate_f32": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp],
@@ -60,7 +65,7 @@ _PROTOS = {
     "gs_append_valid_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
 }
 _RESTYPE = {"gs_last_error": C.c_char_p, "gs_scratch_bytes": _i64, "gs_icp_scratch_bytes": _i64,
-            "gs_knn1_grid_scratch_bytes": _i64}
+            "gs_knn1_grid_scratch_bytes": _i64, "gs_icp_tape_bytes": _i64, "gs_icp_backward_scratch_bytes": _i64}
 EXPORTS = tuple(_PROTOS)
 
 

@@ -1,0 +1,503 @@
+// gs_icp_bwd.hip — K7: backward pass of point_to_plane_gradICP (odometry/icputils.py:479-545).
+//
+// Reverse-mode differentiation of the gradLM loop given the forward tape (gs_icp_tape_f32): the
+// gradient of any scalar loss w.r.t. the source points, the target points, the target normals and
+// the initial transform, from dL/dT.  Nearest-neighbour indices and the dist_thresh filter are
+// constants of the differentiation exactly as in the reference (index / boolean ops are not
+// differentiable, icputils.py:201-208); everything else (rows, normal equations, 6x6 solve, both
+// SE(3) exponentials, the sigmoid damping and step scaling, the running transform) is
+// differentiated analytically.  oracle/icp_backward.py is the float64 numpy restatement, pinned
+// against the reference's own autograd (tests/golden/icp_grad.npz).
+//
+// Per iteration (last to first): scalar stage S1 (adjoint of T_step = exp(sigma xi), of sigma and
+// of the damping) -> point kernel P2 (look-ahead residual, scatter to targets, 12 sums for the
+// adjoint of Tr) -> scalar stage S2 (adjoint of xi through exp and the 6x6 solve) -> point kernel
+// P3 (Gauss-Newton rows, scatter to targets, 12 sums for the next S1).  All arithmetic in float64;
+// scatters are float64 atomics (order-independent to ~1e-16, rounded once at the end).
+#include "gs_icp_math.h"
+
+constexpr int BW_BLOCK = 256;
+constexpr int BW_NV = 12;  // 3x3 outer-product sum + 3-vector sum
+
+struct BwdState {
+  double Tk[65][16];  // running transform before iteration k (Tk[K] = final)
+  double Ts[64][16];  // exp(sigma_k xi_k)
+  double Tr[64][16];  // exp(xi_k)
+  double Tb[16];      // adjoint of the running transform
+  double lam_bar;     // adjoint of the damping carried to the next (earlier) iteration
+  double xi_bar[6];
+  double g_bar[6];
+  double Hs[36];
+  double e_bar, e1_bar;
+};
+
+GS_DEV void d_mm4(const double* A, const double* B, double* C) {
+  double t[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc += A[4 * i + k] * B[4 * k + j];
+      t[4 * i + j] = acc;
+    }
+  for (int i = 0; i < 16; ++i) C[i] = t[i];
+}
+
+GS_DEV void d_hat(const double* w, double* wh) {
+  wh[0] = 0; wh[1] = -w[2]; wh[2] = w[1];
+  wh[3] = w[2]; wh[4] = 0; wh[5] = -w[0];
+  wh[6] = -w[1]; wh[7] = w[0]; wh[8] = 0;
+}
+GS_DEV void d_mm3(const double* A, const double* B, double* C) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// geometry/se3utils.py:77-115 in double
+GS_DEV void d_se3_exp(const double* xi, double* T) {
+  const double* v = xi;
+  const double* w = xi + 3;
+  double wh[9], wh2[9], R[9], V[9];
+  d_hat(w, wh);
+  const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  if ((float)th < 1e-6f) {
+    for (int i = 0; i < 9; ++i) { R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + wh[i]; V[i] = R[i]; }
+  } else {
+    d_mm3(wh, wh, wh2);
+    const double s = sin(th), c = cos(th);
+    const double A = s / th, B = (1 - c) / (th * th), Cc = (th - s) / (th * th * th);
+    for (int i = 0; i < 9; ++i) {
+      const double I = (i % 4 == 0) ? 1.0 : 0.0;
+      R[i] = I + A * wh[i] + B * wh2[i];
+      V[i] = I + B * wh[i] + Cc * wh2[i];
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T[4 * i + j] = R[3 * i + j];
+    T[4 * i + 3] = V[3 * i] * v[0] + V[3 * i + 1] * v[1] + V[3 * i + 2] * v[2];
+  }
+  T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+
+// d <Tbar, Exp(xi)> / d xi (Tbar: 4x4, only its top three rows matter)
+GS_DEV void d_se3_exp_adjoint(const double* xi, const double* Tbar, double* out) {
+  const double* v = xi;
+  const double* w = xi + 3;
+  double Rb[9], tb[3], wh[9], wh2[9], V[9], Vb[9], whb[9];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) Rb[3 * i + j] = Tbar[4 * i + j];
+    tb[i] = Tbar[4 * i + 3];
+  }
+  d_hat(w, wh);
+  d_mm3(wh, wh, wh2);
+  const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  const bool small = (float)th < 1e-6f;
+  double s = 0, c = 1, A = 1, B = 0, Cc = 0;
+  if (small) {
+    for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + wh[i];
+  } else {
+    s = sin(th); c = cos(th);
+    A = s / th; B = (1 - c) / (th * th); Cc = (th - s) / (th * th * th);
+    for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + B * wh[i] + Cc * wh2[i];
+  }
+  for (int j = 0; j < 3; ++j) out[j] = V[j] * tb[0] + V[3 + j] * tb[1] + V[6 + j] * tb[2];  // V^T tb
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Vb[3 * i + j] = tb[i] * v[j];
+  double thb = 0.0;
+  if (small) {
+    for (int i = 0; i < 9; ++i) whb[i] = Rb[i] + Vb[i];
+  } else {
+    double Ab = 0, Bb = 0, Cb = 0, W2b[9], whT[9], t1[9], t2[9];
+    for (int i = 0; i < 9; ++i) {
+      Ab += Rb[i] * wh[i];
+      Bb += Rb[i] * wh2[i] + Vb[i] * wh[i];
+      Cb += Vb[i] * wh2[i];
+      W2b[i] = B * Rb[i] + Cc * Vb[i];
+    }
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) whT[3 * i + j] = wh[3 * j + i];
+    d_mm3(W2b, whT, t1);
+    d_mm3(whT, W2b, t2);
+    for (int i = 0; i < 9; ++i) whb[i] = A * Rb[i] + B * Vb[i] + t1[i] + t2[i];
+    const double dA = (c * th - s) / (th * th);
+    const double dB = (s * th - 2 * (1 - c)) / (th * th * th);
+    const double dC = ((1 - c) * th - 3 * (th - s)) / (th * th * th * th);
+    thb = Ab * dA + Bb * dB + Cb * dC;
+  }
+  out[3] = whb[7] - whb[5];
+  out[4] = whb[2] - whb[6];
+  out[5] = whb[3] - whb[1];
+  if (!small)
+    for (int j = 0; j < 3; ++j) out[3 + j] += thb * w[j] / th;
+}
+
+// 6x6 symmetric positive definite solve in double (un-pivoted Gauss-Jordan)
+GS_DEV void d_solve6(const double* H, const double* rhs, double* x) {
+  double a[6][7];
+  for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 6; ++j) a[i][j] = H[6 * i + j];
+    a[i][6] = rhs[i];
+  }
+  for (int c = 0; c < 6; ++c) {
+    const double inv = 1.0 / a[c][c];
+    for (int j = c; j <= 6; ++j) a[c][j] *= inv;
+    for (int r = 0; r < 6; ++r) {
+      if (r == c) continue;
+      const double f = a[r][c];
+      for (int j = c; j <= 6; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int i = 0; i < 6; ++i) x[i] = a[i][6];
+}
+
+// block sum of BW_NV doubles per thread -> one partial row
+GS_DEV void bw_block_reduce(const double* v, double* __restrict__ partial_row) {
+  __shared__ double red[BW_BLOCK / GS_WAVE][BW_NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < BW_NV; ++i) {
+    const double sum = gs_wave_sum_f64(v[i]);
+    if (lane == 0) red[wave][i] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x < BW_NV) {
+    double t = 0.0;
+    for (int w = 0; w < BW_BLOCK / GS_WAVE; ++w) t += red[w][threadIdx.x];
+    partial_row[threadIdx.x] = t;
+  }
+}
+
+GS_DEV void bw_sum_rows(const double* __restrict__ partials, int nrows, double* G) {
+  // one wave per call site is enough: 12 values, rows strided over the 64 lanes
+  __shared__ double acc[BW_NV];
+  const int lane = threadIdx.x;
+  for (int i = 0; i < BW_NV; ++i) {
+    double s = 0.0;
+    for (int b = lane; b < nrows; b += GS_WAVE) s += partials[(int64_t)b * BW_NV + i];
+    s = gs_wave_sum_f64(s);
+    if (lane == 0) acc[i] = s;
+  }
+  __syncthreads();
+  for (int i = 0; i < BW_NV; ++i) G[i] = acc[i];
+}
+
+// Replays the forward transforms and seeds the adjoints.
+__global__ void gs_bwd_init_kernel(BwdState* __restrict__ bs, GsIcpTape tape, const float* __restrict__ init16,
+                                   const float* __restrict__ T_bar16, int K) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 16; ++i) bs->Tk[0][i] = (double)init16[i];
+  for (int k = 0; k < K; ++k) {
+    double xi[6], xs[6];
+    const double sig = (double)tape.trace[12 * k + 3];
+    for (int i = 0; i < 6; ++i) {
+      xi[i] = (double)tape.trace[12 * k + 4 + i];
+      xs[i] = sig * xi[i];
+    }
+    d_se3_exp(xi, bs->Tr[k]);
+    d_se3_exp(xs, bs->Ts[k]);
+    d_mm4(bs->Ts[k], bs->Tk[k], bs->Tk[k + 1]);
+  }
+  for (int i = 0; i < 16; ++i) bs->Tb[i] = (double)T_bar16[i];
+  bs->lam_bar = 0.0;
+}
+
+// S1 of iteration k: needs G = sum_i sbar_next_i (x) s_k,i and h = sum_i sbar_next_i
+__global__ void __launch_bounds__(GS_WAVE) gs_bwd_s1_kernel(BwdState* __restrict__ bs, GsIcpTape tape, int k,
+                                                            const double* __restrict__ partials, int nrows,
+                                                            gs_icp_params prm) {
+  double G[BW_NV];
+  bw_sum_rows(partials, nrows, G);
+  if (threadIdx.x != 0) return;
+  const double* Tk = bs->Tk[k];
+  const double* Ts = bs->Ts[k];
+  double Tb[16], Tsb[16];
+  for (int i = 0; i < 16; ++i) Tb[i] = bs->Tb[i];
+  // Ts_bar = Tb Tk^T (+ the point-cloud part)
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double acc = 0.0;
+      for (int m = 0; m < 4; ++m) acc += Tb[4 * i + m] * Tk[4 * j + m];
+      Tsb[4 * i + j] = acc;
+    }
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) Tsb[4 * i + j] += G[3 * i + j];
+    Tsb[4 * i + 3] += G[9 + i];
+  }
+  // Tb <- Ts^T Tb
+  double nTb[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double acc = 0.0;
+      for (int m = 0; m < 4; ++m) acc += Ts[4 * m + i] * Tb[4 * m + j];
+      nTb[4 * i + j] = acc;
+    }
+  for (int i = 0; i < 16; ++i) bs->Tb[i] = nTb[i];
+  double xi[6], xs[6], ub[6];
+  const double sig = (double)tape.trace[12 * k + 3];
+  for (int i = 0; i < 6; ++i) {
+    xi[i] = (double)tape.trace[12 * k + 4 + i];
+    xs[i] = sig * xi[i];
+  }
+  d_se3_exp_adjoint(xs, Tsb, ub);
+  double sig_bar = 0.0;
+  for (int i = 0; i < 6; ++i) {
+    sig_bar += ub[i] * xi[i];
+    bs->xi_bar[i] = sig * ub[i];
+  }
+  const float err = tape.trace[12 * k], new_err = tape.trace[12 * k + 1];
+  const double lam = (double)tape.sys[28 * k + 27];
+  const float diff = new_err - err;
+  const bool inside = diff >= -70.0f && diff <= 70.0f;
+  const double d = (double)(diff < -70.0f ? -70.0f : (diff > 70.0f ? 70.0f : diff));
+  const double lmin = (double)(float)(1.0 / (double)prm.lambda_max);
+  const double lrange = (double)(float)((double)prm.lambda_max - 1.0 / (double)prm.lambda_max);
+  const double Bp = (double)prm.B, B2p = (double)prm.B2, nu = (double)prm.nu;
+  const double E = exp(-Bp * d), E2 = exp(-B2p * d);
+  const double q = lmin + lrange / (1 + E);
+  const double dq = lrange * Bp * E / ((1 + E) * (1 + E));
+  const double dsig = (B2p * E2 / nu) * pow(1 + E2, -1.0 / nu - 1.0);
+  double d_bar = sig_bar * dsig + bs->lam_bar * lam * dq;
+  bs->lam_bar = bs->lam_bar * q;
+  if (!inside) d_bar = 0.0;
+  bs->e1_bar = d_bar;
+  bs->e_bar = -d_bar;
+}
+
+// P2 of iteration k: sb_mid = Rs^T sbar_next + look-ahead residual part; scatter; sums for Tr_bar
+__global__ void __launch_bounds__(BW_BLOCK) gs_bwd_p2_kernel(
+    const BwdState* __restrict__ bs, int k, const float* __restrict__ src_k, const int32_t* __restrict__ idx1,
+    int64_t n_src, const float* __restrict__ tgt, const float* __restrict__ tn, const double* __restrict__ sbar_next,
+    double* __restrict__ sbar_mid, double* __restrict__ tgt_bar, double* __restrict__ tn_bar,
+    double* __restrict__ partials) {
+  const int64_t i = (int64_t)blockIdx.x * BW_BLOCK + threadIdx.x;
+  double v[BW_NV];
+#pragma unroll
+  for (int q = 0; q < BW_NV; ++q) v[q] = 0.0;
+  if (i < n_src) {
+    const double* Ts = bs->Ts[k];
+    const double* Tr = bs->Tr[k];
+    const double e1_bar = bs->e1_bar;
+    const double s[3] = {(double)src_k[3 * i], (double)src_k[3 * i + 1], (double)src_k[3 * i + 2]};
+    const double sn[3] = {sbar_next[3 * i], sbar_next[3 * i + 1], sbar_next[3 * i + 2]};
+    double sb[3];
+    for (int j = 0; j < 3; ++j) sb[j] = sn[0] * Ts[j] + sn[1] * Ts[4 + j] + sn[2] * Ts[8 + j];
+    const int32_t j1 = idx1[i];
+    if (j1 >= 0) {
+      double s1[3], n1[3], d1[3];
+      for (int a = 0; a < 3; ++a) {
+        s1[a] = Tr[4 * a] * s[0] + Tr[4 * a + 1] * s[1] + Tr[4 * a + 2] * s[2] + Tr[4 * a + 3];
+        n1[a] = (double)tn[3 * (int64_t)j1 + a];
+        d1[a] = (double)tgt[3 * (int64_t)j1 + a];
+      }
+      const double b1 = n1[0] * (d1[0] - s1[0]) + n1[1] * (d1[1] - s1[1]) + n1[2] * (d1[2] - s1[2]);
+      const double b1_bar = 2 * b1 * e1_bar;
+      double s1b[3];
+      for (int a = 0; a < 3; ++a) {
+        s1b[a] = -n1[a] * b1_bar;
+        atomicAdd(&tgt_bar[3 * (int64_t)j1 + a], n1[a] * b1_bar);
+        atomicAdd(&tn_bar[3 * (int64_t)j1 + a], (d1[a] - s1[a]) * b1_bar);
+      }
+      for (int j = 0; j < 3; ++j) sb[j] += s1b[0] * Tr[j] + s1b[1] * Tr[4 + j] + s1b[2] * Tr[8 + j];
+      for (int a = 0; a < 3; ++a) {
+        for (int j = 0; j < 3; ++j) v[3 * a + j] = s1b[a] * s[j];
+        v[9 + a] = s1b[a];
+      }
+    }
+    for (int j = 0; j < 3; ++j) sbar_mid[3 * i + j] = sb[j];
+  }
+  bw_block_reduce(v, partials + (int64_t)blockIdx.x * BW_NV);
+}
+
+// S2 of iteration k: xi_bar += adjoint through Tr = exp(xi); then through xi = H^-1 g
+__global__ void __launch_bounds__(GS_WAVE) gs_bwd_s2_kernel(BwdState* __restrict__ bs, GsIcpTape tape, int k,
+                                                            const double* __restrict__ partials, int nrows) {
+  double G[BW_NV];
+  bw_sum_rows(partials, nrows, G);
+  if (threadIdx.x != 0) return;
+  double Trb[16];
+  for (int i = 0; i < 16; ++i) Trb[i] = 0.0;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) Trb[4 * i + j] = G[3 * i + j];
+    Trb[4 * i + 3] = G[9 + i];
+  }
+  double xi[6], ub[6], xb[6], H[36], gb[6];
+  for (int i = 0; i < 6; ++i) xi[i] = (double)tape.trace[12 * k + 4 + i];
+  d_se3_exp_adjoint(xi, Trb, ub);
+  for (int i = 0; i < 6; ++i) xb[i] = bs->xi_bar[i] + ub[i];
+  const float lam = tape.sys[28 * k + 27];
+  int q = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) {
+      H[6 * r + c] = H[6 * c + r] = (double)tape.sys[28 * k + q];
+      ++q;
+    }
+  for (int r = 0; r < 6; ++r) H[6 * r + r] += (double)lam;
+  d_solve6(H, xb, gb);
+  double tr = 0.0;
+  for (int r = 0; r < 6; ++r) {
+    bs->g_bar[r] = gb[r];
+    tr += -gb[r] * xi[r];
+  }
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) bs->Hs[6 * r + c] = -(gb[r] * xi[c] + gb[c] * xi[r]);
+  bs->lam_bar += tr;
+}
+
+// P3 of iteration k: Gauss-Newton rows; sbar (adjoint of src_k); scatter; sums for the next S1
+__global__ void __launch_bounds__(BW_BLOCK) gs_bwd_p3_kernel(
+    const BwdState* __restrict__ bs, const float* __restrict__ src_k, const float* __restrict__ src_prev,
+    const int32_t* __restrict__ idx0, int64_t n_src, const float* __restrict__ tgt, const float* __restrict__ tn,
+    const double* __restrict__ sbar_mid, double* __restrict__ sbar_out, double* __restrict__ tgt_bar,
+    double* __restrict__ tn_bar, double* __restrict__ partials) {
+  const int64_t i = (int64_t)blockIdx.x * BW_BLOCK + threadIdx.x;
+  double v[BW_NV];
+#pragma unroll
+  for (int q = 0; q < BW_NV; ++q) v[q] = 0.0;
+  if (i < n_src) {
+    const double s[3] = {(double)src_k[3 * i], (double)src_k[3 * i + 1], (double)src_k[3 * i + 2]};
+    double sb[3] = {sbar_mid[3 * i], sbar_mid[3 * i + 1], sbar_mid[3 * i + 2]};
+    const int32_t j = idx0[i];
+    if (j >= 0) {
+      const double e_bar = bs->e_bar;
+      double n0[3], d0[3], a[6];
+      for (int c = 0; c < 3; ++c) {
+        n0[c] = (double)tn[3 * (int64_t)j + c];
+        d0[c] = (double)tgt[3 * (int64_t)j + c];
+      }
+      a[0] = n0[0]; a[1] = n0[1]; a[2] = n0[2];
+      a[3] = s[1] * n0[2] - s[2] * n0[1];
+      a[4] = s[2] * n0[0] - s[0] * n0[2];
+      a[5] = s[0] * n0[1] - s[1] * n0[0];
+      const double b = n0[0] * (d0[0] - s[0]) + n0[1] * (d0[1] - s[1]) + n0[2] * (d0[2] - s[2]);
+      double ab[6], b_bar = 2 * b * e_bar;
+      for (int r = 0; r < 6; ++r) {
+        double acc = bs->g_bar[r] * b;
+        for (int c = 0; c < 6; ++c) acc += bs->Hs[6 * r + c] * a[c];
+        ab[r] = acc;
+        b_bar += a[r] * bs->g_bar[r];
+      }
+      const double* an = ab;
+      const double* ac = ab + 3;
+      // c = s x n: s_bar += n x c_bar, n_bar += c_bar x s ; b = n.(d - s)
+      sb[0] += -n0[0] * b_bar + (n0[1] * ac[2] - n0[2] * ac[1]);
+      sb[1] += -n0[1] * b_bar + (n0[2] * ac[0] - n0[0] * ac[2]);
+      sb[2] += -n0[2] * b_bar + (n0[0] * ac[1] - n0[1] * ac[0]);
+      const double cxs[3] = {ac[1] * s[2] - ac[2] * s[1], ac[2] * s[0] - ac[0] * s[2], ac[0] * s[1] - ac[1] * s[0]};
+      for (int c = 0; c < 3; ++c) {
+        atomicAdd(&tn_bar[3 * (int64_t)j + c], an[c] + cxs[c] + (d0[c] - s[c]) * b_bar);
+        atomicAdd(&tgt_bar[3 * (int64_t)j + c], n0[c] * b_bar);
+      }
+    }
+    for (int c = 0; c < 3; ++c) sbar_out[3 * i + c] = sb[c];
+    // sums for the adjoint of the transform that produced src_k from src_prev
+    const double sp[3] = {(double)src_prev[3 * i], (double)src_prev[3 * i + 1], (double)src_prev[3 * i + 2]};
+    for (int a = 0; a < 3; ++a) {
+      for (int c = 0; c < 3; ++c) v[3 * a + c] = sb[a] * sp[c];
+      v[9 + a] = sb[a];
+    }
+  }
+  bw_block_reduce(v, partials + (int64_t)blockIdx.x * BW_NV);
+}
+
+// final: init_bar = T0_bar + sums ; src_bar = R_init^T sbar_0 ; float64 scatters -> float32
+__global__ void __launch_bounds__(GS_WAVE) gs_bwd_final_scalar_kernel(const BwdState* __restrict__ bs,
+                                                                      const double* __restrict__ partials, int nrows,
+                                                                      float* __restrict__ init_bar16) {
+  double G[BW_NV];
+  bw_sum_rows(partials, nrows, G);
+  if (threadIdx.x != 0 || !init_bar16) return;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) init_bar16[4 * i + j] = (float)(bs->Tb[4 * i + j] + G[3 * i + j]);
+    init_bar16[4 * i + 3] = (float)(bs->Tb[4 * i + 3] + G[9 + i]);
+  }
+  for (int j = 0; j < 4; ++j) init_bar16[12 + j] = 0.0f;
+}
+__global__ void __launch_bounds__(BW_BLOCK) gs_bwd_src_out_kernel(const double* __restrict__ sbar0, int64_t n_src,
+                                                                  const float* __restrict__ init16,
+                                                                  float* __restrict__ src_bar) {
+  const int64_t i = (int64_t)blockIdx.x * BW_BLOCK + threadIdx.x;
+  if (i >= n_src) return;
+  const double sb[3] = {sbar0[3 * i], sbar0[3 * i + 1], sbar0[3 * i + 2]};
+  for (int j = 0; j < 3; ++j)
+    src_bar[3 * i + j] = (float)(sb[0] * (double)init16[j] + sb[1] * (double)init16[4 + j] + sb[2] * (double)init16[8 + j]);
+}
+__global__ void __launch_bounds__(BW_BLOCK) gs_bwd_cast_kernel(const double* __restrict__ in, int64_t n,
+                                                               float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * BW_BLOCK + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+
+struct BwdScratch {
+  BwdState* state;
+  double* sbar_a;   // [n_src][3]
+  double* sbar_b;   // [n_src][3]
+  double* tgt_bar;  // [n_tgt][3]
+  double* tn_bar;   // [n_tgt][3]
+  double* partials; // [nblk][12]
+};
+static BwdScratch bwd_carve(void* scratch, int64_t n_src, int64_t n_tgt) {
+  char* p = reinterpret_cast<char*>(scratch);
+  BwdScratch s;
+  s.state = reinterpret_cast<BwdState*>(p); p += gs_align(sizeof(BwdState));
+  s.sbar_a = reinterpret_cast<double*>(p); p += gs_align(24 * (size_t)n_src);
+  s.sbar_b = reinterpret_cast<double*>(p); p += gs_align(24 * (size_t)n_src);
+  s.tgt_bar = reinterpret_cast<double*>(p); p += gs_align(24 * (size_t)n_tgt);
+  s.tn_bar = reinterpret_cast<double*>(p); p += gs_align(24 * (size_t)n_tgt);
+  s.partials = reinterpret_cast<double*>(p);
+  return s;
+}
+
+extern "C" int64_t gs_icp_backward_scratch_bytes(int64_t n_src, int64_t n_tgt) {
+  if (n_src < 1) n_src = 1;
+  if (n_tgt < 1) n_tgt = 1;
+  return (int64_t)(gs_align(sizeof(BwdState)) + 2 * gs_align(24 * (size_t)n_src) + 2 * gs_align(24 * (size_t)n_tgt) +
+                   gs_align(8 * BW_NV * (size_t)gs_ceil_div(n_src, BW_BLOCK)) + 4096);
+}
+
+extern "C" int gs_icp_backward_f32(const void* tape, const float* src_in, int64_t n_src, const float* tgt,
+                                   const float* tgt_normals, int64_t n_tgt, const float* init16,
+                                   const gs_icp_params* prm, const float* T_bar16, float* src_bar, float* tgt_bar,
+                                   float* normals_bar, float* init_bar16, void* scratch, void* stream) {
+  GS_REQUIRE(prm && tape && src_in && tgt && tgt_normals && init16 && T_bar16 && scratch, "NULL pointer");
+  GS_REQUIRE(n_src > 0 && n_tgt > 0, "empty point set");
+  GS_REQUIRE(prm->mode == 1, "backward is implemented for gradICP (mode 1)");
+  GS_REQUIRE(prm->numiters >= 0 && prm->numiters <= 64, "numiters must be in [0, 64]");
+  hipStream_t st = gs_stream(stream);
+  const int K = prm->numiters;
+  GsIcpTape tp = gs_icp_tape_carve(const_cast<void*>(tape), n_src, K);
+  BwdScratch sc = bwd_carve(scratch, n_src, n_tgt);
+  const int nblk = (int)gs_ceil_div(n_src, BW_BLOCK);
+  GS_HIP(hipMemsetAsync(sc.sbar_a, 0, 24 * (size_t)n_src, st));
+  GS_HIP(hipMemsetAsync(sc.tgt_bar, 0, 24 * (size_t)n_tgt, st));
+  GS_HIP(hipMemsetAsync(sc.tn_bar, 0, 24 * (size_t)n_tgt, st));
+  GS_HIP(hipMemsetAsync(sc.partials, 0, 8 * BW_NV * (size_t)nblk, st));  // sbar_next = 0 for the last iteration
+  hipLaunchKernelGGL(gs_bwd_init_kernel, dim3(1), dim3(64), 0, st, sc.state, tp, init16, T_bar16, K);
+  double* sbar_next = sc.sbar_a;  // adjoint of src_{k+1}
+  double* sbar_mid = sc.sbar_b;
+  for (int k = K - 1; k >= 0; --k) {
+    const float* src_k = tp.src + (size_t)k * 3 * (size_t)n_src;
+    const float* src_prev = (k > 0) ? tp.src + (size_t)(k - 1) * 3 * (size_t)n_src : src_in;
+    const int32_t* idx0 = tp.idx + ((size_t)k * 2) * (size_t)n_src;
+    const int32_t* idx1 = idx0 + (size_t)n_src;
+    hipLaunchKernelGGL(gs_bwd_s1_kernel, dim3(1), dim3(GS_WAVE), 0, st, sc.state, tp, k, sc.partials, nblk, *prm);
+    hipLaunchKernelGGL(gs_bwd_p2_kernel, dim3(nblk), dim3(BW_BLOCK), 0, st, sc.state, k, src_k, idx1, n_src, tgt,
+                       tgt_normals, sbar_next, sbar_mid, sc.tgt_bar, sc.tn_bar, sc.partials);
+    hipLaunchKernelGGL(gs_bwd_s2_kernel, dim3(1), dim3(GS_WAVE), 0, st, sc.state, tp, k, sc.partials, nblk);
+    // P3 overwrites sbar_next with the adjoint of src_k (it only reads sbar_mid)
+    hipLaunchKernelGGL(gs_bwd_p3_kernel, dim3(nblk), dim3(BW_BLOCK), 0, st, sc.state, src_k, src_prev, idx0, n_src, tgt,
+                       tgt_normals, sbar_mid, sbar_next, sc.tgt_bar, sc.tn_bar, sc.partials);
+  }
+  if (K == 0) {  // T = init: sums stay zero, Tb = T_bar
+    GS_HIP(hipMemsetAsync(sc.partials, 0, 8 * BW_NV * (size_t)nblk, st));
+  }
+  hipLaunchKernelGGL(gs_bwd_final_scalar_kernel, dim3(1), dim3(GS_WAVE), 0, st, sc.state, sc.partials, nblk, init_bar16);
+  if (src_bar)
+    hipLaunchKernelGGL(gs_bwd_src_out_kernel, dim3(nblk), dim3(BW_BLOCK), 0, st, sbar_next, n_src, init16, src_bar);
+  if (tgt_bar)
+    hipLaunchKernelGGL(gs_bwd_cast_kernel, dim3((unsigned)gs_ceil_div(3 * n_tgt, BW_BLOCK)), dim3(BW_BLOCK), 0, st,
+                       sc.tgt_bar, 3 * n_tgt, tgt_bar);
+  if (normals_bar)
+    hipLaunchKernelGGL(gs_bwd_cast_kernel, dim3((unsigned)gs_ceil_div(3 * n_tgt, BW_BLOCK)), dim3(BW_BLOCK), 0, st,
+                       sc.tn_bar, 3 * n_tgt, normals_bar);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}

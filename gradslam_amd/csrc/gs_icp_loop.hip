@@ -26,6 +26,18 @@ struct GsIcpState {
   float trace[64 * 12];   // up to 64 iterations
 };
 
+// Optional forward tape for gs_icp_backward_f32 (layout: gs_icp_math.h:GsIcpTape).
+struct TapePtrs {
+  float* src;    // [K][n_src][3]
+  int32_t* idx;  // [K][2][n_src]
+  float* sys;    // [K][28]
+};
+GS_DEV void tape_write_sys(float* __restrict__ sys, int it, const double* S, float damp) {
+  float* t = sys + 28 * it;
+  for (int i = 0; i < 27; ++i) t[i] = (float)S[i];
+  t[27] = damp;
+}
+
 // ---------------------------------------------------------------- fixed-order sums ------
 // Adds up partial rows (nrows x LIN_NV doubles).  Thread t works on value t%32 and row subset
 // t/32; 16 loads are in flight per thread; the sub-sums are then added in index order.  Every
@@ -82,7 +94,8 @@ __global__ void __launch_bounds__(FS_BLOCK) gs_icp_half_kernel(
     const float* __restrict__ tn, int64_t n_tgt, const GsGrid* __restrict__ gp, const int* __restrict__ cell_start,
     const float4* __restrict__ sorted, float dist_thresh, const double* __restrict__ partials_in, int nrows_in,
     double* __restrict__ partials_out, const IcpSmall* __restrict__ st_in, IcpSmall* __restrict__ st_out,
-    float* __restrict__ trace, gs_icp_params prm, int it, int64_t* __restrict__ out_idx) {
+    float* __restrict__ trace, gs_icp_params prm, int it, int64_t* __restrict__ out_idx,
+    int32_t* __restrict__ tape_idx, float* __restrict__ tape_sys) {
   __shared__ IcpSmall sm;
   __shared__ double S[32];
   __shared__ double sub[FS_BLOCK / 32][32];
@@ -106,6 +119,7 @@ __global__ void __launch_bounds__(FS_BLOCK) gs_icp_half_kernel(
     icp_sum_rows<FS_BLOCK>(partials_in, nrows_in, S, sub);
     if (threadIdx.x == 0) {
       IcpSmall loc = *st_in;
+      if (tape_sys && blockIdx.x == 0) tape_write_sys(tape_sys, it, S, loc.damp);
       icp_solve_math(S, loc);
       sm = loc;
       unres_n = 0;
@@ -159,6 +173,7 @@ __global__ void __launch_bounds__(FS_BLOCK) gs_icp_half_kernel(
     float a[6], res;
     gn_row(qs[threadIdx.x][0], qs[threadIdx.x][1], qs[threadIdx.x][2], tgt, tn, j, a, res);
     if (FULL && out_idx) out_idx[r] = j;
+    if (tape_idx) tape_idx[r] = keep ? (int32_t)j : -1;
     if (keep) {
       if (FULL) {
         int q = 0;
@@ -232,7 +247,7 @@ __global__ void __launch_bounds__(LIN_BLOCK) gs_icp_linearize_kernel(
     const float* __restrict__ src, const float* __restrict__ Tapply, int64_t n_src,
     const float* __restrict__ tgt, const float* __restrict__ tn, int64_t n_tgt,
     unsigned long long* __restrict__ best, float dist_thresh, double* __restrict__ partials,
-    int64_t* __restrict__ out_idx) {
+    int64_t* __restrict__ out_idx, int32_t* __restrict__ tape_idx) {
   __shared__ double red[LIN_BLOCK / GS_WAVE][LIN_NV];
   const int64_t s = (int64_t)blockIdx.x * LIN_BLOCK + threadIdx.x;
   double v[LIN_NV];
@@ -257,6 +272,7 @@ __global__ void __launch_bounds__(LIN_BLOCK) gs_icp_linearize_kernel(
     float a[6], r;
     gn_row(p0, p1, p2, tgt, tn, j, a, r);
     if (FULL && out_idx) out_idx[s] = j;
+    if (tape_idx) tape_idx[s] = keep ? (int32_t)j : -1;
     if (keep) {
       if (FULL) {
         int q = 0;
@@ -284,12 +300,14 @@ __global__ void __launch_bounds__(LIN_BLOCK) gs_icp_linearize_kernel(
 }
 
 __global__ void __launch_bounds__(SUM_BLOCK) gs_icp_solve_kernel(const double* __restrict__ partials, int nrows,
-                                                                 GsIcpState* __restrict__ st) {
+                                                                 GsIcpState* __restrict__ st, int it,
+                                                                 float* __restrict__ tape_sys) {
   __shared__ double S[32];
   __shared__ double sub[SUM_BLOCK / 32][32];
   icp_sum_rows<SUM_BLOCK>(partials, nrows, S, sub);
   if (threadIdx.x != 0) return;
   IcpSmall sm = st->s[0];
+  if (tape_sys) tape_write_sys(tape_sys, it, S, sm.damp);
   icp_solve_math(S, sm);
   st->s[0] = sm;
 }
@@ -367,10 +385,18 @@ extern "C" int64_t gs_icp_scratch_bytes(int64_t n_src, int64_t n_tgt) {
                    4096);
 }
 
-extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, const float* tgt_normals,
-                          int64_t n_tgt, const float* init16, const float* compose16,
-                          const gs_icp_params* prm, float* out_T16, int64_t* out_idx, void* icp_scratch,
-                          void* stream) {
+// the per-iteration trace [err, new_err, damp_after, sigmoid, xi(6), 0, 0] completes the tape
+static int icp_tape_finish(void* tape, const GsIcpState* state, int64_t n_src, int numiters, hipStream_t st) {
+  GsIcpTape t = gs_icp_tape_carve(tape, n_src, numiters);
+  if (numiters > 0)
+    GS_HIP(hipMemcpyAsync(t.trace, state->trace, sizeof(float) * 12 * (size_t)numiters, hipMemcpyDeviceToDevice, st));
+  return GS_OK;
+}
+
+static int icp_run(const float* src, int64_t n_src, const float* tgt, const float* tgt_normals,
+                   int64_t n_tgt, const float* init16, const float* compose16,
+                   const gs_icp_params* prm, float* out_T16, int64_t* out_idx, void* icp_scratch,
+                   void* tape, void* stream) {
   GS_REQUIRE(prm, "params_host must not be NULL");
   GS_REQUIRE(n_src > 0 && n_tgt > 0, "empty point set");
   GS_REQUIRE(n_tgt < 0x7fffffffll && n_src < 0x7fffffffll, "too many points");
@@ -383,6 +409,14 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
                      compose16, out_T16);
   const bool use_grid = icp_grid_enabled() && gs_knn_use_grid(n_src, n_tgt) && prm->numiters > 0;
   float* bufs[2] = {sc.srcA, sc.srcB};
+  TapePtrs tp = {nullptr, nullptr, nullptr};
+  if (tape) {
+    GsIcpTape t = gs_icp_tape_carve(tape, n_src, prm->numiters);
+    tp.src = t.src; tp.idx = t.idx; tp.sys = t.sys;
+  }
+  // iteration it works on the cloud bufs[it & 1], or on its tape slot when a tape is recorded
+  auto cloud = [&](int it) { return tp.src ? tp.src + (size_t)it * 3 * (size_t)n_src : bufs[it & 1]; };
+  auto tidx = [&](int it, int which) { return tp.idx ? tp.idx + ((size_t)it * 2 + which) * (size_t)n_src : nullptr; };
 
   if (use_grid) {
     // the target set is fixed for all 2*numiters searches of this solve: bin it once
@@ -393,7 +427,7 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
     const float* cur_in = src;  // cloud before the pending transform of the half-iteration
     int h = 0;                  // half-iteration index: kernel h reads s[h&1] / partials[(h+1)&1], writes the others
     for (int it = 0; it < prm->numiters; ++it) {
-      float* cur = bufs[it & 1];
+      float* cur = cloud(it);
       {
         // compulsory bytes of one fused half-iteration: source in (+out), 27 cell bounds (8 B) per
         // query, matched target + normal gather, partial rows, one pass over the binned targets
@@ -401,7 +435,7 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
         hipLaunchKernelGGL((gs_icp_half_kernel<true>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur_in, cur, n_src, tgt,
                            tgt_normals, n_tgt, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
                            sc.partials[(h + 1) & 1], nfs, sc.partials[h & 1], &sc.state->s[h & 1],
-                           &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, out_idx);
+                           &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, out_idx, tidx(it, 0), nullptr);
       }
       ++h;
       {
@@ -409,7 +443,7 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
         hipLaunchKernelGGL((gs_icp_half_kernel<false>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur, nullptr, n_src, tgt,
                            tgt_normals, n_tgt, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
                            sc.partials[(h + 1) & 1], nfs, sc.partials[h & 1], &sc.state->s[h & 1],
-                           &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, nullptr);
+                           &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, nullptr, tidx(it, 1), tp.sys);
       }
       ++h;
       cur_in = cur;
@@ -420,6 +454,7 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
                          h & 1, *prm, compose16, out_T16);
     }
     GS_LAUNCH_CHECK();
+    if (tape) return icp_tape_finish(tape, sc.state, n_src, prm->numiters, st);
     return GS_OK;
   }
 
@@ -429,17 +464,17 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
   double* partials = sc.partials[0];
   const float* cur_in = src;
   for (int it = 0; it < prm->numiters; ++it) {
-    float* cur = bufs[it & 1];
+    float* cur = cloud(it);
     // apply the pending transform (initial transform or last T_step) while searching
     gs_knn_brute_launch(cur_in, sc.state->s[0].T_step, cur, n_src, tgt, n_tgt, sc.best, st);
     {
       GsProf prof(GS_PROF_LINEARIZE, 44.0 * (double)n_src, st);  // 8 B best + 12 B src + 24 B gather
       hipLaunchKernelGGL((gs_icp_linearize_kernel<true>), dim3(nblk), dim3(LIN_BLOCK), 0, st, cur, nullptr, n_src,
-                         tgt, tgt_normals, n_tgt, sc.best, prm->dist_thresh, partials, out_idx);
+                         tgt, tgt_normals, n_tgt, sc.best, prm->dist_thresh, partials, out_idx, tidx(it, 0));
     }
     {
       GsProf prof(GS_PROF_SOLVE, 1.0, st);
-      hipLaunchKernelGGL(gs_icp_solve_kernel, dim3(1), dim3(SUM_BLOCK), 0, st, partials, nblk, sc.state);
+      hipLaunchKernelGGL(gs_icp_solve_kernel, dim3(1), dim3(SUM_BLOCK), 0, st, partials, nblk, sc.state, it, tp.sys);
     }
     // look-ahead: one_step = Tr * cur, searched and reduced without materialising it
     gs_knn_brute_launch(cur, sc.state->s[0].Tr, nullptr, n_src, tgt, n_tgt, sc.best, st);
@@ -447,7 +482,7 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
       GsProf prof(GS_PROF_LINEARIZE, 44.0 * (double)n_src, st);
       hipLaunchKernelGGL((gs_icp_linearize_kernel<false>), dim3(nblk), dim3(LIN_BLOCK), 0, st, cur,
                          sc.state->s[0].Tr, n_src, tgt, tgt_normals, n_tgt, sc.best, prm->dist_thresh, partials,
-                         nullptr);
+                         nullptr, tidx(it, 1));
     }
     {
       GsProf prof(GS_PROF_SOLVE, 1.0, st);
@@ -457,7 +492,27 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
     cur_in = cur;
   }
   GS_LAUNCH_CHECK();
+  if (tape) return icp_tape_finish(tape, sc.state, n_src, prm->numiters, st);
   return GS_OK;
+}
+
+extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, const float* tgt_normals,
+                          int64_t n_tgt, const float* init16, const float* compose16,
+                          const gs_icp_params* prm, float* out_T16, int64_t* out_idx, void* icp_scratch,
+                          void* stream) {
+  return icp_run(src, n_src, tgt, tgt_normals, n_tgt, init16, compose16, prm, out_T16, out_idx, icp_scratch, nullptr,
+                 stream);
+}
+
+extern "C" int64_t gs_icp_tape_bytes(int64_t n_src, int numiters) { return (int64_t)gs_icp_tape_size(n_src, numiters); }
+
+extern "C" int gs_icp_tape_f32(const float* src, int64_t n_src, const float* tgt, const float* tgt_normals,
+                               int64_t n_tgt, const float* init16, const float* compose16,
+                               const gs_icp_params* prm, float* out_T16, int64_t* out_idx, void* icp_scratch,
+                               void* tape, void* stream) {
+  GS_REQUIRE(tape, "tape must not be NULL");
+  return icp_run(src, n_src, tgt, tgt_normals, n_tgt, init16, compose16, prm, out_T16, out_idx, icp_scratch, tape,
+                 stream);
 }
 
 extern "C" int gs_icp_trace_f32(const void* icp_scratch, int numiters, float* trace_out, void* stream) {

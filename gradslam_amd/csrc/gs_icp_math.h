@@ -232,3 +232,30 @@ GS_DEV void icp_write_result(const IcpSmall& s, const float* __restrict__ compos
 #pragma unroll
   for (int i = 0; i < 16; ++i) out_T16[i] = out[i];
 }
+
+// ---------------------------------------------------------------- forward tape ----------
+// Everything the backward pass needs from a gradICP forward, in one caller-owned buffer:
+//   trace [K][12] float  (err, new_err, damp_after, sigmoid, xi(6), 0, 0)
+//   sys   [K][28] float  (21 upper-triangular AtA, 6 Atb, damping before the iteration)
+//   src   [K][n_src][3] float  source cloud at the start of each iteration
+//   idx   [K][2][n_src] int32  neighbour of the first / look-ahead search, -1 if filtered out
+struct GsIcpTape {
+  float* trace;
+  float* sys;
+  float* src;
+  int32_t* idx;
+};
+static inline size_t gs_icp_tape_size(int64_t n_src, int numiters) {
+  const size_t K = (size_t)(numiters > 0 ? numiters : 1), n = (size_t)(n_src > 0 ? n_src : 1);
+  return gs_align(4 * 12 * K) + gs_align(4 * 28 * K) + gs_align(12 * K * n) + gs_align(8 * K * n) + 256;
+}
+static inline GsIcpTape gs_icp_tape_carve(void* tape, int64_t n_src, int numiters) {
+  const size_t K = (size_t)(numiters > 0 ? numiters : 1), n = (size_t)(n_src > 0 ? n_src : 1);
+  char* p = reinterpret_cast<char*>(tape);
+  GsIcpTape t;
+  t.trace = reinterpret_cast<float*>(p); p += gs_align(4 * 12 * K);
+  t.sys = reinterpret_cast<float*>(p); p += gs_align(4 * 28 * K);
+  t.src = reinterpret_cast<float*>(p); p += gs_align(12 * K * n);
+  t.idx = reinterpret_cast<int32_t*>(p);
+  return t;
+}

@@ -120,8 +120,9 @@ def point_to_plane_gradICP(src_pc: torch.Tensor, tgt_pc: torch.Tensor, tgt_norma
         raise TypeError("Expected nu to be of type float or int; got {0}".format(type(nu)))
     _init_checks(initial_transform)
     from .. import ops
-    T, idx = ops.icp(src_pc[0], tgt_pc[0], tgt_normals[0], init=initial_transform, mode=1, numiters=numiters,
-                     damp=damp, dist_thresh=dist_thresh, lambda_max=lambda_max, B=B, B2=B2, nu=nu)
+    # differentiable (hand-written HIP backward) when any input requires grad
+    T, idx = ops.grad_icp(src_pc[0], tgt_pc[0], tgt_normals[0], init=initial_transform, numiters=numiters,
+                          damp=damp, dist_thresh=dist_thresh, lambda_max=lambda_max, B=B, B2=B2, nu=nu)
     return T, idx
 
 

@@ -336,3 +336,71 @@ def append_valid_(points, normals, colors, ccounts, n_map, gvertex, gnormal, rgb
     if c > cap:
         raise _C.HipExtensionError("gs_append_valid_f32: surfel store overflow (%d > %d)" % (c, cap))
     return c
+
+
+# ----------------------------------------------------------------------------------- K7 (autograd)
+def icp_with_tape(src, tgt, tgt_normals, init=None, numiters=20, damp=1e-8, dist_thresh=None, lambda_max=2.0,
+                  B=1.0, B2=1.0, nu=200.0):
+    """gradICP forward that also records the tape gs_icp_backward_f32 needs.  Returns (T, idx, tape, prm)."""
+    src, tgt, tn = _c(src), _c(tgt), _c(tgt_normals)
+    dev = require_device(src, tgt, tn)
+    init = torch.eye(4, dtype=f32, device=dev) if init is None else _c(init)
+    require_device(init)
+    ns, nt = src.shape[0], tgt.shape[0]
+    prm = _C.IcpParams(1, int(numiters), float(damp), -1.0 if dist_thresh is None else float(dist_thresh),
+                       float(lambda_max), float(B), float(B2), float(nu))
+    T = torch.empty((4, 4), dtype=f32, device=dev)
+    idx = torch.empty(ns, dtype=torch.int64, device=dev)
+    scratch = Workspace.get(dev).bytes("icp", lib().gs_icp_scratch_bytes(ns, nt))
+    tape = torch.empty(lib().gs_icp_tape_bytes(ns, int(numiters)), dtype=torch.uint8, device=dev)
+    check(lib().gs_icp_tape_f32(ptr(src), ns, ptr(tgt), ptr(tn), nt, ptr(init), None, prm, ptr(T), ptr(idx),
+                                ptr(scratch), ptr(tape), stream(dev)), "gs_icp_tape_f32")
+    return T, idx, tape, prm
+
+
+def icp_backward(tape, prm, src, tgt, tgt_normals, init, T_bar, need=(True, True, True, True)):
+    """dL/dT -> (dL/dsrc, dL/dtgt, dL/dnormals, dL/dinit); entries not needed are None."""
+    src, tgt, tn, init, T_bar = _c(src), _c(tgt), _c(tgt_normals), _c(init), _c(T_bar)
+    dev = require_device(tape, src, tgt, tn, init, T_bar)
+    ns, nt = src.shape[0], tgt.shape[0]
+    gs = torch.empty_like(src) if need[0] else None
+    gt = torch.empty_like(tgt) if need[1] else None
+    gn = torch.empty_like(tn) if need[2] else None
+    gi = torch.empty((4, 4), dtype=f32, device=dev) if need[3] else None
+    scratch = Workspace.get(dev).bytes("icp_bwd", lib().gs_icp_backward_scratch_bytes(ns, nt))
+    check(lib().gs_icp_backward_f32(ptr(tape), ptr(src), ns, ptr(tgt), ptr(tn), nt, ptr(init), prm, ptr(T_bar),
+                                    ptr(gs), ptr(gt), ptr(gn), ptr(gi), ptr(scratch), stream(dev)),
+          "gs_icp_backward_f32")
+    return gs, gt, gn, gi
+
+
+class GradICPFunction(torch.autograd.Function):
+    """point_to_plane_gradICP as a differentiable op: forward = gs_icp_tape_f32, backward =
+    gs_icp_backward_f32 (hand-written reverse mode; no PyTorch ops on the tape)."""
+
+    @staticmethod
+    def forward(ctx, src, tgt, tgt_normals, init, numiters, damp, dist_thresh, lambda_max, B, B2, nu):
+        T, idx, tape, prm = icp_with_tape(src, tgt, tgt_normals, init, numiters, damp, dist_thresh, lambda_max, B, B2,
+                                          nu)
+        ctx.save_for_backward(src, tgt, tgt_normals, init, tape)
+        ctx.prm = prm
+        ctx.mark_non_differentiable(idx)
+        return T, idx
+
+    @staticmethod
+    def backward(ctx, T_bar, _idx_bar):
+        src, tgt, tn, init, tape = ctx.saved_tensors
+        need = tuple(ctx.needs_input_grad[:4])
+        gs, gt, gn, gi = icp_backward(tape, ctx.prm, src, tgt, tn, init, T_bar.contiguous(), need)
+        return (gs, gt, gn, gi) + (None,) * 7
+
+
+def grad_icp(src, tgt, tgt_normals, init=None, numiters=20, damp=1e-8, dist_thresh=None, lambda_max=2.0, B=1.0,
+             B2=1.0, nu=200.0):
+    """Differentiable gradICP: (T (4,4), idx (Ns,)).  Uses the plain forward when nothing requires grad."""
+    dev = src.device
+    init = torch.eye(4, dtype=f32, device=dev) if init is None else init
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (src, tgt, tgt_normals, init)):
+        return GradICPFunction.apply(src, tgt, tgt_normals, init, numiters, damp, dist_thresh, lambda_max, B, B2, nu)
+    return icp(src, tgt, tgt_normals, init=init, mode=1, numiters=numiters, damp=damp, dist_thresh=dist_thresh,
+               lambda_max=lambda_max, B=B, B2=B2, nu=nu)

@@ -186,6 +186,26 @@ GS_API int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, const f
                const gs_icp_params* params_host, float* out_T16, int64_t* out_idx,
                void* icp_scratch, void* stream);
 
+/* ------------------------------------------------------------- K7: gradICP backward ----
+ * Differentiable gradICP (config C3): gs_icp_tape_f32 is gs_icp_f32 that additionally records the
+ * forward tape (caller-owned, gs_icp_tape_bytes(n_src, numiters) bytes: per-iteration source cloud,
+ * neighbour indices of both searches, float32 normal equations, trace).  gs_icp_backward_f32 then
+ * turns dL/dT (T_bar16, the gradient w.r.t. the UN-composed transform returned with compose16 ==
+ * NULL) into dL/d(src), dL/d(tgt), dL/d(tgt_normals), dL/d(init) exactly as PyTorch autograd does
+ * through odometry/icputils.py:479-545 (indices and the dist_thresh filter are constants).  Any of
+ * the four outputs may be NULL.  mode must be 1 (gradICP).  scratch: gs_icp_backward_scratch_bytes. */
+GS_API int64_t gs_icp_tape_bytes(int64_t n_src, int numiters);
+GS_API int gs_icp_tape_f32(const float* src, int64_t n_src, const float* tgt, const float* tgt_normals,
+                           int64_t n_tgt, const float* init16, const float* compose16,
+                           const gs_icp_params* params_host, float* out_T16, int64_t* out_idx,
+                           void* icp_scratch, void* tape, void* stream);
+GS_API int64_t gs_icp_backward_scratch_bytes(int64_t n_src, int64_t n_tgt);
+GS_API int gs_icp_backward_f32(const void* tape, const float* src, int64_t n_src, const float* tgt,
+                               const float* tgt_normals, int64_t n_tgt, const float* init16,
+                               const gs_icp_params* params_host, const float* T_bar16, float* src_bar,
+                               float* tgt_bar, float* normals_bar, float* init_bar16, void* scratch,
+                               void* stream);
+
 /* Per-iteration record kept in icp_scratch for the backward pass / diagnostics:
  * gs_icp_trace_f32 copies (numiters, 12) floats = [err, new_err, damp_after, sigmoid, xi(6), pad(2)]. */
 GS_API int gs_icp_trace_f32(const void* icp_scratch, int numiters, float* trace_out, void* stream);

@@ -533,9 +533,14 @@ typedef struct gs_icp_params {
 /* point_to_plane_ICP (odometry/icputils.py:310-367, mode 0) and point_to_plane_gradICP
  * (:479-545, mode 1).  trace (may be NULL): numiters x 12 floats
  * [err, new_err, damp_after, sigmoid, xi0..5, 0, 0]. */
-EXPORT void gs_or_icp(const float* src_in, int64_t ns, const float* tgt, const float* tn,
-                      int64_t nt, const float* init16, const float* compose16,
-                      const gs_icp_params* prm, float* out_T16, int64_t* out_idx, float* trace) {
+/* Forward "tape" for the backward pass (tests of gs_icp_backward_f32): per iteration the source
+ * cloud at the start of the iteration (tape_src [K][ns][3]), the neighbour indices of both searches
+ * (tape_idx [K][2][ns] int32, -1 for rows removed by dist_thresh) and the float32 normal equations
+ * the solve used (tape_sys [K][28]: 21 upper-triangular AtA, 6 Atb, damping before the iteration). */
+static void icp_impl(const float* src_in, int64_t ns, const float* tgt, const float* tn,
+                     int64_t nt, const float* init16, const float* compose16,
+                     const gs_icp_params* prm, float* out_T16, int64_t* out_idx, float* trace,
+                     float* tape_src, int32_t* tape_idx, float* tape_sys) {
   size_t nsz = (size_t)(ns > 0 ? ns : 1);
   float* src = (float*)malloc(sizeof(float) * 3 * nsz);
   float* one = (float*)malloc(sizeof(float) * 3 * nsz);
@@ -556,6 +561,14 @@ EXPORT void gs_or_icp(const float* src_in, int64_t ns, const float* tgt, const f
     gs_or_gauss_newton_rows(src, ns, tgt, tn, nt, prm->dist_thresh, A, b, idx, keep);
     float AtA[36], Atb[6], err, xi[6], Tr[16];
     normal_eq_f64(A, b, keep, ns, AtA, Atb, &err);
+    if (tape_src) memcpy(tape_src + (size_t)it * 3 * nsz, src, sizeof(float) * 3 * (size_t)ns);
+    if (tape_sys) {
+      float* ts = tape_sys + 28 * it;
+      int q = 0;
+      for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) ts[q++] = AtA[6 * r + c];
+      for (int r = 0; r < 6; ++r) ts[21 + r] = Atb[r];
+      ts[27] = damp;
+    }
     solve_from_normal_eq(AtA, Atb, damp, xi);
     gs_or_se3_exp(xi, Tr);
     gs_or_transform_points(src, ns, Tr, one);
@@ -563,6 +576,13 @@ EXPORT void gs_or_icp(const float* src_in, int64_t ns, const float* tgt, const f
     double e1 = 0;
     for (int64_t i = 0; i < ns; ++i) if (keep1[i]) e1 += (double)b1[i] * (double)b1[i];
     float new_err = (float)e1;
+    if (tape_idx) {
+      int32_t* t0 = tape_idx + (size_t)it * 2 * nsz;
+      for (int64_t i = 0; i < ns; ++i) {
+        t0[i] = keep[i] ? (int32_t)idx[i] : -1;
+        t0[nsz + i] = keep1[i] ? (int32_t)idx1[i] : -1;
+      }
+    }
     float sig = 1.0f;
     if (prm->mode == 0) {
       if (new_err < err) {
@@ -599,6 +619,20 @@ EXPORT void gs_or_icp(const float* src_in, int64_t ns, const float* tgt, const f
   if (out_idx) memcpy(out_idx, idx, sizeof(int64_t) * (size_t)ns);
   if (compose16) compose_rigid(T, compose16, out_T16); else memcpy(out_T16, T, sizeof(T));
   free(src); free(one); free(A); free(b); free(b1); free(idx); free(idx1); free(keep); free(keep1);
+}
+
+EXPORT void gs_or_icp(const float* src_in, int64_t ns, const float* tgt, const float* tn,
+                      int64_t nt, const float* init16, const float* compose16,
+                      const gs_icp_params* prm, float* out_T16, int64_t* out_idx, float* trace) {
+  icp_impl(src_in, ns, tgt, tn, nt, init16, compose16, prm, out_T16, out_idx, trace, NULL, NULL, NULL);
+}
+
+EXPORT void gs_or_icp_tape(const float* src_in, int64_t ns, const float* tgt, const float* tn,
+                           int64_t nt, const float* init16, const float* compose16,
+                           const gs_icp_params* prm, float* out_T16, int64_t* out_idx, float* trace,
+                           float* tape_src, int32_t* tape_idx, float* tape_sys) {
+  icp_impl(src_in, ns, tgt, tn, nt, init16, compose16, prm, out_T16, out_idx, trace, tape_src, tape_idx,
+           tape_sys);
 }
 
 /* ------------------------------------------------- K5: surfel association (PointFusion) - */

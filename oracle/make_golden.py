@@ -13,6 +13,7 @@ Fixtures
                   PointFusion(gradicp|icp|gt) and ICPSLAM(gradicp), final maps.
   synth120.npz    seeded synthetic 120x160x4 sequence: depths + poses/counts of PointFusion(gradicp).
   icp_unit.npz    gauss_newton_solve / solve_linear_system / se3_exp / ICP / gradICP on small clouds.
+  icp_grad.npz    the reference's autograd gradients of point_to_plane_gradICP (config C3, test size).
   fusion_kat.npz  hand-made known-answer cases for find_best_unique_correspondences and
                   fuse_with_map (mirrors tests/slam/test_fusionutils.py:672-750, :918-986).
 """
@@ -143,6 +144,23 @@ def main():
         g["gradicp%d_T" % it], g["gradicp%d_idx" % it] = Tg.numpy(), ig.numpy()
     g["true_T"] = (np.linalg.inv(s["poses"][0].astype(np.float64)) @ s["poses"][1].astype(np.float64)).astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "icp_unit.npz"), **g)
+
+    # ------------------------------------------------------------------ icp_grad (config C3 at test size)
+    # the reference's own autograd through point_to_plane_gradICP: d<W,T>/d(src, tgt, normals)
+    gi = np.load(os.path.join(OUT, "icp_unit.npz"))
+    Wt = np.random.default_rng(0).standard_normal((4, 4)).astype(np.float32)
+    gg = dict(W=Wt)
+    for K, thr in ((1, None), (5, None), (20, None), (5, 1e-4)):
+        leaf = [T(gi[k]).clone().requires_grad_(True) for k in ("src", "tgt", "tgt_normals")]
+        Tg, _ = icputils.point_to_plane_gradICP(leaf[0][None], leaf[1][None], leaf[2][None], torch.eye(4), numiters=K,
+                                                dist_thresh=thr)
+        (Tg * T(Wt)).sum().backward()
+        tag = "K%d%s" % (K, "" if thr is None else "_thr")
+        gg[tag + "_T"] = Tg.detach().numpy()
+        for name, t in zip(("src", "tgt", "tn"), leaf):
+            gg[tag + "_" + name] = t.grad.numpy()
+    gg["thr"] = np.float32(1e-4)
+    np.savez_compressed(os.path.join(OUT, "icp_grad.npz"), **gg)
 
     # ------------------------------------------------------------------ fusion_kat
     rng = np.random.default_rng(7)

@@ -1,0 +1,107 @@
+"""Config C3: gradients through point_to_plane_gradICP.
+
+CPU: the float64 numpy oracle of the backward pass (oracle/icp_backward.py) is pinned against the
+reference's OWN autograd gradients (tests/golden/icp_grad.npz, from oracle/make_golden.py).
+GPU: the hand-written HIP backward (gs_icp_backward_f32, through torch.autograd) against that
+oracle on the same tape semantics, against the golden gradients, and at 640x480 size."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import icp_backward as ib
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(b).max(), 1e-30))
+
+
+CASES = [(1, None, "K1"), (5, None, "K5"), (20, None, "K20"), (5, 1e-4, "K5_thr")]
+
+
+@pytest.mark.parametrize("K,thr,tag", CASES)
+def test_numpy_backward_oracle_matches_reference_autograd(golden, K, thr, tag):
+    g, u = golden("icp_grad"), golden("icp_unit")
+    T, tape = ib.icp_forward_tape(u["src"], u["tgt"], u["tgt_normals"], numiters=K, dist_thresh=thr)
+    np.testing.assert_allclose(T, g[tag + "_T"], atol=2e-5, rtol=0)
+    sb, tb, nb, ibar = ib.icp_backward(tape, u["tgt"], u["tgt_normals"], g["W"], u["src"])
+    assert rel(sb, g[tag + "_src"]) < 5e-4 and rel(tb, g[tag + "_tgt"]) < 5e-4 and rel(nb, g[tag + "_tn"]) < 5e-4
+    assert ibar.shape == (4, 4) and np.all(ibar[3] == 0)
+
+
+def test_se3_exp_adjoint_by_finite_differences():
+    rng = np.random.default_rng(1)
+    for xi in (rng.standard_normal(6) * 0.3, np.array([0.1, 0.2, -0.1, 1e-9, 0, 0]), rng.standard_normal(6) * 2.0):
+        W = rng.standard_normal((4, 4))
+        W[3] = 0
+        ana = ib.se3_exp_adjoint(xi, W)
+        num = np.zeros(6)
+        for i in range(6):
+            e = np.zeros(6)
+            e[i] = 1e-6
+            num[i] = np.sum(W * (ib.se3_exp(xi + e) - ib.se3_exp(xi - e))) / 2e-6
+        np.testing.assert_allclose(ana, num, rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,thr,tag", CASES)
+def test_hip_backward_matches_oracle_and_reference(golden, K, thr, tag):
+    from gradslam_amd.odometry import icputils
+    g, u = golden("icp_grad"), golden("icp_unit")
+    leaf = [dev(u[k]).requires_grad_(True) for k in ("src", "tgt", "tgt_normals")]
+    init = torch.eye(4, device="cuda", requires_grad=True)
+    T, idx = icputils.point_to_plane_gradICP(leaf[0][None], leaf[1][None], leaf[2][None], init, numiters=K,
+                                             dist_thresh=thr)
+    assert T.requires_grad and not idx.requires_grad
+    (T * dev(g["W"])).sum().backward()
+    np.testing.assert_allclose(T.detach().cpu().numpy(), g[tag + "_T"], atol=2e-5, rtol=0)
+    # oracle backward on the oracle tape (same algorithm, float64 numpy)
+    _, tape = ib.icp_forward_tape(u["src"], u["tgt"], u["tgt_normals"], numiters=K, dist_thresh=thr)
+    sb, tb, nb, ibar = ib.icp_backward(tape, u["tgt"], u["tgt_normals"], g["W"], u["src"])
+    got = [t.grad.cpu().numpy() for t in leaf]
+    for have, orc, name in zip(got, (sb, tb, nb), ("src", "tgt", "tn")):
+        assert rel(have, orc) < 2e-4, name                      # vs oracle
+        assert rel(have, g[tag + "_" + name]) < 5e-4, name       # vs the reference's autograd
+    assert rel(init.grad.cpu().numpy(), ibar) < 2e-4
+
+
+@pytest.mark.gpu
+def test_no_grad_path_is_unchanged_and_idx_matches(golden):
+    from gradslam_amd import ops
+    u = golden("icp_unit")
+    src, tgt, tn = (dev(u[k]) for k in ("src", "tgt", "tgt_normals"))
+    T0, idx0 = ops.icp(src, tgt, tn, mode=1, numiters=7)
+    T1, idx1 = ops.grad_icp(src.clone().requires_grad_(True), tgt, tn, numiters=7)
+    assert torch.equal(T0, T1.detach()) and torch.equal(idx0, idx1)
+
+
+@pytest.mark.gpu
+def test_backward_at_640x480_grid_engine():
+    """BASELINE config C3 size: ~18k x ~18k points, 20 iterations, grid engine + tape; the HIP
+    gradient must agree with the float64 oracle backward evaluated on the oracle's own tape."""
+    from gradslam_amd import ops
+    from gradslam_amd.datasets.synthetic import make_sequence
+    s = make_sequence(2, 480, 640, seed=8)
+    K = torch.from_numpy(s["intrinsics"][0]).cuda()
+    pts = []
+    for f in range(2):
+        d = torch.from_numpy(s["depths"][f, ..., 0]).cuda()
+        v, n, _, _ = ops.frame_maps(d, K)
+        gv, gn = ops.global_maps(v, n, d, torch.from_numpy(s["poses"][0]).cuda())
+        pts.append(ops.downsample_frame(gv, gn, None, d, 4)[:2])
+    (tgt, tn), (src, _) = pts
+    W = torch.from_numpy(np.random.default_rng(2).standard_normal((4, 4)).astype(np.float32)).cuda()
+    src_l = src.clone().requires_grad_(True)
+    tgt_l = tgt.clone().requires_grad_(True)
+    T, _ = ops.grad_icp(src_l, tgt_l, tn, numiters=20)
+    (T * W).sum().backward()
+    assert torch.isfinite(src_l.grad).all() and torch.isfinite(tgt_l.grad).all() and float(src_l.grad.abs().max()) > 0
+    To, tape = ib.icp_forward_tape(src.cpu().numpy(), tgt.cpu().numpy(), tn.cpu().numpy(), numiters=20)
+    np.testing.assert_allclose(T.detach().cpu().numpy(), To, atol=1e-6, rtol=0)
+    sb, tb, _, _ = ib.icp_backward(tape, tgt.cpu().numpy(), tn.cpu().numpy(), W.cpu().numpy(), src.cpu().numpy())
+    assert rel(src_l.grad.cpu().numpy(), sb) < 1e-3
+    assert rel(tgt_l.grad.cpu().numpy(), tb) < 1e-3
