@@ -105,6 +105,17 @@ __global__ void __launch_bounds__(FS_BLOCK) gs_icp_half_kernel(
   __shared__ int unres_n;
   __shared__ unsigned long long red[FS_BLOCK / GS_WAVE];
 
+  // the source point of this group does not depend on the prologue: issue its load first so that
+  // the global-memory latency hides behind the scalar stage
+  const int lane = threadIdx.x & (GQ_G - 1), slot = threadIdx.x / GQ_G;
+  const int64_t s = (int64_t)blockIdx.x * FS_QPB + slot;
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
+  if (s < n_src) {
+    p0 = src_in[3 * s];
+    p1 = src_in[3 * s + 1];
+    p2 = src_in[3 * s + 2];
+  }
+
   // ---- prologue: finish the previous half-iteration (identical in every block)
   if (FULL) {
     double e1 = 0.0;
@@ -129,14 +140,12 @@ __global__ void __launch_bounds__(FS_BLOCK) gs_icp_half_kernel(
   if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(IcpSmall) / 4))
     reinterpret_cast<float*>(st_out)[threadIdx.x] = reinterpret_cast<const float*>(&sm)[threadIdx.x];
 
-  // ---- search: one source point per 16-lane group, pending transform applied on load
-  const int lane = threadIdx.x & (GQ_G - 1), slot = threadIdx.x / GQ_G;
-  const int64_t s = (int64_t)blockIdx.x * FS_QPB + slot;
+  // ---- search: one source point per 16-lane group, pending transform applied to the loaded point
   if (s < n_src) {
     const GsGrid g = *gp;
     const float* T = FULL ? sm.T_step : sm.Tr;
     float qx, qy, qz;
-    gs_rigid_fma(T, src_in[3 * s], src_in[3 * s + 1], src_in[3 * s + 2], qx, qy, qz);
+    gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
     bool done;
     const unsigned long long key = grid_search16(g, cell_start, sorted, qx, qy, qz, lane, &done);
     if (lane == 0) {

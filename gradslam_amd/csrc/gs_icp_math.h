@@ -69,6 +69,94 @@ GS_DEV void gs_solve_normal(const float* AtA, const float* Atb, float damp, int 
   }
 }
 
+// ---------------------------------------------------------------- fast scalar functions --
+// The scalar stages of the LM loop run on ONE lane and sit on the critical path of every
+// half-iteration; libm's general-range double sin / cos / exp / pow are several hundred dependent
+// instructions each.  These versions cover the ranges the loop actually visits with short Horner
+// polynomials accurate to ~1 ulp(double) (results are rounded to float32 afterwards, so they match
+// the oracle's libm values) and fall back to libm outside.
+GS_DEV void gs_sincos_fast(double x, double* s, double* c) {
+  if (!(fabs(x) <= 1.0)) {
+    *s = sin(x);
+    *c = cos(x);
+    return;
+  }
+  const double z = x * x;
+  // Taylor in z = x^2: terms up to x^21 / x^22 (next term < 1e-21)
+  double ps = -1.0 / 51090942171709440000.0;   // -1/21!
+  ps = ps * z + 1.0 / 121645100408832000.0;    // 1/19!
+  ps = ps * z - 1.0 / 355687428096000.0;       // 1/17!
+  ps = ps * z + 1.0 / 1307674368000.0;         // 1/15!
+  ps = ps * z - 1.0 / 6227020800.0;            // 1/13!
+  ps = ps * z + 1.0 / 39916800.0;              // 1/11!
+  ps = ps * z - 1.0 / 362880.0;                // 1/9!
+  ps = ps * z + 1.0 / 5040.0;                  // 1/7!
+  ps = ps * z - 1.0 / 120.0;                   // 1/5!
+  ps = ps * z + 1.0 / 6.0;                     // 1/3!
+  *s = x - x * z * ps;
+  double pc = 1.0 / 1124000727777607680000.0;  // 1/22!
+  pc = pc * z - 1.0 / 2432902008176640000.0;   // 1/20!
+  pc = pc * z + 1.0 / 6402373705728000.0;      // 1/18!
+  pc = pc * z - 1.0 / 20922789888000.0;        // 1/16!
+  pc = pc * z + 1.0 / 87178291200.0;           // 1/14!
+  pc = pc * z - 1.0 / 479001600.0;             // 1/12!
+  pc = pc * z + 1.0 / 3628800.0;               // 1/10!
+  pc = pc * z - 1.0 / 40320.0;                 // 1/8!
+  pc = pc * z + 1.0 / 720.0;                   // 1/6!
+  pc = pc * z - 1.0 / 24.0;                    // 1/4!
+  pc = pc * z + 0.5;                           // 1/2!
+  *c = 1.0 - z * pc;
+}
+
+GS_DEV double gs_exp_fast(double x) {
+  if (!(fabs(x) <= 700.0)) return exp(x);
+  const double k = rint(x * 1.4426950408889634074);
+  // ln2 split so that k * hi is exact for |k| < 2^11
+  double r = x - k * 6.93147180369123816490e-01;
+  r = r - k * 1.90821492927058770002e-10;
+  // Taylor on |r| <= 0.3466: terms up to r^14 / 14! (< 5e-18)
+  double p = 1.0 / 87178291200.0;
+  p = p * r + 1.0 / 6227020800.0;
+  p = p * r + 1.0 / 479001600.0;
+  p = p * r + 1.0 / 39916800.0;
+  p = p * r + 1.0 / 3628800.0;
+  p = p * r + 1.0 / 362880.0;
+  p = p * r + 1.0 / 40320.0;
+  p = p * r + 1.0 / 5040.0;
+  p = p * r + 1.0 / 720.0;
+  p = p * r + 1.0 / 120.0;
+  p = p * r + 1.0 / 24.0;
+  p = p * r + 1.0 / 6.0;
+  p = p * r + 0.5;
+  p = p * r + 1.0;
+  p = p * r + 1.0;
+  return ldexp(p, (int)k);
+}
+
+GS_DEV double gs_log_fast(double y) {
+  if (!(y > 1e-300 && y < 1e300)) return log(y);
+  int e;
+  double m = frexp(y, &e);  // y = m * 2^e, m in [0.5, 1)
+  if (m < 0.70710678118654752440) {
+    m *= 2.0;
+    e -= 1;
+  }
+  const double z = (m - 1.0) / (m + 1.0), z2 = z * z;  // |z| <= 0.1716
+  double p = 1.0 / 23.0;
+  p = p * z2 + 1.0 / 21.0;
+  p = p * z2 + 1.0 / 19.0;
+  p = p * z2 + 1.0 / 17.0;
+  p = p * z2 + 1.0 / 15.0;
+  p = p * z2 + 1.0 / 13.0;
+  p = p * z2 + 1.0 / 11.0;
+  p = p * z2 + 1.0 / 9.0;
+  p = p * z2 + 1.0 / 7.0;
+  p = p * z2 + 1.0 / 5.0;
+  p = p * z2 + 1.0 / 3.0;
+  p = p * z2 + 1.0;
+  return 2.0 * z * p + (double)e * 0.69314718055994530942;
+}
+
 // geometry/se3utils.py:77-115 in double, rounded once (same order as the oracle).
 GS_DEV void gs_se3_exp_dev(const float* xi6, float* T16) {
   const double v[3] = {xi6[0], xi6[1], xi6[2]}, w[3] = {xi6[3], xi6[4], xi6[5]};
@@ -88,7 +176,8 @@ GS_DEV void gs_se3_exp_dev(const float* xi6, float* T16) {
         for (int k = 0; k < 3; ++k) s += wh[3 * i + k] * wh[3 * k + j];
         wh2[3 * i + j] = s;
       }
-    const double s = sin(theta), c = cos(theta);
+    double s, c;
+    gs_sincos_fast(theta, &s, &c);
     const double Ac = s / theta, Bc = (1 - c) / (theta * theta), Cc = (theta - s) / (theta * theta * theta);
     for (int i = 0; i < 9; ++i) {
       const double I = (i % 4 == 0) ? 1.0 : 0.0;
@@ -191,11 +280,11 @@ GS_DEV void icp_update_math(float new_err, IcpSmall& s, const gs_icp_params& prm
     const float lrange = (float)((double)prm.lambda_max - 1.0 / (double)prm.lambda_max);
     float errdiff = new_err - err;
     errdiff = errdiff < -70.0f ? -70.0f : (errdiff > 70.0f ? 70.0f : errdiff);
-    const float e_b = (float)exp((double)((float)(-(double)prm.B) * errdiff));
+    const float e_b = (float)gs_exp_fast((double)((float)(-(double)prm.B) * errdiff));
     const float damp_new = lmin + lrange / (1.0f + e_b);
     damp = damp * damp_new;
-    const float e_b2 = (float)exp((double)((float)(-(double)prm.B2) * errdiff));
-    const float pw = (float)pow((double)(1.0f + e_b2), (double)(float)(1.0 / (double)prm.nu));
+    const float e_b2 = (float)gs_exp_fast((double)((float)(-(double)prm.B2) * errdiff));
+    const float pw = (float)gs_exp_fast((double)(float)(1.0 / (double)prm.nu) * gs_log_fast((double)(1.0f + e_b2)));
     sig = 1.0f / pw;
     float xs[6];
 #pragma unroll
