@@ -40,20 +40,22 @@ GS_DEV void tape_write_sys(float* __restrict__ sys, int it, const double* S, flo
 
 // ---------------------------------------------------------------- fixed-order sums ------
 // Adds up partial rows (nrows x LIN_NV doubles).  Thread t works on value t%32 and row subset
-// t/32; 16 loads are in flight per thread; the sub-sums are then added in index order.  Every
+// t/32; up to 40 independent loads are in flight per thread (one memory round for a 640x480
+// solve); the sub-sums are then added in index order.  Every
 // block that runs this on the same rows gets bit-identical sums.
 template <int BLOCK>
 GS_DEV void icp_sum_rows(const double* __restrict__ partials, int nrows, double* S, double (*sub)[32]) {
   constexpr int STEP = BLOCK / 32;
+  constexpr int CH = 40;  // rows per thread fetched in ONE round of independent loads (640x480: 37)
   const int i = threadIdx.x & 31, j = threadIdx.x >> 5;
   double s = 0.0;
   if (i < LIN_NV) {
-    for (int b = j; b < nrows; b += 16 * STEP) {
-      double a[16];
+    for (int b = j; b < nrows; b += CH * STEP) {
+      double a[CH];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) a[u] = (b + u * STEP < nrows) ? partials[(int64_t)(b + u * STEP) * LIN_NV + i] : 0.0;
+      for (int u = 0; u < CH; ++u) a[u] = (b + u * STEP < nrows) ? partials[(int64_t)(b + u * STEP) * LIN_NV + i] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) s += a[u];
+      for (int u = 0; u < CH; ++u) s += a[u];
     }
   }
   sub[j][i] = s;

@@ -94,7 +94,7 @@ GS_DEV unsigned long long grid_key(float qx, float qy, float qz, const float4 p)
 // The candidates of all 16 slots are treated as ONE flat list (prefix sum of the slot lengths over
 // the group); lane l takes flat positions l, l+16, ... and finds (slot, offset) of each by a
 // 4-step binary search on the prefix with shuffles.  Gather addresses therefore depend on
-// registers only, so the two gathers of a pass are in flight together instead of one dependent
+// registers only, so the four gathers of a pass are in flight together instead of one dependent
 // global load per slot.  Every lane runs the same number of passes (shuffles need all 16 lanes).
 GS_DEV int grid_flat_index(int t, int sb, int excl) {
   int j = 0;
@@ -117,15 +117,21 @@ GS_DEV unsigned long long grid_scan_slots(int sb, int se, int lane, float qx, fl
   }
   const int excl = incl - len;
   const int total = __shfl(incl, GQ_G - 1, GQ_G);
-  for (int t0 = 0; t0 < total; t0 += 2 * GQ_G) {
-    const int ta = t0 + lane, tb = t0 + GQ_G + lane;
-    const int ia = grid_flat_index(ta < total ? ta : 0, sb, excl);
-    const int ib = grid_flat_index(tb < total ? tb : 0, sb, excl);
-    const float4 pa = sorted[ia], pb = sorted[ib];  // total > 0: index 0 of the list is always valid
-    const unsigned long long ka = ta < total ? grid_key(qx, qy, qz, pa) : ~0ull;
-    const unsigned long long kb = tb < total ? grid_key(qx, qy, qz, pb) : ~0ull;
-    key = ka < key ? ka : key;
-    key = kb < key ? kb : key;
+  for (int t0 = 0; t0 < total; t0 += 4 * GQ_G) {  // four independent gathers in flight per lane
+    int t[4], ix[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      t[u] = t0 + u * GQ_G + lane;
+      ix[u] = grid_flat_index(t[u] < total ? t[u] : 0, sb, excl);  // total > 0: position 0 is always valid
+    }
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = sorted[ix[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned long long k2 = t[u] < total ? grid_key(qx, qy, qz, p[u]) : ~0ull;
+      key = k2 < key ? k2 : key;
+    }
   }
   return key;
 }
