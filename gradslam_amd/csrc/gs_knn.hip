@@ -20,19 +20,20 @@
 //    brute-force kernel.  Work drops from Ns*Nt pair distances to ~10^2 per query.
 #include "gs_knn.h"
 
+#include <stdlib.h>
+
 constexpr int KNN_BLOCK = 256;
-constexpr int KNN_SPT = 4;
-constexpr int KNN_STILE = KNN_BLOCK * KNN_SPT;
 constexpr int KNN_TCHUNK = 512;
 
 // ---------------------------------------------------------------- brute force ----------
 // LISTED: source indices come from list[0 .. *count) (the grid engine's unresolved queries) and
 // source tiles are strided over gridDim.x; otherwise tile = blockIdx.x over all n_src points.
-template <bool LISTED>
+template <bool LISTED, int KNN_SPT>
 __global__ void __launch_bounds__(KNN_BLOCK) gs_knn1_kernel(
     const float* __restrict__ src_in, const float* __restrict__ Tapply, float* __restrict__ src_out,
     int64_t n_src, const float* __restrict__ tgt, int64_t n_tgt, unsigned long long* __restrict__ best,
     const int* __restrict__ list, const int* __restrict__ count) {
+  constexpr int KNN_STILE = KNN_BLOCK * KNN_SPT;
   __shared__ float4 tl[KNN_TCHUNK];
   const int64_t n_q = LISTED ? (int64_t)(*count) : n_src;
   if (LISTED && n_q == 0) return;
@@ -102,10 +103,24 @@ __global__ void __launch_bounds__(KNN_BLOCK) gs_knn1_kernel(
 
 int gs_knn_brute_launch(const float* src_in, const float* Tapply, float* src_out, int64_t n_src,
                         const float* tgt, int64_t n_tgt, unsigned long long* best, hipStream_t st) {
-  dim3 grid((unsigned)gs_ceil_div(n_src, KNN_STILE), (unsigned)gs_ceil_div(n_tgt, KNN_TCHUNK));
+  // source points per thread: 8 amortises the LDS broadcast and loop overhead over more pairs on
+  // large problems; 4 keeps more workgroups in flight on small ones (GRADSLAM_HIP_KNN_SPT overrides)
+  static int spt_env = -1;
+  if (spt_env < 0) {
+    const char* e = getenv("GRADSLAM_HIP_KNN_SPT");
+    spt_env = e ? atoi(e) : 0;
+  }
+  const int spt = spt_env == 4 || spt_env == 8 ? spt_env : (n_src * n_tgt >= (int64_t)1 << 27 ? 8 : 4);
   GsProf prof(GS_PROF_KNN, (double)n_src * (double)n_tgt, st);  // work unit: pair distances
-  hipLaunchKernelGGL((gs_knn1_kernel<false>), grid, dim3(KNN_BLOCK), 0, st, src_in, Tapply, src_out, n_src, tgt,
-                     n_tgt, best, nullptr, nullptr);
+  if (spt == 8) {
+    dim3 grid((unsigned)gs_ceil_div(n_src, KNN_BLOCK * 8), (unsigned)gs_ceil_div(n_tgt, KNN_TCHUNK));
+    hipLaunchKernelGGL((gs_knn1_kernel<false, 8>), grid, dim3(KNN_BLOCK), 0, st, src_in, Tapply, src_out, n_src, tgt,
+                       n_tgt, best, nullptr, nullptr);
+  } else {
+    dim3 grid((unsigned)gs_ceil_div(n_src, KNN_BLOCK * 4), (unsigned)gs_ceil_div(n_tgt, KNN_TCHUNK));
+    hipLaunchKernelGGL((gs_knn1_kernel<false, 4>), grid, dim3(KNN_BLOCK), 0, st, src_in, Tapply, src_out, n_src, tgt,
+                       n_tgt, best, nullptr, nullptr);
+  }
   return GS_OK;
 }
 
@@ -317,10 +332,10 @@ int gs_knn_grid_query(const float* src_in, const float* Tapply, float* src_out, 
   hipLaunchKernelGGL(gs_grid_query_kernel, dim3((unsigned)gs_ceil_div(n_src * GQ_G, GQ_BLOCK)), dim3(GQ_BLOCK), 0, st,
                      src_in, Tapply, src_out, n_src, m.g, m.cell_start, m.sorted, best, cnt, nxt, m.unres_list);
   // unresolved queries (device-side count; blocks exit at once when it is zero)
-  unsigned gx = (unsigned)gs_ceil_div(n_src, KNN_STILE);
+  unsigned gx = (unsigned)gs_ceil_div(n_src, KNN_BLOCK * 4);
   gx = gx > 4 ? 4 : gx;
   dim3 grid(gx, (unsigned)gs_ceil_div(n_tgt, KNN_TCHUNK));
-  hipLaunchKernelGGL((gs_knn1_kernel<true>), grid, dim3(KNN_BLOCK), 0, st, src_in, Tapply, nullptr, n_src, tgt,
+  hipLaunchKernelGGL((gs_knn1_kernel<true, 4>), grid, dim3(KNN_BLOCK), 0, st, src_in, Tapply, nullptr, n_src, tgt,
                      n_tgt, best, m.unres_list, cnt);
   return GS_OK;
 }

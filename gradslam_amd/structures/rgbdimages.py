@@ -32,12 +32,12 @@ class RGBDImages(object):
         *,
         pixel_pos: Optional[torch.Tensor] = None,
     ):
-        if not torch.is_tensor(rgb_image):
-            raise TypeError("Expected rgb_image to be of type tensor; got {}".format(type(rgb_image)))
-        if not torch.is_tensor(depth_image):
-            raise TypeError("Expected depth_image to be of type tensor; got {}".format(type(depth_image)))
-        if not torch.is_tensor(intrinsics):
-            raise TypeError("Expected intrinsics to be of type tensor; got {}".format(type(intrinsics)))
+        # argument checks, table driven (same exception types and messages as the reference ctor)
+        required = (("rgb_image", rgb_image), ("depth_image", depth_image), ("intrinsics", intrinsics))
+        optional = (("poses", poses), ("pixel_pos", pixel_pos))
+        for name, val in required:
+            if not torch.is_tensor(val):
+                raise TypeError("Expected {} to be of type tensor; got {}".format(name, type(val)))
         if not (poses is None or torch.is_tensor(poses)):
             raise TypeError("Expected poses to be of type tensor or None; got {}".format(type(poses)))
         if not isinstance(channels_first, bool):
@@ -45,48 +45,34 @@ class RGBDImages(object):
         if not (pixel_pos is None or torch.is_tensor(pixel_pos)):
             raise TypeError("Expected pixel_pos to be of type tensor or None; got {}".format(type(pixel_pos)))
         self._channels_first = channels_first
+        for name, val, nd in (("rgb_image", rgb_image, 5), ("depth_image", depth_image, 5),
+                              ("intrinsics", intrinsics, 4), ("poses", poses, 4)):
+            if val is not None and val.ndim != nd:
+                raise ValueError("{} should have ndim={}, but had ndim={}".format(name, nd, val.ndim))
 
-        if rgb_image.ndim != 5:
-            raise ValueError("rgb_image should have ndim=5, but had ndim={}".format(rgb_image.ndim))
-        if depth_image.ndim != 5:
-            raise ValueError("depth_image should have ndim=5, but had ndim={}".format(depth_image.ndim))
-        if intrinsics.ndim != 4:
-            raise ValueError("intrinsics should have ndim=4, but had ndim={}".format(intrinsics.ndim))
-        if poses is not None and poses.ndim != 4:
-            raise ValueError("poses should have ndim=4, but had ndim={}".format(poses.ndim))
-
+        full = tuple(rgb_image.shape)
+        c = self.cdim
         self._rgb_image_shape = rgb_image.shape
-        self._depth_shape = tuple(v if i != self.cdim else 1 for i, v in enumerate(rgb_image.shape))
-        self._depth_image_shape = self._depth_shape
-        self._intrinsics_shape = (rgb_image.shape[0], 1, 4, 4)
-        self._poses_shape = (*rgb_image.shape[:2], 4, 4)
-        self._pixel_pos_shape = (*rgb_image.shape[: self.cdim], *rgb_image.shape[self.cdim + 1:], 3)
-
-        if rgb_image.shape[self.cdim] != 3:
-            raise ValueError("Expected rgb_image to have 3 channels on dimension {0}. Got {1} instead".format(
-                self.cdim, rgb_image.shape[self.cdim]))
-        if depth_image.shape != self._depth_shape:
-            raise ValueError("Expected depth_image to have shape {0}. Got {1} instead".format(
-                self._depth_shape, depth_image.shape))
-        if intrinsics.shape != self._intrinsics_shape:
-            raise ValueError("Expected intrinsics to have shape {0}. Got {1} instead".format(
-                self._intrinsics_shape, intrinsics.shape))
-        if poses is not None and (poses.shape != self._poses_shape):
-            raise ValueError("Expected poses to have shape {0}. Got {1} instead".format(self._poses_shape, poses.shape))
-        if pixel_pos is not None and (pixel_pos.shape != self._pixel_pos_shape):
-            raise ValueError("Expected pixel_pos to have shape {0}. Got {1} instead".format(
-                self._pixel_pos_shape, pixel_pos.shape))
-
-        devices = [x.device for x in (rgb_image, depth_image, intrinsics, poses, pixel_pos) if x is not None]
-        if len(set(devices)) != 1:
-            raise ValueError("All inputs must be on same device, but got more than 1 device: {}".format(set(devices)))
+        self._depth_shape = self._depth_image_shape = full[:c] + (1,) + full[c + 1:]
+        self._intrinsics_shape = (full[0], 1, 4, 4)
+        self._poses_shape = full[:2] + (4, 4)
+        self._pixel_pos_shape = full[:c] + full[c + 1:] + (3,)
+        if full[c] != 3:
+            raise ValueError("Expected rgb_image to have 3 channels on dimension {0}. Got {1} instead".format(c, full[c]))
+        for name, val, want in (("depth_image", depth_image, self._depth_shape),
+                                ("intrinsics", intrinsics, self._intrinsics_shape), ("poses", poses, self._poses_shape),
+                                ("pixel_pos", pixel_pos, self._pixel_pos_shape)):
+            if val is not None and tuple(val.shape) != tuple(want):
+                raise ValueError("Expected {0} to have shape {1}. Got {2} instead".format(name, want, val.shape))
+        devices = {t.device for _, t in required + optional if t is not None}
+        if len(devices) != 1:
+            raise ValueError("All inputs must be on same device, but got more than 1 device: {}".format(devices))
 
         self._rgb_image = rgb_image if device is None else rgb_image.to(device)
         self.device = self._rgb_image.device
-        self._depth_image = depth_image.to(self.device)
-        self._intrinsics = intrinsics.to(self.device)
-        self._poses = poses.to(self.device) if poses is not None else None
-        self._pixel_pos = pixel_pos.to(self.device) if pixel_pos is not None else None
+        self._depth_image, self._intrinsics = depth_image.to(self.device), intrinsics.to(self.device)
+        self._poses = None if poses is None else poses.to(self.device)
+        self._pixel_pos = None if pixel_pos is None else pixel_pos.to(self.device)
 
         self._vertex_map = None
         self._global_vertex_map = None
