@@ -200,6 +200,30 @@ extern "C" int gs_downsample_frame_f32(const float* gvertex, const float* gnorma
                     count_out, 0, -1, scratch, gs_stream(stream));
 }
 
+// backward of gs_downsample_frame_f32 (points): scatter the compact adjoints back to their pixels
+struct EmitFrameLatticeScatter {
+  int W, ds, Wl;
+  const float* pts_bar;
+  float* gvertex_bar;
+  __device__ void operator()(int64_t e, int64_t pos) const {
+    const int64_t h = (e / Wl) * ds, w = (e % Wl) * ds, p = h * W + w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gvertex_bar[3 * p + k] = pts_bar[3 * pos + k];
+  }
+};
+
+extern "C" int gs_downsample_frame_backward_f32(const float* pts_bar, const float* depth, int H, int W, int ds,
+                                                float* gvertex_bar, void* scratch, void* stream) {
+  GS_REQUIRE(H > 0 && W > 0 && ds > 0 && pts_bar && depth && gvertex_bar && scratch, "bad arguments");
+  hipStream_t st = gs_stream(stream);
+  GS_HIP(hipMemsetAsync(gvertex_bar, 0, 12 * (size_t)H * W, st));
+  const int Hl = (H + ds - 1) / ds, Wl = (W + ds - 1) / ds;
+  // the count lands in the (unused) first slot after the compaction scratch
+  int64_t* cnt = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(scratch) + gs_cp_scratch_bytes((int64_t)H * W));
+  return gs_compact((int64_t)Hl * Wl, PredFrameLattice{depth, W, ds, Wl},
+                    EmitFrameLatticeScatter{W, ds, Wl, pts_bar, gvertex_bar}, cnt, 0, -1, scratch, st);
+}
+
 // ---------------------------------------------------------------- K5b: similarity ------
 // slam/fusionutils.py:396-399 for map point n against frame pixel p.
 GS_DEV bool gs_is_similar(const float* __restrict__ points, const float* __restrict__ normals,

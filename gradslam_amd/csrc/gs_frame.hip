@@ -268,3 +268,155 @@ extern "C" int gs_alpha_f32(const float* points, int64_t n, float two_sigma_sq, 
   GS_LAUNCH_CHECK();
   return GS_OK;
 }
+
+// ------------------------------------------------------------------ K7: backward of K1 ---
+// Reverse mode of gs_frame_maps_f32 w.r.t. depth (vertex, normal and alpha paths) and of
+// gs_global_maps_f32 w.r.t. the local maps, matching PyTorch autograd through
+// structures/rgbdimages.py:643-762 and slam/fusionutils.py:69-72.  Two passes keep it
+// deterministic: pass 1 turns the normal adjoint of every pixel into the adjoints of its two
+// forward differences, pass 2 GATHERS the (at most six) difference adjoints that touch a vertex.
+GS_DEV void fb_ray(int h, int w, const GsKinv& k, float& rx, float& ry) {
+  rx = k.k00 * (float)w + k.k02;
+  ry = k.k11 * (float)h + k.k12;
+}
+GS_DEV void fb_vertex(const float* __restrict__ depth, int W, int h, int w, const GsKinv& k, float* v) {
+  const float d = depth[(size_t)h * W + w];
+  float rx, ry;
+  fb_ray(h, w, k, rx, ry);
+  const float m = d > 0.0f ? 1.0f : 0.0f;
+  v[0] = rx * d * m; v[1] = ry * d * m; v[2] = d * m;
+}
+
+__global__ void __launch_bounds__(256) gs_frame_bwd_diff_kernel(const float* __restrict__ depth,
+                                                                const float* __restrict__ K16, int H, int W,
+                                                                const float* __restrict__ normal_bar,
+                                                                float* __restrict__ dhdv_bar) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (int64_t)H * W) return;
+  const int h = (int)(p / W), w = (int)(p % W);
+  const GsKinv k = gs_kinv(K16);
+  const int w0 = (w < W - 1) ? w : W - 2, h0 = (h < H - 1) ? h : H - 2;
+  float a0[3], a1[3], b0[3], b1[3];
+  fb_vertex(depth, W, h, w0, k, a0);
+  fb_vertex(depth, W, h, w0 + 1, k, a1);
+  fb_vertex(depth, W, h0, w, k, b0);
+  fb_vertex(depth, W, h0 + 1, w, k, b1);
+  const float dh[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]};
+  const float dv[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
+  const float nr[3] = {dh[1] * dv[2] - dh[2] * dv[1], dh[2] * dv[0] - dh[0] * dv[2], dh[0] * dv[1] - dh[1] * dv[0]};
+  const float nrm = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+  const float m = depth[p] > 0.0f ? 1.0f : 0.0f;
+  const float g[3] = {normal_bar[3 * p] * m, normal_bar[3 * p + 1] * m, normal_bar[3 * p + 2] * m};
+  float nb[3];
+  if (nrm > 0.0f) {  // n = nr / |nr|
+    const float inv = 1.0f / nrm;
+    const float nh[3] = {nr[0] * inv, nr[1] * inv, nr[2] * inv};
+    const float dot = nh[0] * g[0] + nh[1] * g[1] + nh[2] * g[2];
+    for (int c = 0; c < 3; ++c) nb[c] = (g[c] - nh[c] * dot) * inv;
+  } else {  // divided by 1 in the forward pass
+    for (int c = 0; c < 3; ++c) nb[c] = g[c];
+  }
+  // nr = dh x dv  ->  dh_bar = dv x nr_bar, dv_bar = nr_bar x dh
+  float* o = dhdv_bar + 6 * p;
+  o[0] = dv[1] * nb[2] - dv[2] * nb[1];
+  o[1] = dv[2] * nb[0] - dv[0] * nb[2];
+  o[2] = dv[0] * nb[1] - dv[1] * nb[0];
+  o[3] = nb[1] * dh[2] - nb[2] * dh[1];
+  o[4] = nb[2] * dh[0] - nb[0] * dh[2];
+  o[5] = nb[0] * dh[1] - nb[1] * dh[0];
+}
+
+__global__ void __launch_bounds__(256) gs_frame_bwd_depth_kernel(
+    const float* __restrict__ depth, const float* __restrict__ K16, int H, int W, float two_sigma_sq,
+    const float* __restrict__ vertex_bar, const float* __restrict__ alpha_bar, const float* __restrict__ dhdv_bar,
+    float* __restrict__ depth_bar) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (int64_t)H * W) return;
+  const int h = (int)(p / W), w = (int)(p % W);
+  const GsKinv k = gs_kinv(K16);
+  float vb[3] = {0.0f, 0.0f, 0.0f};
+  if (vertex_bar)
+    for (int c = 0; c < 3; ++c) vb[c] = vertex_bar[3 * p + c];
+  const float d = depth[p];
+  const float m = d > 0.0f ? 1.0f : 0.0f;
+  float rx, ry;
+  fb_ray(h, w, k, rx, ry);
+  if (alpha_bar) {  // alpha = clamp(exp(-|v|^2 / (2 sigma^2)), 1e-7, 1.01)
+    const float v[3] = {rx * d * m, ry * d * m, d * m};
+    const float a = gs_alpha_of(v[0], v[1], v[2], two_sigma_sq, 1e-7f);
+    if (a > 1e-7f && a < 1.01f) {
+      const float f = alpha_bar[p] * a * (-2.0f / two_sigma_sq);
+      for (int c = 0; c < 3; ++c) vb[c] += f * v[c];
+    }
+  }
+  if (dhdv_bar) {
+    auto DH = [&](int hh, int ww, int c) { return dhdv_bar[6 * ((int64_t)hh * W + ww) + c]; };
+    auto DV = [&](int hh, int ww, int c) { return dhdv_bar[6 * ((int64_t)hh * W + ww) + 3 + c]; };
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.0f;
+      // horizontal difference of pixel (h, w'): a1 = (h, min(w', W-2) + 1), a0 = (h, min(w', W-2))
+      if (w >= 1) acc += DH(h, w - 1, c);
+      if (w == W - 1) acc += DH(h, W - 1, c);
+      if (w <= W - 2) acc -= DH(h, w, c);
+      if (w == W - 2) acc -= DH(h, W - 1, c);
+      // vertical difference of pixel (h', w)
+      if (h >= 1) acc += DV(h - 1, w, c);
+      if (h == H - 1) acc += DV(H - 1, w, c);
+      if (h <= H - 2) acc -= DV(h, w, c);
+      if (h == H - 2) acc -= DV(H - 1, w, c);
+      vb[c] += acc;
+    }
+  }
+  depth_bar[p] = m * (vb[0] * rx + vb[1] * ry + vb[2]);
+}
+
+extern "C" int gs_frame_maps_backward_f32(const float* depth, const float* K16, int H, int W, float two_sigma_sq,
+                                          const float* vertex_bar, const float* normal_bar, const float* alpha_bar,
+                                          float* depth_bar, float* scratch_6hw, void* stream) {
+  GS_REQUIRE(depth && K16 && depth_bar, "NULL pointer");
+  GS_REQUIRE(H >= 2 && W >= 2, "image must be at least 2x2");
+  GS_REQUIRE(!normal_bar || scratch_6hw, "normal_bar needs scratch of 6*H*W floats");
+  hipStream_t st = gs_stream(stream);
+  const unsigned nb = (unsigned)gs_ceil_div((int64_t)H * W, 256);
+  if (normal_bar)
+    hipLaunchKernelGGL(gs_frame_bwd_diff_kernel, dim3(nb), dim3(256), 0, st, depth, K16, H, W, normal_bar, scratch_6hw);
+  hipLaunchKernelGGL(gs_frame_bwd_depth_kernel, dim3(nb), dim3(256), 0, st, depth, K16, H, W, two_sigma_sq, vertex_bar,
+                     alpha_bar, normal_bar ? scratch_6hw : nullptr, depth_bar);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+__global__ void __launch_bounds__(256) gs_global_maps_bwd_kernel(const float* __restrict__ gvertex_bar,
+                                                                 const float* __restrict__ gnormal_bar,
+                                                                 const float* __restrict__ depth,
+                                                                 const float* __restrict__ pose16, int64_t P,
+                                                                 float* __restrict__ vertex_bar,
+                                                                 float* __restrict__ normal_bar) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  float T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = pose16[i];
+  if (vertex_bar) {  // g = (R v + t) * m
+    const float m = depth[p] > 0.0f ? 1.0f : 0.0f;
+    const float g[3] = {gvertex_bar[3 * p] * m, gvertex_bar[3 * p + 1] * m, gvertex_bar[3 * p + 2] * m};
+    for (int c = 0; c < 3; ++c) vertex_bar[3 * p + c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
+  }
+  if (normal_bar) {  // gn = R n
+    const float g[3] = {gnormal_bar[3 * p], gnormal_bar[3 * p + 1], gnormal_bar[3 * p + 2]};
+    for (int c = 0; c < 3; ++c) normal_bar[3 * p + c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
+  }
+}
+
+extern "C" int gs_global_maps_backward_f32(const float* gvertex_bar, const float* gnormal_bar, const float* depth,
+                                           const float* pose16, int H, int W, float* vertex_bar, float* normal_bar,
+                                           void* stream) {
+  GS_REQUIRE(H > 0 && W > 0 && pose16, "bad arguments");
+  GS_REQUIRE(!vertex_bar || (gvertex_bar && depth), "vertex_bar needs gvertex_bar and depth");
+  GS_REQUIRE(!normal_bar || gnormal_bar, "normal_bar needs gnormal_bar");
+  const int64_t P = (int64_t)H * W;
+  hipLaunchKernelGGL(gs_global_maps_bwd_kernel, dim3((unsigned)gs_ceil_div(P, 256)), dim3(256), 0, gs_stream(stream),
+                     gvertex_bar, gnormal_bar, depth, pose16, P, vertex_bar, normal_bar);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}

@@ -160,7 +160,10 @@ def downsample_rgbdimages(rgbdimages: RGBDImages, ds_ratio: int) -> Pointclouds:
     fr = rgbdimages.to_channels_last()
     pts, nrm, col = [], [], []
     for b in range(len(fr)):
-        p, n, c = ops.downsample_frame(fr.global_vertex_map[b, 0], fr.global_normal_map[b, 0], fr.rgb_image[b, 0],
+        gvm = fr.global_vertex_map[b, 0]
+        p, n, c = ops.downsample_frame(gvm, fr.global_normal_map[b, 0], fr.rgb_image[b, 0],
                                        fr.depth_image[b, 0, ..., 0], ds_ratio)
+        if torch.is_grad_enabled() and gvm.requires_grad:  # keep the points on the autograd tape
+            p = ops.DownsampleFramePointsFunction.apply(gvm, fr.depth_image[b, 0, ..., 0].detach(), ds_ratio)
         pts.append(p); nrm.append(n); col.append(c)
     return Pointclouds(points=pts, normals=nrm, colors=col)

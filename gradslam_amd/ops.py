@@ -404,3 +404,75 @@ def grad_icp(src, tgt, tgt_normals, init=None, numiters=20, damp=1e-8, dist_thre
         return GradICPFunction.apply(src, tgt, tgt_normals, init, numiters, damp, dist_thresh, lambda_max, B, B2, nu)
     return icp(src, tgt, tgt_normals, init=init, mode=1, numiters=numiters, damp=damp, dist_thresh=dist_thresh,
                lambda_max=lambda_max, B=B, B2=B2, nu=nu)
+
+
+class FrameMapsFunction(torch.autograd.Function):
+    """depth (H,W) -> (vertex, normal, alpha); differentiable w.r.t. depth (gs_frame_maps_backward_f32)."""
+
+    @staticmethod
+    def forward(ctx, depth, K, sigma):
+        v, n, a, _ = frame_maps(depth, K, sigma, want_valid=False)
+        ctx.save_for_backward(depth, K)
+        ctx.sigma = sigma
+        return v, n, a
+
+    @staticmethod
+    def backward(ctx, v_bar, n_bar, a_bar):
+        depth, K = ctx.saved_tensors
+        depth_c, K_c = _c(depth), _c(K)
+        dev = require_device(depth_c, K_c)
+        H, W = depth_c.shape
+        v_bar, n_bar, a_bar = _c(v_bar), _c(n_bar), _c(a_bar)
+        d_bar = torch.empty((H, W), dtype=f32, device=dev)
+        scratch = torch.empty((H, W, 6), dtype=f32, device=dev) if n_bar is not None else None
+        check(lib().gs_frame_maps_backward_f32(ptr(depth_c), ptr(K_c), H, W, two_sigma_sq(ctx.sigma), ptr(v_bar),
+                                               ptr(n_bar), ptr(a_bar), ptr(d_bar), ptr(scratch), stream(dev)),
+              "gs_frame_maps_backward_f32")
+        return d_bar, None, None
+
+
+class GlobalMapsFunction(torch.autograd.Function):
+    """(vertex, normal) + pose -> (gvertex, gnormal); differentiable w.r.t. the local maps."""
+
+    @staticmethod
+    def forward(ctx, vertex, normal, depth, pose):
+        gv, gn = global_maps(vertex, normal, depth, pose)
+        ctx.save_for_backward(depth, pose)
+        return gv, gn
+
+    @staticmethod
+    def backward(ctx, gv_bar, gn_bar):
+        depth, pose = ctx.saved_tensors
+        depth_c, pose_c = _c(depth), _c(pose)
+        dev = require_device(depth_c, pose_c)
+        H, W = depth_c.shape[:2]
+        gv_bar, gn_bar = _c(gv_bar), _c(gn_bar)
+        v_bar = torch.empty((H, W, 3), dtype=f32, device=dev) if gv_bar is not None else None
+        n_bar = torch.empty((H, W, 3), dtype=f32, device=dev) if gn_bar is not None else None
+        check(lib().gs_global_maps_backward_f32(ptr(gv_bar), ptr(gn_bar), ptr(depth_c), ptr(pose_c), H, W, ptr(v_bar),
+                                                ptr(n_bar), stream(dev)), "gs_global_maps_backward_f32")
+        return v_bar, n_bar, None, None
+
+
+class DownsampleFramePointsFunction(torch.autograd.Function):
+    """global vertex map -> compact lattice points; backward scatters the adjoints to their pixels."""
+
+    @staticmethod
+    def forward(ctx, gvertex, depth, ds):
+        pts, _, _ = downsample_frame(gvertex, None, None, depth, ds)
+        ctx.save_for_backward(depth)
+        ctx.ds = ds
+        return pts
+
+    @staticmethod
+    def backward(ctx, pts_bar):
+        (depth,) = ctx.saved_tensors
+        depth_c, pts_bar = _c(depth), _c(pts_bar)
+        dev = require_device(depth_c, pts_bar)
+        H, W = depth_c.shape[:2]
+        gv_bar = torch.empty((H, W, 3), dtype=f32, device=dev)
+        ws = Workspace.get(dev)
+        check(lib().gs_downsample_frame_backward_f32(ptr(pts_bar), ptr(depth_c), H, W, ctx.ds, ptr(gv_bar),
+                                                     ptr(ws.scratch(0, H * W)), stream(dev)),
+              "gs_downsample_frame_backward_f32")
+        return gv_bar, None, None

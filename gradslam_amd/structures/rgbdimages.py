@@ -153,12 +153,24 @@ class RGBDImages(object):
     def _from_cl(self, t):
         return t.permute(0, 1, 4, 2, 3).contiguous() if self.channels_first else t
 
+    def _wants_grad(self):
+        return torch.is_grad_enabled() and self._depth_image.requires_grad
+
     def _compute_local_maps(self, sigma=None):
-        """vertex + normal (+ alpha when sigma is given) for every (b, l) frame: one kernel each."""
+        """vertex + normal (+ alpha when sigma is given) for every (b, l) frame: one kernel each.
+        When depth requires grad the maps stay on the autograd tape (hand-written HIP backward)."""
         from .. import ops
         B, L, H, W = self.shape
         depth = self._cl(self._depth_image)
         K = self._intrinsics.contiguous().float()
+        if self._wants_grad():
+            sg = 0.6 if sigma is None else float(sigma)
+            rows = [[ops.FrameMapsFunction.apply(depth[b, s, ..., 0], K[b, 0], sg) for s in range(L)] for b in range(B)]
+            vm = torch.stack([torch.stack([r[0] for r in row]) for row in rows])
+            nm = torch.stack([torch.stack([r[1] for r in row]) for row in rows])
+            self._vertex_map, self._normal_map = self._from_cl(vm), self._from_cl(nm)
+            self._alpha_cache = (sg, torch.stack([torch.stack([r[2] for r in row]) for row in rows]).unsqueeze(-1))
+            return
         vm = torch.empty((B, L, H, W, 3), dtype=torch.float32, device=self.device)
         nm = torch.empty_like(vm)
         am = torch.empty((B, L, H, W, 1), dtype=torch.float32, device=self.device) if sigma is not None else None
@@ -200,10 +212,16 @@ class RGBDImages(object):
             return
         depth = self._cl(self._depth_image)
         poses = self._poses.contiguous().float()
-        gv, gn = torch.empty_like(vm), torch.empty_like(nm)
-        for b in range(B):
-            for s in range(L):
-                ops.global_maps(vm[b, s], nm[b, s], depth[b, s, ..., 0], poses[b, s], out=(gv[b, s], gn[b, s]))
+        if torch.is_grad_enabled() and (vm.requires_grad or nm.requires_grad):
+            rows = [[ops.GlobalMapsFunction.apply(vm[b, s], nm[b, s], depth[b, s, ..., 0], poses[b, s]) for s in range(L)]
+                    for b in range(B)]
+            gv = torch.stack([torch.stack([r[0] for r in row]) for row in rows])
+            gn = torch.stack([torch.stack([r[1] for r in row]) for row in rows])
+        else:
+            gv, gn = torch.empty_like(vm), torch.empty_like(nm)
+            for b in range(B):
+                for s in range(L):
+                    ops.global_maps(vm[b, s], nm[b, s], depth[b, s, ..., 0], poses[b, s], out=(gv[b, s], gn[b, s]))
         self._global_vertex_map, self._global_normal_map = self._from_cl(gv), self._from_cl(gn)
 
     @property

@@ -186,6 +186,24 @@ GS_API int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, const f
                const gs_icp_params* params_host, float* out_T16, int64_t* out_idx,
                void* icp_scratch, void* stream);
 
+/* ------------------------------------------------- K7: backward of the frame maps ------
+ * Reverse mode of gs_frame_maps_f32 w.r.t. depth: depth_bar (H,W) from the adjoints of the local
+ * vertex map, normal map and alpha (any may be NULL), as PyTorch autograd does through
+ * structures/rgbdimages.py:643-743 and slam/fusionutils.py:69-72.  scratch_6hw: 6*H*W floats,
+ * needed when normal_bar is given.  Gradients w.r.t. the intrinsics are not produced. */
+GS_API int gs_frame_maps_backward_f32(const float* depth, const float* K16, int H, int W, float two_sigma_sq,
+                                      const float* vertex_bar, const float* normal_bar, const float* alpha_bar,
+                                      float* depth_bar, float* scratch_6hw, void* stream);
+/* Reverse mode of gs_global_maps_f32 w.r.t. the local maps (rgbdimages.py:681-762):
+ * vertex_bar = R^T (gvertex_bar * valid), normal_bar = R^T gnormal_bar.  (No pose gradient.) */
+GS_API int gs_global_maps_backward_f32(const float* gvertex_bar, const float* gnormal_bar, const float* depth,
+                                       const float* pose16, int H, int W, float* vertex_bar, float* normal_bar,
+                                       void* stream);
+/* Reverse mode of gs_downsample_frame_f32 (points): gvertex_bar (H,W,3) = zeros with the compact
+ * adjoints pts_bar scattered back to the valid lattice pixels (odometry/icputils.py:654-660). */
+GS_API int gs_downsample_frame_backward_f32(const float* pts_bar, const float* depth, int H, int W, int ds,
+                                            float* gvertex_bar, void* scratch, void* stream);
+
 /* ------------------------------------------------------------- K7: gradICP backward ----
  * Differentiable gradICP (config C3): gs_icp_tape_f32 is gs_icp_f32 that additionally records the
  * forward tape (caller-owned, gs_icp_tape_bytes(n_src, numiters) bytes: per-iteration source cloud,

@@ -14,6 +14,8 @@ Fixtures
   synth120.npz    seeded synthetic 120x160x4 sequence: depths + poses/counts of PointFusion(gradicp).
   icp_unit.npz    gauss_newton_solve / solve_linear_system / se3_exp / ICP / gradICP on small clouds.
   icp_grad.npz    the reference's autograd gradients of point_to_plane_gradICP (config C3, test size).
+  depth_grad.npz  the reference's autograd d/d(depth) through vertex/normal/alpha maps and through
+                  depth -> downsample_rgbdimages -> point_to_plane_gradICP (96x128).
   fusion_kat.npz  hand-made known-answer cases for find_best_unique_correspondences and
                   fuse_with_map (mirrors tests/slam/test_fusionutils.py:672-750, :918-986).
 """
@@ -161,6 +163,32 @@ def main():
             gg[tag + "_" + name] = t.grad.numpy()
     gg["thr"] = np.float32(1e-4)
     np.savez_compressed(os.path.join(OUT, "icp_grad.npz"), **gg)
+
+    # ------------------------------------------------------------------ depth_grad: autograd through the maps
+    # (a) d/d depth of <Wv, vertex_map> + <Wn, normal_map> + <Wa, alpha>; (b) depth -> global vertex map ->
+    # downsample_rgbdimages -> point_to_plane_gradICP -> <W, T>, both by the reference's autograd
+    sq = make_sequence(2, 96, 128, seed=5)
+    rg = np.random.default_rng(11)
+    Wv = rg.standard_normal((96, 128, 3)).astype(np.float32)
+    Wn = rg.standard_normal((96, 128, 3)).astype(np.float32)
+    Wa = rg.standard_normal((96, 128)).astype(np.float32)
+    dg = dict(depths=sq["depths"], intrinsics=sq["intrinsics"][0], poses=sq["poses"], Wv=Wv, Wn=Wn, Wa=Wa)
+    d1 = T(sq["depths"][None, 1:2]).clone().requires_grad_(True)
+    f1 = RGBDImages(T(sq["colors"][None, 1:2]), d1, T(sq["intrinsics"][None]), T(sq["poses"][None, :1]))
+    al = fu.get_alpha(f1.vertex_map, dim=4, keepdim=True, sigma=sigma)
+    ((f1.vertex_map[0, 0] * T(Wv)).sum() + (f1.normal_map[0, 0] * T(Wn)).sum() + (al[0, 0, ..., 0] * T(Wa)).sum()).backward()
+    dg["maps_depth_grad"] = d1.grad[0, 0, ..., 0].numpy().copy()
+    d1 = T(sq["depths"][None, 1:2]).clone().requires_grad_(True)
+    f1 = RGBDImages(T(sq["colors"][None, 1:2]), d1, T(sq["intrinsics"][None]), T(sq["poses"][None, :1]))
+    f0 = RGBDImages(T(sq["colors"][None, 0:1]), T(sq["depths"][None, 0:1]), T(sq["intrinsics"][None]), T(sq["poses"][None, :1]))
+    tg = icputils.downsample_rgbdimages(f0, 4)
+    sr = icputils.downsample_rgbdimages(f1, 4)
+    Tg, _ = icputils.point_to_plane_gradICP(sr.points_list[0][None], tg.points_list[0][None].detach(),
+                                            tg.normals_list[0][None].detach(), torch.eye(4), numiters=5)
+    (Tg * T(Wt)).sum().backward()
+    dg["chain_T"], dg["chain_W"] = Tg.detach().numpy(), Wt
+    dg["chain_depth_grad"] = d1.grad[0, 0, ..., 0].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "depth_grad.npz"), **dg)
 
     # ------------------------------------------------------------------ fusion_kat
     rng = np.random.default_rng(7)

@@ -108,3 +108,46 @@ def test_backward_at_640x480_grid_engine():
     sb, tb, _, _ = ib.icp_backward(tape, tgt.cpu().numpy(), tn.cpu().numpy(), W.cpu().numpy(), src.cpu().numpy())
     assert rel(src_l.grad.cpu().numpy(), sb) < 1e-3
     assert rel(tgt_l.grad.cpu().numpy(), tb) < 1e-3
+
+
+@pytest.mark.gpu
+def test_depth_gradients_through_frame_maps(golden):
+    """d/d(depth) of <Wv, vertex_map> + <Wn, normal_map> + <Wa, alpha> vs the reference's autograd."""
+    import gradslam_amd as gs
+    from gradslam_amd.slam import fusionutils as fu
+    g = golden("depth_grad")
+    d1 = dev(g["depths"][None, 1:2]).requires_grad_(True)
+    rgb = torch.zeros((1, 1, 96, 128, 3), device="cuda")
+    f1 = gs.RGBDImages(rgb, d1, dev(g["intrinsics"][None, None]), dev(g["poses"][None, :1]))
+    alpha = f1._alpha_map(0.6)
+    loss = ((f1.vertex_map[0, 0] * dev(g["Wv"])).sum() + (f1.normal_map[0, 0] * dev(g["Wn"])).sum()
+            + (alpha[0, 0, ..., 0] * dev(g["Wa"])).sum())
+    loss.backward()
+    got, ref = d1.grad[0, 0, ..., 0].cpu().numpy(), g["maps_depth_grad"]
+    assert np.isfinite(got).all()
+    # float32 normal normalisation amplifies rounding on a few near-degenerate pixels: compare robustly
+    err = np.abs(got - ref)
+    assert np.median(err) < 1e-4 * np.abs(ref).max() and (err < 1e-2 * np.abs(ref).max()).mean() > 0.999
+    assert fu.get_alpha(f1.vertex_map, 0.6, dim=4, keepdim=True).shape == alpha.shape
+
+
+@pytest.mark.gpu
+def test_depth_to_pose_chain_matches_reference_autograd(golden):
+    """depth -> vertex -> global vertex -> downsample_rgbdimages -> point_to_plane_gradICP -> <W,T>."""
+    import gradslam_amd as gs
+    from gradslam_amd.odometry import icputils
+    g = golden("depth_grad")
+    K, P0 = dev(g["intrinsics"][None, None]), dev(g["poses"][None, :1])
+    rgb = torch.zeros((1, 1, 96, 128, 3), device="cuda")
+    d1 = dev(g["depths"][None, 1:2]).requires_grad_(True)
+    f1 = gs.RGBDImages(rgb, d1, K, P0)
+    f0 = gs.RGBDImages(rgb, dev(g["depths"][None, 0:1]), K, P0)
+    tg, sr = icputils.downsample_rgbdimages(f0, 4), icputils.downsample_rgbdimages(f1, 4)
+    assert sr.points_list[0].requires_grad and not tg.points_list[0].requires_grad
+    T, _ = icputils.point_to_plane_gradICP(sr.points_list[0][None], tg.points_list[0][None], tg.normals_list[0][None],
+                                           torch.eye(4, device="cuda"), numiters=5)
+    np.testing.assert_allclose(T.detach().cpu().numpy(), g["chain_T"], atol=2e-5, rtol=0)
+    (T * dev(g["chain_W"])).sum().backward()
+    got, ref = d1.grad[0, 0, ..., 0].cpu().numpy(), g["chain_depth_grad"]
+    assert (got != 0).sum() == (ref != 0).sum()          # only valid lattice pixels receive gradient
+    assert rel(got, ref) < 2e-3
