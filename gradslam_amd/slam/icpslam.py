@@ -100,10 +100,15 @@ class ICPSLAM(nn.Module):
             K = prev_frame.intrinsics[:, 0].contiguous().float()
             prev_poses = prev_frame.poses[:, 0].contiguous().float()
             src_pts, tgt_pts, tgt_nrm = [], [], []
+            gvm = fr.global_vertex_map
+            taped = torch.is_grad_enabled() and gvm.requires_grad and self.odom == "gradicp"
             for b in range(B):
                 # downsample_rgbdimages(live_frame): valid lattice pixels of the global vertex map
-                p, _, _ = ops.downsample_frame(fr.global_vertex_map[b, 0], None, None, fr.depth_image[b, 0, ..., 0],
-                                               self.dsratio)
+                if taped:
+                    p = ops.DownsampleFramePointsFunction.apply(gvm[b, 0], fr.depth_image[b, 0, ..., 0].detach(),
+                                                                self.dsratio)
+                else:
+                    p, _, _ = ops.downsample_frame(gvm[b, 0], None, None, fr.depth_image[b, 0, ..., 0], self.dsratio)
                 src_pts.append(p)
                 # find_active_map_points(pointclouds, prev_frame) + downsample_pointclouds, without tables
                 P, N = pointclouds.points_list[b], pointclouds.normals_list[b]
@@ -111,6 +116,17 @@ class ICPSLAM(nn.Module):
                 tp, tn, _ = ops.select_targets(pix, W, self.dsratio, P, N)
                 tgt_pts.append(tp)
                 tgt_nrm.append(tn)
+            if taped and isinstance(self.odomprov, GradICPOdometryProvider):
+                # differentiable pose path: depth -> vertex -> global vertex -> ICP source -> gradICP -> pose.
+                # The map (ICP target) is a constant here; the reference additionally differentiates
+                # through the map built from EARLIER frames (not implemented: fusion has no backward yet).
+                o = self.odomprov
+                out = []
+                for b in range(B):
+                    T, _ = ops.grad_icp(src_pts[b], tgt_pts[b], tgt_nrm[b], None, o.numiters, o.damp, o.dist_thresh,
+                                        o.lambda_max, o.B, o.B2, o.nu)
+                    out.append(T)
+                return _compose(torch.stack(out), prev_poses).unsqueeze(1)
             maps_pc = Pointclouds(points=tgt_pts, normals=tgt_nrm)
             frames_pc = Pointclouds(points=src_pts)
             if isinstance(self.odomprov, ICPOdometryProvider):

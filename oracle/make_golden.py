@@ -190,6 +190,20 @@ def main():
     dg["chain_depth_grad"] = d1.grad[0, 0, ..., 0].numpy().copy()
     np.savez_compressed(os.path.join(OUT, "depth_grad.npz"), **dg)
 
+    # (c) the whole driver on two 64x64 frames: d <W, recovered_poses[1]> / d depth[1] (the pose path
+    # through the ICP source; depth[0] additionally feeds the map in the reference)
+    s2 = make_sequence(2, 64, 64, seed=1)
+    dd = T(s2["depths"][None]).clone().requires_grad_(True)
+    pp = T(s2["poses"][None]).clone()
+    pp[:, 1:] = pp[:, :1]
+    _, rp2 = PointFusion(odom="gradicp")(RGBDImages(T(s2["colors"][None]), dd, T(s2["intrinsics"][None]), pp))
+    (rp2[0, 1] * T(Wt)).sum().backward()
+    dgrad = dict(np.load(os.path.join(OUT, "depth_grad.npz")))
+    dgrad["slam_depths"], dgrad["slam_colors"] = s2["depths"], s2["colors"]
+    dgrad["slam_intrinsics"], dgrad["slam_poses"] = s2["intrinsics"][0], s2["poses"]
+    dgrad["slam_pose1"], dgrad["slam_depth1_grad"] = rp2[0, 1].detach().numpy(), dd.grad[0, 1, ..., 0].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "depth_grad.npz"), **dgrad)
+
     # ------------------------------------------------------------------ fusion_kat
     rng = np.random.default_rng(7)
     H, W = 3, 4

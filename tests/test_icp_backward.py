@@ -151,3 +151,20 @@ def test_depth_to_pose_chain_matches_reference_autograd(golden):
     got, ref = d1.grad[0, 0, ..., 0].cpu().numpy(), g["chain_depth_grad"]
     assert (got != 0).sum() == (ref != 0).sum()          # only valid lattice pixels receive gradient
     assert rel(got, ref) < 2e-3
+
+
+@pytest.mark.gpu
+def test_pointfusion_driver_pose_gradient_wrt_live_depth(golden):
+    """PointFusion(odom='gradicp')(frames): d <W, pose_1> / d depth_1 through the hand-written backward
+    chain equals the reference's autograd (frame 1 reaches pose_1 only through the ICP source)."""
+    import gradslam_amd as gs
+    g = golden("depth_grad")
+    dd = dev(g["slam_depths"][None]).requires_grad_(True)
+    pp = dev(g["slam_poses"][None]).clone()
+    pp[:, 1:] = pp[:, :1]
+    frames = gs.RGBDImages(dev(g["slam_colors"][None]), dd, dev(g["slam_intrinsics"][None, None]), pp)
+    _, rp = gs.slam.PointFusion(odom="gradicp", device="cuda")(frames)
+    np.testing.assert_allclose(rp[0, 1].detach().cpu().numpy(), g["slam_pose1"], atol=2e-5, rtol=0)
+    (rp[0, 1] * dev(g["chain_W"])).sum().backward()
+    got, ref = dd.grad[0, 1, ..., 0].cpu().numpy(), g["slam_depth1_grad"]
+    assert rel(got, ref) < 5e-3 and (got != 0).sum() == (ref != 0).sum()
