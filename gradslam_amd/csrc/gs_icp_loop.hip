@@ -40,13 +40,14 @@ GS_DEV void tape_write_sys(float* __restrict__ sys, int it, const double* S, flo
 
 // ---------------------------------------------------------------- fixed-order sums ------
 // Adds up partial rows (nrows x LIN_NV doubles).  Thread t works on value t%32 and row subset
-// t/32; up to 40 independent loads are in flight per thread (one memory round for a 640x480
+// t/32; up to 20 independent loads are in flight per thread (two memory rounds for a 640x480
 // solve); the sub-sums are then added in index order.  Every
 // block that runs this on the same rows gets bit-identical sums.
 template <int BLOCK>
 GS_DEV void icp_sum_rows(const double* __restrict__ partials, int nrows, double* S, double (*sub)[32]) {
   constexpr int STEP = BLOCK / 32;
-  constexpr int CH = 40;  // rows per thread fetched in ONE round of independent loads (640x480: 37)
+  constexpr int CH = 20;  // rows per thread per round of independent loads (more would push the kernel past
+                          // 80 VGPRs and cost the third resident block per CU; 640x480 needs 37 rows = 2 rounds)
   const int i = threadIdx.x & 31, j = threadIdx.x >> 5;
   double s = 0.0;
   if (i < LIN_NV) {
@@ -91,7 +92,7 @@ constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 32 queries per block, their rows are
 // FULL = false: look-ahead half              (prologue: solve + se3_exp, then search with Tr
 //               applied, residual only)
 template <bool FULL>
-__global__ void __launch_bounds__(FS_BLOCK) gs_icp_half_kernel(
+__global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
     const float* __restrict__ src_in, float* __restrict__ src_out, int64_t n_src, const float* __restrict__ tgt,
     const float* __restrict__ tn, int64_t n_tgt, const GsGrid* __restrict__ gp, const int* __restrict__ cell_start,
     const float4* __restrict__ sorted, float dist_thresh, const double* __restrict__ partials_in, int nrows_in,
