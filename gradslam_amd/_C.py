@@ -50,6 +50,7 @@ _PROTOS = {
     "gs_icp_scratch_bytes": [_i64, _i64],
     "gs_icp_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, C.POINTER(IcpParams), _vp, _vp, _vp, _vp],
     "gs_icp_trace_f32": [_vp, _i32, _vp, _vp],
+    "gs_icp_dc_f32": [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, C.POINTER(IcpParams), _vp, _vp, _vp, _vp],
     "gs_frame_maps_backward_f32": [_vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "gs_global_maps_backward_f32": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gs_downsample_frame_backward_f32": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],

@@ -139,6 +139,19 @@ GS_DEV void gs_rigid_fma(const float* __restrict__ T, float p0, float p1, float 
   o2 = gs_dot3_fma(T[8], T[9], T[10], p0, p1, p2) + T[11];
 }
 
+// A size that may live on the device: `host` is always a valid UPPER BOUND (used for launch
+// geometry and buffer sizes); when `dev` is non-NULL the kernels use min(*dev, host) as the actual
+// element count, so that the host never has to read a count back (no sync inside the frame loop).
+struct GsCount {
+  int64_t host;
+  const int64_t* dev;
+};
+GS_DEV int64_t gs_count(const GsCount c) {
+  if (!c.dev) return c.host;
+  const int64_t v = *c.dev;
+  return v < c.host ? (v < 0 ? 0 : v) : c.host;
+}
+
 // ---------------------------------------------------------------- block primitives -----
 constexpr int GS_WAVE = 64;
 

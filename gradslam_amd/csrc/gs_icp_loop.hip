@@ -93,9 +93,9 @@ constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 32 queries per block, their rows are
 //               applied, residual only)
 template <bool FULL>
 __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
-    const float* __restrict__ src_in, float* __restrict__ src_out, int64_t n_src, const float* __restrict__ tgt,
-    const float* __restrict__ tn, int64_t n_tgt, const GsGrid* __restrict__ gp, const int* __restrict__ cell_start,
-    const float4* __restrict__ sorted, float dist_thresh, const double* __restrict__ partials_in, int nrows_in,
+    const float* __restrict__ src_in, float* __restrict__ src_out, GsCount n_src_c, const float* __restrict__ tgt,
+    const float* __restrict__ tn, GsCount n_tgt_c, const GsGrid* __restrict__ gp, const int* __restrict__ cell_start,
+    const float4* __restrict__ sorted, float dist_thresh, const double* __restrict__ partials_in,
     double* __restrict__ partials_out, const IcpSmall* __restrict__ st_in, IcpSmall* __restrict__ st_out,
     float* __restrict__ trace, gs_icp_params prm, int it, int64_t* __restrict__ out_idx,
     int32_t* __restrict__ tape_idx, float* __restrict__ tape_sys) {
@@ -108,6 +108,9 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   __shared__ int unres_n;
   __shared__ unsigned long long red[FS_BLOCK / GS_WAVE];
 
+  const int64_t n_src = gs_count(n_src_c), n_tgt = gs_count(n_tgt_c);
+  const int nrows_in = (int)((n_src + FS_QPB - 1) / FS_QPB);  // rows the previous kernel produced
+  if ((int64_t)blockIdx.x * FS_QPB >= n_src && blockIdx.x != 0) return;  // beyond the actual count (bound-sized grid)
   // the source point of this group does not depend on the prologue: issue its load first so that
   // the global-memory latency hides behind the scalar stage
   const int lane = threadIdx.x & (GQ_G - 1), slot = threadIdx.x / GQ_G;
@@ -234,11 +237,12 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
 }
 
 // After the last look-ahead: final LM / gradLM update and the (composed) result.
-__global__ void __launch_bounds__(FS_BLOCK) gs_icp_finish_kernel(const double* __restrict__ partials_in, int nrows_in,
+__global__ void __launch_bounds__(FS_BLOCK) gs_icp_finish_kernel(const double* __restrict__ partials_in, GsCount n_src_c,
                                                                  GsIcpState* __restrict__ st, int buf,
                                                                  gs_icp_params prm, const float* __restrict__ compose16,
                                                                  float* __restrict__ out_T16) {
   __shared__ double red[FS_BLOCK / GS_WAVE];
+  const int nrows_in = (int)((gs_count(n_src_c) + FS_QPB - 1) / FS_QPB);
   const double e1 = icp_sum_col27<FS_BLOCK>(partials_in, nrows_in, red);
   if (threadIdx.x != 0) return;
   IcpSmall sm = st->s[buf];
@@ -408,7 +412,8 @@ static int icp_tape_finish(void* tape, const GsIcpState* state, int64_t n_src, i
 static int icp_run(const float* src, int64_t n_src, const float* tgt, const float* tgt_normals,
                    int64_t n_tgt, const float* init16, const float* compose16,
                    const gs_icp_params* prm, float* out_T16, int64_t* out_idx, void* icp_scratch,
-                   void* tape, void* stream) {
+                   void* tape, void* stream, const int64_t* n_src_dev = nullptr,
+                   const int64_t* n_tgt_dev = nullptr) {
   GS_REQUIRE(prm, "params_host must not be NULL");
   GS_REQUIRE(n_src > 0 && n_tgt > 0, "empty point set");
   GS_REQUIRE(n_tgt < 0x7fffffffll && n_src < 0x7fffffffll, "too many points");
@@ -419,7 +424,10 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
   IcpScratch sc = icp_carve(icp_scratch, n_src);
   hipLaunchKernelGGL(gs_icp_init_kernel, dim3(1), dim3(64), 0, st, sc.state, init16, prm->damp, prm->numiters,
                      compose16, out_T16);
-  const bool use_grid = icp_grid_enabled() && gs_knn_use_grid(n_src, n_tgt) && prm->numiters > 0;
+  // device-side counts (n_src / n_tgt are then upper bounds) always take the grid path
+  const bool dev_counts = n_src_dev || n_tgt_dev;
+  const bool use_grid = prm->numiters > 0 && (dev_counts || (icp_grid_enabled() && gs_knn_use_grid(n_src, n_tgt)));
+  const GsCount n_src_c{n_src, n_src_dev}, n_tgt_c{n_tgt, n_tgt_dev};
   float* bufs[2] = {sc.srcA, sc.srcB};
   TapePtrs tp = {nullptr, nullptr, nullptr};
   if (tape) {
@@ -432,7 +440,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
 
   if (use_grid) {
     // the target set is fixed for all 2*numiters searches of this solve: bin it once
-    int rc = gs_knn_grid_build(tgt, n_tgt, n_src, sc.grid, st);
+    int rc = gs_knn_grid_build(tgt, n_tgt_c, n_src, sc.grid, st);
     if (rc != GS_OK) return rc;
     GridMem gm = grid_carve(sc.grid, n_src, n_tgt);
     const int nfs = (int)icp_rows(n_src);
@@ -444,17 +452,17 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
         // compulsory bytes of one fused half-iteration: source in (+out), 27 cell bounds (8 B) per
         // query, matched target + normal gather, partial rows, one pass over the binned targets
         GsProf prof(GS_PROF_ICP_FUSED, (double)n_src * 271.0 + 16.0 * (double)n_tgt, st);
-        hipLaunchKernelGGL((gs_icp_half_kernel<true>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur_in, cur, n_src, tgt,
-                           tgt_normals, n_tgt, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
-                           sc.partials[(h + 1) & 1], nfs, sc.partials[h & 1], &sc.state->s[h & 1],
+        hipLaunchKernelGGL((gs_icp_half_kernel<true>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur_in, cur, n_src_c, tgt,
+                           tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
+                           sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
                            &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, out_idx, tidx(it, 0), nullptr);
       }
       ++h;
       {
         GsProf prof(GS_PROF_ICP_FUSED, (double)n_src * 259.0 + 16.0 * (double)n_tgt, st);
-        hipLaunchKernelGGL((gs_icp_half_kernel<false>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur, nullptr, n_src, tgt,
-                           tgt_normals, n_tgt, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
-                           sc.partials[(h + 1) & 1], nfs, sc.partials[h & 1], &sc.state->s[h & 1],
+        hipLaunchKernelGGL((gs_icp_half_kernel<false>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur, nullptr, n_src_c, tgt,
+                           tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
+                           sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
                            &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, nullptr, tidx(it, 1), tp.sys);
       }
       ++h;
@@ -462,8 +470,8 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
     }
     if (prm->numiters > 0) {
       GsProf prof(GS_PROF_SOLVE, 1.0, st);
-      hipLaunchKernelGGL(gs_icp_finish_kernel, dim3(1), dim3(FS_BLOCK), 0, st, sc.partials[(h + 1) & 1], nfs, sc.state,
-                         h & 1, *prm, compose16, out_T16);
+      hipLaunchKernelGGL(gs_icp_finish_kernel, dim3(1), dim3(FS_BLOCK), 0, st, sc.partials[(h + 1) & 1], n_src_c,
+                         sc.state, h & 1, *prm, compose16, out_T16);
     }
     GS_LAUNCH_CHECK();
     if (tape) return icp_tape_finish(tape, sc.state, n_src, prm->numiters, st);
@@ -514,6 +522,14 @@ extern "C" int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, con
                           void* stream) {
   return icp_run(src, n_src, tgt, tgt_normals, n_tgt, init16, compose16, prm, out_T16, out_idx, icp_scratch, nullptr,
                  stream);
+}
+
+extern "C" int gs_icp_dc_f32(const float* src, int64_t n_src_bound, const int64_t* n_src_dev, const float* tgt,
+                             const float* tgt_normals, int64_t n_tgt_bound, const int64_t* n_tgt_dev,
+                             const float* init16, const float* compose16, const gs_icp_params* prm, float* out_T16,
+                             int64_t* out_idx, void* icp_scratch, void* stream) {
+  return icp_run(src, n_src_bound, tgt, tgt_normals, n_tgt_bound, init16, compose16, prm, out_T16, out_idx,
+                 icp_scratch, nullptr, stream, n_src_dev, n_tgt_dev);
 }
 
 extern "C" int64_t gs_icp_tape_bytes(int64_t n_src, int numiters) { return (int64_t)gs_icp_tape_size(n_src, numiters); }

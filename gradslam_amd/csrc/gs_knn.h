@@ -55,7 +55,7 @@ static inline GridMem grid_carve(void* scratch, int64_t n_src, int64_t n_tgt) {
 }
 
 size_t gs_knn_grid_scratch_bytes(int64_t n_src, int64_t n_tgt);
-int gs_knn_grid_build(const float* tgt, int64_t n_tgt, int64_t n_src, void* grid_scratch, hipStream_t st);
+int gs_knn_grid_build(const float* tgt, GsCount n_tgt, int64_t n_src, void* grid_scratch, hipStream_t st);
 int gs_knn_grid_query(const float* src_in, const float* Tapply, float* src_out, int64_t n_src,
                       const float* tgt, int64_t n_tgt, unsigned long long* best, void* grid_scratch,
                       hipStream_t st);

@@ -134,8 +134,9 @@ size_t gs_knn_grid_scratch_bytes(int64_t n_src, int64_t n_tgt) {
 // sampled surface (spacing ~ sqrt(area / n)) or, failing that, a volume (spacing ~ cbrt(V / n));
 // the cell edge is the larger of 1.5 surface spacings and 0.5 volume spacings (3 shells then
 // still reach 1.75 volume spacings), grown until the grid fits GS_GRID_MAXCELL cells.  Any positive cell size is CORRECT; the choice only affects speed.
-__global__ void __launch_bounds__(1024) gs_grid_bbox_kernel(const float* __restrict__ tgt, int64_t n_tgt,
+__global__ void __launch_bounds__(1024) gs_grid_bbox_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
                                                             GsGrid* __restrict__ g, int* __restrict__ unres_count) {
+  const int64_t n_tgt = gs_count(n_tgt_c);
   __shared__ float red[6][1024 / GS_WAVE];
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   for (int64_t i = threadIdx.x; i < n_tgt; i += 1024) {
@@ -197,11 +198,11 @@ __global__ void __launch_bounds__(1024) gs_grid_bbox_kernel(const float* __restr
   }
 }
 
-__global__ void __launch_bounds__(256) gs_grid_count_kernel(const float* __restrict__ tgt, int64_t n_tgt,
+__global__ void __launch_bounds__(256) gs_grid_count_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
                                                             const GsGrid* __restrict__ gp,
                                                             int* __restrict__ cell_count) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_tgt) return;
+  if (i >= gs_count(n_tgt_c)) return;
   const GsGrid g = *gp;
   atomicAdd(&cell_count[grid_cell(g, tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2])], 1);
 }
@@ -249,13 +250,13 @@ __global__ void __launch_bounds__(256) gs_grid_scan_kernel(const int* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __restrict__ tgt, int64_t n_tgt,
+__global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
                                                               const GsGrid* __restrict__ gp,
                                                               const int* __restrict__ cell_start,
                                                               int* __restrict__ cell_count,
                                                               float4* __restrict__ sorted) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_tgt) return;
+  if (i >= gs_count(n_tgt_c)) return;
   const GsGrid g = *gp;
   const float x = tgt[3 * i], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
   const int cid = grid_cell(g, x, y, z);
@@ -265,20 +266,21 @@ __global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __res
   sorted[slot] = make_float4(x, y, z, __int_as_float((int)i));
 }
 
-int gs_knn_grid_build(const float* tgt, int64_t n_tgt, int64_t n_src, void* grid_scratch, hipStream_t st) {
+int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* grid_scratch, hipStream_t st) {
+  const int64_t n_tgt = n_tgt_c.host;  // upper bound: launch geometry and scratch layout
   GridMem m = grid_carve(grid_scratch, n_src, n_tgt);
   GsProf prof(GS_PROF_COMPACT, 28.0 * (double)n_tgt + 8.0 * GS_GRID_MAXCELL, st);
   hipError_t e = hipMemsetAsync(m.cell_count, 0, 4 * (size_t)(GS_GRID_MAXCELL + 1), st);
   if (e != hipSuccess) { gs_set_error("gs_knn_grid_build: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
-  hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3(1), dim3(1024), 0, st, tgt, n_tgt, m.g, m.unres_count);
-  hipLaunchKernelGGL(gs_grid_count_kernel, dim3((unsigned)gs_ceil_div(n_tgt, 256)), dim3(256), 0, st, tgt, n_tgt,
+  hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3(1), dim3(1024), 0, st, tgt, n_tgt_c, m.g, m.unres_count);
+  hipLaunchKernelGGL(gs_grid_count_kernel, dim3((unsigned)gs_ceil_div(n_tgt, 256)), dim3(256), 0, st, tgt, n_tgt_c,
                      m.g, m.cell_count);
   const unsigned ntile = (unsigned)gs_ceil_div(GS_GRID_MAXCELL + 1, GS_GRID_TILE);
   hipLaunchKernelGGL(gs_grid_tile_sum_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums);
   hipLaunchKernelGGL(gs_grid_scan_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums,
                      m.cell_start);
   hipLaunchKernelGGL(gs_grid_scatter_kernel, dim3((unsigned)gs_ceil_div(n_tgt, 256)), dim3(256), 0, st, tgt,
-                     n_tgt, m.g, m.cell_start, m.cell_count, m.sorted);
+                     n_tgt_c, m.g, m.cell_start, m.cell_count, m.sorted);
   return GS_OK;
 }
 
@@ -381,7 +383,7 @@ extern "C" int gs_knn1_grid_f32(const float* src, int64_t n_src, const float* tg
   unsigned long long* best = reinterpret_cast<unsigned long long*>(scratch);
   void* gscratch = reinterpret_cast<char*>(scratch) + gs_align(8 * (size_t)n_src);
   GS_HIP(hipMemsetAsync(best, 0xff, 8 * (size_t)n_src, st));
-  int rc = gs_knn_grid_build(tgt, n_tgt, n_src, gscratch, st);
+  int rc = gs_knn_grid_build(tgt, GsCount{n_tgt, nullptr}, n_src, gscratch, st);
   if (rc != GS_OK) return rc;
   GridMem m = grid_carve(gscratch, n_src, n_tgt);
   rc = gs_knn_grid_query(src, nullptr, nullptr, n_src, tgt, n_tgt, best, gscratch, st);

@@ -71,7 +71,9 @@ def alpha_of_points(points, sigma, eps=1e-7):
 
 
 # ----------------------------------------------------------------------------------- K2
-def downsample_frame(gvertex, gnormal, rgb, depth, ds):
+def downsample_frame(gvertex, gnormal, rgb, depth, ds, sync=True):
+    """sync=False: no host read-back; returns the bound-sized buffers and the DEVICE count tensor
+    (pts, nrm, col, count) for consumers that take device-side counts (icp(n_src_dev=...))."""
     gvertex, gnormal, rgb, depth = _c(gvertex), _c(gnormal), _c(rgb), _c(depth)
     dev = require_device(gvertex, gnormal, rgb, depth)
     H, W = depth.shape[:2]
@@ -84,6 +86,8 @@ def downsample_frame(gvertex, gnormal, rgb, depth, ds):
     check(lib().gs_downsample_frame_f32(ptr(gvertex), ptr(gnormal), ptr(rgb), ptr(depth), H, W, ds, ptr(pts),
                                         ptr(nrm), ptr(col), ptr(cnt), ptr(ws.scratch(0, H * W)), stream(dev)),
           "gs_downsample_frame_f32")
+    if not sync:
+        return pts, nrm, col, cnt
     c = _count(cnt)
     return pts[:c], (nrm[:c] if nrm is not None else None), (col[:c] if col is not None else None)
 
@@ -109,7 +113,8 @@ def active_table(pix, W, b=0):
     return rows[: _count(cnt)]
 
 
-def select_targets(pix, W, ds, points, normals, colors=None, cap=None):
+def select_targets(pix, W, ds, points, normals, colors=None, cap=None, sync=True):
+    """sync=False: no host read-back; returns (pts, nrm, col, count) with bound-sized buffers."""
     points, normals, colors = _c(points), _c(normals), _c(colors)
     dev = require_device(pix, points, normals, colors)
     n = pix.shape[0]
@@ -122,6 +127,8 @@ def select_targets(pix, W, ds, points, normals, colors=None, cap=None):
     check(lib().gs_select_targets_f32(ptr(pix), n, W, ds, ptr(points), ptr(normals), ptr(colors), ptr(op), ptr(on),
                                       ptr(oc), cap, ptr(cnt), ptr(ws.scratch(n, 0)), stream(dev)),
           "gs_select_targets_f32")
+    if not sync:
+        return op, on, oc, cnt
     c = _count(cnt)
     if c > cap:
         raise _C.HipExtensionError("gs_select_targets_f32: %d targets exceed capacity %d" % (c, cap))
@@ -216,8 +223,11 @@ def transform_points(pts, T):
 
 
 def icp(src, tgt, tgt_normals, init=None, compose=None, mode=1, numiters=20, damp=1e-8, dist_thresh=None,
-        lambda_max=2.0, B=1.0, B2=1.0, nu=200.0, return_idx=True, return_trace=False):
-    """Whole (grad)LM point-to-plane ICP on the device; returns T (4,4) [, idx (Ns,)] [, trace]."""
+        lambda_max=2.0, B=1.0, B2=1.0, nu=200.0, return_idx=True, return_trace=False, n_src_dev=None,
+        n_tgt_dev=None):
+    """Whole (grad)LM point-to-plane ICP on the device; returns T (4,4) [, idx (Ns,)] [, trace].
+    n_src_dev / n_tgt_dev: device int64 tensors holding the actual point counts (the row counts of
+    src / tgt are then upper bounds): nothing is read back to the host (gs_icp_dc_f32)."""
     src, tgt, tn = _c(src), _c(tgt), _c(tgt_normals)
     dev = require_device(src, tgt, tn)
     init = torch.eye(4, dtype=f32, device=dev) if init is None else _c(init)
@@ -230,8 +240,13 @@ def icp(src, tgt, tgt_normals, init=None, compose=None, mode=1, numiters=20, dam
     idx = torch.empty(ns, dtype=torch.int64, device=dev) if return_idx else None
     ws = Workspace.get(dev)
     scratch = ws.bytes("icp", lib().gs_icp_scratch_bytes(ns, nt))
-    check(lib().gs_icp_f32(ptr(src), ns, ptr(tgt), ptr(tn), nt, ptr(init), ptr(compose), prm, ptr(T), ptr(idx),
-                           ptr(scratch), stream(dev)), "gs_icp_f32")
+    if n_src_dev is not None or n_tgt_dev is not None:
+        require_device(n_src_dev, n_tgt_dev)
+        check(lib().gs_icp_dc_f32(ptr(src), ns, ptr(n_src_dev), ptr(tgt), ptr(tn), nt, ptr(n_tgt_dev), ptr(init),
+                                  ptr(compose), prm, ptr(T), ptr(idx), ptr(scratch), stream(dev)), "gs_icp_dc_f32")
+    else:
+        check(lib().gs_icp_f32(ptr(src), ns, ptr(tgt), ptr(tn), nt, ptr(init), ptr(compose), prm, ptr(T), ptr(idx),
+                               ptr(scratch), stream(dev)), "gs_icp_f32")
     out = [T]
     if return_idx:
         out.append(idx)

@@ -102,6 +102,19 @@ class ICPSLAM(nn.Module):
             src_pts, tgt_pts, tgt_nrm = [], [], []
             gvm = fr.global_vertex_map
             taped = torch.is_grad_enabled() and gvm.requires_grad and self.odom == "gradicp"
+            if not taped and type(self.odomprov) in (ICPOdometryProvider, GradICPOdometryProvider):
+                # fast path: the sizes of the ICP point sets stay on the device (no host read-back between
+                # selecting the sets and solving); buffers are sized by their upper bounds
+                out = []
+                for b in range(B):
+                    depth_b = fr.depth_image[b, 0, ..., 0]
+                    src, _, _, n_src = ops.downsample_frame(gvm[b, 0], None, None, depth_b, self.dsratio, sync=False)
+                    P, N = pointclouds.points_list[b], pointclouds.normals_list[b]
+                    pix = ops.project_map(P, prev_poses[b], K[b], H, W)
+                    tgt, tn, _, n_tgt = ops.select_targets(pix, W, self.dsratio, P, N, sync=False)
+                    out.append(ops.icp(src, tgt, tn, compose=prev_poses[b], mode=self.odomprov._mode,
+                                       return_idx=False, n_src_dev=n_src, n_tgt_dev=n_tgt, **self.odomprov._kwargs()))
+                return torch.stack(out).unsqueeze(1)
             for b in range(B):
                 # downsample_rgbdimages(live_frame): valid lattice pixels of the global vertex map
                 if taped:

@@ -224,6 +224,16 @@ GS_API int gs_icp_backward_f32(const void* tape, const float* src, int64_t n_src
                                float* tgt_bar, float* normals_bar, float* init_bar16, void* scratch,
                                void* stream);
 
+/* gs_icp_f32 with DEVICE-SIDE point counts: n_src_bound / n_tgt_bound are upper bounds used for
+ * launch geometry and scratch sizing (src / tgt buffers must hold that many rows); the actual
+ * counts are read on the device from n_src_dev / n_tgt_dev (e.g. the count_out of
+ * gs_downsample_frame_f32 / gs_select_targets_f32), so the host never reads them back: no sync
+ * between selecting the ICP point sets and solving.  Either pointer may be NULL (= the bound is exact). */
+GS_API int gs_icp_dc_f32(const float* src, int64_t n_src_bound, const int64_t* n_src_dev, const float* tgt,
+                         const float* tgt_normals, int64_t n_tgt_bound, const int64_t* n_tgt_dev,
+                         const float* init16, const float* compose16, const gs_icp_params* params_host,
+                         float* out_T16, int64_t* out_idx, void* icp_scratch, void* stream);
+
 /* Per-iteration record kept in icp_scratch for the backward pass / diagnostics:
  * gs_icp_trace_f32 copies (numiters, 12) floats = [err, new_err, damp_after, sigmoid, xi(6), pad(2)]. */
 GS_API int gs_icp_trace_f32(const void* icp_scratch, int numiters, float* trace_out, void* stream);

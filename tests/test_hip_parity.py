@@ -328,3 +328,31 @@ def test_icp_full_size_properties(ops):
     # and the hard-LM variant agrees with the soft one on this well-posed problem
     T2 = ops.icp(src, tgt, tn, mode=0, numiters=20, return_idx=False)
     assert np.abs(host(T2) - true_T).max() < 2e-3
+
+
+def test_icp_with_device_side_counts(ops, golden):
+    """gs_icp_dc_f32: point counts read on the device from bound-sized buffers (no host read-back)
+    must give exactly the transform of the host-count call on the same points."""
+    s = make_sequence(2, 240, 320, seed=12)
+    K = dev(s["intrinsics"][0])
+    d0, d1 = dev(s["depths"][0, ..., 0]), dev(s["depths"][1, ..., 0])
+    pose = dev(s["poses"][0])
+    v0, n0, _, _ = ops.frame_maps(d0, K)
+    gv0, gn0 = ops.global_maps(v0, n0, d0, pose)
+    v1, n1, _, _ = ops.frame_maps(d1, K)
+    gv1, gn1 = ops.global_maps(v1, n1, d1, pose)
+    tgt, tn, _ = ops.downsample_frame(gv0, gn0, None, d0, 2)
+    src, _, _ = ops.downsample_frame(gv1, gn1, None, d1, 2)
+    assert tgt.shape[0] > 2048
+    T_ref, idx_ref = ops.icp(src, tgt, tn, mode=1, numiters=20)
+    # bound-sized buffers with garbage beyond the actual counts
+    srcb, _, _, n_src = ops.downsample_frame(gv1, gn1, None, d1, 2, sync=False)
+    tgtb, tnb, _, n_tgt = ops.downsample_frame(gv0, gn0, None, d0, 2, sync=False)
+    assert srcb.shape[0] > src.shape[0] and int(n_src) == src.shape[0] and int(n_tgt) == tgt.shape[0]
+    srcb[src.shape[0]:] = float("nan")
+    tgtb[tgt.shape[0]:] = 1e9
+    tnb[tgt.shape[0]:] = 7.0
+    T, idx = ops.icp(srcb, tgtb, tnb, mode=1, numiters=20, n_src_dev=n_src, n_tgt_dev=n_tgt)
+    assert torch.equal(T, T_ref) and torch.equal(idx[: src.shape[0]], idx_ref)
+    T0 = ops.icp(srcb, tgtb, tnb, mode=0, numiters=5, n_src_dev=n_src, n_tgt_dev=n_tgt, return_idx=False)
+    assert torch.equal(T0, ops.icp(src, tgt, tn, mode=0, numiters=5, return_idx=False))
