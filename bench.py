@@ -159,9 +159,12 @@ def main():
     roofline, roofline_hbm, roofline_brute = None, None, None
     if snapshot is not None and rank == 0:
         pc2, prev2 = snapshot
+        from gradslam_amd import ops as _ops
+        dc_mode, _ops.DEVICE_COUNTS = _ops.DEVICE_COUNTS, False  # exact host counts -> exact algorithmic bytes
         _C.check(lib.gs_profile_begin(64 * K + 1024), "gs_profile_begin")
         run_steps(slam, pc2, frames, prev2, Wm, L)
         _C.check(lib.gs_profile_end(), "gs_profile_end")
+        _ops.DEVICE_COUNTS = dc_mode
         ms, n, nbytes = read_profile(lib, 8)
         if n > 0:  # dominant kernel by GPU time: the fused exact-NN search + Gauss-Newton linearisation
             gbs = nbytes / (ms * 1e-3) / 1e9
@@ -226,6 +229,7 @@ def main():
                        "sequences_per_gpu": 1, "frames_timed_per_gpu": K, "map_surfels_end": n_map,
                        "parity_mode": "renormalize_unmatched=True (reference-identical merge)",
                        "final_gather_ms": gather_ms, "api": "gradslam_amd.slam.PointFusion.step",
+                       "host_readbacks_per_frame": 0 if gs.ops.DEVICE_COUNTS else 3,
                        "ate_vs_ground_truth_m_rank0": ate_gt},
             "roofline": roofline, "roofline_hbm": roofline_hbm, "roofline_bruteforce": roofline_brute,
             "cpu_baseline": cpu,

@@ -67,6 +67,13 @@ _PROTOS = {
     "gs_fuse_append_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                            _vp, _vp, _vp],
     "gs_append_valid_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
+    "gs_project_map_dc_f32": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "gs_select_targets_dc_f32": [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "gs_associate_dc_f32": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp],
+    "gs_fuse_append_dc_f32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
+                              _vp, _vp, _vp],
+    "gs_append_valid_dc_f32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
+                               _vp],
 }
 _RESTYPE = {"gs_last_error": C.c_char_p, "gs_scratch_bytes": _i64, "gs_icp_scratch_bytes": _i64,
             "gs_knn1_grid_scratch_bytes": _i64, "gs_icp_tape_bytes": _i64, "gs_icp_backward_scratch_bytes": _i64}

@@ -56,16 +56,17 @@ GS_DEV int32_t gs_project_point(const GsCamera& c, float p0, float p1, float p2,
 }
 
 __global__ void __launch_bounds__(256) gs_project_map_kernel(
-    const float* __restrict__ points, int64_t n_map, const float* __restrict__ pose16,
+    const float* __restrict__ points, GsCount n_map_c, const float* __restrict__ pose16,
     const float* __restrict__ K16, int H, int W, float u_hi, float v_hi, int32_t* __restrict__ pix) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= n_map) return;
+  if (n >= gs_count(n_map_c)) return;
   const GsCamera c = gs_camera(pose16, K16);
   pix[n] = gs_project_point(c, points[3 * n], points[3 * n + 1], points[3 * n + 2], H, W, u_hi, v_hi);
 }
 
-extern "C" int gs_project_map_f32(const float* points, int64_t n_map, const float* pose16,
-                                  const float* K16, int H, int W, int32_t* pix, void* stream) {
+static int project_map(const float* points, GsCount n_map_c, const float* pose16, const float* K16, int H, int W,
+                       int32_t* pix, void* stream) {
+  const int64_t n_map = n_map_c.host;
   GS_REQUIRE(n_map >= 0 && H > 0 && W > 0, "bad sizes");
   if (n_map == 0) return GS_OK;
   GS_REQUIRE(points && pose16 && K16 && pix, "NULL pointer");
@@ -73,9 +74,20 @@ extern "C" int gs_project_map_f32(const float* points, int64_t n_map, const floa
   const float u_hi = (float)((double)W - 0.999), v_hi = (float)((double)H - 0.999);
   GsProf prof(GS_PROF_PROJECT, 16.0 * (double)n_map, gs_stream(stream));  // 12 B point read + 4 B pix write
   hipLaunchKernelGGL(gs_project_map_kernel, dim3((unsigned)gs_ceil_div(n_map, 256)), dim3(256), 0,
-                     gs_stream(stream), points, n_map, pose16, K16, H, W, u_hi, v_hi, pix);
+                     gs_stream(stream), points, n_map_c, pose16, K16, H, W, u_hi, v_hi, pix);
   GS_LAUNCH_CHECK();
   return GS_OK;
+}
+
+extern "C" int gs_project_map_f32(const float* points, int64_t n_map, const float* pose16,
+                                  const float* K16, int H, int W, int32_t* pix, void* stream) {
+  return project_map(points, GsCount{n_map, nullptr}, pose16, K16, H, W, pix, stream);
+}
+extern "C" int gs_project_map_dc_f32(const float* points, int64_t n_map_bound, const int64_t* n_map_dev,
+                                     const float* pose16, const float* K16, int H, int W, int32_t* pix,
+                                     void* stream) {
+  GS_REQUIRE(n_map_dev, "NULL device count");
+  return project_map(points, GsCount{n_map_bound, n_map_dev}, pose16, K16, H, W, pix, stream);
 }
 
 // ---------------------------------------------------------------- ordered tables -------
@@ -136,14 +148,28 @@ struct EmitGatherByN {
   __device__ void operator()(int64_t n, int64_t pos) const { g.copy(n, pos); }
 };
 
+static int select_targets(const int32_t* pix, GsCount n_map, int W, int ds, const float* points,
+                          const float* normals, const float* colors, float* out_pts, float* out_nrm,
+                          float* out_rgb, int64_t cap, int64_t* count_out, void* scratch, void* stream) {
+  GS_REQUIRE(n_map.host >= 0 && W > 0 && ds > 0 && count_out && scratch && out_pts, "bad arguments");
+  Gather3 g{points, normals, colors, out_pts, normals ? out_nrm : nullptr, colors ? out_rgb : nullptr};
+  return gs_compact(n_map, PredLattice{pix, W, ds}, EmitGatherByN{g}, count_out, GsCount{0, nullptr}, cap,
+                    scratch, gs_stream(stream));
+}
 extern "C" int gs_select_targets_f32(const int32_t* pix, int64_t n_map, int W, int ds,
                                      const float* points, const float* normals, const float* colors,
                                      float* out_pts, float* out_nrm, float* out_rgb, int64_t cap,
                                      int64_t* count_out, void* scratch, void* stream) {
-  GS_REQUIRE(n_map >= 0 && W > 0 && ds > 0 && count_out && scratch && out_pts, "bad arguments");
-  Gather3 g{points, normals, colors, out_pts, normals ? out_nrm : nullptr, colors ? out_rgb : nullptr};
-  return gs_compact(n_map, PredLattice{pix, W, ds}, EmitGatherByN{g}, count_out, 0, cap, scratch,
-                    gs_stream(stream));
+  return select_targets(pix, GsCount{n_map, nullptr}, W, ds, points, normals, colors, out_pts, out_nrm, out_rgb,
+                        cap, count_out, scratch, stream);
+}
+extern "C" int gs_select_targets_dc_f32(const int32_t* pix, int64_t n_map_bound, const int64_t* n_map_dev, int W,
+                                        int ds, const float* points, const float* normals,
+                                        const float* colors, float* out_pts, float* out_nrm, float* out_rgb,
+                                        int64_t cap, int64_t* count_out, void* scratch, void* stream) {
+  GS_REQUIRE(n_map_dev, "NULL device count");
+  return select_targets(pix, GsCount{n_map_bound, n_map_dev}, W, ds, points, normals, colors, out_pts, out_nrm,
+                        out_rgb, cap, count_out, scratch, stream);
 }
 
 struct PredRowLattice {
@@ -364,13 +390,13 @@ extern "C" int gs_best_unique_rows_f32(const int64_t* rows, int64_t n_rows, cons
 
 // fused path: pix[] straight to best_pix[] (no tables)
 __global__ void __launch_bounds__(256) gs_assoc_key_kernel(
-    const int32_t* __restrict__ pix, int64_t n_map, const float* __restrict__ points,
+    const int32_t* __restrict__ pix, GsCount n_map_c, const float* __restrict__ points,
     const float* __restrict__ normals, const float* __restrict__ ccounts,
     const float* __restrict__ gvertex, const float* __restrict__ gnormal, float dist_th, float dot_th,
     uint64_t* __restrict__ key_pt, unsigned long long* __restrict__ key_pix,
     uint8_t* __restrict__ similar) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= n_map) return;
+  if (n >= gs_count(n_map_c)) return;
   const int32_t p = pix[n];
   bool sim = false;
   uint64_t k = ~0ull;
@@ -383,20 +409,21 @@ __global__ void __launch_bounds__(256) gs_assoc_key_kernel(
   if (similar) similar[n] = sim ? 1 : 0;
 }
 __global__ void __launch_bounds__(256) gs_assoc_pick_kernel(
-    const int32_t* __restrict__ pix, int64_t n_map, const uint64_t* __restrict__ key_pt,
+    const int32_t* __restrict__ pix, GsCount n_map_c, const uint64_t* __restrict__ key_pt,
     const uint64_t* __restrict__ key_pix, int32_t* __restrict__ best_pix) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= n_map) return;
+  if (n >= gs_count(n_map_c)) return;
   const uint64_t k = key_pt[n];
   if (k == ~0ull) return;  // not similar (a real key can never be all ones: ray is not NaN-coded)
   const int32_t p = pix[n];
   if (k == key_pix[p]) atomicMin(&best_pix[p], (int32_t)n);
 }
 
-extern "C" int gs_associate_f32(const int32_t* pix, int64_t n_map, const float* points,
-                                const float* normals, const float* ccounts, const float* gvertex,
-                                const float* gnormal, int H, int W, float dist_th, float dot_th,
-                                int32_t* best_pix, uint8_t* similar, void* scratch, void* stream) {
+static int associate(const int32_t* pix, GsCount n_map_c, const float* points, const float* normals,
+                     const float* ccounts, const float* gvertex, const float* gnormal, int H, int W,
+                     float dist_th, float dot_th, int32_t* best_pix, uint8_t* similar, void* scratch,
+                     void* stream) {
+  const int64_t n_map = n_map_c.host;
   GS_REQUIRE(n_map >= 0 && H > 0 && W > 0 && best_pix && scratch, "bad arguments");
   GS_REQUIRE(n_map < 0x7fffffff, "map too large for int32 indices");
   hipStream_t st = gs_stream(stream);
@@ -411,15 +438,32 @@ extern "C" int gs_associate_f32(const int32_t* pix, int64_t n_map, const float* 
   hipLaunchKernelGGL(gs_fill_i32_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, best_pix, P, 0x7fffffff);
   if (n_map > 0) {
     GS_REQUIRE(pix && points && normals && ccounts && gvertex && gnormal, "NULL pointer");
-    hipLaunchKernelGGL(gs_assoc_key_kernel, dim3(gs_blocks(n_map)), dim3(256), 0, st, pix, n_map, points,
+    hipLaunchKernelGGL(gs_assoc_key_kernel, dim3(gs_blocks(n_map)), dim3(256), 0, st, pix, n_map_c, points,
                        normals, ccounts, gvertex, gnormal, dist_th, dot_th, key_pt,
                        reinterpret_cast<unsigned long long*>(key_pix), similar);
-    hipLaunchKernelGGL(gs_assoc_pick_kernel, dim3(gs_blocks(n_map)), dim3(256), 0, st, pix, n_map, key_pt,
+    hipLaunchKernelGGL(gs_assoc_pick_kernel, dim3(gs_blocks(n_map)), dim3(256), 0, st, pix, n_map_c, key_pt,
                        key_pix, best_pix);
   }
   hipLaunchKernelGGL(gs_best_fix_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, best_pix, P);
   GS_LAUNCH_CHECK();
   return GS_OK;
+}
+
+extern "C" int gs_associate_f32(const int32_t* pix, int64_t n_map, const float* points,
+                                const float* normals, const float* ccounts, const float* gvertex,
+                                const float* gnormal, int H, int W, float dist_th, float dot_th,
+                                int32_t* best_pix, uint8_t* similar, void* scratch, void* stream) {
+  return associate(pix, GsCount{n_map, nullptr}, points, normals, ccounts, gvertex, gnormal, H, W, dist_th,
+                   dot_th, best_pix, similar, scratch, stream);
+}
+extern "C" int gs_associate_dc_f32(const int32_t* pix, int64_t n_map_bound, const int64_t* n_map_dev,
+                                   const float* points, const float* normals, const float* ccounts,
+                                   const float* gvertex, const float* gnormal, int H, int W, float dist_th,
+                                   float dot_th, int32_t* best_pix, uint8_t* similar, void* scratch,
+                                   void* stream) {
+  GS_REQUIRE(n_map_dev, "NULL device count");
+  return associate(pix, GsCount{n_map_bound, n_map_dev}, points, normals, ccounts, gvertex, gnormal, H, W,
+                   dist_th, dot_th, best_pix, similar, scratch, stream);
 }
 
 __global__ void __launch_bounds__(256) gs_rows_to_best_kernel(const int64_t* __restrict__ rows,

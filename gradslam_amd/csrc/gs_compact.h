@@ -21,9 +21,10 @@ static inline size_t gs_cp_scratch_bytes(int64_t n) {
 }
 
 template <class Pred>
-__global__ void __launch_bounds__(GS_CP_BLOCK) gs_cp_count_kernel(int64_t n, Pred pred,
+__global__ void __launch_bounds__(GS_CP_BLOCK) gs_cp_count_kernel(GsCount n_c, Pred pred,
                                                                    int32_t* __restrict__ tile_counts) {
   __shared__ int smem[GS_CP_BLOCK / GS_WAVE + 1];
+  const int64_t n = gs_count(n_c);
   const int64_t base = (int64_t)blockIdx.x * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
   int c = 0;
 #pragma unroll
@@ -41,12 +42,16 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_cp_count_kernel(int64_t n, Pre
 // scatter pass clips (it never writes past cap).
 __global__ void gs_cp_scan_tiles_kernel(const int32_t* __restrict__ tile_counts, int64_t ntiles,
                                         int64_t* __restrict__ tile_offsets,
-                                        int64_t* __restrict__ count_out, int64_t base_count);
+                                        int64_t* __restrict__ count_out, GsCount base_count);
 
 template <class Pred, class Emit>
 __global__ void __launch_bounds__(GS_CP_BLOCK) gs_cp_scatter_kernel(
-    int64_t n, Pred pred, Emit emit, const int64_t* __restrict__ tile_offsets, int64_t cap) {
+    GsCount n_c, Pred pred, Emit emit, const int64_t* __restrict__ tile_offsets, GsCount base_c,
+    int64_t cap_abs) {
   __shared__ int smem[GS_CP_BLOCK / GS_WAVE + 1];
+  const int64_t n = gs_count(n_c);
+  // output slots are [base, cap_abs): survivors that would land beyond the capacity are dropped
+  const int64_t cap = cap_abs < 0 ? -1 : cap_abs - gs_count(base_c);
   const int64_t base = (int64_t)blockIdx.x * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
   bool keep[GS_CP_ITEMS];
   int c = 0;
@@ -68,11 +73,22 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_cp_scatter_kernel(
   }
 }
 
-// Host driver.  count_out: device int64[1] <- base_count + survivors.
+template <class Pred, class Emit>
+static int gs_compact(GsCount n, Pred pred, Emit emit, int64_t* count_out, GsCount base_count,
+                      int64_t cap_abs, void* scratch, hipStream_t st);
 template <class Pred, class Emit>
 static int gs_compact(int64_t n, Pred pred, Emit emit, int64_t* count_out, int64_t base_count,
-                      int64_t cap, void* scratch, hipStream_t st) {
-  const int64_t ntiles = gs_cp_tiles(n);
+                      int64_t cap_abs, void* scratch, hipStream_t st) {
+  return gs_compact(GsCount{n, nullptr}, pred, emit, count_out, GsCount{base_count, nullptr}, cap_abs, scratch, st);
+}
+
+// Host driver.  count_out: device int64[1] <- base_count + survivors.  n and base_count may live on
+// the device (GsCount): the launch geometry then comes from their host-side upper bounds.
+// cap_abs < 0: unlimited; otherwise survivor k is emitted only while base_count + k < cap_abs.
+template <class Pred, class Emit>
+static int gs_compact(GsCount n, Pred pred, Emit emit, int64_t* count_out, GsCount base_count,
+                      int64_t cap_abs, void* scratch, hipStream_t st) {
+  const int64_t ntiles = gs_cp_tiles(n.host);
   int32_t* tile_counts = reinterpret_cast<int32_t*>(scratch);
   int64_t* tile_offsets = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(scratch) +
                                                      gs_align(sizeof(int32_t) * ntiles));
@@ -81,7 +97,7 @@ static int gs_compact(int64_t n, Pred pred, Emit emit, int64_t* count_out, int64
   hipLaunchKernelGGL(gs_cp_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, tile_counts, ntiles,
                      tile_offsets, count_out, base_count);
   hipLaunchKernelGGL((gs_cp_scatter_kernel<Pred, Emit>), dim3((unsigned)ntiles), dim3(GS_CP_BLOCK), 0,
-                     st, n, pred, emit, tile_offsets, cap);
+                     st, n, pred, emit, tile_offsets, base_count, cap_abs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     gs_set_error("gs_compact: %s", hipGetErrorString(e));

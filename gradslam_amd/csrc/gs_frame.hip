@@ -83,7 +83,7 @@ extern "C" int64_t gs_scratch_bytes(int64_t n_map, int64_t n_pix) {
 
 __global__ void gs_cp_scan_tiles_kernel(const int32_t* __restrict__ tile_counts, int64_t ntiles,
                                         int64_t* __restrict__ tile_offsets,
-                                        int64_t* __restrict__ count_out, int64_t base_count) {
+                                        int64_t* __restrict__ count_out, GsCount base_count) {
   __shared__ int smem[1024 / GS_WAVE + 1];
   __shared__ int64_t carry;
   if (threadIdx.x == 0) carry = 0;
@@ -98,7 +98,7 @@ __global__ void gs_cp_scan_tiles_kernel(const int32_t* __restrict__ tile_counts,
     if (threadIdx.x == 0) carry += total;
     __syncthreads();
   }
-  if (threadIdx.x == 0 && count_out) count_out[0] = base_count + carry;
+  if (threadIdx.x == 0 && count_out) count_out[0] = gs_count(base_count) + carry;
 }
 
 // ------------------------------------------------------------------ K1 -----------------

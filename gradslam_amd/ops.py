@@ -1,12 +1,19 @@
 """Tensor-level wrappers of the C-ABI (one sequence per call).  Each function validates
 devices, allocates outputs with torch, and enqueues the HIP kernels on torch's current stream.
 Nothing here computes with torch: arithmetic happens in libgradslam_hip.so or not at all."""
+import os
+
 import torch
 
 from . import _C
 from ._C import Workspace, check, lib, ptr, require_device, stream
 
 f32 = torch.float32
+
+# True: the in-place SLAM drivers keep the surfel count of the map on the device between frames
+# (the *_dc entry points) so that a frame never waits for a host read-back.  False: every count
+# is read back as soon as it is produced (exact sizes on the host at all times).
+DEVICE_COUNTS = os.environ.get("GRADSLAM_HIP_DEVICE_COUNTS", "1") != "0"
 
 
 def two_sigma_sq(sigma):
@@ -92,11 +99,16 @@ def downsample_frame(gvertex, gnormal, rgb, depth, ds, sync=True):
     return pts[:c], (nrm[:c] if nrm is not None else None), (col[:c] if col is not None else None)
 
 
-def project_map(points, pose, K, H, W):
+def project_map(points, pose, K, H, W, n_dev=None):
+    """n_dev: device int64[1] holding the actual row count (points.shape[0] is then an upper bound)."""
     points, pose, K = _c(points), _c(pose), _c(K)
     dev = require_device(points, pose, K)
     n = points.shape[0]
     pix = torch.empty(n, dtype=torch.int32, device=dev)
+    if n_dev is not None:
+        check(lib().gs_project_map_dc_f32(ptr(points), n, ptr(n_dev), ptr(pose), ptr(K), H, W, ptr(pix), stream(dev)),
+              "gs_project_map_dc_f32")
+        return pix
     check(lib().gs_project_map_f32(ptr(points), n, ptr(pose), ptr(K), H, W, ptr(pix), stream(dev)),
           "gs_project_map_f32")
     return pix
@@ -113,7 +125,7 @@ def active_table(pix, W, b=0):
     return rows[: _count(cnt)]
 
 
-def select_targets(pix, W, ds, points, normals, colors=None, cap=None, sync=True):
+def select_targets(pix, W, ds, points, normals, colors=None, cap=None, sync=True, n_dev=None):
     """sync=False: no host read-back; returns (pts, nrm, col, count) with bound-sized buffers."""
     points, normals, colors = _c(points), _c(normals), _c(colors)
     dev = require_device(pix, points, normals, colors)
@@ -124,9 +136,14 @@ def select_targets(pix, W, ds, points, normals, colors=None, cap=None, sync=True
     oc = torch.empty((cap, 3), dtype=f32, device=dev) if colors is not None else None
     cnt = torch.empty(1, dtype=torch.int64, device=dev)
     ws = Workspace.get(dev)
-    check(lib().gs_select_targets_f32(ptr(pix), n, W, ds, ptr(points), ptr(normals), ptr(colors), ptr(op), ptr(on),
-                                      ptr(oc), cap, ptr(cnt), ptr(ws.scratch(n, 0)), stream(dev)),
-          "gs_select_targets_f32")
+    if n_dev is not None:
+        check(lib().gs_select_targets_dc_f32(ptr(pix), n, ptr(n_dev), W, ds, ptr(points), ptr(normals), ptr(colors),
+                                             ptr(op), ptr(on), ptr(oc), cap, ptr(cnt), ptr(ws.scratch(n, 0)),
+                                             stream(dev)), "gs_select_targets_dc_f32")
+    else:
+        check(lib().gs_select_targets_f32(ptr(pix), n, W, ds, ptr(points), ptr(normals), ptr(colors), ptr(op),
+                                          ptr(on), ptr(oc), cap, ptr(cnt), ptr(ws.scratch(n, 0)), stream(dev)),
+              "gs_select_targets_f32")
     if not sync:
         return op, on, oc, cnt
     c = _count(cnt)
@@ -285,7 +302,7 @@ def best_unique_rows(rows, points, ccounts, gvertex, b=0):
     return out[: _count(cnt)], best
 
 
-def associate(pix, points, normals, ccounts, gvertex, gnormal, dist_th, dot_th, want_similar=False):
+def associate(pix, points, normals, ccounts, gvertex, gnormal, dist_th, dot_th, want_similar=False, n_dev=None):
     points, normals, ccounts, gvertex, gnormal = _c(points), _c(normals), _c(ccounts), _c(gvertex), _c(gnormal)
     dev = require_device(pix, points, normals, ccounts, gvertex, gnormal)
     H, W = gvertex.shape[:2]
@@ -293,9 +310,14 @@ def associate(pix, points, normals, ccounts, gvertex, gnormal, dist_th, dot_th, 
     best = torch.empty(H * W, dtype=torch.int32, device=dev)
     sim = torch.empty(n, dtype=torch.uint8, device=dev) if want_similar else None
     ws = Workspace.get(dev)
-    check(lib().gs_associate_f32(ptr(pix), n, ptr(points), ptr(normals), ptr(ccounts), ptr(gvertex), ptr(gnormal),
-                                 H, W, float(dist_th), float(dot_th), ptr(best), ptr(sim),
-                                 ptr(ws.scratch(n, H * W)), stream(dev)), "gs_associate_f32")
+    if n_dev is not None:
+        check(lib().gs_associate_dc_f32(ptr(pix), n, ptr(n_dev), ptr(points), ptr(normals), ptr(ccounts),
+                                        ptr(gvertex), ptr(gnormal), H, W, float(dist_th), float(dot_th), ptr(best),
+                                        ptr(sim), ptr(ws.scratch(n, H * W)), stream(dev)), "gs_associate_dc_f32")
+    else:
+        check(lib().gs_associate_f32(ptr(pix), n, ptr(points), ptr(normals), ptr(ccounts), ptr(gvertex),
+                                     ptr(gnormal), H, W, float(dist_th), float(dot_th), ptr(best), ptr(sim),
+                                     ptr(ws.scratch(n, H * W)), stream(dev)), "gs_associate_f32")
     return (best, sim.view(torch.bool)) if want_similar else best
 
 
@@ -319,34 +341,53 @@ def rows_to_best_pix(rows, H, W):
 
 # ----------------------------------------------------------------------------------- K6
 def fuse_append_(points, normals, colors, ccounts, n_map, best_pix, gvertex, gnormal, rgb, alpha, depth,
-                 renorm_all=True):
-    """In-place on capacity-backed buffers (rows >= n_map are free space).  Returns the new count."""
+                 renorm_all=True, n_dev=None, sync=True):
+    """In-place on capacity-backed buffers (rows >= n_map are free space).  Returns the new count
+    (sync=False: as the device int64[1] tensor the kernels wrote, nothing is read back).
+    n_dev: device-side count of the map (n_map is then its upper bound)."""
     gvertex, gnormal, rgb, alpha, depth = _c(gvertex), _c(gnormal), _c(rgb), _c(alpha), _c(depth)
     dev = require_device(points, normals, colors, ccounts, best_pix, gvertex, gnormal, rgb, alpha, depth)
     H, W = depth.shape[:2]
     cap = points.shape[0]
     cnt = torch.empty(1, dtype=torch.int64, device=dev)
     ws = Workspace.get(dev)
-    check(lib().gs_fuse_append_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map), cap,
-                                   ptr(best_pix), ptr(gvertex), ptr(gnormal), ptr(rgb), ptr(alpha), ptr(depth), H, W,
-                                   1 if renorm_all else 0, ptr(cnt), ptr(ws.scratch(n_map, H * W)), stream(dev)),
-          "gs_fuse_append_f32")
+    if n_dev is not None:
+        check(lib().gs_fuse_append_dc_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map),
+                                          ptr(n_dev), cap, ptr(best_pix), ptr(gvertex), ptr(gnormal), ptr(rgb),
+                                          ptr(alpha), ptr(depth), H, W, 1 if renorm_all else 0, ptr(cnt),
+                                          ptr(ws.scratch(n_map, H * W)), stream(dev)), "gs_fuse_append_dc_f32")
+    else:
+        check(lib().gs_fuse_append_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map), cap,
+                                       ptr(best_pix), ptr(gvertex), ptr(gnormal), ptr(rgb), ptr(alpha), ptr(depth),
+                                       H, W, 1 if renorm_all else 0, ptr(cnt), ptr(ws.scratch(n_map, H * W)),
+                                       stream(dev)), "gs_fuse_append_f32")
+    if not sync:
+        return cnt
     c = _count(cnt)
     if c > cap:
         raise _C.HipExtensionError("gs_fuse_append_f32: surfel store overflow (%d > %d)" % (c, cap))
     return c
 
 
-def append_valid_(points, normals, colors, ccounts, n_map, gvertex, gnormal, rgb, alpha, depth):
+def append_valid_(points, normals, colors, ccounts, n_map, gvertex, gnormal, rgb, alpha, depth, n_dev=None,
+                  sync=True):
     gvertex, gnormal, rgb, alpha, depth = _c(gvertex), _c(gnormal), _c(rgb), _c(alpha), _c(depth)
     dev = require_device(points, normals, colors, ccounts, gvertex, gnormal, rgb, alpha, depth)
     H, W = depth.shape[:2]
     cap = points.shape[0]
     cnt = torch.empty(1, dtype=torch.int64, device=dev)
     ws = Workspace.get(dev)
-    check(lib().gs_append_valid_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map), cap,
-                                    ptr(gvertex), ptr(gnormal), ptr(rgb), ptr(alpha), ptr(depth), H, W, ptr(cnt),
-                                    ptr(ws.scratch(n_map, H * W)), stream(dev)), "gs_append_valid_f32")
+    if n_dev is not None:
+        check(lib().gs_append_valid_dc_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map),
+                                           ptr(n_dev), cap, ptr(gvertex), ptr(gnormal), ptr(rgb), ptr(alpha),
+                                           ptr(depth), H, W, ptr(cnt), ptr(ws.scratch(n_map, H * W)), stream(dev)),
+              "gs_append_valid_dc_f32")
+    else:
+        check(lib().gs_append_valid_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map), cap,
+                                        ptr(gvertex), ptr(gnormal), ptr(rgb), ptr(alpha), ptr(depth), H, W, ptr(cnt),
+                                        ptr(ws.scratch(n_map, H * W)), stream(dev)), "gs_append_valid_f32")
+    if not sync:
+        return cnt
     c = _count(cnt)
     if c > cap:
         raise _C.HipExtensionError("gs_append_valid_f32: surfel store overflow (%d > %d)" % (c, cap))

@@ -236,13 +236,15 @@ def _best_pix_per_sequence(pointclouds, rgbdimages, dist_th, dot_th):
     _, _, H, W = fr.shape
     best = []
     for b in range(len(rgbdimages)):
-        if not pointclouds.has_points or pointclouds._n[b] == 0:
+        n_b, n_dev = pointclouds._count_of(b) if len(pointclouds) else (0, None)
+        if pointclouds._buf["points"] is None or n_b == 0:
             best.append(torch.full((H * W,), -1, dtype=torch.int32, device=fr.device))
             continue
-        P, N, F = pointclouds.points_list[b], pointclouds.normals_list[b], pointclouds.features_list[b]
-        pix = ops.project_map(P, poses[b], K[b], H, W)
+        # rows [0, n_b) of the capacity-backed store; n_dev (if any) holds the exact count on the device
+        P, N, F = (pointclouds._buf[k][b][:n_b] for k in ("points", "normals", "features"))
+        pix = ops.project_map(P, poses[b], K[b], H, W, n_dev=n_dev)
         best.append(ops.associate(pix, P, N, F[:, :1], fr.global_vertex_map[b, 0], fr.global_normal_map[b, 0],
-                                  dist_th, dot_th))
+                                  dist_th, dot_th, n_dev=n_dev))
     return best
 
 
@@ -284,6 +286,16 @@ def _fuse(pointclouds, rgbdimages, best_pix, sigma, inplace):
     if not inplace:
         out._init_empty_batch(B, pointclouds._buf["features"][0].shape[-1])
     for b in range(B):
+        if inplace and ops.DEVICE_COUNTS:
+            # the count stays on the device: no read-back, the host only tracks an upper bound
+            n0, n_dev = pointclouds._count_of(b)
+            P, N, C, F = pointclouds._reserve(b, H * W)
+            if P.dtype != torch.float32 or F.shape[-1] != 1:
+                raise ValueError("map fusion needs float32 surfels with one feature column (the confidence count)")
+            cnt = ops.fuse_append_(P, N, C, F, n0, best_pix[b], gv[b, 0], gn[b, 0], rgb[b, 0], alpha[b, 0, ..., 0],
+                                   depth[b, 0, ..., 0], RENORMALIZE_UNMATCHED, n_dev=n_dev, sync=False)
+            pointclouds._set_count_dev(b, cnt, H * W)
+            continue
         n0 = pointclouds._n[b]
         P, N, C, F = pointclouds._reserve(b, H * W)
         if P.dtype != torch.float32 or F.shape[-1] != 1:
@@ -340,6 +352,13 @@ def update_map_aggregate(pointclouds: Pointclouds, rgbdimages: RGBDImages, inpla
         raise ValueError("pointclouds to append and to be appended must either both have or not have features: "
                          "(False != True)")
     for b in range(B):
+        if inplace and ops.DEVICE_COUNTS:
+            n0, n_dev = pointclouds._count_of(b)
+            P, N, C, _ = pointclouds._reserve(b, H * W)
+            cnt = ops.append_valid_(P, N, C, None, n0, gv[b, 0], gn[b, 0], rgb[b, 0], None, depth[b, 0, ..., 0],
+                                    n_dev=n_dev, sync=False)
+            pointclouds._set_count_dev(b, cnt, H * W)
+            continue
         P, N, C, _ = pointclouds._reserve(b, H * W)
         n1 = ops.append_valid_(P, N, C, None, pointclouds._n[b], gv[b, 0], gn[b, 0], rgb[b, 0], None,
                                depth[b, 0, ..., 0])
@@ -353,7 +372,8 @@ def update_map_fusion(pointclouds: Pointclouds, rgbdimages: RGBDImages, dist_th:
     _check_pc(pointclouds)
     _check_rgbd(rgbdimages)
     _check_seq1(rgbdimages)
-    if pointclouds.has_points:
+    # a map whose counts are device-side has had frames fused into it: no read-back just for this check
+    if pointclouds._dcount or pointclouds.has_points:
         _check_batch(pointclouds, rgbdimages)
     best = _best_pix_per_sequence(pointclouds, rgbdimages, dist_th, dot_th)
     return _fuse(pointclouds, rgbdimages, best, sigma, inplace)

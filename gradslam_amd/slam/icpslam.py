@@ -109,9 +109,10 @@ class ICPSLAM(nn.Module):
                 for b in range(B):
                     depth_b = fr.depth_image[b, 0, ..., 0]
                     src, _, _, n_src = ops.downsample_frame(gvm[b, 0], None, None, depth_b, self.dsratio, sync=False)
-                    P, N = pointclouds.points_list[b], pointclouds.normals_list[b]
-                    pix = ops.project_map(P, prev_poses[b], K[b], H, W)
-                    tgt, tn, _, n_tgt = ops.select_targets(pix, W, self.dsratio, P, N, sync=False)
+                    n_b, n_dev = pointclouds._count_of(b)
+                    P, N = pointclouds._buf["points"][b][:n_b], pointclouds._buf["normals"][b][:n_b]
+                    pix = ops.project_map(P, prev_poses[b], K[b], H, W, n_dev=n_dev)
+                    tgt, tn, _, n_tgt = ops.select_targets(pix, W, self.dsratio, P, N, sync=False, n_dev=n_dev)
                     out.append(ops.icp(src, tgt, tn, compose=prev_poses[b], mode=self.odomprov._mode,
                                        return_idx=False, n_src_dev=n_src, n_tgt_dev=n_tgt, **self.odomprov._kwargs()))
                 return torch.stack(out).unsqueeze(1)

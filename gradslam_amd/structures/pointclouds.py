@@ -25,6 +25,49 @@ def _canon_device(device):
     return torch.Tensor().to(device).device
 
 
+class _DeviceCount(object):
+    """Surfel count of one sequence that lives ON THE DEVICE (written by the fuse/append kernels).
+
+    The host only keeps an upper bound (launch geometry, capacity).  Every update queues an
+    asynchronous copy of the count into pinned memory; `poll()` tightens the bound from the copies
+    that have already landed and never waits, so the frame loop has no host<->device sync.
+    `resolve()` is the one blocking read-back, used when the exact count is finally needed."""
+    RING = 8
+
+    def __init__(self, dev, bound):
+        self.dev, self.bound = dev, int(bound)
+        self._pin = torch.empty(self.RING, dtype=torch.int64).pin_memory()
+        self._events = [torch.cuda.Event() for _ in range(self.RING)]
+        self._pending = []   # [slot, rows that may have been added since that copy]
+        self._slot = 0
+        self._queue_copy()
+
+    def _queue_copy(self):
+        if len(self._pending) == self.RING:
+            return
+        s = self._slot
+        self._slot = (s + 1) % self.RING
+        self._pin[s:s + 1].copy_(self.dev, non_blocking=True)
+        self._events[s].record()
+        self._pending.append([s, 0])
+
+    def advance(self, dev, max_growth):
+        self.dev = dev
+        self.bound += int(max_growth)
+        for p in self._pending:
+            p[1] += int(max_growth)
+        self._queue_copy()
+        self.poll()
+
+    def poll(self):
+        while self._pending and self._events[self._pending[0][0]].query():
+            s, grown = self._pending.pop(0)
+            self.bound = min(self.bound, int(self._pin[s]) + grown)
+
+    def resolve(self):
+        return int(self.dev.item())
+
+
 class Pointclouds(object):
     r"""Batch of pointclouds (with varying numbers of points).
 
@@ -53,7 +96,8 @@ class Pointclouds(object):
             raise ValueError("len(points) (= 0) should be > 0")
 
         self._buf = {k: None for k in _ATTRS}   # per attribute: list of (cap_b, C) tensors or None
-        self._n: List[int] = []                 # points per sequence
+        self._dcount = {}                       # b -> _DeviceCount while the count of b is device-side
+        self._n_host: List[int] = []            # points per sequence (see the `_n` property)
         self._padded_cache = {}
         self.equisized = None
 
@@ -107,12 +151,27 @@ class Pointclouds(object):
             self.device = _canon_device(device) if device is not None else torch.device("cpu")
 
     # ------------------------------------------------------------------ basic protocol
+    @property
+    def _n(self):
+        """Points per sequence.  Reading it resolves device-side counts (one read-back each)."""
+        if self._dcount:
+            for b, dc in self._dcount.items():
+                self._n_host[b] = dc.resolve()
+            self._dcount = {}
+            self._invalidate()
+        return self._n_host
+
+    @_n.setter
+    def _n(self, value):
+        self._n_host = value
+        self._dcount = {}
+
     def __len__(self):
-        return len(self._n)
+        return len(self._n_host)
 
     @property
     def _B(self):
-        return len(self._n)
+        return len(self._n_host)
 
     @property
     def _N(self):
@@ -266,7 +325,8 @@ class Pointclouds(object):
     def _reserve(self, b, extra):
         """Guarantees room for `extra` more rows in sequence b (geometric growth) and returns the
         capacity-backed buffers (points, normals, colors, features)."""
-        need = self._n[b] + int(extra)
+        n_b = self._count_of(b)[0]
+        need = n_b + int(extra)
         cap = self._buf["points"][b].shape[0]
         if need > cap:
             new_cap = max(need, int(cap * 2), 1024)
@@ -275,7 +335,7 @@ class Pointclouds(object):
                     continue
                 old = self._buf[k][b]
                 new = torch.empty((new_cap, old.shape[-1]), dtype=old.dtype, device=self.device)
-                new[: self._n[b]] = old[: self._n[b]]
+                new[:n_b] = old[:n_b]
                 self._buf[k][b] = new
             self._padded_cache.clear()
         return tuple(None if self._buf[k] is None else self._buf[k][b] for k in _ATTRS)
@@ -283,6 +343,25 @@ class Pointclouds(object):
     def _set_count(self, b, n):
         self._n[b] = int(n)
         self._invalidate()
+
+    def _count_of(self, b):
+        """(upper bound on the host, device int64[1] tensor or None when the host count is exact)."""
+        dc = self._dcount.get(b)
+        if dc is None:
+            return self._n_host[b], None
+        dc.poll()
+        return dc.bound, dc.dev
+
+    def _set_count_dev(self, b, dev_count, max_growth):
+        """The kernels wrote the new count of sequence b to `dev_count`; at most `max_growth` rows
+        were added.  Nothing is read back (see _DeviceCount)."""
+        dc = self._dcount.get(b)
+        if dc is None:
+            self._dcount[b] = _DeviceCount(dev_count, self._n_host[b] + int(max_growth))
+        else:
+            dc.advance(dev_count, max_growth)
+        self._padded_cache.clear()
+        self.equisized = True if len(self._n_host) == 1 else None
 
     # ------------------------------------------------------------------ copies / moves
     def clone(self):

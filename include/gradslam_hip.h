@@ -292,6 +292,35 @@ GS_API int gs_append_valid_f32(float* points, float* normals, float* colors, flo
                         const float* depth, int H, int W, int64_t* new_count_out, void* scratch,
                         void* stream);
 
+/* ---- the per-frame map pipeline with the surfel count kept ON THE DEVICE -------------------
+ * Same kernels and results as the functions they are named after; `n_map_bound` (host) is an
+ * upper bound of the surfel count used for launch geometry / scratch sizing, the actual count is
+ * read by the kernels from `n_map_dev` (int64[1], typically the new_count_out of the previous
+ * frame's gs_fuse_append_dc_f32).  With these, one PointFusion frame (slam/icpslam.py:137-161 +
+ * slam/fusionutils.py:761-789) never returns to the host: no read-back, no stream sync.
+ * new_count_out must not alias n_map_dev.  Capacity must cover n_map_bound + H*W rows. */
+GS_API int gs_project_map_dc_f32(const float* points, int64_t n_map_bound, const int64_t* n_map_dev,
+                                 const float* pose16, const float* K16, int H, int W, int32_t* pix,
+                                 void* stream);
+GS_API int gs_select_targets_dc_f32(const int32_t* pix, int64_t n_map_bound, const int64_t* n_map_dev, int W,
+                                    int ds, const float* points, const float* normals, const float* colors,
+                                    float* out_pts, float* out_nrm, float* out_rgb, int64_t cap,
+                                    int64_t* count_out, void* scratch, void* stream);
+GS_API int gs_associate_dc_f32(const int32_t* pix, int64_t n_map_bound, const int64_t* n_map_dev,
+                               const float* points, const float* normals, const float* ccounts,
+                               const float* gvertex, const float* gnormal, int H, int W, float dist_th,
+                               float dot_th, int32_t* best_pix, uint8_t* similar, void* scratch, void* stream);
+GS_API int gs_fuse_append_dc_f32(float* points, float* normals, float* colors, float* ccounts,
+                                 int64_t n_map_bound, const int64_t* n_map_dev, int64_t capacity,
+                                 const int32_t* best_pix, const float* gvertex, const float* gnormal,
+                                 const float* rgb, const float* alpha, const float* depth, int H, int W,
+                                 int renorm_all, int64_t* new_count_out, void* scratch, void* stream);
+GS_API int gs_append_valid_dc_f32(float* points, float* normals, float* colors, float* ccounts,
+                                  int64_t n_map_bound, const int64_t* n_map_dev, int64_t capacity,
+                                  const float* gvertex, const float* gnormal, const float* rgb,
+                                  const float* alpha, const float* depth, int H, int W,
+                                  int64_t* new_count_out, void* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -356,3 +356,53 @@ def test_icp_with_device_side_counts(ops, golden):
     assert torch.equal(T, T_ref) and torch.equal(idx[: src.shape[0]], idx_ref)
     T0 = ops.icp(srcb, tgtb, tnb, mode=0, numiters=5, n_src_dev=n_src, n_tgt_dev=n_tgt, return_idx=False)
     assert torch.equal(T0, ops.icp(src, tgt, tn, mode=0, numiters=5, return_idx=False))
+
+
+def test_device_side_map_counts_match_host_counts(ops):
+    """PointFusion with the surfel count kept on the device (no read-back per frame) must build
+    exactly the map and poses of the run that reads every count back."""
+    import gradslam_amd as gs
+    s = make_sequence(6, 120, 160, seed=5)
+    poses = s["poses"].copy()
+    poses[1:] = poses[:1]
+
+    def run(dc):
+        old, ops.DEVICE_COUNTS = ops.DEVICE_COUNTS, dc
+        try:
+            frames = gs.RGBDImages(dev(s["colors"][None]), dev(s["depths"][None]), dev(s["intrinsics"][None]),
+                                   dev(poses[None]))
+            slam = gs.slam.PointFusion(odom="gradicp", device="cuda")
+            pc, prev, out = gs.Pointclouds(device="cuda"), None, []
+            for t in range(6):
+                live = frames[:, t]
+                pc, pose = slam.step(pc, live, prev, inplace=True)
+                assert bool(pc._dcount) == dc
+                prev = live
+                out.append(pose)
+            return pc, torch.stack(out)
+        finally:
+            ops.DEVICE_COUNTS = old
+
+    pc_h, poses_h = run(False)
+    pc_d, poses_d = run(True)
+    assert pc_d._count_of(0)[0] >= pc_h._n[0]          # the host bound never undercuts the count
+    assert torch.equal(poses_d, poses_h)
+    for k in ("points_list", "normals_list", "colors_list", "features_list"):
+        assert torch.equal(getattr(pc_d, k)[0], getattr(pc_h, k)[0]), k
+    assert not pc_d._dcount                             # resolved by the first exact access
+    # and the aggregate map (ICPSLAM)
+    for dc in (False, True):
+        old, ops.DEVICE_COUNTS = ops.DEVICE_COUNTS, dc
+        frames = gs.RGBDImages(dev(s["colors"][None]), dev(s["depths"][None]), dev(s["intrinsics"][None]),
+                               dev(poses[None]))
+        pc, prev = gs.Pointclouds(device="cuda"), None
+        slam = gs.slam.ICPSLAM(odom="icp", device="cuda")
+        for t in range(3):
+            live = frames[:, t]
+            pc, _ = slam.step(pc, live, prev, inplace=True)
+            prev = live
+        ops.DEVICE_COUNTS = old
+        if dc:
+            assert torch.equal(pc.points_list[0], ref_pts)
+        else:
+            ref_pts = pc.points_list[0].clone()
