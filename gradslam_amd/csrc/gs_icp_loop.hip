@@ -236,259 +236,6 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   }
 }
 
-// ---------------------------------------------------------------- persistent grid path ----
-// The whole LM loop as ONE cooperative launch: every block keeps its rows of queries for all
-// iterations and the 2 x numiters global dependencies (all rows -> solve, all residuals -> LM
-// update) are grid-wide barriers instead of kernel boundaries.  The LAST block to arrive at a
-// barrier adds up the partial rows in index order (same order as icp_sum_rows in the multi-launch
-// path: identical bits) and runs the scalar stage once, then releases the others.  This removes
-// the ~4.5 us launch floor of 2 x numiters kernels and the redundant per-block prologue.
-// The blocks must be co-resident: launched with hipLaunchCooperativeKernel (which refuses grids
-// that do not fit); waits are bounded so that a lost block poisons the result instead of hanging.
-struct GsIcpSync {
-  unsigned arrive, gen, abort, pad;
-};
-
-struct FsShared {
-  IcpSmall sm;
-  double S[32];
-  double sub[FS_BLOCK / 32][32];
-  unsigned long long keys_s[FS_QPB];
-  float qs[FS_QPB][3];
-  int unres_q[FS_QPB];
-  int unres_n;
-  int last;
-  unsigned long long red[FS_BLOCK / GS_WAVE];
-  double rows_s[FS_QPB][LIN_NV + 1];
-  double sub_s[8][LIN_NV];
-};
-
-struct IcpPersist {
-  const float* src;
-  float* bufA;
-  float* bufB;
-  float* tape_src;
-  int32_t* tape_idx;
-  float* tape_sys;
-  GsCount n_src, n_tgt;
-  const float* tgt;
-  const float* tn;
-  const GsGrid* gp;
-  const int* cell_start;
-  const float4* sorted;
-  double* partials;
-  GsIcpState* state;
-  GsIcpSync* sync;
-  gs_icp_params prm;
-  int64_t* out_idx;
-  const float* compose16;
-  float* out_T16;
-};
-
-// One block-row (FS_QPB queries) of one half-iteration; sh.sm holds the state, sh.unres_n == 0.
-template <bool FULL>
-GS_DEV void fs_half_row(FsShared& sh, const int64_t row, const float* __restrict__ src_in, float* __restrict__ src_out,
-                        const int64_t n_src, const float* __restrict__ tgt, const float* __restrict__ tn,
-                        const int64_t n_tgt, const GsGrid& g, const int* __restrict__ cell_start,
-                        const float4* __restrict__ sorted, const float dist_thresh, double* __restrict__ partials_out,
-                        int64_t* __restrict__ out_idx, int32_t* __restrict__ tape_idx) {
-  const int lane = threadIdx.x & (GQ_G - 1), slot = threadIdx.x / GQ_G;
-  const int64_t s = row * FS_QPB + slot;
-  if (s < n_src) {
-    const float p0 = src_in[3 * s], p1 = src_in[3 * s + 1], p2 = src_in[3 * s + 2];
-    const float* T = FULL ? sh.sm.T_step : sh.sm.Tr;
-    float qx, qy, qz;
-    gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
-    bool done;
-    const unsigned long long key = grid_search16(g, cell_start, sorted, qx, qy, qz, lane, &done);
-    if (lane == 0) {
-      if (FULL) {
-        src_out[3 * s] = qx;
-        src_out[3 * s + 1] = qy;
-        src_out[3 * s + 2] = qz;
-      }
-      sh.qs[slot][0] = qx; sh.qs[slot][1] = qy; sh.qs[slot][2] = qz;
-      sh.keys_s[slot] = key;
-      if (!done) sh.unres_q[atomicAdd(&sh.unres_n, 1)] = slot;
-    }
-  }
-  __syncthreads();
-  const int nun = sh.unres_n;  // block-uniform
-  for (int u = 0; u < nun; ++u) {
-    const int us = sh.unres_q[u];
-    const unsigned long long key = block_brute_min<FS_BLOCK>(sh.qs[us][0], sh.qs[us][1], sh.qs[us][2], tgt, n_tgt, sh.red);
-    if (threadIdx.x == 0) sh.keys_s[us] = key;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) sh.unres_n = 0;  // re-armed for the next row (a barrier follows before its use)
-
-  double v[LIN_NV];
-#pragma unroll
-  for (int i = 0; i < LIN_NV; ++i) v[i] = 0.0;
-  const int64_t r = row * FS_QPB + threadIdx.x;
-  if (threadIdx.x < FS_QPB && r < n_src) {
-    const unsigned long long bb = sh.keys_s[threadIdx.x];
-    int64_t j = (int64_t)(bb & 0xffffffffull);
-    if (j >= n_tgt) j = 0;  // only when every distance was NaN
-    const float d2 = __uint_as_float((uint32_t)(bb >> 32));
-    const bool keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
-    float a[6], res;
-    gn_row(sh.qs[threadIdx.x][0], sh.qs[threadIdx.x][1], sh.qs[threadIdx.x][2], tgt, tn, j, a, res);
-    if (FULL && out_idx) out_idx[r] = j;
-    if (tape_idx) tape_idx[r] = keep ? (int32_t)j : -1;
-    if (keep) {
-      if (FULL) {
-        int q = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int k = i; k < 6; ++k) v[q++] = (double)a[i] * (double)a[k];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) v[21 + i] = (double)a[i] * (double)res;
-      }
-      v[27] = (double)res * (double)res;
-    }
-  }
-  if (!FULL) {
-    if (threadIdx.x < GS_WAVE) {
-      const double sum = gs_wave_sum_f64(v[27]);
-      if (threadIdx.x == 0) partials_out[row * LIN_NV + 27] = sum;
-    }
-    __syncthreads();
-    return;
-  }
-  if (threadIdx.x < FS_QPB) {
-#pragma unroll
-    for (int i = 0; i < LIN_NV; ++i) sh.rows_s[threadIdx.x][i] = v[i];
-  }
-  __syncthreads();
-  if (threadIdx.x < 8 * LIN_NV) {
-    const int i = threadIdx.x % LIN_NV, part = threadIdx.x / LIN_NV;
-    double t = sh.rows_s[4 * part][i];
-    t += sh.rows_s[4 * part + 1][i];
-    t += sh.rows_s[4 * part + 2][i];
-    t += sh.rows_s[4 * part + 3][i];
-    sh.sub_s[part][i] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x < LIN_NV) {
-    double t = sh.sub_s[0][threadIdx.x];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) t += sh.sub_s[k][threadIdx.x];
-    partials_out[row * LIN_NV + threadIdx.x] = t;
-  }
-  __syncthreads();
-}
-
-// true in exactly one block: the last one to arrive (its reads then see every block's rows)
-GS_DEV bool fs_arrive(GsIcpSync* sy, unsigned nblocks, FsShared& sh) {
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(&sy->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    sh.last = (t == nblocks - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  const bool last = sh.last != 0;
-  if (last) __threadfence();
-  return last;
-}
-GS_DEV void fs_release(GsIcpSync* sy, unsigned gen) {
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(&sy->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&sy->gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-GS_DEV void fs_wait(GsIcpSync* sy, unsigned gen) {
-  if (threadIdx.x == 0) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(&sy->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
-      if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 21)) {  // ~1 s: a block of this grid is not running; give up, poison the result
-        __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  __threadfence();
-}
-
-// The scalar stages run in one block, once per half-iteration: out of line, so that their register
-// appetite (float64 Gauss-Jordan, se3_exp, 20 loads in flight per thread) spills there and not in
-// the search loop of every block.
-__attribute__((noinline)) GS_DEV void fs_stage_solve(FsShared& sh, const IcpPersist& a, int nrows, int it) {
-  icp_sum_rows<FS_BLOCK>(a.partials, nrows, sh.S, sh.sub);
-  if (threadIdx.x == 0) {
-    IcpSmall loc = sh.sm;
-    if (a.tape_sys) tape_write_sys(a.tape_sys, it, sh.S, loc.damp);
-    icp_solve_math(sh.S, loc);
-    a.state->s[0] = loc;
-  }
-}
-__attribute__((noinline)) GS_DEV void fs_stage_update(FsShared& sh, const IcpPersist& a, int nrows, int it) {
-  const double e1 = icp_sum_col27<FS_BLOCK>(a.partials, nrows, reinterpret_cast<double*>(sh.red));
-  if (threadIdx.x == 0) {
-    IcpSmall loc = sh.sm;
-    icp_update_math((float)e1, loc, a.prm, it < 64 ? a.state->trace + 12 * it : nullptr);
-    a.state->s[0] = loc;
-    if (it == a.prm.numiters - 1) {
-      icp_write_result(loc, a.compose16, a.out_T16);
-      if (__hip_atomic_load(&a.sync->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-        for (int i = 0; i < 16; ++i) a.out_T16[i] = __builtin_nanf("");
-    }
-  }
-}
-
-__global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_persist_kernel(const IcpPersist a) {
-  __shared__ FsShared sh;
-  const int64_t n_src = gs_count(a.n_src), n_tgt = gs_count(a.n_tgt);
-  const int64_t nrows = (n_src + FS_QPB - 1) / FS_QPB;
-  const unsigned G = gridDim.x;
-  const GsGrid g = *a.gp;
-  const float dist_thresh = a.prm.dist_thresh;
-  IcpSmall* st = &a.state->s[0];
-  unsigned gen = 0;
-  if (threadIdx.x == 0) sh.unres_n = 0;
-  for (int it = 0; it < a.prm.numiters; ++it) {
-    const float* cur_in = (it == 0) ? a.src
-                                    : (a.tape_src ? a.tape_src + (size_t)(it - 1) * 3 * (size_t)a.n_src.host
-                                                  : (((it - 1) & 1) ? a.bufB : a.bufA));
-    float* cur = a.tape_src ? a.tape_src + (size_t)it * 3 * (size_t)a.n_src.host : ((it & 1) ? a.bufB : a.bufA);
-    int32_t* tidx0 = a.tape_idx ? a.tape_idx + ((size_t)it * 2) * (size_t)a.n_src.host : nullptr;
-    int32_t* tidx1 = a.tape_idx ? a.tape_idx + ((size_t)it * 2 + 1) * (size_t)a.n_src.host : nullptr;
-    // ---- first half: T_step of the previous iteration (or the initial transform) applied, full rows
-    if (threadIdx.x < (int)(sizeof(IcpSmall) / 4))
-      reinterpret_cast<float*>(&sh.sm)[threadIdx.x] = reinterpret_cast<const float*>(st)[threadIdx.x];
-    __syncthreads();
-    for (int64_t row = blockIdx.x; row < nrows; row += G)
-      fs_half_row<true>(sh, row, cur_in, cur, n_src, a.tgt, a.tn, n_tgt, g, a.cell_start, a.sorted, dist_thresh,
-                        a.partials, a.out_idx, tidx0);
-    ++gen;
-    if (fs_arrive(a.sync, G, sh)) {
-      fs_stage_solve(sh, a, (int)nrows, it);
-      fs_release(a.sync, gen);
-    }
-    fs_wait(a.sync, gen);
-    // ---- look-ahead half: residual of Tr * cloud
-    if (threadIdx.x < (int)(sizeof(IcpSmall) / 4))
-      reinterpret_cast<float*>(&sh.sm)[threadIdx.x] = reinterpret_cast<const float*>(st)[threadIdx.x];
-    __syncthreads();
-    for (int64_t row = blockIdx.x; row < nrows; row += G)
-      fs_half_row<false>(sh, row, cur, nullptr, n_src, a.tgt, a.tn, n_tgt, g, a.cell_start, a.sorted, dist_thresh,
-                         a.partials, nullptr, tidx1);
-    ++gen;
-    if (fs_arrive(a.sync, G, sh)) {
-      fs_stage_update(sh, a, (int)nrows, it);
-      fs_release(a.sync, gen);
-    }
-    fs_wait(a.sync, gen);
-  }
-}
-
 // After the last look-ahead: final LM / gradLM update and the (composed) result.
 __global__ void __launch_bounds__(FS_BLOCK) gs_icp_finish_kernel(const double* __restrict__ partials_in, GsCount n_src_c,
                                                                  GsIcpState* __restrict__ st, int buf,
@@ -596,10 +343,8 @@ __global__ void __launch_bounds__(SUM_BLOCK) gs_icp_update_kernel(const double* 
 
 // ---------------------------------------------------------------- host side ------------
 __global__ void gs_icp_init_kernel(GsIcpState* __restrict__ st, const float* __restrict__ init16, float damp,
-                                   int numiters, const float* __restrict__ compose16, float* __restrict__ out_T16,
-                                   GsIcpSync* __restrict__ sync) {
+                                   int numiters, const float* __restrict__ compose16, float* __restrict__ out_T16) {
   if (threadIdx.x != 0) return;
-  sync->arrive = 0; sync->gen = 0; sync->abort = 0; sync->pad = 0;
   IcpSmall sm;
   for (int i = 0; i < 16; ++i) {
     sm.T_total[i] = init16[i];
@@ -617,7 +362,6 @@ __global__ void gs_icp_init_kernel(GsIcpState* __restrict__ st, const float* __r
 
 struct IcpScratch {
   GsIcpState* state;
-  GsIcpSync* sync;
   unsigned long long* best;
   float* srcA;
   float* srcB;
@@ -629,7 +373,6 @@ static IcpScratch icp_carve(void* scratch, int64_t n_src) {
   char* p = reinterpret_cast<char*>(scratch);
   IcpScratch s;
   s.state = reinterpret_cast<GsIcpState*>(p); p += gs_align(sizeof(GsIcpState));
-  s.sync = reinterpret_cast<GsIcpSync*>(p); p += gs_align(sizeof(GsIcpSync));
   s.best = reinterpret_cast<unsigned long long*>(p); p += gs_align(8 * (size_t)n_src);
   s.srcA = reinterpret_cast<float*>(p); p += gs_align(12 * (size_t)n_src);
   s.srcB = reinterpret_cast<float*>(p); p += gs_align(12 * (size_t)n_src);
@@ -651,31 +394,9 @@ static bool icp_grid_enabled() {
   return v == 1;
 }
 
-// GRADSLAM_HIP_ICP=launches selects the one-kernel-per-half-iteration path (A/B runs; identical
-// results).  Otherwise: number of co-resident blocks a cooperative launch of the persistent kernel
-// may use on this device (0: cooperative launches unsupported).
-static int icp_persist_blocks() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("GRADSLAM_HIP_ICP");
-    v = 0;
-    if (!(e && strcmp(e, "launches") == 0)) {
-      int dev = 0, coop = 0, cus = 0, per_cu = 0;
-      if (hipGetDevice(&dev) == hipSuccess &&
-          hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && coop &&
-          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(gs_icp_persist_kernel),
-                                                       FS_BLOCK, 0) == hipSuccess)
-        v = cus * per_cu;
-      (void)hipGetLastError();
-    }
-  }
-  return v;
-}
-
 extern "C" int64_t gs_icp_scratch_bytes(int64_t n_src, int64_t n_tgt) {
   if (n_src < 1) n_src = 1;
-  return (int64_t)(gs_align(sizeof(GsIcpState)) + gs_align(sizeof(GsIcpSync)) + gs_align(8 * (size_t)n_src) + 2 * gs_align(12 * (size_t)n_src) +
+  return (int64_t)(gs_align(sizeof(GsIcpState)) + gs_align(8 * (size_t)n_src) + 2 * gs_align(12 * (size_t)n_src) +
                    2 * gs_align(sizeof(double) * LIN_NV * icp_rows(n_src)) + gs_knn_grid_scratch_bytes(n_src, n_tgt) +
                    4096);
 }
@@ -702,7 +423,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
   hipStream_t st = gs_stream(stream);
   IcpScratch sc = icp_carve(icp_scratch, n_src);
   hipLaunchKernelGGL(gs_icp_init_kernel, dim3(1), dim3(64), 0, st, sc.state, init16, prm->damp, prm->numiters,
-                     compose16, out_T16, sc.sync);
+                     compose16, out_T16);
   // device-side counts (n_src / n_tgt are then upper bounds) always take the grid path
   const bool dev_counts = n_src_dev || n_tgt_dev;
   const bool use_grid = prm->numiters > 0 && (dev_counts || (icp_grid_enabled() && gs_knn_use_grid(n_src, n_tgt)));
@@ -723,30 +444,6 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
     if (rc != GS_OK) return rc;
     GridMem gm = grid_carve(sc.grid, n_src, n_tgt);
     const int nfs = (int)icp_rows(n_src);
-    const int coop = icp_persist_blocks();
-    if (coop > 0) {
-      IcpPersist a;
-      a.src = src; a.bufA = sc.srcA; a.bufB = sc.srcB;
-      a.tape_src = tp.src; a.tape_idx = tp.idx; a.tape_sys = tp.sys;
-      a.n_src = n_src_c; a.n_tgt = n_tgt_c;
-      a.tgt = tgt; a.tn = tgt_normals; a.gp = gm.g; a.cell_start = gm.cell_start; a.sorted = gm.sorted;
-      a.partials = sc.partials[0]; a.state = sc.state; a.sync = sc.sync; a.prm = *prm; a.out_idx = out_idx;
-      a.compose16 = compose16; a.out_T16 = out_T16;
-      void* args[] = {&a};
-      hipError_t e;
-      {
-        // 2 x numiters half-iterations in one launch (bytes as in the multi-launch path below)
-        GsProf prof(GS_PROF_ICP_FUSED, (double)prm->numiters * ((double)n_src * 530.0 + 32.0 * (double)n_tgt), st);
-        e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gs_icp_persist_kernel),
-                                       dim3((unsigned)(nfs < coop ? nfs : coop)), dim3(FS_BLOCK), args, 0, st);
-      }
-      if (e == hipSuccess) {
-        GS_LAUNCH_CHECK();
-        if (tape) return icp_tape_finish(tape, sc.state, n_src, prm->numiters, st);
-        return GS_OK;
-      }
-      (void)hipGetLastError();  // cooperative launch not possible here: multi-launch path
-    }
     const float* cur_in = src;  // cloud before the pending transform of the half-iteration
     int h = 0;                  // half-iteration index: kernel h reads s[h&1] / partials[(h+1)&1], writes the others
     for (int it = 0; it < prm->numiters; ++it) {
