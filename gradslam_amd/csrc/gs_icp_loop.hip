@@ -46,8 +46,9 @@ GS_DEV void tape_write_sys(float* __restrict__ sys, int it, const double* S, flo
 template <int BLOCK>
 GS_DEV void icp_sum_rows(const double* __restrict__ partials, int nrows, double* S, double (*sub)[32]) {
   constexpr int STEP = BLOCK / 32;
-  constexpr int CH = 20;  // rows per thread per round of independent loads (more would push the kernel past
-                          // 80 VGPRs and cost the third resident block per CU; 640x480 needs 37 rows = 2 rounds)
+  constexpr int CH = 18;  // rows per thread per round of independent loads: a 640x480 solve (400 rows of 48
+                          // queries, 17 per thread at 768 threads) is ONE round of memory latency; more rows
+                          // in flight would push the kernel past 80 VGPRs (2 resident blocks per CU)
   const int i = threadIdx.x & 31, j = threadIdx.x >> 5;
   double s = 0.0;
   if (i < LIN_NV) {
@@ -84,8 +85,10 @@ GS_DEV double icp_sum_col27(const double* __restrict__ partials, int nrows, doub
 }
 
 // ---------------------------------------------------------------- grid path -------------
-constexpr int FS_BLOCK = 512;            // 8 waves; 2-3 blocks per CU keep every block of a 640x480 solve resident
-constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 32 queries per block, their rows are built by wave 0
+constexpr int FS_BLOCK = 768;            // 12 waves; 2 blocks per CU keep all 400 blocks of a 640x480 solve resident
+constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 48 queries per block, their rows are built by wave 0
+constexpr int FS_RG = FS_QPB / 4;        // row groups of 4 in the block reduction
+static_assert(FS_QPB <= GS_WAVE && FS_QPB % 4 == 0 && FS_RG * LIN_NV <= FS_BLOCK, "block shape");
 
 // FULL = true : first half of iteration `it`  (prologue: LM update of iteration it-1, then search
 //               with T_step applied, full normal equations)
@@ -122,12 +125,19 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
     p2 = src_in[3 * s + 2];
   }
 
+  // the state of the previous half and the grid header are fetched while the partial rows are summed
+  // (their latency is off the critical path; the sums' __syncthreads publish sm)
+  const GsGrid g = *gp;
+  if (threadIdx.x >= GS_WAVE && threadIdx.x < GS_WAVE + (int)(sizeof(IcpSmall) / 4))
+    reinterpret_cast<float*>(&sm)[threadIdx.x - GS_WAVE] = reinterpret_cast<const float*>(st_in)[threadIdx.x - GS_WAVE];
+
   // ---- prologue: finish the previous half-iteration (identical in every block)
   if (FULL) {
     double e1 = 0.0;
     if (it > 0) e1 = icp_sum_col27<FS_BLOCK>(partials_in, nrows_in, reinterpret_cast<double*>(red));
+    else __syncthreads();
     if (threadIdx.x == 0) {
-      IcpSmall loc = *st_in;  // scalar stage in registers, published through LDS
+      IcpSmall loc = sm;  // scalar stage in registers, published through LDS
       if (it > 0) icp_update_math((float)e1, loc, prm, (blockIdx.x == 0 && it - 1 < 64) ? trace + 12 * (it - 1) : nullptr);
       sm = loc;
       unres_n = 0;
@@ -135,7 +145,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   } else {
     icp_sum_rows<FS_BLOCK>(partials_in, nrows_in, S, sub);
     if (threadIdx.x == 0) {
-      IcpSmall loc = *st_in;
+      IcpSmall loc = sm;
       if (tape_sys && blockIdx.x == 0) tape_write_sys(tape_sys, it, S, loc.damp);
       icp_solve_math(S, loc);
       sm = loc;
@@ -148,7 +158,6 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
 
   // ---- search: one source point per 16-lane group, pending transform applied to the loaded point
   if (s < n_src) {
-    const GsGrid g = *gp;
     const float* T = FULL ? sm.T_step : sm.Tr;
     float qx, qy, qz;
     gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
@@ -209,17 +218,17 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
     }
     return;
   }
-  // 32 rows x 28 values through LDS (a 28-fold wave shuffle reduction costs ~6 us of dependent
-  // cross-lane traffic in one wave): 8 groups of 28 threads add 4 rows each, then 28 threads add
-  // the 8 sub-sums, always in index order.
+  // FS_QPB rows x 28 values through LDS (a 28-fold wave shuffle reduction costs ~6 us of dependent
+  // cross-lane traffic in one wave): FS_RG groups of 28 threads add 4 rows each, then 28 threads
+  // add the sub-sums, always in index order.
   __shared__ double rows_s[FS_QPB][LIN_NV + 1];
-  __shared__ double sub_s[8][LIN_NV];
+  __shared__ double sub_s[FS_RG][LIN_NV];
   if (threadIdx.x < FS_QPB) {
 #pragma unroll
     for (int i = 0; i < LIN_NV; ++i) rows_s[threadIdx.x][i] = v[i];
   }
   __syncthreads();
-  if (threadIdx.x < 8 * LIN_NV) {
+  if (threadIdx.x < FS_RG * LIN_NV) {
     const int i = threadIdx.x % LIN_NV, part = threadIdx.x / LIN_NV;
     double t = rows_s[4 * part][i];
     t += rows_s[4 * part + 1][i];
@@ -231,7 +240,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   if (threadIdx.x < LIN_NV) {
     double t = sub_s[0][threadIdx.x];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += sub_s[k][threadIdx.x];
+    for (int k = 1; k < FS_RG; ++k) t += sub_s[k][threadIdx.x];
     partials_out[(int64_t)blockIdx.x * LIN_NV + threadIdx.x] = t;
   }
 }
