@@ -30,6 +30,17 @@ def _c(t, dtype=f32):
     return t.contiguous()
 
 
+_IDENTITY4 = {}
+
+
+def _identity4(dev):
+    """read-only 4x4 identity of a device (the default initial transform of every ICP solve)"""
+    t = _IDENTITY4.get(dev)
+    if t is None:
+        t = _IDENTITY4[dev] = torch.eye(4, dtype=f32, device=dev)
+    return t
+
+
 def _count(t):
     """Reads a device int64 counter back (one host sync)."""
     return int(t.item())
@@ -241,19 +252,21 @@ def transform_points(pts, T):
 
 def icp(src, tgt, tgt_normals, init=None, compose=None, mode=1, numiters=20, damp=1e-8, dist_thresh=None,
         lambda_max=2.0, B=1.0, B2=1.0, nu=200.0, return_idx=True, return_trace=False, n_src_dev=None,
-        n_tgt_dev=None):
+        n_tgt_dev=None, out=None):
     """Whole (grad)LM point-to-plane ICP on the device; returns T (4,4) [, idx (Ns,)] [, trace].
     n_src_dev / n_tgt_dev: device int64 tensors holding the actual point counts (the row counts of
-    src / tgt are then upper bounds): nothing is read back to the host (gs_icp_dc_f32)."""
+    src / tgt are then upper bounds): nothing is read back to the host (gs_icp_dc_f32).
+    out: optional contiguous (4, 4) float32 tensor that receives T."""
     src, tgt, tn = _c(src), _c(tgt), _c(tgt_normals)
     dev = require_device(src, tgt, tn)
-    init = torch.eye(4, dtype=f32, device=dev) if init is None else _c(init)
+    init = _identity4(dev) if init is None else _c(init)
     compose = _c(compose)
     require_device(init, compose)
     ns, nt = src.shape[0], tgt.shape[0]
     prm = _C.IcpParams(int(mode), int(numiters), float(damp), -1.0 if dist_thresh is None else float(dist_thresh),
                        float(lambda_max), float(B), float(B2), float(nu))
-    T = torch.empty((4, 4), dtype=f32, device=dev)
+    T = torch.empty((4, 4), dtype=f32, device=dev) if out is None else out
+    assert T.shape == (4, 4) and T.dtype == f32 and T.is_contiguous() and T.device == dev
     idx = torch.empty(ns, dtype=torch.int64, device=dev) if return_idx else None
     ws = Workspace.get(dev)
     scratch = ws.bytes("icp", lib().gs_icp_scratch_bytes(ns, nt))

@@ -105,7 +105,7 @@ class ICPSLAM(nn.Module):
             if not taped and type(self.odomprov) in (ICPOdometryProvider, GradICPOdometryProvider):
                 # fast path: the sizes of the ICP point sets stay on the device (no host read-back between
                 # selecting the sets and solving); buffers are sized by their upper bounds
-                out = []
+                out = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=gvm.device)
                 for b in range(B):
                     depth_b = fr.depth_image[b, 0, ..., 0]
                     src, _, _, n_src = ops.downsample_frame(gvm[b, 0], None, None, depth_b, self.dsratio, sync=False)
@@ -113,9 +113,9 @@ class ICPSLAM(nn.Module):
                     P, N = pointclouds._buf["points"][b][:n_b], pointclouds._buf["normals"][b][:n_b]
                     pix = ops.project_map(P, prev_poses[b], K[b], H, W, n_dev=n_dev)
                     tgt, tn, _, n_tgt = ops.select_targets(pix, W, self.dsratio, P, N, sync=False, n_dev=n_dev)
-                    out.append(ops.icp(src, tgt, tn, compose=prev_poses[b], mode=self.odomprov._mode,
-                                       return_idx=False, n_src_dev=n_src, n_tgt_dev=n_tgt, **self.odomprov._kwargs()))
-                return torch.stack(out).unsqueeze(1)
+                    ops.icp(src, tgt, tn, compose=prev_poses[b], mode=self.odomprov._mode, return_idx=False,
+                            n_src_dev=n_src, n_tgt_dev=n_tgt, out=out[b, 0], **self.odomprov._kwargs())
+                return out
             for b in range(B):
                 # downsample_rgbdimages(live_frame): valid lattice pixels of the global vertex map
                 if taped:

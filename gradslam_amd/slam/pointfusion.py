@@ -39,5 +39,12 @@ class PointFusion(ICPSLAM):
         self.dot_th = torch.cos(rad_th) if torch.is_tensor(rad_th) else math.cos(rad_th)
         self.sigma = sigma
 
+    def _localize(self, pointclouds: Pointclouds, live_frame: RGBDImages, prev_frame: RGBDImages):
+        if isinstance(live_frame, RGBDImages):
+            # the fusion step needs the sample confidences exp(-|v|^2 / 2 sigma^2): have the kernel that
+            # builds the vertex / normal maps of this frame emit them in the same pass
+            live_frame._sigma_hint = float(self.sigma)
+        return super()._localize(pointclouds, live_frame, prev_frame)
+
     def _map(self, pointclouds: Pointclouds, live_frame: RGBDImages, inplace: bool = False):
         return update_map_fusion(pointclouds, live_frame, self.dist_th, self.dot_th, self.sigma, inplace)

@@ -33,9 +33,11 @@ class _DeviceCount(object):
     that have already landed and never waits, so the frame loop has no host<->device sync.
     `resolve()` is the one blocking read-back, used when the exact count is finally needed."""
     RING = 8
+    EVERY = 4   # one asynchronous read-back per EVERY updates (each one is a copy + an event on the stream)
 
     def __init__(self, dev, bound):
         self.dev, self.bound = dev, int(bound)
+        self._updates = 0
         self._pin = torch.empty(self.RING, dtype=torch.int64).pin_memory()
         self._events = [torch.cuda.Event() for _ in range(self.RING)]
         self._pending = []   # [slot, rows that may have been added since that copy]
@@ -56,7 +58,9 @@ class _DeviceCount(object):
         self.bound += int(max_growth)
         for p in self._pending:
             p[1] += int(max_growth)
-        self._queue_copy()
+        self._updates += 1
+        if self._updates % self.EVERY == 0:   # the bound may lag EVERY + in-flight updates behind the count
+            self._queue_copy()
         self.poll()
 
     def poll(self):

@@ -80,6 +80,7 @@ class RGBDImages(object):
         self._global_normal_map = None
         self._valid_depth_mask = None
         self._alpha_cache = None  # (sigma, alpha map) computed by the same kernel as the vertex map
+        self._sigma_hint = None   # sigma a later consumer (PointFusion) will ask the alpha map for
 
         self._B, self._L = self._rgb_image.shape[:2]
         self.h = self._rgb_image.shape[3] if self._channels_first else self._rgb_image.shape[2]
@@ -163,6 +164,8 @@ class RGBDImages(object):
         B, L, H, W = self.shape
         depth = self._cl(self._depth_image)
         K = self._intrinsics.contiguous().float()
+        if sigma is None:
+            sigma = getattr(self, "_sigma_hint", None)
         if self._wants_grad():
             sg = 0.6 if sigma is None else float(sigma)
             rows = [[ops.FrameMapsFunction.apply(depth[b, s, ..., 0], K[b, 0], sg) for s in range(L)] for b in range(B)]
