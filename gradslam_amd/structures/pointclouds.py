@@ -33,7 +33,10 @@ class _DeviceCount(object):
     that have already landed and never waits, so the frame loop has no host<->device sync.
     `resolve()` is the one blocking read-back, used when the exact count is finally needed."""
     RING = 8
-    EVERY = 4   # one asynchronous read-back per EVERY updates (each one is a copy + an event on the stream)
+    EVERY = 2       # one asynchronous read-back per EVERY updates (each one is a copy + an event on the stream)
+    MAX_AHEAD = 2   # read-backs in flight before the host waits for the oldest: the host never runs more than
+                    # ~EVERY * (MAX_AHEAD + 1) frames ahead of the device, which keeps the bound (launch sizes,
+                    # capacity) within a few frames of the true count while the device always has work queued
 
     def __init__(self, dev, bound):
         self.dev, self.bound = dev, int(bound)
@@ -59,8 +62,10 @@ class _DeviceCount(object):
         for p in self._pending:
             p[1] += int(max_growth)
         self._updates += 1
-        if self._updates % self.EVERY == 0:   # the bound may lag EVERY + in-flight updates behind the count
+        if self._updates % self.EVERY == 0:
             self._queue_copy()
+            if len(self._pending) > self.MAX_AHEAD:
+                self._events[self._pending[0][0]].synchronize()   # frames old: the device is still busy behind it
         self.poll()
 
     def poll(self):
