@@ -94,6 +94,17 @@ static_assert(FS_QPB <= GS_WAVE && FS_QPB % 4 == 0 && FS_RG * LIN_NV <= FS_BLOCK
 //               with T_step applied, full normal equations)
 // FULL = false: look-ahead half              (prologue: solve + se3_exp, then search with Tr
 //               applied, residual only)
+// Workgroups are dealt round-robin to the 8 XCDs (block i runs on XCD i % 8), each with its own L2.
+// Logical block ids are therefore assigned so that every XCD works on ONE contiguous eighth of the
+// query rows: consecutive queries are neighbouring pixels of the frame, so the slice of the binned
+// target set an XCD touches is an eighth of the whole (+ halo) and stays resident in its L2 across
+// the 2 x numiters kernels of a solve (the full set of a 1296x968 frame is larger than one L2).
+constexpr unsigned GS_XCDS = 8;
+GS_DEV unsigned gs_xcd_block(unsigned b, unsigned nb) {
+  const unsigned q = nb / GS_XCDS, r = nb % GS_XCDS, x = b % GS_XCDS;
+  return x * q + (x < r ? x : r) + b / GS_XCDS;
+}
+
 template <bool FULL>
 __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
     const float* __restrict__ src_in, float* __restrict__ src_out, GsCount n_src_c, const float* __restrict__ tgt,
@@ -101,7 +112,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
     const float4* __restrict__ sorted, float dist_thresh, const double* __restrict__ partials_in,
     double* __restrict__ partials_out, const IcpSmall* __restrict__ st_in, IcpSmall* __restrict__ st_out,
     float* __restrict__ trace, gs_icp_params prm, int it, int64_t* __restrict__ out_idx,
-    int32_t* __restrict__ tape_idx, float* __restrict__ tape_sys) {
+    int32_t* __restrict__ tape_idx, float* __restrict__ tape_sys, int rows_in_reduced) {
   __shared__ IcpSmall sm;
   __shared__ double S[32];
   __shared__ double sub[FS_BLOCK / 32][32];
@@ -112,12 +123,14 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   __shared__ unsigned long long red[FS_BLOCK / GS_WAVE];
 
   const int64_t n_src = gs_count(n_src_c), n_tgt = gs_count(n_tgt_c);
-  const int nrows_in = (int)((n_src + FS_QPB - 1) / FS_QPB);  // rows the previous kernel produced
-  if ((int64_t)blockIdx.x * FS_QPB >= n_src && blockIdx.x != 0) return;  // beyond the actual count (bound-sized grid)
+  // rows the previous kernel produced (already added up to one row by gs_icp_reduce_rows_kernel for large solves)
+  const int nrows_in = rows_in_reduced ? 1 : (int)((n_src + FS_QPB - 1) / FS_QPB);
+  const unsigned lb = gs_xcd_block(blockIdx.x, gridDim.x);  // logical block: which FS_QPB queries this block owns
+  if ((int64_t)lb * FS_QPB >= n_src && lb != 0) return;  // beyond the actual count (bound-sized grid)
   // the source point of this group does not depend on the prologue: issue its load first so that
   // the global-memory latency hides behind the scalar stage
   const int lane = threadIdx.x & (GQ_G - 1), slot = threadIdx.x / GQ_G;
-  const int64_t s = (int64_t)blockIdx.x * FS_QPB + slot;
+  const int64_t s = (int64_t)lb * FS_QPB + slot;
   float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
   if (s < n_src) {
     p0 = src_in[3 * s];
@@ -138,7 +151,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
     else __syncthreads();
     if (threadIdx.x == 0) {
       IcpSmall loc = sm;  // scalar stage in registers, published through LDS
-      if (it > 0) icp_update_math((float)e1, loc, prm, (blockIdx.x == 0 && it - 1 < 64) ? trace + 12 * (it - 1) : nullptr);
+      if (it > 0) icp_update_math((float)e1, loc, prm, (lb == 0 && it - 1 < 64) ? trace + 12 * (it - 1) : nullptr);
       sm = loc;
       unres_n = 0;
     }
@@ -146,14 +159,14 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
     icp_sum_rows<FS_BLOCK>(partials_in, nrows_in, S, sub);
     if (threadIdx.x == 0) {
       IcpSmall loc = sm;
-      if (tape_sys && blockIdx.x == 0) tape_write_sys(tape_sys, it, S, loc.damp);
+      if (tape_sys && lb == 0) tape_write_sys(tape_sys, it, S, loc.damp);
       icp_solve_math(S, loc);
       sm = loc;
       unres_n = 0;
     }
   }
   __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(IcpSmall) / 4))
+  if (lb == 0 && threadIdx.x < (int)(sizeof(IcpSmall) / 4))
     reinterpret_cast<float*>(st_out)[threadIdx.x] = reinterpret_cast<const float*>(&sm)[threadIdx.x];
 
   // ---- search: one source point per 16-lane group, pending transform applied to the loaded point
@@ -187,7 +200,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   double v[LIN_NV];
 #pragma unroll
   for (int i = 0; i < LIN_NV; ++i) v[i] = 0.0;
-  const int64_t r = (int64_t)blockIdx.x * FS_QPB + threadIdx.x;
+  const int64_t r = (int64_t)lb * FS_QPB + threadIdx.x;
   if (threadIdx.x < FS_QPB && r < n_src) {
     const unsigned long long bb = keys_s[threadIdx.x];
     int64_t j = (int64_t)(bb & 0xffffffffull);
@@ -214,7 +227,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   if (!FULL) {  // residual only: one value, a plain wave reduction is enough
     if (threadIdx.x < GS_WAVE) {
       const double sum = gs_wave_sum_f64(v[27]);
-      if (threadIdx.x == 0) partials_out[(int64_t)blockIdx.x * LIN_NV + 27] = sum;
+      if (threadIdx.x == 0) partials_out[(int64_t)lb * LIN_NV + 27] = sum;
     }
     return;
   }
@@ -241,8 +254,21 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
     double t = sub_s[0][threadIdx.x];
 #pragma unroll
     for (int k = 1; k < FS_RG; ++k) t += sub_s[k][threadIdx.x];
-    partials_out[(int64_t)blockIdx.x * LIN_NV + threadIdx.x] = t;
+    partials_out[(int64_t)lb * LIN_NV + threadIdx.x] = t;
   }
+}
+
+// Large solves (more rows than FS_REDUCE_ROWS): every block of the next kernel adding up all rows is
+// O(rows^2) L2 traffic (1634 rows of a 1296x968 frame: 366 KB per block, 600 MB per launch).  One
+// extra single-block launch adds them up once, in the same order, into a one-row buffer.
+constexpr int FS_REDUCE_ROWS = 640;
+__global__ void __launch_bounds__(FS_BLOCK) gs_icp_reduce_rows_kernel(const double* __restrict__ partials_in,
+                                                                      GsCount n_src_c, double* __restrict__ row_out) {
+  __shared__ double S[32];
+  __shared__ double sub[FS_BLOCK / 32][32];
+  const int nrows = (int)((gs_count(n_src_c) + FS_QPB - 1) / FS_QPB);
+  icp_sum_rows<FS_BLOCK>(partials_in, nrows, S, sub);
+  if (threadIdx.x < LIN_NV) row_out[threadIdx.x] = S[threadIdx.x];
 }
 
 // After the last look-ahead: final LM / gradLM update and the (composed) result.
@@ -371,6 +397,7 @@ __global__ void gs_icp_init_kernel(GsIcpState* __restrict__ st, const float* __r
 
 struct IcpScratch {
   GsIcpState* state;
+  double* rowred;  // one partial row (large solves: gs_icp_reduce_rows_kernel)
   unsigned long long* best;
   float* srcA;
   float* srcB;
@@ -382,6 +409,7 @@ static IcpScratch icp_carve(void* scratch, int64_t n_src) {
   char* p = reinterpret_cast<char*>(scratch);
   IcpScratch s;
   s.state = reinterpret_cast<GsIcpState*>(p); p += gs_align(sizeof(GsIcpState));
+  s.rowred = reinterpret_cast<double*>(p); p += gs_align(sizeof(double) * 32);
   s.best = reinterpret_cast<unsigned long long*>(p); p += gs_align(8 * (size_t)n_src);
   s.srcA = reinterpret_cast<float*>(p); p += gs_align(12 * (size_t)n_src);
   s.srcB = reinterpret_cast<float*>(p); p += gs_align(12 * (size_t)n_src);
@@ -405,7 +433,7 @@ static bool icp_grid_enabled() {
 
 extern "C" int64_t gs_icp_scratch_bytes(int64_t n_src, int64_t n_tgt) {
   if (n_src < 1) n_src = 1;
-  return (int64_t)(gs_align(sizeof(GsIcpState)) + gs_align(8 * (size_t)n_src) + 2 * gs_align(12 * (size_t)n_src) +
+  return (int64_t)(gs_align(sizeof(GsIcpState)) + gs_align(sizeof(double) * 32) + gs_align(8 * (size_t)n_src) + 2 * gs_align(12 * (size_t)n_src) +
                    2 * gs_align(sizeof(double) * LIN_NV * icp_rows(n_src)) + gs_knn_grid_scratch_bytes(n_src, n_tgt) +
                    4096);
 }
@@ -453,6 +481,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
     if (rc != GS_OK) return rc;
     GridMem gm = grid_carve(sc.grid, n_src, n_tgt);
     const int nfs = (int)icp_rows(n_src);
+    const bool reduce_rows = nfs > FS_REDUCE_ROWS;
     const float* cur_in = src;  // cloud before the pending transform of the half-iteration
     int h = 0;                  // half-iteration index: kernel h reads s[h&1] / partials[(h+1)&1], writes the others
     for (int it = 0; it < prm->numiters; ++it) {
@@ -464,15 +493,21 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
         hipLaunchKernelGGL((gs_icp_half_kernel<true>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur_in, cur, n_src_c, tgt,
                            tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
                            sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
-                           &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, out_idx, tidx(it, 0), nullptr);
+                           &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, out_idx, tidx(it, 0), nullptr, 0);
       }
       ++h;
+      if (reduce_rows) {
+        GsProf prof(GS_PROF_SOLVE, 1.0, st);
+        hipLaunchKernelGGL(gs_icp_reduce_rows_kernel, dim3(1), dim3(FS_BLOCK), 0, st, sc.partials[(h + 1) & 1], n_src_c,
+                           sc.rowred);
+      }
       {
         GsProf prof(GS_PROF_ICP_FUSED, (double)n_src * 259.0 + 16.0 * (double)n_tgt, st);
         hipLaunchKernelGGL((gs_icp_half_kernel<false>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur, nullptr, n_src_c, tgt,
                            tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
-                           sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
-                           &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, nullptr, tidx(it, 1), tp.sys);
+                           reduce_rows ? sc.rowred : sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
+                           &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, nullptr, tidx(it, 1), tp.sys,
+                           reduce_rows ? 1 : 0);
       }
       ++h;
       cur_in = cur;

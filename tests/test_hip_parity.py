@@ -406,3 +406,23 @@ def test_device_side_map_counts_match_host_counts(ops):
             assert torch.equal(pc.points_list[0], ref_pts)
         else:
             ref_pts = pc.points_list[0].clone()
+
+
+def test_icp_large_solve_matches_oracle(ops):
+    """A solve with more query rows than FS_REDUCE_ROWS (the path with the extra row-reduction launch and
+    several waves of blocks per XCD): transform within 1e-6 of the oracle, neighbours identical."""
+    s = make_sequence(2, 484, 648, seed=21)            # ds=2 lattice: ~74k source points
+    K = dev(s["intrinsics"][0])
+    pose = dev(s["poses"][0])
+    sets = []
+    for f in (0, 1):
+        d = dev(s["depths"][f, ..., 0])
+        v, n, _, _ = ops.frame_maps(d, K)
+        gv, gn = ops.global_maps(v, n, d, pose)
+        sets.append(ops.downsample_frame(gv, gn, None, d, 2))
+    (tgt, tn, _), (src, _, _) = sets
+    assert src.shape[0] > 640 * 48 * 2
+    T, idx = ops.icp(src, tgt, tn, mode=1, numiters=4)
+    To, idxo = o.icp(host(src), host(tgt), host(tn), mode=1, numiters=4)[:2]
+    assert np.abs(host(T) - To).max() <= 1e-6
+    same_bits(host(idx), idxo)
