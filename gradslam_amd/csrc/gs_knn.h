@@ -32,6 +32,7 @@ struct GsGrid {
 
 struct GridMem {
   GsGrid* g;
+  unsigned* bbox;    // [6] order-preserving codes of the bounding box (max of ~code(lo), code(hi)); zeroed per build
   int* unres_count;  // [2], ping-pong between consecutive queries
   int* cell_count;   // [MAXCELL + 1]
   int* cell_start;   // [MAXCELL + 1]
@@ -43,7 +44,8 @@ struct GridMem {
 static inline GridMem grid_carve(void* scratch, int64_t n_src, int64_t n_tgt) {
   char* p = reinterpret_cast<char*>(scratch);
   GridMem m;
-  m.g = reinterpret_cast<GsGrid*>(p); p += 256;
+  m.g = reinterpret_cast<GsGrid*>(p); p += 128;
+  m.bbox = reinterpret_cast<unsigned*>(p); p += 128;
   m.unres_count = reinterpret_cast<int*>(p); p += 256;
   m.cell_count = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1));
   m.cell_start = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1));

@@ -130,22 +130,37 @@ size_t gs_knn_grid_scratch_bytes(int64_t n_src, int64_t n_tgt) {
          gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1)) + gs_align(4 * (size_t)(n_src > 0 ? n_src : 1)) + 256;
 }
 
-// One block: bounding box of the finite targets, then the cell size.  Heuristic: targets are a
-// sampled surface (spacing ~ sqrt(area / n)) or, failing that, a volume (spacing ~ cbrt(V / n));
-// the cell edge is the larger of 1.5 surface spacings and 0.5 volume spacings (3 shells then
-// still reach 1.75 volume spacings), grown until the grid fits GS_GRID_MAXCELL cells.  Any positive cell size is CORRECT; the choice only affects speed.
-__global__ void __launch_bounds__(1024) gs_grid_bbox_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
-                                                            GsGrid* __restrict__ g, int* __restrict__ unres_count) {
+// Bounding box of the finite targets: block-local min / max, then 6 atomicMax on order-preserving
+// codes (min and max are order-independent, so the result is deterministic).  code(v) grows with v;
+// the lower corner is kept as max(~code): zero-initialised words mean "nothing seen yet".
+GS_DEV unsigned grid_code(float v) {
+  const unsigned b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+GS_DEV float grid_decode(unsigned c) {
+  return __uint_as_float((c & 0x80000000u) ? (c & 0x7fffffffu) : ~c);
+}
+constexpr int GB_BLOCK = 256;
+constexpr int GB_ITEMS = 8;
+__global__ void __launch_bounds__(GB_BLOCK) gs_grid_bbox_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
+                                                                 unsigned* __restrict__ bbox,
+                                                                 int* __restrict__ unres_count) {
   const int64_t n_tgt = gs_count(n_tgt_c);
-  __shared__ float red[6][1024 / GS_WAVE];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { unres_count[0] = 0; unres_count[1] = 0; }
+  if ((int64_t)blockIdx.x * GB_BLOCK * GB_ITEMS >= n_tgt) return;
+  __shared__ float red[6][GB_BLOCK / GS_WAVE];
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int64_t i = threadIdx.x; i < n_tgt; i += 1024) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float v = tgt[3 * i + k];
-      if (v > -3.0e38f && v < 3.0e38f) {  // finite
-        lo[k] = v < lo[k] ? v : lo[k];
-        hi[k] = v > hi[k] ? v : hi[k];
+  for (int u = 0; u < GB_ITEMS; ++u) {
+    const int64_t i = ((int64_t)blockIdx.x * GB_ITEMS + u) * GB_BLOCK + threadIdx.x;
+    if (i < n_tgt) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float v = tgt[3 * i + k];
+        if (v > -3.0e38f && v < 3.0e38f) {  // finite
+          lo[k] = v < lo[k] ? v : lo[k];
+          hi[k] = v > hi[k] ? v : hi[k];
+        }
       }
     }
   }
@@ -162,48 +177,75 @@ __global__ void __launch_bounds__(1024) gs_grid_bbox_kernel(const float* __restr
     if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = b; }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float o[3], m[3];
-    for (int k = 0; k < 3; ++k) {
-      float a = red[k][0], b = red[3 + k][0];
-      for (int w = 1; w < 1024 / GS_WAVE; ++w) {
-        a = red[k][w] < a ? red[k][w] : a;
-        b = red[3 + k][w] > b ? red[3 + k][w] : b;
-      }
-      if (!(a <= b)) { a = 0.0f; b = 0.0f; }  // no finite coordinate on this axis
-      o[k] = a; m[k] = b;
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    float a = red[k][0], b = red[3 + k][0];
+    for (int w = 1; w < GB_BLOCK / GS_WAVE; ++w) {
+      a = red[k][w] < a ? red[k][w] : a;
+      b = red[3 + k][w] > b ? red[3 + k][w] : b;
     }
-    const float tiny = 1e-6f;
-    const float ex = (m[0] - o[0]) + tiny, ey = (m[1] - o[1]) + tiny, ez = (m[2] - o[2]) + tiny;
-    const float n = (float)(n_tgt > 0 ? n_tgt : 1);
-    const float area = ex * ey + ey * ez + ex * ez;
-    float c = 1.5f * sqrtf(area / n);
-    const float cv = 0.5f * cbrtf((ex * ey * ez) / n);
-    c = cv > c ? cv : c;
-    const float emax = ex > ey ? (ex > ez ? ex : ez) : (ey > ez ? ey : ez);
-    c = c > emax * (1.0f / 1024.0f) ? c : emax * (1.0f / 1024.0f);
-    c = c > 1e-6f ? c : 1e-6f;
-    int nx, ny, nz;
-    for (;;) {
-      nx = (int)(ex / c) + 1; ny = (int)(ey / c) + 1; nz = (int)(ez / c) + 1;
-      if ((double)nx * (double)ny * (double)nz <= (double)GS_GRID_MAXCELL) break;
-      c *= 1.26f;
+    if (a <= b) {  // at least one finite coordinate on this axis in this block
+      atomicMax(&bbox[k], ~grid_code(a));
+      atomicMax(&bbox[3 + k], grid_code(b));
     }
-    g->ox = o[0]; g->oy = o[1]; g->oz = o[2];
-    g->mx = m[0]; g->my = m[1]; g->mz = m[2];
-    g->c = c; g->inv_c = 1.0f / c;
-    g->nx = nx; g->ny = ny; g->nz = nz; g->ncell = nx * ny * nz;
-    unres_count[0] = 0;
-    unres_count[1] = 0;
   }
 }
 
+// Cell size from the bounding box.  Heuristic: targets are a sampled surface (spacing ~ sqrt(area / n))
+// or, failing that, a volume (spacing ~ cbrt(V / n)); the cell edge is the larger of 1.5 surface
+// spacings and 0.5 volume spacings (3 shells then still reach 1.75 volume spacings), grown until the
+// grid fits GS_GRID_MAXCELL cells.  Any positive cell size is CORRECT; the choice only affects speed.
+// Pure function of (bbox, n_tgt): every block that evaluates it gets the same grid.
+GS_DEV GsGrid grid_from_bbox(const unsigned* __restrict__ bbox, int64_t n_tgt) {
+  float o[3], m[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const unsigned cl = bbox[k], ch = bbox[3 + k];
+    float a = 0.0f, b = 0.0f;  // no finite coordinate on this axis
+    if (cl != 0u && ch != 0u) { a = grid_decode(~cl); b = grid_decode(ch); }
+    o[k] = a; m[k] = b;
+  }
+  const float tiny = 1e-6f;
+  const float ex = (m[0] - o[0]) + tiny, ey = (m[1] - o[1]) + tiny, ez = (m[2] - o[2]) + tiny;
+  const float n = (float)(n_tgt > 0 ? n_tgt : 1);
+  const float area = ex * ey + ey * ez + ex * ez;
+  float c = 1.5f * sqrtf(area / n);
+  const float cv = 0.5f * cbrtf((ex * ey * ez) / n);
+  c = cv > c ? cv : c;
+  const float emax = ex > ey ? (ex > ez ? ex : ez) : (ey > ez ? ey : ez);
+  c = c > emax * (1.0f / 1024.0f) ? c : emax * (1.0f / 1024.0f);
+  c = c > 1e-6f ? c : 1e-6f;
+  int nx, ny, nz;
+  for (;;) {
+    nx = (int)(ex / c) + 1; ny = (int)(ey / c) + 1; nz = (int)(ez / c) + 1;
+    if ((double)nx * (double)ny * (double)nz <= (double)GS_GRID_MAXCELL) break;
+    c *= 1.26f;
+  }
+  GsGrid g;
+  g.ox = o[0]; g.oy = o[1]; g.oz = o[2];
+  g.mx = m[0]; g.my = m[1]; g.mz = m[2];
+  g.c = c; g.inv_c = 1.0f / c;
+  g.nx = nx; g.ny = ny; g.nz = nz; g.ncell = nx * ny * nz;
+  return g;
+}
+
+// Every block derives the grid header from the bounding box (block 0 publishes it for the kernels
+// that follow), then counts its targets per cell.
 __global__ void __launch_bounds__(256) gs_grid_count_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
-                                                            const GsGrid* __restrict__ gp,
+                                                            const unsigned* __restrict__ bbox,
+                                                            GsGrid* __restrict__ gp,
                                                             int* __restrict__ cell_count) {
+  __shared__ GsGrid gsh;
+  const int64_t n_tgt = gs_count(n_tgt_c);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= gs_count(n_tgt_c)) return;
-  const GsGrid g = *gp;
+  if ((int64_t)blockIdx.x * 256 >= n_tgt && blockIdx.x != 0) return;
+  if (threadIdx.x == 0) {
+    gsh = grid_from_bbox(bbox, n_tgt);
+    if (blockIdx.x == 0) *gp = gsh;
+  }
+  __syncthreads();
+  if (i >= n_tgt) return;
+  const GsGrid g = gsh;
   atomicAdd(&cell_count[grid_cell(g, tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2])], 1);
 }
 
@@ -270,11 +312,14 @@ int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* gr
   const int64_t n_tgt = n_tgt_c.host;  // upper bound: launch geometry and scratch layout
   GridMem m = grid_carve(grid_scratch, n_src, n_tgt);
   GsProf prof(GS_PROF_COMPACT, 28.0 * (double)n_tgt + 8.0 * GS_GRID_MAXCELL, st);
-  hipError_t e = hipMemsetAsync(m.cell_count, 0, 4 * (size_t)(GS_GRID_MAXCELL + 1), st);
+  // one memset: bbox codes + unresolved counters + cell counts (contiguous in the scratch layout)
+  hipError_t e = hipMemsetAsync(m.bbox, 0, (size_t)(reinterpret_cast<char*>(m.cell_count) - reinterpret_cast<char*>(m.bbox)) +
+                                               4 * (size_t)(GS_GRID_MAXCELL + 1), st);
   if (e != hipSuccess) { gs_set_error("gs_knn_grid_build: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
-  hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3(1), dim3(1024), 0, st, tgt, n_tgt_c, m.g, m.unres_count);
-  hipLaunchKernelGGL(gs_grid_count_kernel, dim3((unsigned)gs_ceil_div(n_tgt, 256)), dim3(256), 0, st, tgt, n_tgt_c,
-                     m.g, m.cell_count);
+  hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, GB_BLOCK * GB_ITEMS)),
+                     dim3(GB_BLOCK), 0, st, tgt, n_tgt_c, m.bbox, m.unres_count);
+  hipLaunchKernelGGL(gs_grid_count_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, 256)), dim3(256), 0, st,
+                     tgt, n_tgt_c, m.bbox, m.g, m.cell_count);
   const unsigned ntile = (unsigned)gs_ceil_div(GS_GRID_MAXCELL + 1, GS_GRID_TILE);
   hipLaunchKernelGGL(gs_grid_tile_sum_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums);
   hipLaunchKernelGGL(gs_grid_scan_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums,
