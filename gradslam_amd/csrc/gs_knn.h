@@ -19,7 +19,7 @@ int gs_knn_brute_launch(const float* src_in, const float* Tapply, float* src_out
 // (same distances, same tie-break); queries the grid cannot resolve within GS_GRID_RINGS shells
 // are finished by brute force (a separate pass in gs_knn_grid_query, in-block in the fused ICP
 // kernels).
-constexpr int GS_GRID_MAXCELL = 1 << 20;
+constexpr int GS_GRID_MAXCELL = 1 << 22;
 constexpr int GS_GRID_RINGS = 3;
 constexpr int GS_GRID_TILE = 1024;
 

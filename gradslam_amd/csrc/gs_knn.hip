@@ -194,9 +194,9 @@ __global__ void __launch_bounds__(GB_BLOCK) gs_grid_bbox_kernel(const float* __r
 // Cell size from the bounding box.  Heuristic: targets are a sampled surface (spacing ~ sqrt(area / n))
 // or, failing that, a volume (spacing ~ cbrt(V / n)); the cell edge is the larger of 1.5 surface
 // spacings and 0.5 volume spacings (3 shells then still reach 1.75 volume spacings), grown until the
-// grid fits GS_GRID_MAXCELL cells.  Any positive cell size is CORRECT; the choice only affects speed.
+// grid fits cells_cap cells.  Any positive cell size is CORRECT; the choice only affects speed.
 // Pure function of (bbox, n_tgt): every block that evaluates it gets the same grid.
-GS_DEV GsGrid grid_from_bbox(const unsigned* __restrict__ bbox, int64_t n_tgt) {
+GS_DEV GsGrid grid_from_bbox(const unsigned* __restrict__ bbox, int64_t n_tgt, int cells_cap) {
   float o[3], m[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -218,7 +218,7 @@ GS_DEV GsGrid grid_from_bbox(const unsigned* __restrict__ bbox, int64_t n_tgt) {
   int nx, ny, nz;
   for (;;) {
     nx = (int)(ex / c) + 1; ny = (int)(ey / c) + 1; nz = (int)(ez / c) + 1;
-    if ((double)nx * (double)ny * (double)nz <= (double)GS_GRID_MAXCELL) break;
+    if ((double)nx * (double)ny * (double)nz <= (double)cells_cap) break;
     c *= 1.26f;
   }
   GsGrid g;
@@ -234,13 +234,13 @@ GS_DEV GsGrid grid_from_bbox(const unsigned* __restrict__ bbox, int64_t n_tgt) {
 __global__ void __launch_bounds__(256) gs_grid_count_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
                                                             const unsigned* __restrict__ bbox,
                                                             GsGrid* __restrict__ gp,
-                                                            int* __restrict__ cell_count) {
+                                                            int* __restrict__ cell_count, int cells_cap) {
   __shared__ GsGrid gsh;
   const int64_t n_tgt = gs_count(n_tgt_c);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if ((int64_t)blockIdx.x * 256 >= n_tgt && blockIdx.x != 0) return;
   if (threadIdx.x == 0) {
-    gsh = grid_from_bbox(bbox, n_tgt);
+    gsh = grid_from_bbox(bbox, n_tgt, cells_cap);
     if (blockIdx.x == 0) *gp = gsh;
   }
   __syncthreads();
@@ -311,16 +311,24 @@ __global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __res
 int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* grid_scratch, hipStream_t st) {
   const int64_t n_tgt = n_tgt_c.host;  // upper bound: launch geometry and scratch layout
   GridMem m = grid_carve(grid_scratch, n_src, n_tgt);
-  GsProf prof(GS_PROF_COMPACT, 28.0 * (double)n_tgt + 8.0 * GS_GRID_MAXCELL, st);
+  // Cells the grid of this build may use (what is cleared and scanned per build): the target density the
+  // cell size has to follow grows with the query lattice (the targets are map surfels seen on the same
+  // lattice, several per pixel in a mature map), so the budget is tied to n_src; a host-exact n_tgt
+  // (API calls) may raise it.  1M cells for a 640x480 frame, 4M for 1296x968.
+  int64_t want = 48 * n_src;
+  if (!n_tgt_c.dev && 16 * n_tgt > want) want = 16 * n_tgt;
+  int cells_cap = 1 << 20;
+  while (cells_cap < GS_GRID_MAXCELL && cells_cap < want) cells_cap <<= 1;
+  GsProf prof(GS_PROF_COMPACT, 28.0 * (double)n_tgt + 8.0 * (double)cells_cap, st);
   // one memset: bbox codes + unresolved counters + cell counts (contiguous in the scratch layout)
   hipError_t e = hipMemsetAsync(m.bbox, 0, (size_t)(reinterpret_cast<char*>(m.cell_count) - reinterpret_cast<char*>(m.bbox)) +
-                                               4 * (size_t)(GS_GRID_MAXCELL + 1), st);
+                                               4 * (size_t)(cells_cap + 1), st);
   if (e != hipSuccess) { gs_set_error("gs_knn_grid_build: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
   hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, GB_BLOCK * GB_ITEMS)),
                      dim3(GB_BLOCK), 0, st, tgt, n_tgt_c, m.bbox, m.unres_count);
   hipLaunchKernelGGL(gs_grid_count_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, 256)), dim3(256), 0, st,
-                     tgt, n_tgt_c, m.bbox, m.g, m.cell_count);
-  const unsigned ntile = (unsigned)gs_ceil_div(GS_GRID_MAXCELL + 1, GS_GRID_TILE);
+                     tgt, n_tgt_c, m.bbox, m.g, m.cell_count, cells_cap);
+  const unsigned ntile = (unsigned)gs_ceil_div(cells_cap + 1, GS_GRID_TILE);
   hipLaunchKernelGGL(gs_grid_tile_sum_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums);
   hipLaunchKernelGGL(gs_grid_scan_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums,
                      m.cell_start);
