@@ -303,13 +303,19 @@ extern "C" int gs_similar_rows_f32(const int64_t* rows, int64_t n_rows, const fl
 // Two order-independent (hence deterministic) atomic passes replace the reference's
 // torch.unique(dim=0) sort: pass 1 takes the per-pixel minimum of the (1/cc, ray) key, pass 2
 // the minimum map index among the rows that attain it.
-__global__ void __launch_bounds__(256) gs_fill_u64_kernel(uint64_t* p, int64_t n, uint64_t v) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = v;
-}
+// best_pix starts as -1 = 0xffffffff: the winners are then reduced with an UNSIGNED atomicMin, so a
+// pixel nobody claims keeps -1 ("no correspondence") and no fix-up pass is needed.
 __global__ void __launch_bounds__(256) gs_fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = v;
+}
+__global__ void __launch_bounds__(256) gs_assoc_init_kernel(uint64_t* __restrict__ key_pix,
+                                                            int32_t* __restrict__ best_pix, int64_t P) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < P) {
+    key_pix[i] = ~0ull;
+    best_pix[i] = -1;
+  }
 }
 
 __global__ void __launch_bounds__(256) gs_rows_key_kernel(
@@ -329,12 +335,7 @@ __global__ void __launch_bounds__(256) gs_rows_pick_kernel(
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= n_rows) return;
   const int64_t n = rows[4 * r + 1], p = rows[4 * r + 2] * W + rows[4 * r + 3];
-  // best_pix holds n | 0x80000000-free encoding: initialised to INT32_MAX, min over winners
-  if (key_row[r] == key_pix[p]) atomicMin(&best_pix[p], (int32_t)n);
-}
-__global__ void __launch_bounds__(256) gs_best_fix_kernel(int32_t* __restrict__ best_pix, int64_t P) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < P && best_pix[i] == 0x7fffffff) best_pix[i] = -1;
+  if (key_row[r] == key_pix[p]) atomicMin(reinterpret_cast<unsigned*>(&best_pix[p]), (unsigned)n);
 }
 
 struct PredBest {
@@ -374,15 +375,13 @@ extern "C" int gs_best_unique_rows_f32(const int64_t* rows, int64_t n_rows, cons
   char* base = reinterpret_cast<char*>(scratch) + gs_cp_scratch_bytes(P > n_rows ? P : n_rows);
   uint64_t* key_pix = reinterpret_cast<uint64_t*>(base);
   uint64_t* key_row = reinterpret_cast<uint64_t*>(base + gs_align(8 * (size_t)P));
-  hipLaunchKernelGGL(gs_fill_u64_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, key_pix, P, ~0ull);
-  hipLaunchKernelGGL(gs_fill_i32_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, best_pix, P, 0x7fffffff);
+  hipLaunchKernelGGL(gs_assoc_init_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, key_pix, best_pix, P);
   if (n_rows > 0) {
     hipLaunchKernelGGL(gs_rows_key_kernel, dim3(gs_blocks(n_rows)), dim3(256), 0, st, rows, n_rows, points,
                        ccounts, gvertex, W, key_row, reinterpret_cast<unsigned long long*>(key_pix));
     hipLaunchKernelGGL(gs_rows_pick_kernel, dim3(gs_blocks(n_rows)), dim3(256), 0, st, rows, n_rows, W,
                        key_row, key_pix, best_pix);
   }
-  hipLaunchKernelGGL(gs_best_fix_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, best_pix, P);
   GS_LAUNCH_CHECK();
   if (rows_out) return gs_best_table_i64(best_pix, H, W, b, rows_out, count_out, scratch, stream);
   return GS_OK;
@@ -416,7 +415,7 @@ __global__ void __launch_bounds__(256) gs_assoc_pick_kernel(
   const uint64_t k = key_pt[n];
   if (k == ~0ull) return;  // not similar (a real key can never be all ones: ray is not NaN-coded)
   const int32_t p = pix[n];
-  if (k == key_pix[p]) atomicMin(&best_pix[p], (int32_t)n);
+  if (k == key_pix[p]) atomicMin(reinterpret_cast<unsigned*>(&best_pix[p]), (unsigned)n);
 }
 
 static int associate(const int32_t* pix, GsCount n_map_c, const float* points, const float* normals,
@@ -431,11 +430,10 @@ static int associate(const int32_t* pix, GsCount n_map_c, const float* points, c
   char* base = reinterpret_cast<char*>(scratch) + gs_cp_scratch_bytes(P > n_map ? P : n_map);
   uint64_t* key_pix = reinterpret_cast<uint64_t*>(base);
   uint64_t* key_pt = reinterpret_cast<uint64_t*>(base + gs_align(8 * (size_t)P));
-  // 4 launches: map rows 4+12+12+4 B read, 8 B key write, 4+8 B re-read; frame gathers 24 B per
-  // active point (counted as all points); per pixel 12 B init + 8 B key + 8 B winner traffic
-  GsProf prof(GS_PROF_ASSOC, 76.0 * (double)n_map + 28.0 * (double)P, st);
-  hipLaunchKernelGGL(gs_fill_u64_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, key_pix, P, ~0ull);
-  hipLaunchKernelGGL(gs_fill_i32_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, best_pix, P, 0x7fffffff);
+  // 3 launches: map rows 4+12+12+4 B read, 8 B key write, 4+8 B re-read; frame gathers 24 B per
+  // active point (counted as all points); per pixel 12 B init + 8 B key traffic
+  GsProf prof(GS_PROF_ASSOC, 76.0 * (double)n_map + 20.0 * (double)P, st);
+  hipLaunchKernelGGL(gs_assoc_init_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, key_pix, best_pix, P);
   if (n_map > 0) {
     GS_REQUIRE(pix && points && normals && ccounts && gvertex && gnormal, "NULL pointer");
     hipLaunchKernelGGL(gs_assoc_key_kernel, dim3(gs_blocks(n_map)), dim3(256), 0, st, pix, n_map_c, points,
@@ -444,7 +442,6 @@ static int associate(const int32_t* pix, GsCount n_map_c, const float* points, c
     hipLaunchKernelGGL(gs_assoc_pick_kernel, dim3(gs_blocks(n_map)), dim3(256), 0, st, pix, n_map_c, key_pt,
                        key_pix, best_pix);
   }
-  hipLaunchKernelGGL(gs_best_fix_kernel, dim3(gs_blocks(P)), dim3(256), 0, st, best_pix, P);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

@@ -5,9 +5,12 @@
 // per appended pixel.
 #include "gs_compact.h"
 
-__global__ void __launch_bounds__(256) gs_fill_i32_kernel2(int32_t* p, int64_t n, int32_t v) {
+// pix_of[] = -1 and the "table is non-empty" flag = 0, in one launch
+__global__ void __launch_bounds__(256) gs_fuse_init_kernel(int32_t* __restrict__ pix_of, int64_t n,
+                                                           int32_t* __restrict__ any_flag) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = v;
+  if (i == 0) *any_flag = 0;
+  if (i < n) pix_of[i] = -1;
 }
 
 // pixel -> matched map row scatter; also raises the "table is non-empty" flag.
@@ -100,9 +103,8 @@ static int fuse_append(float* points, float* normals, float* colors, float* ccou
   // parity mode rewrites every row (2 x 40 B) + 8 B pix_of traffic; appended pixels 40 B + 40 B
   GsProf prof(GS_PROF_FUSE, 88.0 * (double)n_map + 45.0 * (double)P, st);
   if (n_map > 0) {
-    GS_HIP(hipMemsetAsync(any_flag, 0, 4, st));
-    hipLaunchKernelGGL(gs_fill_i32_kernel2, dim3((unsigned)gs_ceil_div(n_map, 256)), dim3(256), 0, st,
-                       pix_of, n_map, -1);
+    hipLaunchKernelGGL(gs_fuse_init_kernel, dim3((unsigned)gs_ceil_div(n_map, 256)), dim3(256), 0, st,
+                       pix_of, n_map, any_flag);
     hipLaunchKernelGGL(gs_fuse_scatter_kernel, dim3((unsigned)gs_ceil_div(P, 256)), dim3(256), 0, st,
                        best_pix, P, n_map_c, pix_of, any_flag);
     hipLaunchKernelGGL(gs_fuse_merge_kernel, dim3((unsigned)gs_ceil_div(n_map, 256)), dim3(256), 0, st,
