@@ -39,10 +39,10 @@ GS_DEV void tape_write_sys(float* __restrict__ sys, int it, const double* S, flo
 }
 
 // ---------------------------------------------------------------- fixed-order sums ------
-// Adds up partial rows (nrows x LIN_NV doubles).  Thread t works on value t%32 and row subset
-// t/32; up to 20 independent loads are in flight per thread (two memory rounds for a 640x480
-// solve); the sub-sums are then added in index order.  Every
-// block that runs this on the same rows gets bit-identical sums.
+// Adds up partial rows (nrows x LIN_NV doubles).  Thread t works on value t%32 and the contiguous
+// chunk of CH rows number t/32 (then every STEP*CH rows further): its CH loads are 224 B apart, i.e.
+// one base address with immediate offsets, all in flight together; the chunk sums are then added in
+// chunk order.  Every block that runs this on the same rows gets bit-identical sums.
 template <int BLOCK>
 GS_DEV void icp_sum_rows(const double* __restrict__ partials, int nrows, double* S, double (*sub)[32]) {
   constexpr int STEP = BLOCK / 32;
@@ -52,10 +52,12 @@ GS_DEV void icp_sum_rows(const double* __restrict__ partials, int nrows, double*
   const int i = threadIdx.x & 31, j = threadIdx.x >> 5;
   double s = 0.0;
   if (i < LIN_NV) {
-    for (int b = j; b < nrows; b += CH * STEP) {
+    for (int b = j * CH; b < nrows; b += CH * STEP) {
+      const double* base = partials + (int64_t)b * LIN_NV + i;
+      const int left = nrows - b;
       double a[CH];
 #pragma unroll
-      for (int u = 0; u < CH; ++u) a[u] = (b + u * STEP < nrows) ? partials[(int64_t)(b + u * STEP) * LIN_NV + i] : 0.0;
+      for (int u = 0; u < CH; ++u) a[u] = (u < left) ? base[u * LIN_NV] : 0.0;
 #pragma unroll
       for (int u = 0; u < CH; ++u) s += a[u];
     }
@@ -149,19 +151,17 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
     double e1 = 0.0;
     if (it > 0) e1 = icp_sum_col27<FS_BLOCK>(partials_in, nrows_in, reinterpret_cast<double*>(red));
     else __syncthreads();
-    if (threadIdx.x == 0) {
-      IcpSmall loc = sm;  // scalar stage in registers, published through LDS
-      if (it > 0) icp_update_math((float)e1, loc, prm, (lb == 0 && it - 1 < 64) ? trace + 12 * (it - 1) : nullptr);
-      sm = loc;
+    if (threadIdx.x == 0) {  // scalar stage, in place on the LDS copy of the state
+      if (it > 0) icp_update_math((float)e1, sm, prm, (lb == 0 && it - 1 < 64) ? trace + 12 * (it - 1) : nullptr);
       unres_n = 0;
     }
   } else {
     icp_sum_rows<FS_BLOCK>(partials_in, nrows_in, S, sub);
+    if (threadIdx.x < GS_WAVE) gs_solve_spd6_wave(S, sm.damp, sm.xi);  // 6x6 solve across the lanes of wave 0
+    __syncthreads();
     if (threadIdx.x == 0) {
-      IcpSmall loc = sm;
-      if (tape_sys && lb == 0) tape_write_sys(tape_sys, it, S, loc.damp);
-      icp_solve_math(S, loc);
-      sm = loc;
+      if (tape_sys && lb == 0) tape_write_sys(tape_sys, it, S, sm.damp);
+      icp_solve_finish(S, sm);
       unres_n = 0;
     }
   }
@@ -196,37 +196,41 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   }
   __syncthreads();
 
-  // ---- rows: lane t < 32 of wave 0 builds the row of query t
-  double v[LIN_NV];
-#pragma unroll
-  for (int i = 0; i < LIN_NV; ++i) v[i] = 0.0;
+  // ---- rows: lane t < FS_QPB of wave 0 builds the row of query t; the 28 products go straight to LDS
+  // (held in registers they would be 56 VGPRs per lane)
+  __shared__ double rows_s[FS_QPB][LIN_NV + 1];
+  __shared__ double sub_s[FS_RG][LIN_NV];
   const int64_t r = (int64_t)lb * FS_QPB + threadIdx.x;
-  if (threadIdx.x < FS_QPB && r < n_src) {
-    const unsigned long long bb = keys_s[threadIdx.x];
-    int64_t j = (int64_t)(bb & 0xffffffffull);
-    if (j >= n_tgt) j = 0;  // only when every distance was NaN
-    const float d2 = __uint_as_float((uint32_t)(bb >> 32));
-    const bool keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
-    float a[6], res;
-    gn_row(qs[threadIdx.x][0], qs[threadIdx.x][1], qs[threadIdx.x][2], tgt, tn, j, a, res);
-    if (FULL && out_idx) out_idx[r] = j;
-    if (tape_idx) tape_idx[r] = keep ? (int32_t)j : -1;
-    if (keep) {
-      if (FULL) {
-        int q = 0;
+  double rr = 0.0;
+  if (threadIdx.x < FS_QPB) {
+    bool keep = false;
+    float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, res = 0.0f;
+    if (r < n_src) {
+      const unsigned long long bb = keys_s[threadIdx.x];
+      int64_t j = (int64_t)(bb & 0xffffffffull);
+      if (j >= n_tgt) j = 0;  // only when every distance was NaN
+      const float d2 = __uint_as_float((uint32_t)(bb >> 32));
+      keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
+      gn_row(qs[threadIdx.x][0], qs[threadIdx.x][1], qs[threadIdx.x][2], tgt, tn, j, a, res);
+      if (FULL && out_idx) out_idx[r] = j;
+      if (tape_idx) tape_idx[r] = keep ? (int32_t)j : -1;
+    }
+    if (keep) rr = (double)res * (double)res;
+    if (FULL) {
+      double* row = rows_s[threadIdx.x];
+      int q = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+      for (int i = 0; i < 6; ++i)
 #pragma unroll
-          for (int k = i; k < 6; ++k) v[q++] = (double)a[i] * (double)a[k];
+        for (int k = i; k < 6; ++k) row[q++] = keep ? (double)a[i] * (double)a[k] : 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v[21 + i] = (double)a[i] * (double)res;
-      }
-      v[27] = (double)res * (double)res;
+      for (int i = 0; i < 6; ++i) row[21 + i] = keep ? (double)a[i] * (double)res : 0.0;
+      row[27] = rr;
     }
   }
   if (!FULL) {  // residual only: one value, a plain wave reduction is enough
     if (threadIdx.x < GS_WAVE) {
-      const double sum = gs_wave_sum_f64(v[27]);
+      const double sum = gs_wave_sum_f64(rr);
       if (threadIdx.x == 0) partials_out[(int64_t)lb * LIN_NV + 27] = sum;
     }
     return;
@@ -234,12 +238,6 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   // FS_QPB rows x 28 values through LDS (a 28-fold wave shuffle reduction costs ~6 us of dependent
   // cross-lane traffic in one wave): FS_RG groups of 28 threads add 4 rows each, then 28 threads
   // add the sub-sums, always in index order.
-  __shared__ double rows_s[FS_QPB][LIN_NV + 1];
-  __shared__ double sub_s[FS_RG][LIN_NV];
-  if (threadIdx.x < FS_QPB) {
-#pragma unroll
-    for (int i = 0; i < LIN_NV; ++i) rows_s[threadIdx.x][i] = v[i];
-  }
   __syncthreads();
   if (threadIdx.x < FS_RG * LIN_NV) {
     const int i = threadIdx.x % LIN_NV, part = threadIdx.x / LIN_NV;
@@ -355,11 +353,16 @@ __global__ void __launch_bounds__(SUM_BLOCK) gs_icp_solve_kernel(const double* _
                                                                  float* __restrict__ tape_sys) {
   __shared__ double S[32];
   __shared__ double sub[SUM_BLOCK / 32][32];
+  __shared__ float xi_s[8];
   icp_sum_rows<SUM_BLOCK>(partials, nrows, S, sub);
+  if (threadIdx.x >= GS_WAVE) return;
+  gs_solve_spd6_wave(S, st->s[0].damp, xi_s);  // same wave: LDS accesses of a wave are ordered
+  __builtin_amdgcn_wave_barrier();
   if (threadIdx.x != 0) return;
   IcpSmall sm = st->s[0];
   if (tape_sys) tape_write_sys(tape_sys, it, S, sm.damp);
-  icp_solve_math(S, sm);
+  for (int k = 0; k < 6; ++k) sm.xi[k] = xi_s[k];
+  icp_solve_finish(S, sm);
   st->s[0] = sm;
 }
 

@@ -157,37 +157,46 @@ GS_DEV double gs_log_fast(double y) {
   return 2.0 * z * p + (double)e * 0.69314718055994530942;
 }
 
-// geometry/se3utils.py:77-115 in double, rounded once (same order as the oracle).
+// geometry/se3utils.py:77-115 in double, rounded once (same order as the oracle).  Written row by
+// row (each entry: the same operations in the same order as the matrix form) so that only a handful
+// of doubles are live at a time: this runs on one lane inside kernels capped at 80 VGPRs.
 GS_DEV void gs_se3_exp_dev(const float* xi6, float* T16) {
   const double v[3] = {xi6[0], xi6[1], xi6[2]}, w[3] = {xi6[3], xi6[4], xi6[5]};
-  const double wh[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
-  double R[9], V[9];
   const double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-  if ((float)theta < 1e-6f) {
-    for (int i = 0; i < 9; ++i) {
-      R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + wh[i];
-      V[i] = R[i];
-    }
-  } else {
-    double wh2[9];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) {
-        double s = 0;
-        for (int k = 0; k < 3; ++k) s += wh[3 * i + k] * wh[3 * k + j];
-        wh2[3 * i + j] = s;
-      }
-    double s, c;
-    gs_sincos_fast(theta, &s, &c);
-    const double Ac = s / theta, Bc = (1 - c) / (theta * theta), Cc = (theta - s) / (theta * theta * theta);
-    for (int i = 0; i < 9; ++i) {
-      const double I = (i % 4 == 0) ? 1.0 : 0.0;
-      R[i] = I + Ac * wh[i] + Bc * wh2[i];
-      V[i] = I + Bc * wh[i] + Cc * wh2[i];
-    }
+  const bool small = (float)theta < 1e-6f;
+  double Ac = 0.0, Bc = 0.0, Cc = 0.0;
+  if (!small) {
+    double sn, cs;
+    gs_sincos_fast(theta, &sn, &cs);
+    Ac = sn / theta; Bc = (1 - cs) / (theta * theta); Cc = (theta - sn) / (theta * theta * theta);
   }
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
-    for (int j = 0; j < 3; ++j) T16[4 * i + j] = (float)R[3 * i + j];
-    T16[4 * i + 3] = (float)(V[3 * i] * v[0] + V[3 * i + 1] * v[1] + V[3 * i + 2] * v[2]);
+    // row i of the hat matrix: wh[i][j]
+    const double whi[3] = {i == 0 ? 0.0 : (i == 1 ? w[2] : -w[1]), i == 0 ? -w[2] : (i == 1 ? 0.0 : w[0]),
+                           i == 0 ? w[1] : (i == 1 ? -w[0] : 0.0)};
+    double Ri[3], Vi[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double I = (i == j) ? 1.0 : 0.0;
+      if (small) {
+        Ri[j] = I + whi[j];
+        Vi[j] = Ri[j];
+      } else {
+        // wh2[i][j] = sum_k wh[i][k] * wh[k][j], k ascending, starting from 0
+        double s2 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double wkj = (k == j) ? 0.0
+                             : (k == 0 ? (j == 1 ? -w[2] : w[1]) : (k == 1 ? (j == 0 ? w[2] : -w[0]) : (j == 0 ? -w[1] : w[0])));
+          s2 += whi[k] * wkj;
+        }
+        Ri[j] = I + Ac * whi[j] + Bc * s2;
+        Vi[j] = I + Bc * whi[j] + Cc * s2;
+      }
+      T16[4 * i + j] = (float)Ri[j];
+    }
+    T16[4 * i + 3] = (float)(Vi[0] * v[0] + Vi[1] * v[1] + Vi[2] * v[2]);
   }
   T16[12] = 0; T16[13] = 0; T16[14] = 0; T16[15] = 1;
 }
@@ -233,8 +242,47 @@ struct IcpSmall {
   float pad[2];
 };
 
+// gs_solve_spd<6> spread over one wave: lane l < 42 owns a[r][j] (r = l / 7, j = l % 7) of the augmented
+// matrix; every element sees exactly the operations of the serial code, in the same order, so x is
+// bit-identical -- but the 84 VGPRs of a[6][7] in one lane become one double per lane and the 6 pivot
+// steps cost a division and three shuffles each.  All 64 lanes of the wave must call it.
+// S = the 28 sums (21 upper-triangular AtA, 6 Atb, rtr); x_out receives the 6 solution components.
+GS_DEV void gs_solve_spd6_wave(const double* S, float damp, float* x_out) {
+  const int l = threadIdx.x & 63, r = l / 7, j = l % 7;
+  const bool active = l < 42;
+  double a = 0.0;
+  if (active) {
+    if (j < 6) {
+      const int lo = r < j ? r : j, hi = r < j ? j : r;
+      const float v = (float)S[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+      const float e = (r == j) ? 1.0f : 0.0f;
+      a = (double)(v + e * damp);  // At_A + damp_matrix * damp, in float32
+    } else {
+      a = (double)(float)S[21 + r];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double piv = __shfl(a, c * 7 + c, 64);
+    const double rowv = __shfl(a, c * 7 + j, 64);
+    const double f = __shfl(a, (r < 6 ? r : 0) * 7 + c, 64);
+    const double inv = 1.0 / piv;
+    if (active && j >= c) {
+      const double sc = rowv * inv;
+      a = (r == c) ? sc : a - f * sc;
+    }
+  }
+  if (active && j == 6) x_out[r] = (float)a;
+}
+
 // After the first linearisation of an iteration (S = the 28 normal-equation sums, float64):
 // err = r.r, xi = (AtA + damp I)^-1 Atb, Tr = se3_exp(xi)   (odometry/icputils.py:328-337 / :498-507)
+// Two-step form used by the kernels: gs_solve_spd6_wave(S, s.damp, s.xi) by one wave, a barrier, then
+// icp_solve_finish by one lane.  icp_solve_math is the same computation on a single lane.
+GS_DEV void icp_solve_finish(const double* S, IcpSmall& s) {
+  s.err = (float)S[27];
+  gs_se3_exp_dev(s.xi, s.Tr);
+}
 GS_DEV void icp_solve_math(const double* S, IcpSmall& s) {
   float AtA[36], Atb[6], xi[6];
   int q = 0;
@@ -258,21 +306,20 @@ GS_DEV void icp_solve_math(const double* S, IcpSmall& s) {
 // odometry/icputils.py:356-365) or the gradLM soft update (mode 1, :527-543).  Sets T_step,
 // T_total, damp; trace_row (12 floats, may be NULL) = [err, new_err, damp, sigmoid, xi(6), 0, 0].
 GS_DEV void icp_update_math(float new_err, IcpSmall& s, const gs_icp_params& prm, float* trace_row) {
+  // works in place on `s` (LDS in the fused kernels): T_step is written where it lives and T_total is
+  // updated through gs_mm4's 16-float temporary, so few values are live at a time
   const float err = s.err;
   float damp = s.damp;
-  float Tstep[16], Ttot[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) Ttot[i] = s.T_total[i];
   float sig = 1.0f;
   if (prm.mode == 0) {
     if (new_err < err) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) Tstep[i] = s.Tr[i];
+      for (int i = 0; i < 16; ++i) s.T_step[i] = s.Tr[i];
       damp = damp / 2;
-      gs_mm4(Tstep, Ttot, Ttot);
+      gs_mm4(s.T_step, s.T_total, s.T_total);
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) Tstep[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+      for (int i = 0; i < 16; ++i) s.T_step[i] = (i % 5 == 0) ? 1.0f : 0.0f;
       damp = damp * 2;
     }
   } else {
@@ -289,15 +336,10 @@ GS_DEV void icp_update_math(float new_err, IcpSmall& s, const gs_icp_params& prm
     float xs[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) xs[k] = sig * s.xi[k];
-    gs_se3_exp_dev(xs, Tstep);
-    gs_mm4(Tstep, Ttot, Ttot);
+    gs_se3_exp_dev(xs, s.T_step);
+    gs_mm4(s.T_step, s.T_total, s.T_total);
   }
   s.damp = damp;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    s.T_step[i] = Tstep[i];
-    s.T_total[i] = Ttot[i];
-  }
   if (trace_row) {
     trace_row[0] = err; trace_row[1] = new_err; trace_row[2] = damp; trace_row[3] = sig;
 #pragma unroll
