@@ -54,6 +54,52 @@ extern "C" int gs_se3_exp_f32(const float* xi6, float* T16, void* stream) {
   return GS_OK;
 }
 
+// relative_transformation (geometry/geometryutils.py:413-478, orthogonal_rotations=False):
+// inv(T01) by Gauss-Jordan with partial pivoting in double, rounded once, then kornia's
+// compose_transformations ([R1 R2, R1 t2 + t1], plain float32, ascending k).  One lane per pair.
+__global__ void __launch_bounds__(64) gs_relative_pose_kernel(const float* __restrict__ T01, const float* __restrict__ T02,
+                                                              int64_t n, float* __restrict__ out) {
+  const int64_t m = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (m >= n) return;
+  double a[4][8];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      a[i][j] = (double)T01[16 * m + 4 * i + j];
+      a[i][4 + j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < 4; ++c) {
+    int p = c;
+    for (int r = c + 1; r < 4; ++r)
+      if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
+    if (p != c)
+      for (int j = 0; j < 8; ++j) { const double t = a[c][j]; a[c][j] = a[p][j]; a[p][j] = t; }
+    const double inv = 1.0 / a[c][c];
+    for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+    for (int r = 0; r < 4; ++r) {
+      if (r == c) continue;
+      const double f = a[r][c];
+      for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  float A[16], B[16], C[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      A[4 * i + j] = (float)a[i][4 + j];
+      B[4 * i + j] = T02[16 * m + 4 * i + j];
+    }
+  gs_compose_rigid(A, B, C);
+  for (int i = 0; i < 16; ++i) out[16 * m + i] = C[i];
+}
+extern "C" int gs_relative_pose_f32(const float* T01, const float* T02, int64_t n, float* out, void* stream) {
+  GS_REQUIRE(n >= 0, "bad size");
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(T01 && T02 && out, "NULL pointer");
+  hipLaunchKernelGGL(gs_relative_pose_kernel, dim3((unsigned)gs_ceil_div(n, 64)), dim3(64), 0, gs_stream(stream), T01,
+                     T02, n, out);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 __global__ void __launch_bounds__(256) gs_transform_points_kernel(const float* __restrict__ pts, int64_t n,
                                                                   const float* __restrict__ T16,
                                                                   float* __restrict__ out) {

@@ -241,6 +241,16 @@ def se3_exp(xi):
     return T
 
 
+def relative_pose(T01, T02):
+    """(n, 4, 4) x (n, 4, 4) -> compose(inv(T01), T02) (relative_transformation of the reference)."""
+    T01, T02 = _c(T01), _c(T02)
+    dev = require_device(T01, T02)
+    out = torch.empty_like(T02)
+    check(lib().gs_relative_pose_f32(ptr(T01), ptr(T02), T02.numel() // 16, ptr(out), stream(dev)),
+          "gs_relative_pose_f32")
+    return out
+
+
 def transform_points(pts, T):
     pts, T = _c(pts), _c(T)
     dev = require_device(pts, T)

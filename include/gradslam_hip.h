@@ -157,6 +157,12 @@ GS_API int gs_solve_normal_eq_f32(const float* A, const float* b, const uint8_t*
 /* se3_exp (geometry/se3utils.py:77-115): xi(6) -> T(4x4). */
 GS_API int gs_se3_exp_f32(const float* xi6, float* T16, void* stream);
 
+/* relative_transformation(T01, T02, orthogonal_rotations=False) (geometry/geometryutils.py:413-478; the
+ * arithmetic of GroundTruthOdometryProvider.provide, odometry/groundtruth.py:74-78, and of the dataset
+ * loaders' pose preprocessing, datasets/tum.py:497-499): out[m] = compose(inv(T01[m]), T02[m]) for n
+ * pairs of 4x4 float32 matrices. */
+GS_API int gs_relative_pose_f32(const float* T01, const float* T02, int64_t n, float* out, void* stream);
+
 /* transform_pointcloud (geometry/geometryutils.py:737-794): out = R p + t. */
 GS_API int gs_transform_points_f32(const float* pts, int64_t n, const float* T16, float* out,
                             void* stream);

@@ -458,6 +458,45 @@ EXPORT void gs_or_solve_normal_eq(const float* A, const float* b, const uint8_t*
 }
 
 /* geometry/se3utils.py:77-115, evaluated in double from the float32 xi and rounded once. */
+/* relative_transformation(T01, T02, orthogonal_rotations=False) (geometry/geometryutils.py:413-478):
+ * torch.inverse(T01) restated as double Gauss-Jordan with partial pivoting rounded once, then kornia's
+ * compose_transformations in float32. */
+EXPORT void gs_or_relative_pose(const float* T01, const float* T02, int64_t n, float* out) {
+  for (int64_t m = 0; m < n; ++m) {
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) { a[i][j] = (double)T01[16 * m + 4 * i + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+      int p = c;
+      for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
+      if (p != c) for (int j = 0; j < 8; ++j) { double t = a[c][j]; a[c][j] = a[p][j]; a[p][j] = t; }
+      double inv = 1.0 / a[c][c];
+      for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+      for (int r = 0; r < 4; ++r) {
+        if (r == c) continue;
+        double f = a[r][c];
+        for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+      }
+    }
+    float A[16], C[16];
+    const float* B = T02 + 16 * m;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) A[4 * i + j] = (float)a[i][4 + j];
+    for (int i = 0; i < 16; ++i) C[i] = 0.0f;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) {
+        float acc = A[4 * i] * B[j];
+        for (int k = 1; k < 3; ++k) acc = acc + A[4 * i + k] * B[4 * k + j];
+        C[4 * i + j] = acc;
+      }
+      float acc = A[4 * i] * B[3];
+      for (int k = 1; k < 3; ++k) acc = acc + A[4 * i + k] * B[4 * k + 3];
+      C[4 * i + 3] = acc + A[4 * i + 3];
+    }
+    C[15] = 1.0f;
+    for (int i = 0; i < 16; ++i) out[16 * m + i] = C[i];
+  }
+}
+
 EXPORT void gs_or_se3_exp(const float* xi6, float* T16) {
   double v[3] = {xi6[0], xi6[1], xi6[2]}, w[3] = {xi6[3], xi6[4], xi6[5]};
   double wh[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};

@@ -1,0 +1,50 @@
+"""Round-1 additions to tests/golden (same rules as make_golden.py: the REAL reference, imported from
+/root/reference through oracle/refimport.py, on fixed inputs; build-container only).
+
+    python -m oracle.make_golden_extra
+
+  gt_odom.npz   GroundTruthOdometryProvider.provide / relative_transformation on seeded poses
+                (odometry/groundtruth.py:74-78, geometry/geometryutils.py:413-478).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+from oracle import refimport  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def random_poses(rng, n):
+    from scipy.spatial.transform import Rotation
+    T = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+    T[:, :3, :3] = Rotation.from_rotvec(rng.normal(size=(n, 3)) * 0.7).as_matrix().astype(np.float32)
+    T[:, :3, 3] = rng.normal(size=(n, 3)).astype(np.float32) * 2
+    return T
+
+
+def main():
+    refimport.import_reference()
+    import torch
+    import gradslam
+    from gradslam.geometry.geometryutils import relative_transformation
+    from gradslam.odometry.groundtruth import GroundTruthOdometryProvider
+    rng = np.random.default_rng(7)
+    B = 6
+    T1, T2 = random_poses(rng, B), random_poses(rng, B)
+    T1[0, :3, :3] *= 1.01   # an imperfect rotation: the general inverse must be used
+    mk = lambda T: gradslam.RGBDImages(torch.zeros(B, 1, 4, 4, 3), torch.ones(B, 1, 4, 4, 1),  # noqa: E731
+                                       torch.eye(4).repeat(B, 1, 1, 1), torch.from_numpy(T).unsqueeze(1))
+    rel = GroundTruthOdometryProvider().provide(mk(T1), mk(T2))
+    rel2 = relative_transformation(torch.from_numpy(T1), torch.from_numpy(T2))
+    assert torch.equal(rel[:, 0], rel2)
+    np.savez_compressed(os.path.join(OUT, "gt_odom.npz"), T1=T1, T2=T2, rel=rel.numpy())
+    print("gt_odom.npz", rel.shape)
+
+
+if __name__ == "__main__":
+    main()

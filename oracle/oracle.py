@@ -185,6 +185,13 @@ def solve_normal_eq(A, b, damp=1e-8, keep=None):
     return x
 
 
+def relative_pose(T01, T02):
+    T01, T02 = _c(T01, np.float32).reshape(-1, 4, 4), _c(T02, np.float32).reshape(-1, 4, 4)
+    out = np.empty_like(T02)
+    lib().gs_or_relative_pose(_f(T01), _f(T02), C.c_int64(T02.shape[0]), _f(out))
+    return out
+
+
 def se3_exp(xi):
     xi = _c(xi, np.float32).reshape(6)
     T = np.empty((4, 4), np.float32)

@@ -252,3 +252,20 @@ def test_scannet_resolution_map_growth(gs):
     rec = torch.stack([frames[:, 0].poses[0, 0]] + [prev.poses[0, 0]])  # first and last
     assert ate(host(prev.poses[0]), s["poses"][L - 1:L]) < 5e-3
     assert rec.shape == (2, 4, 4)
+
+
+def test_groundtruth_provider_and_relative_pose(ops, golden):
+    """gs_relative_pose_f32 == oracle (bit-exact: same double Gauss-Jordan), and within float32 ulps of the
+    reference's GroundTruthOdometryProvider output."""
+    import gradslam_amd as gs
+    g = golden("gt_odom")
+    T1, T2 = torch.from_numpy(g["T1"]).cuda(), torch.from_numpy(g["T2"]).cuda()
+    rel = ops.relative_pose(T1, T2)
+    assert np.array_equal(rel.cpu().numpy(), o.relative_pose(g["T1"], g["T2"]))
+    B = T1.shape[0]
+    mk = lambda T: gs.RGBDImages(torch.zeros(B, 1, 4, 4, 3).cuda(), torch.ones(B, 1, 4, 4, 1).cuda(),  # noqa: E731
+                                 torch.eye(4).repeat(B, 1, 1, 1).cuda(), T.unsqueeze(1))
+    out = gs.odometry.GroundTruthOdometryProvider().provide(mk(T1), mk(T2))
+    assert out.shape == (B, 1, 4, 4) and out.is_cuda
+    assert np.abs(out.cpu().numpy() - g["rel"]).max() <= 2e-6
+    assert torch.equal(gs.geometry.geometryutils.relative_transformation(T1[0], T2[0]), rel[0])

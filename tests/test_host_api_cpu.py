@@ -214,3 +214,32 @@ def test_icputils_and_slam_validation_messages():
     from gradslam_amd.odometry.icp import ICPOdometryProvider
     with pytest.raises(ValueError, match="maps_pointclouds missing normals"):
         ICPOdometryProvider().provide(gs.Pointclouds(points=[a[0]]), gs.Pointclouds(points=[a[0]]))
+
+
+def test_groundtruth_provider_validation():
+    """GroundTruthOdometryProvider rejects bad inputs with the reference's exception types and messages
+    (odometry/groundtruth.py:30-72) before anything touches the device."""
+    import torch
+    import gradslam_amd as gs
+    from gradslam_amd.odometry import GroundTruthOdometryProvider, OdometryProvider
+    prov = GroundTruthOdometryProvider()
+    assert isinstance(prov, OdometryProvider)
+    mk = lambda B, L, poses=True: gs.RGBDImages(torch.zeros(B, L, 4, 4, 3), torch.ones(B, L, 4, 4, 1),  # noqa: E731
+                                                torch.eye(4).repeat(B, 1, 1, 1),
+                                                torch.eye(4).repeat(B, L, 1, 1) if poses else None)
+    with pytest.raises(TypeError, match="Expected input 1"):
+        prov.provide(torch.eye(4), mk(1, 1))
+    with pytest.raises(TypeError, match="Expected input 2"):
+        prov.provide(mk(1, 1), None)
+    with pytest.raises(ValueError, match="Input 1 .* missing poses"):
+        prov.provide(mk(1, 1, False), mk(1, 1))
+    with pytest.raises(ValueError, match="Input 2 .* missing poses"):
+        prov.provide(mk(1, 1), mk(1, 1, False))
+    with pytest.raises(ValueError, match="Sequence length of rgbdimages1 must be 1"):
+        prov.provide(mk(1, 2), mk(1, 1))
+    with pytest.raises(ValueError, match="Batch size of rgbdimages1 and rgbdimages2 should be equal"):
+        prov.provide(mk(2, 1), mk(1, 1))
+    with pytest.raises(TypeError, match="trans_01"):
+        gs.geometry.geometryutils.relative_transformation(None, torch.eye(4))
+    with pytest.raises(ValueError, match="dims must match"):
+        gs.geometry.geometryutils.relative_transformation(torch.eye(4), torch.eye(4)[None])

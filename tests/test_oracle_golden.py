@@ -170,3 +170,12 @@ def test_sequence_120(golden):
     m, rp = oslam.run_sequence(s["colors"], g["depths"], g["intrinsics"], poses)
     assert ate(rp, g["pf_gradicp_poses"]) <= 1e-4
     assert len(m) == int(g["pf_gradicp_count"])
+
+
+def test_relative_pose_matches_reference(golden):
+    """gs_or_relative_pose against GroundTruthOdometryProvider / relative_transformation of the reference
+    (torch.inverse in float32 there, double Gauss-Jordan here: equal to a few float32 ulps)."""
+    g = golden("gt_odom")
+    rel = o.relative_pose(g["T1"], g["T2"])
+    assert np.abs(rel - g["rel"][:, 0]).max() <= 2e-6
+    assert np.array_equal(rel[:, 3], np.tile(np.array([0, 0, 0, 1], np.float32), (rel.shape[0], 1)))
