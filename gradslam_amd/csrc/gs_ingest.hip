@@ -1,0 +1,87 @@
+// gs_ingest.hip — dataset -> device ingest: raw sensor frames (uint16 depth, uint8 colour, as decoded
+// from the PNGs) to the float32 images RGBDImages consumes, with the resize the reference's loaders
+// apply on the host through OpenCV (datasets/tum.py:448-477, datasets/icl.py, datasets/scannet.py:
+// depth cv2.INTER_NEAREST then / scaling_factor; colour cv2.INTER_LINEAR then optional / 255).
+// The reference does this arithmetic in float64 and casts to float32 last; so do these kernels.
+// HBM-bound: 2 B read + 4 B written per depth pixel, <= 12 B read + 12 B written per colour pixel.
+#include "gs_common.h"
+
+// cv2.INTER_NEAREST (resizeNN): source index = min(floor(dst * (1 / (dst_size / src_size))), src_size - 1)
+GS_DEV int ingest_nn(int d, double inv_scale, int n_src) {
+  const int s = (int)floor((double)d * inv_scale);
+  return s < n_src - 1 ? s : n_src - 1;
+}
+
+__global__ void __launch_bounds__(256) gs_ingest_depth_kernel(const uint16_t* __restrict__ raw, int H0, int W0,
+                                                              float* __restrict__ out, int H, int W,
+                                                              double ify, double ifx, double scale_div) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (int64_t)H * W) return;
+  const int y = (int)(p / W), x = (int)(p % W);
+  const int sy = (H == H0) ? y : ingest_nn(y, ify, H0), sx = (W == W0) ? x : ingest_nn(x, ifx, W0);
+  out[p] = (float)((double)raw[(int64_t)sy * W0 + sx] / scale_div);
+}
+
+extern "C" int gs_ingest_depth_u16_f32(const uint16_t* raw, int H0, int W0, float* out, int H, int W,
+                                       double scale_div, void* stream) {
+  GS_REQUIRE(raw && out && H0 > 0 && W0 > 0 && H > 0 && W > 0 && scale_div != 0.0, "bad arguments");
+  const double ify = 1.0 / ((double)H / (double)H0), ifx = 1.0 / ((double)W / (double)W0);
+  hipLaunchKernelGGL(gs_ingest_depth_kernel, dim3((unsigned)gs_ceil_div((int64_t)H * W, 256)), dim3(256), 0,
+                     gs_stream(stream), raw, H0, W0, out, H, W, ify, ifx, scale_div);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// cv2.INTER_LINEAR on a float64 image (resizeGeneric_, HResizeLinear<double,double,float>, VResizeLinear):
+// f = (float)((d + 0.5) * scale - 0.5); s = floor(f); f -= s; clamped at both borders with weight 0;
+// the two weights are float32 (1.f - f, f), the sums double: first along x for the two source rows,
+// then along y.
+GS_DEV void ingest_lin(int d, double scale, int n_src, int& s0, int& s1, float& a0, float& a1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { f = 0.0f; s = 0; }
+  if (s >= n_src - 1) { f = 0.0f; s = n_src - 1; }
+  s0 = s;
+  s1 = s + 1 < n_src ? s + 1 : n_src - 1;
+  a0 = 1.0f - f;
+  a1 = f;
+}
+
+__global__ void __launch_bounds__(256) gs_ingest_color_kernel(const uint8_t* __restrict__ raw, int H0, int W0,
+                                                              float* __restrict__ out, int H, int W, double sy_scale,
+                                                              double sx_scale, int normalize) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (int64_t)H * W) return;
+  const int y = (int)(p / W), x = (int)(p % W);
+  double v[3];
+  if (H == H0 && W == W0) {  // cv2.resize to the same size is a copy
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = (double)raw[3 * p + c];
+  } else {
+    int x0, x1, y0, y1;
+    float a0, a1, b0, b1;
+    ingest_lin(x, sx_scale, W0, x0, x1, a0, a1);
+    ingest_lin(y, sy_scale, H0, y0, y1, b0, b1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double r0 = (double)raw[3 * ((int64_t)y0 * W0 + x0) + c] * (double)a0 +
+                        (double)raw[3 * ((int64_t)y0 * W0 + x1) + c] * (double)a1;
+      const double r1 = (double)raw[3 * ((int64_t)y1 * W0 + x0) + c] * (double)a0 +
+                        (double)raw[3 * ((int64_t)y1 * W0 + x1) + c] * (double)a1;
+      v[c] = r0 * (double)b0 + r1 * (double)b1;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[3 * p + c] = (float)(normalize ? v[c] / 255.0 : v[c]);
+}
+
+extern "C" int gs_ingest_color_u8_f32(const uint8_t* raw, int H0, int W0, float* out, int H, int W, int normalize,
+                                      void* stream) {
+  GS_REQUIRE(raw && out && H0 > 0 && W0 > 0 && H > 0 && W > 0, "bad arguments");
+  const double sy = 1.0 / ((double)H / (double)H0), sx = 1.0 / ((double)W / (double)W0);
+  hipLaunchKernelGGL(gs_ingest_color_kernel, dim3((unsigned)gs_ceil_div((int64_t)H * W, 256)), dim3(256), 0,
+                     gs_stream(stream), raw, H0, W0, out, H, W, sy, sx, normalize);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}

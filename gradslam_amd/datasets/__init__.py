@@ -1,0 +1,2 @@
+from . import datautils, tumutils  # noqa: F401
+from .tum import TUM  # noqa: F401

@@ -241,6 +241,28 @@ def se3_exp(xi):
     return T
 
 
+def ingest_depth(raw_u16, H, W, scale_div):
+    """(H0, W0) uint16 depth as decoded from the PNG -> (H, W) float32 metres."""
+    raw = raw_u16.contiguous()
+    assert raw.dtype in (torch.uint16, torch.int16) and raw.ndim == 2
+    dev = require_device(raw)
+    out = torch.empty((H, W), dtype=f32, device=dev)
+    check(lib().gs_ingest_depth_u16_f32(ptr(raw), raw.shape[0], raw.shape[1], ptr(out), H, W, float(scale_div),
+                                        stream(dev)), "gs_ingest_depth_u16_f32")
+    return out
+
+
+def ingest_color(raw_u8, H, W, normalize=False):
+    """(H0, W0, 3) uint8 colour -> (H, W, 3) float32 in [0, 255] (or [0, 1] when normalize)."""
+    raw = raw_u8.contiguous()
+    assert raw.dtype == torch.uint8 and raw.ndim == 3 and raw.shape[2] == 3
+    dev = require_device(raw)
+    out = torch.empty((H, W, 3), dtype=f32, device=dev)
+    check(lib().gs_ingest_color_u8_f32(ptr(raw), raw.shape[0], raw.shape[1], ptr(out), H, W, 1 if normalize else 0,
+                                       stream(dev)), "gs_ingest_color_u8_f32")
+    return out
+
+
 def relative_pose(T01, T02):
     """(n, 4, 4) x (n, 4, 4) -> compose(inv(T01), T02) (relative_transformation of the reference)."""
     T01, T02 = _c(T01), _c(T02)

@@ -298,6 +298,16 @@ GS_API int gs_append_valid_f32(float* points, float* normals, float* colors, flo
                         const float* depth, int H, int W, int64_t* new_count_out, void* scratch,
                         void* stream);
 
+/* ---- dataset -> device ingest (datasets/tum.py:448-477 _preprocess_color / _preprocess_depth; the same
+ * two steps in datasets/icl.py and datasets/scannet.py).  raw: the decoded PNG on the device (depth
+ * uint16 (H0, W0); colour uint8 (H0, W0, 3)); out: float32 (H, W) / (H, W, 3).  Depth: cv2.INTER_NEAREST
+ * to (H, W), then / scale_div (TUM 5000, ICL 5000, ScanNet 1000) in float64, cast last.  Colour:
+ * cv2.INTER_LINEAR in float64 with float32 weights, optional / 255.  Same size: exact copy. */
+GS_API int gs_ingest_depth_u16_f32(const uint16_t* raw, int H0, int W0, float* out, int H, int W,
+                                   double scale_div, void* stream);
+GS_API int gs_ingest_color_u8_f32(const uint8_t* raw, int H0, int W0, float* out, int H, int W, int normalize,
+                                  void* stream);
+
 /* ---- the per-frame map pipeline with the surfel count kept ON THE DEVICE -------------------
  * Same kernels and results as the functions they are named after; `n_map_bound` (host) is an
  * upper bound of the surfel count used for launch geometry / scratch sizing, the actual count is

@@ -5,6 +5,9 @@
 
   gt_odom.npz   GroundTruthOdometryProvider.provide / relative_transformation on seeded poses
                 (odometry/groundtruth.py:74-78, geometry/geometryutils.py:413-478).
+  tum_items.npz what the reference's TUM loader (datasets/tum.py) returns for the synthetic TUM-format
+                dataset of tests/tum_fixture.py (native-size frames: the cv2 shim only copies), for
+                every sequence of two constructor configurations.
 """
 import os
 import sys
@@ -46,5 +49,31 @@ def main():
     print("gt_odom.npz", rel.shape)
 
 
+def tum_items():
+    import tempfile
+    refimport.import_reference()
+    from gradslam.datasets.tum import TUM
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tum_fixture", os.path.join(REPO, "tests", "tum_fixture.py"))
+    tum_fixture = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tum_fixture)
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        tum_fixture.write(root)
+        for case, kw in tum_fixture.CASES.items():
+            ds = TUM(root, **kw)
+            out[case + "/len"] = np.array(len(ds))
+            for i in range(len(ds)):
+                colors, depths, K, poses, transforms, names, stamps = ds[i]
+                for k, v in (("colors", colors), ("depths", depths), ("intrinsics", K), ("poses", poses),
+                             ("transforms", transforms)):
+                    out["%s/%d/%s" % (case, i, k)] = v.numpy()
+                out["%s/%d/names" % (case, i)] = np.array(names)
+                out["%s/%d/stamps" % (case, i)] = np.array(stamps)
+    np.savez_compressed(os.path.join(OUT, "tum_items.npz"), **out)
+    print("tum_items.npz", {k: int(out[k]) for k in out if k.endswith("/len")})
+
+
 if __name__ == "__main__":
     main()
+    tum_items()

@@ -185,6 +185,43 @@ def solve_normal_eq(A, b, damp=1e-8, keep=None):
     return x
 
 
+def ingest_depth(raw_u16, H, W, scale_div):
+    """datasets/tum.py:463-477 (_preprocess_depth): cv2.INTER_NEAREST on the float64 image, / scaling_factor,
+    float32 last.  cv2 resizeNN: source index = min(floor(dst * (1 / (dst_size / src_size))), src_size - 1)."""
+    raw = np.asarray(raw_u16)
+    H0, W0 = raw.shape
+    ys = np.arange(H) if H == H0 else np.minimum(np.floor(np.arange(H) * (1.0 / (H / H0))).astype(np.int64), H0 - 1)
+    xs = np.arange(W) if W == W0 else np.minimum(np.floor(np.arange(W) * (1.0 / (W / W0))).astype(np.int64), W0 - 1)
+    return (raw[np.ix_(ys, xs)].astype(np.float64) / float(scale_div)).astype(np.float32)
+
+
+def _lin_coeffs(n_dst, n_src):
+    scale = 1.0 / (n_dst / n_src)
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    f = np.where(s < 0, np.float32(0), f)
+    s = np.maximum(s, 0)
+    f = np.where(s >= n_src - 1, np.float32(0), f).astype(np.float32)
+    s = np.minimum(s, n_src - 1)
+    return s, np.minimum(s + 1, n_src - 1), (np.float32(1) - f).astype(np.float32), f
+
+
+def ingest_color(raw_u8, H, W, normalize=False):
+    """datasets/tum.py:448-461 (_preprocess_color): cv2.INTER_LINEAR on the float64 image (OpenCV's
+    resizeGeneric_ with float32 weights and float64 sums, x first, then y), optional / 255, float32 last."""
+    raw = np.asarray(raw_u8).astype(np.float64)
+    H0, W0 = raw.shape[:2]
+    if (H, W) != (H0, W0):
+        x0, x1, a0, a1 = _lin_coeffs(W, W0)
+        y0, y1, b0, b1 = _lin_coeffs(H, H0)
+        rows = raw[:, x0] * a0.astype(np.float64)[None, :, None] + raw[:, x1] * a1.astype(np.float64)[None, :, None]
+        raw = rows[y0] * b0.astype(np.float64)[:, None, None] + rows[y1] * b1.astype(np.float64)[:, None, None]
+    if normalize:
+        raw = raw / 255
+    return raw.astype(np.float32)
+
+
 def relative_pose(T01, T02):
     T01, T02 = _c(T01, np.float32).reshape(-1, 4, 4), _c(T02, np.float32).reshape(-1, 4, 4)
     out = np.empty_like(T02)

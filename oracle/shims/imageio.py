@@ -1,1 +1,9 @@
-# Test-infrastructure shim: the reference imports open3d only for visualisation.
+# Test-infrastructure shim: PNG decoding for the reference's dataset loaders (lossless, so PIL gives
+# the same pixels imageio would).
+import numpy as np
+
+
+def imread(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im)

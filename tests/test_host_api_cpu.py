@@ -1,6 +1,9 @@
 """CPU-only tests of the host layer: container logic of Pointclouds / RGBDImages and the
 reference's error behaviour (type / shape checks run before any HIP call, with the reference's
 messages: tests/slam/test_fusionutils.py:369-398, :543-669 style)."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -8,6 +11,7 @@ import gradslam_amd as gs
 from gradslam_amd._C import HipExtensionError
 from gradslam_amd.odometry import icputils
 from gradslam_amd.slam import fusionutils as fu
+from oracle import oracle as o
 
 
 def rgbd(B=1, L=2, H=4, W=5, poses=True):
@@ -243,3 +247,75 @@ def test_groundtruth_provider_validation():
         gs.geometry.geometryutils.relative_transformation(None, torch.eye(4))
     with pytest.raises(ValueError, match="dims must match"):
         gs.geometry.geometryutils.relative_transformation(torch.eye(4), torch.eye(4)[None])
+
+
+# ------------------------------------------------------------------ dataset loader (host logic)
+def _tum(tmp_path):
+    from tests import tum_fixture
+    return tum_fixture, tum_fixture.write(str(tmp_path))
+
+
+def test_tum_loader_host_logic_matches_reference(tmp_path, golden):
+    """Frame association, sequence extraction, names, time stamps and intrinsics of our TUM loader against
+    what the reference's loader returned on the same files (tests/golden/tum_items.npz)."""
+    import torch
+    from gradslam_amd.datasets import TUM
+    fx, root = _tum(tmp_path)
+    g = golden("tum_items")
+    for case, kw in fx.CASES.items():
+        ds = TUM(root, device="cpu", **kw)
+        assert len(ds) == int(g[case + "/len"])
+        for i in range(len(ds)):
+            assert ds.framenames[i] == str(g["%s/%d/names" % (case, i)])
+            stamps = "\n".join("rgb {} depth {} pose {}".format(*t) for t in ds.timestamps[i])
+            assert stamps == str(g["%s/%d/stamps" % (case, i)])
+            assert torch.equal(ds.intrinsics, torch.from_numpy(g["%s/%d/intrinsics" % (case, i)]))
+            # poses: host quaternion conversion + the oracle's relative pose == reference within float32 ulps
+            P = np.stack(ds._homogenPoses(ds.poses[i]))
+            rel = o.relative_pose(np.repeat(P[:1], len(P), 0), P)
+            assert np.abs(rel - g["%s/%d/poses" % (case, i)]).max() <= 2e-6
+            tr = np.concatenate([np.eye(4, dtype=np.float32)[None], o.relative_pose(P[:-1], P[1:])])
+            assert np.abs(tr - g["%s/%d/transforms" % (case, i)]).max() <= 2e-6
+
+
+def test_tum_ingest_oracle_matches_reference_pixels(tmp_path, golden):
+    """The oracle restatement of the ingest stage reproduces the reference loader's colour and depth
+    tensors exactly (native-size frames; resized frames are not pinned: OpenCV is not available here)."""
+    from PIL import Image
+    from gradslam_amd.datasets import TUM
+    fx, root = _tum(tmp_path)
+    g = golden("tum_items")
+    for case, kw in fx.CASES.items():
+        ds = TUM(root, device="cpu", **kw)
+        for i in range(len(ds)):
+            col = np.stack([o.ingest_color(np.asarray(Image.open(p)), fx.H, fx.W, kw.get("normalize_color", False))
+                            for p in ds.colorfiles[i]])
+            dep = np.stack([o.ingest_depth(np.asarray(Image.open(p)), fx.H, fx.W, 5000.0)[..., None]
+                            for p in ds.depthfiles[i]])
+            if kw.get("channels_first"):
+                col, dep = col.transpose(0, 3, 1, 2), dep.transpose(0, 3, 1, 2)
+            assert np.array_equal(col, g["%s/%d/colors" % (case, i)])
+            assert np.array_equal(dep, g["%s/%d/depths" % (case, i)])
+
+
+def test_tum_loader_validation_and_no_cpu_fallback(tmp_path):
+    from gradslam_amd import _C
+    from gradslam_amd.datasets import TUM
+    fx, root = _tum(tmp_path)
+    with pytest.raises(TypeError, match='"seqlen" must be int'):
+        TUM(root, seqlen=2.0)
+    with pytest.raises(ValueError, match='"end" .* must be None or greater than start'):
+        TUM(root, start=4, end=2)
+    with pytest.raises(ValueError, match="sequences not available in basedir"):
+        TUM(root, sequences=("rgbd_dataset_freiburg1_alpha", "rgbd_dataset_freiburg3_missing"))
+    with pytest.raises(ValueError, match="Incorrect folder structure in basedir"):
+        TUM(root, sequences=("rgbd_dataset_freiburg3_missing",))
+    with pytest.raises(TypeError, match='"sequences" should either be path'):
+        TUM(root, sequences=["rgbd_dataset_freiburg1_alpha"])
+    os.makedirs(os.path.join(root, "not_a_tum_dir"))
+    with pytest.raises(ValueError, match="Incorrect folder names"):
+        TUM(root)
+    os.rmdir(os.path.join(root, "not_a_tum_dir"))
+    ds = TUM(root, device="cpu", **fx.CASES["default"])
+    with pytest.raises(_C.HipExtensionError):      # the ingest stage is a HIP kernel: no CPU fallback
+        ds[0]

@@ -1,0 +1,50 @@
+"""A tiny TUM-format dataset written to a temp directory (two sequences, un-synchronised colour / depth /
+pose stamps, a comment header, a dropped pose line).  Shared by oracle/make_golden_extra.py (which runs
+the reference's TUM loader on it) and the dataset tests (which run ours on the same bytes)."""
+import os
+
+import numpy as np
+
+H, W = 24, 32
+
+
+def write(root, n_frames=9, seed=3):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    for si, name in enumerate(("rgbd_dataset_freiburg1_alpha", "rgbd_dataset_freiburg2_beta")):
+        d = os.path.join(root, name)
+        os.makedirs(os.path.join(d, "rgb"), exist_ok=True)
+        os.makedirs(os.path.join(d, "depth"), exist_ok=True)
+        t0 = 1305031100.0 + 50 * si
+        rgb_lines, depth_lines, gt_lines = ["# color images", "# timestamp filename"], ["# depth maps"], ["# ground truth"]
+        for k in range(n_frames):
+            tr = t0 + 0.0333 * k + 0.002 * rng.random()
+            td = tr + 0.004 + 0.003 * rng.random()
+            rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            dep = rng.integers(0, 40000, (H, W), dtype=np.uint16)
+            dep[rng.random((H, W)) < 0.1] = 0
+            fr, fd = "rgb/%.6f.png" % tr, "depth/%.6f.png" % td
+            Image.fromarray(rgb).save(os.path.join(d, fr))
+            Image.fromarray(dep).save(os.path.join(d, fd))
+            rgb_lines.append("%.6f %s" % (tr, fr))
+            depth_lines.append("%.6f %s" % (td, fd))
+        for k in range(4 * n_frames):   # poses at 4x the frame rate
+            tp = t0 - 0.01 + 0.0333 / 4 * k
+            ang = 0.02 * k + 0.3 * si
+            q = np.array([0.1 * np.sin(ang), np.sin(ang / 2) * 0.7, 0.05, np.cos(ang / 2)])
+            q /= np.linalg.norm(q)
+            if k == 5:
+                q[:] = 0          # the loaders drop all-zero quaternions
+            gt_lines.append("%.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f" % (tp, 0.01 * k, -0.02 * k, 0.5 + 0.001 * k, *q))
+        for fname, lines in (("rgb.txt", rgb_lines), ("depth.txt", depth_lines), ("groundtruth.txt", gt_lines)):
+            with open(os.path.join(d, fname), "w") as f:
+                f.write("\n".join(lines) + "\n")
+        open(os.path.join(d, "accelerometer.txt"), "w").write("# unused\n")
+    return root
+
+
+CASES = {
+    "default": dict(seqlen=3, height=H, width=W),
+    "strided": dict(seqlen=2, dilation=1, stride=2, start=1, end=8, height=H, width=W, normalize_color=True,
+                    channels_first=True, sequences=("rgbd_dataset_freiburg2_beta",)),
+}
