@@ -153,7 +153,7 @@ class TUM(torch.utils.data.Dataset):
     # ------------------------------------------------------------------ host -> device staging
     def _to_device(self, key, arr):
         """pinned staging buffer (reused per shape / dtype) + asynchronous copy on the current stream"""
-        t = torch.from_numpy(np.ascontiguousarray(arr))
+        t = torch.from_numpy(np.array(arr, order="C"))   # decoded images are read-only views: copy
         if self.device.type != "cuda":
             return t.to(self.device)
         slot = self._stage.get((key, t.shape, t.dtype))
