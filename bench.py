@@ -71,6 +71,23 @@ def run_steps(slam, pc, frames, prev, first, last, poses_out=None):
     return pc, prev
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the newest committed profiles/*_pmc_hbm_traffic.txt (produced by
+    tools/collect_profiles.sh + tools/summarize_profiles.py from separate PMC passes); (None, None) if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_hbm_traffic.txt")))
+    if not files:
+        return None, None
+    tot, calls = 0.0, 0
+    for line in open(files[-1]):
+        if line.startswith("void " + kernel_prefix) or line.startswith(kernel_prefix):
+            f = line.split()
+            c, fetch_kb, write_kb = int(f[-5]), float(f[-3]), float(f[-2])
+            tot += c * (fetch_kb + write_kb) * 1024.0
+            calls += c
+    return (tot / calls, "profiles/" + os.path.basename(files[-1])) if calls else (None, None)
+
+
 def read_profile(lib, kind):
     ms, n, work = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
     lib.gs_profile_read(kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(work))
@@ -168,15 +185,19 @@ def main():
         ms, n, nbytes = read_profile(lib, 8)
         if n > 0:  # dominant kernel by GPU time: the fused exact-NN search + Gauss-Newton linearisation
             gbs = nbytes / (ms * 1e-3) / 1e9
-            roofline = {"kernel": "gs_icp_search_linearize_kernel (K3+K4 fused: exact grid 1-NN + GN rows + partial "
-                                  "sums), %d launches per frame" % (n // K),
+            traffic, traffic_src = pmc_traffic("gs_icp_half_kernel")
+            roofline = {"kernel": "gs_icp_half_kernel<FULL> (K3+K4 fused: prologue = row sums + 6x6 solve / LM update of the "
+                                  "previous half-iteration, then exact grid 1-NN + GN rows + one partial row per block), "
+                                  "%d launches per frame" % (n // K),
                         "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                        "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "launches": n, "avg_launch_us": ms * 1e3 / n, "alg_bytes_per_launch": nbytes / n,
-                        "note": "latency-bound, not bandwidth-bound: ~19k queries x ~60 dependent L2 gathers per "
-                                "launch; compulsory bytes = Ns*(24 src io + 216 cell bounds + 24 match gather + 7 "
-                                "partials) + 16*Nt. PMC traffic per launch: profiles/r01_c_pmc_hbm_traffic.txt "
-                                "(6.9 MB fetched, 0.34 MB written). The same search as brute force is the "
+                        "note": "latency-bound, not bandwidth-bound: a launch is ~4.5 us of dispatch floor + one "
+                                "memory round trip for the partial rows + a one-wave float64 scalar stage + ~19k "
+                                "queries x 3 dependent L2 gathers; compulsory bytes = Ns*(24 src io + 216 cell bounds + "
+                                "24 match gather + 7 partials) + 16*Nt. `traffic` = HBM bytes per launch from separate "
+                                "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH x2 per MI355X_MICROARCH.md), "
+                                "averaged over the two kernel variants. The same search as brute force is the "
                                 "fp32-VALU-bound kernel in roofline_bruteforce."}
         groups = {}
         for kind, name in ((2, "K1 frame maps"), (3, "K5a map projection"), (4, "K5 association"),
