@@ -47,13 +47,15 @@ enum GsProfKind { GS_PROF_KNN = 0, GS_PROF_LINEARIZE = 1, GS_PROF_FRAME = 2, GS_
                   GS_PROF_ASSOC = 4, GS_PROF_FUSE = 5, GS_PROF_COMPACT = 6, GS_PROF_SOLVE = 7, GS_PROF_ICP_FUSED = 8,
                   GS_PROF_KINDS = 9 };
 extern bool g_gs_prof_on;
-int gs_prof_open(int kind, double work, hipStream_t st);
+int gs_prof_open(int kind, double work, hipStream_t st, int launches);
 void gs_prof_close(int slot, hipStream_t st);
 struct GsProf {
   int slot;
   hipStream_t st;
-  GsProf(int kind, double work, hipStream_t s) : slot(-1), st(s) {
-    if (g_gs_prof_on) slot = gs_prof_open(kind, work, s);
+  // `launches` kernels are enqueued back to back between the two events (one event pair per kernel would
+  // put two extra packets between consecutive kernels and inflate the per-launch time of launch-bound loops)
+  GsProf(int kind, double work, hipStream_t s, int launches = 1) : slot(-1), st(s) {
+    if (g_gs_prof_on) slot = gs_prof_open(kind, work, s, launches);
   }
   ~GsProf() {
     if (slot >= 0) gs_prof_close(slot, st);

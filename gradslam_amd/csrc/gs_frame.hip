@@ -21,17 +21,17 @@ void gs_set_error(const char* fmt, ...) {
 #include <vector>
 bool g_gs_prof_on = false;
 namespace {
-struct ProfRec { hipEvent_t a, b; int kind; double work; bool closed; };
+struct ProfRec { hipEvent_t a, b; int kind; double work; bool closed; int launches; };
 std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
 double g_prof_ms[GS_PROF_KINDS], g_prof_work[GS_PROF_KINDS];
 int64_t g_prof_n[GS_PROF_KINDS];
 }  // namespace
 
-int gs_prof_open(int kind, double work, hipStream_t st) {
+int gs_prof_open(int kind, double work, hipStream_t st, int launches) {
   if (g_prof_used >= g_prof.size()) return -1;
   ProfRec& r = g_prof[g_prof_used];
-  r.kind = kind; r.work = work; r.closed = false;
+  r.kind = kind; r.work = work; r.closed = false; r.launches = launches;
   if (hipEventRecord(r.a, st) != hipSuccess) return -1;
   return (int)g_prof_used++;
 }
@@ -45,7 +45,7 @@ extern "C" int gs_profile_begin(int max_records) {
     ProfRec r;
     GS_HIP(hipEventCreate(&r.a));
     GS_HIP(hipEventCreate(&r.b));
-    r.kind = 0; r.work = 0; r.closed = false;
+    r.kind = 0; r.work = 0; r.closed = false; r.launches = 1;
     g_prof.push_back(r);
   }
   g_prof_used = 0;
@@ -61,7 +61,7 @@ extern "C" int gs_profile_end(void) {
     if (!r.closed) continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
-    g_prof_ms[r.kind] += ms; g_prof_work[r.kind] += r.work; g_prof_n[r.kind] += 1;
+    g_prof_ms[r.kind] += ms; g_prof_work[r.kind] += r.work; g_prof_n[r.kind] += r.launches;
   }
   return GS_OK;
 }

@@ -487,12 +487,14 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
     const bool reduce_rows = nfs > FS_REDUCE_ROWS;
     const float* cur_in = src;  // cloud before the pending transform of the half-iteration
     int h = 0;                  // half-iteration index: kernel h reads s[h&1] / partials[(h+1)&1], writes the others
+    // one event pair around the 2 x numiters half-iteration kernels.  Compulsory bytes of a half-iteration:
+    // source in (+out), 27 cell bounds (8 B) per query, matched target + normal gather, partial rows, one
+    // pass over the binned targets: 271 B (full) / 259 B (look-ahead) per query + 16 B per target
+    GsProf* prof_loop = new GsProf(GS_PROF_ICP_FUSED, (double)prm->numiters * ((double)n_src * 530.0 + 32.0 * (double)n_tgt),
+                                   st, 2 * prm->numiters);
     for (int it = 0; it < prm->numiters; ++it) {
       float* cur = cloud(it);
       {
-        // compulsory bytes of one fused half-iteration: source in (+out), 27 cell bounds (8 B) per
-        // query, matched target + normal gather, partial rows, one pass over the binned targets
-        GsProf prof(GS_PROF_ICP_FUSED, (double)n_src * 271.0 + 16.0 * (double)n_tgt, st);
         hipLaunchKernelGGL((gs_icp_half_kernel<true>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur_in, cur, n_src_c, tgt,
                            tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
                            sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
@@ -505,7 +507,6 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
                            sc.rowred);
       }
       {
-        GsProf prof(GS_PROF_ICP_FUSED, (double)n_src * 259.0 + 16.0 * (double)n_tgt, st);
         hipLaunchKernelGGL((gs_icp_half_kernel<false>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur, nullptr, n_src_c, tgt,
                            tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
                            reduce_rows ? sc.rowred : sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
@@ -515,6 +516,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
       ++h;
       cur_in = cur;
     }
+    delete prof_loop;  // closing event right behind the last half-iteration kernel
     if (prm->numiters > 0) {
       GsProf prof(GS_PROF_SOLVE, 1.0, st);
       hipLaunchKernelGGL(gs_icp_finish_kernel, dim3(1), dim3(FS_BLOCK), 0, st, sc.partials[(h + 1) & 1], n_src_c,
