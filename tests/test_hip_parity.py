@@ -426,3 +426,52 @@ def test_icp_large_solve_matches_oracle(ops):
     To, idxo = o.icp(host(src), host(tgt), host(tn), mode=1, numiters=4)[:2]
     assert np.abs(host(T) - To).max() <= 1e-6
     same_bits(host(idx), idxo)
+
+
+def test_device_side_counts_batch_and_container_ops(ops):
+    """B=2 ragged batch through the read-back-free frame loop, then the Pointclouds API on a map whose
+    counts are still on the device: every accessor must resolve them and agree with the host-count run."""
+    import gradslam_amd as gs
+    sA, sB = make_sequence(4, 96, 128, seed=1), make_sequence(4, 96, 128, seed=2, hole_frac=0.3)
+    colors = np.stack([sA["colors"], sB["colors"]])
+    depths = np.stack([sA["depths"], sB["depths"]])
+    depths[1, 2] = 0.0                       # a frame without a single valid pixel in sequence 1
+    K = np.stack([sA["intrinsics"], sB["intrinsics"]])
+    poses = np.stack([sA["poses"], sB["poses"]])
+    poses[:, 1:] = poses[:, :1]
+
+    def run(dc):
+        old, ops.DEVICE_COUNTS = ops.DEVICE_COUNTS, dc
+        try:
+            frames = gs.RGBDImages(dev(colors), dev(depths), dev(K), dev(poses))
+            slam = gs.slam.PointFusion(odom="icp", device="cuda")
+            pc, prev = gs.Pointclouds(device="cuda"), None
+            for t in range(4):
+                live = frames[:, t]
+                pc, _ = slam.step(pc, live, prev, inplace=True)
+                prev = live
+            return pc
+        finally:
+            ops.DEVICE_COUNTS = old
+
+    ref = run(False)
+    n_ref = [p.shape[0] for p in ref.points_list]
+    assert n_ref[0] != n_ref[1]
+    # each accessor on a fresh device-count map
+    pc = run(True)
+    assert pc._dcount and len(pc) == 2 and pc._dcount      # len() does not need the counts
+    assert pc.num_points_per_pointcloud.tolist() == n_ref and not pc._dcount
+    pc = run(True)
+    assert torch.equal(pc.points_padded, ref.points_padded) and torch.equal(pc.nonpad_mask, ref.nonpad_mask)
+    pc = run(True)
+    c = pc.clone()
+    assert [p.shape[0] for p in c.points_list] == n_ref and torch.equal(c.features_list[1], ref.features_list[1])
+    pc = run(True)
+    one = pc[1]
+    assert torch.equal(one.points_list[0], ref.points_list[1]) and torch.equal(one.colors_list[0], ref.colors_list[1])
+    pc = run(True)
+    pc.append_points(ref)
+    assert [p.shape[0] for p in pc.points_list] == [2 * n for n in n_ref]
+    assert torch.equal(pc.normals_list[0][n_ref[0]:], ref.normals_list[0])
+    pc = run(True)
+    assert pc.has_points and pc.cpu().points_list[1].shape[0] == n_ref[1]
