@@ -1,2 +1,3 @@
 from . import datautils, tumutils  # noqa: F401
+from .icl import ICL  # noqa: F401
 from .tum import TUM  # noqa: F401

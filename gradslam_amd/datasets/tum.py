@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from . import datautils, tumutils
+from ._base import SequenceDataset, window_ids
 
 __all__ = ["TUM"]
 
@@ -22,19 +23,7 @@ _LAYOUT = ("TUM folder should look something like:\n\n| ├── basedir\n| │
            "| │   │   └── groundtruth.txt\n| │   │   └── rgb.txt\n| │   ├── ...")
 
 
-def _opt_int(name, value, quote=True):
-    if not (isinstance(value, int) or value is None):
-        raise TypeError(('"{0}" must be int or None. Got {1}.' if quote else "{0} must be int or None. Got {1}.")
-                        .format(name, type(value)))
-
-
-def _read_png(path):
-    from PIL import Image
-    with Image.open(path) as im:
-        return np.asarray(im)
-
-
-class TUM(torch.utils.data.Dataset):
+class TUM(SequenceDataset):
     r"""Sequences of `seqlen` frames (every `dilation + 1`-th frame, starting every `stride` frames) from
     extracted TUM RGB-D sequences under `basedir`.  `__getitem__` returns, in this order and as enabled
     by the `return_*` flags: colours (L, H, W, 3), depths (L, H, W, 1) in metres, intrinsics (1, 4, 4),
@@ -42,7 +31,6 @@ class TUM(torch.utils.data.Dataset):
     time stamps -- channels first when `channels_first`."""
 
     scaling_factor = 5000.0   # depth PNG units per metre
-    native_size = (480, 640)
 
     def __init__(self, basedir: str, sequences: Union[tuple, str, None] = None, seqlen: int = 4,
                  dilation: Optional[int] = None, stride: Optional[int] = None, start: Optional[int] = None,
@@ -52,34 +40,12 @@ class TUM(torch.utils.data.Dataset):
                  return_timestamps: bool = True, device: Union[torch.device, str] = "cuda"):
         super().__init__()
         basedir = os.path.normpath(basedir)
-        self.device = torch.device(device)
-        self.height, self.width = height, width
-        self.height_downsample_ratio = float(height) / self.native_size[0]
-        self.width_downsample_ratio = float(width) / self.native_size[1]
-        self.channels_first, self.normalize_color = channels_first, normalize_color
         self.return_depth, self.return_intrinsics = return_depth, return_intrinsics
         self.return_pose, self.return_transform = return_pose, return_transform
         self.return_names, self.return_timestamps = return_names, return_timestamps
         self.load_poses = return_pose or return_transform
-
-        if not isinstance(seqlen, int):
-            raise TypeError('"seqlen" must be int. Got {0}.'.format(type(seqlen)))
-        _opt_int("stride", stride)
-        _opt_int("dilation", dilation, quote=False)
-        dilation = 0 if dilation is None else dilation
-        stride = seqlen * (dilation + 1) if stride is None else stride
-        self.seqlen, self.stride, self.dilation = seqlen, stride, dilation
-        for name, v in (("seqlen", seqlen), ("dilation", dilation), ("stride", stride)):
-            if v < 0:
-                raise ValueError('"{0}" must be positive. Got {1}.'.format(name, v))
-        _opt_int("start", start)
-        _opt_int("end", end)
-        start = 0 if start is None else start
-        self.start, self.end = start, end
-        if start < 0:
-            raise ValueError('"start" must be None or positive. Got {0}.'.format(stride))
-        if not (end is None or end > start):
-            raise ValueError('"end" ({0}) must be None or greater than start ({1})'.format(end, start))
+        self._init_common(seqlen, dilation, stride, start, end, height, width, channels_first, normalize_color,
+                          device, quoted=True)
 
         if isinstance(sequences, str):
             if not os.path.isfile(sequences):
@@ -111,7 +77,6 @@ class TUM(torch.utils.data.Dataset):
                              + ", ".join(map(os.path.basename, seq_dirs)) + "\n" + _LAYOUT)
 
         self.colorfiles, self.depthfiles, self.poses, self.framenames, self.timestamps = [], [], [], [], []
-        offsets = np.arange(seqlen) * (dilation + 1)
         for seq_dir in seq_dirs:
             files = {}
             for key, fname, label in (("rgb", "rgb.txt", '"rgb.txt" file'), ("depth", "depth.txt", '"depth.txt" file'),
@@ -130,10 +95,7 @@ class TUM(torch.utils.data.Dataset):
             colors = [os.path.normpath(os.path.join(seq_dir, a[0])) for a in assoc]
             depths = [os.path.normpath(os.path.join(seq_dir, a[1])) for a in assoc]
             names = [name.strip("/\\") + "/" + a[0][3:-4] for a in assoc]
-            for first in range(0, len(assoc), stride):
-                if first + offsets[-1] >= len(assoc):
-                    break
-                ids = first + offsets
+            for ids in window_ids(len(assoc), self.seqlen, self.dilation, self.stride):
                 self.colorfiles.append([colors[i] for i in ids])
                 self.depthfiles.append([depths[i] for i in ids])
                 self.framenames.append(", ".join(names[i] for i in ids))
@@ -141,69 +103,13 @@ class TUM(torch.utils.data.Dataset):
                 if self.load_poses:
                     self.poses.append([assoc[i][2] for i in ids])
         self.num_sequences = len(self.colorfiles)
-
-        K = torch.tensor([[525.0, 0, 319.5, 0], [0, 525.0, 239.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]]).float()
-        self.intrinsics = datautils.scale_intrinsics(K, self.height_downsample_ratio,
-                                                     self.width_downsample_ratio).unsqueeze(0).to(self.device)
-        self._stage = {}
-
-    def __len__(self):
-        return self.num_sequences
-
-    # ------------------------------------------------------------------ host -> device staging
-    def _to_device(self, key, arr):
-        """pinned staging buffer (reused per shape / dtype) + asynchronous copy on the current stream"""
-        t = torch.from_numpy(np.array(arr, order="C"))   # decoded images are read-only views: copy
-        if self.device.type != "cuda":
-            return t.to(self.device)
-        slot = self._stage.get((key, t.shape, t.dtype))
-        if slot is None:
-            slot = self._stage[(key, t.shape, t.dtype)] = [torch.empty(t.shape, dtype=t.dtype).pin_memory(),
-                                                          torch.cuda.Event()]
-        pinned, done = slot
-        done.synchronize()          # the previous copy out of this buffer has finished
-        pinned.copy_(t)
-        dev = pinned.to(self.device, non_blocking=True)
-        done.record()
-        return dev
-
-    def _preprocess_color(self, color: np.ndarray):
-        from .. import ops
-        if color.ndim == 2:
-            color = np.repeat(color[..., None], 3, -1)
-        raw = self._to_device("color", color[..., :3].astype(np.uint8, copy=False))
-        out = ops.ingest_color(raw, self.height, self.width, self.normalize_color)
-        return out.permute(2, 0, 1).contiguous() if self.channels_first else out
-
-    def _preprocess_depth(self, depth: np.ndarray):
-        from .. import ops
-        raw = self._to_device("depth", depth.astype(np.uint16, copy=False))
-        out = ops.ingest_depth(raw, self.height, self.width, self.scaling_factor)
-        return out.unsqueeze(0) if self.channels_first else out.unsqueeze(-1)
-
-    def _preprocess_poses(self, poses: torch.Tensor):
-        from .. import ops
-        return ops.relative_pose(poses[:1].expand_as(poses).contiguous(), poses)
+        self._set_intrinsics([[525.0, 0, 319.5, 0], [0, 525.0, 239.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
 
     def _homogenPoses(self, poses_point_quaternion):
         return [datautils.pointquaternion_to_homogeneous(p) for p in poses_point_quaternion]
 
     def __getitem__(self, idx: int):
-        from .. import ops
-        colors = torch.stack([self._preprocess_color(_read_png(p)) for p in self.colorfiles[idx]], 0)
-        out = [colors]
-        if self.return_depth:
-            out.append(torch.stack([self._preprocess_depth(_read_png(p)) for p in self.depthfiles[idx]], 0))
-        if self.return_intrinsics:
-            out.append(self.intrinsics)
-        if self.load_poses:
-            poses = torch.from_numpy(np.stack(self._homogenPoses(self.poses[idx]))).float().to(self.device)
-        if self.return_pose:
-            out.append(self._preprocess_poses(poses))
-        if self.return_transform:
-            eye = torch.eye(4, dtype=torch.float32, device=self.device)[None]
-            rel = ops.relative_pose(poses[:-1].contiguous(), poses[1:].contiguous()) if len(poses) > 1 else eye[:0]
-            out.append(torch.cat([eye, rel], 0))
+        out = self._images_and_poses(idx, self._homogenPoses(self.poses[idx]) if self.load_poses else None)
         if self.return_names:
             out.append(self.framenames[idx])
         if self.return_timestamps:

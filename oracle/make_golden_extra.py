@@ -5,6 +5,7 @@
 
   gt_odom.npz   GroundTruthOdometryProvider.provide / relative_transformation on seeded poses
                 (odometry/groundtruth.py:74-78, geometry/geometryutils.py:413-478).
+  icl_items.npz the same for the reference's ICL loader (datasets/icl.py) on tests/tum_fixture.py:write_icl.
   tum_items.npz what the reference's TUM loader (datasets/tum.py) returns for the synthetic TUM-format
                 dataset of tests/tum_fixture.py (native-size frames: the cv2 shim only copies), for
                 every sequence of two constructor configurations.
@@ -72,6 +73,22 @@ def tum_items():
                 out["%s/%d/stamps" % (case, i)] = np.array(stamps)
     np.savez_compressed(os.path.join(OUT, "tum_items.npz"), **out)
     print("tum_items.npz", {k: int(out[k]) for k in out if k.endswith("/len")})
+    # the same for the reference's ICL loader (datasets/icl.py)
+    from gradslam.datasets.icl import ICL
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        tum_fixture.write_icl(root)
+        for case, kw in tum_fixture.ICL_CASES.items():
+            ds = ICL(root, **kw)
+            out[case + "/len"] = np.array(len(ds))
+            for i in range(len(ds)):
+                colors, depths, K, poses, transforms, names = ds[i]
+                for k, v in (("colors", colors), ("depths", depths), ("intrinsics", K), ("poses", poses),
+                             ("transforms", transforms)):
+                    out["%s/%d/%s" % (case, i, k)] = v.numpy()
+                out["%s/%d/names" % (case, i)] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "icl_items.npz"), **out)
+    print("icl_items.npz", {k: int(out[k]) for k in out if k.endswith("/len")})
 
 
 if __name__ == "__main__":

@@ -319,3 +319,21 @@ def test_ingest_kernels_match_oracle(ops, size):
     for div in (5000.0, 1000.0):
         out = ops.ingest_depth(torch.from_numpy(raw_d).cuda(), H, W, div)
         assert np.array_equal(out.cpu().numpy(), o.ingest_depth(raw_d, H, W, div))
+
+
+def test_icl_loader_on_device_matches_reference(tmp_path, golden):
+    from gradslam_amd.datasets import ICL
+    from tests import tum_fixture as fx
+    root = fx.write_icl(str(tmp_path))
+    g = golden("icl_items")
+    for case, kw in fx.ICL_CASES.items():
+        ds = ICL(root, **kw)
+        gold = {str(g["%s/%d/names" % (case, j)]): j for j in range(int(g[case + "/len"]))}
+        for k in range(len(ds)):
+            colors, depths, K, poses, transforms, names = ds[k]
+            i = gold[names]
+            assert np.array_equal(colors.cpu().numpy(), g["%s/%d/colors" % (case, i)])
+            assert np.array_equal(depths.cpu().numpy(), g["%s/%d/depths" % (case, i)])
+            assert np.array_equal(K.cpu().numpy(), g["%s/%d/intrinsics" % (case, i)])
+            assert np.abs(poses.cpu().numpy() - g["%s/%d/poses" % (case, i)]).max() <= 2e-6
+            assert np.abs(transforms.cpu().numpy() - g["%s/%d/transforms" % (case, i)]).max() <= 2e-6

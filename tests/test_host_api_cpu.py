@@ -323,3 +323,39 @@ def test_tum_loader_validation_and_no_cpu_fallback(tmp_path):
     ds = TUM(root, device="cpu", **fx.CASES["default"])
     with pytest.raises(_C.HipExtensionError):      # the ingest stage is a HIP kernel: no CPU fallback
         ds[0]
+
+
+def test_icl_loader_host_logic_matches_reference(tmp_path, golden):
+    """File discovery, the traj0 special case, sequence extraction, names, intrinsics (fy < 0) and poses of
+    our ICL loader against the reference loader's items (tests/golden/icl_items.npz)."""
+    import torch
+    from PIL import Image
+    from gradslam_amd.datasets import ICL
+    from tests import tum_fixture as fx
+    root = fx.write_icl(str(tmp_path))
+    g = golden("icl_items")
+    for case, kw in fx.ICL_CASES.items():
+        ds = ICL(root, device="cpu", **kw)
+        assert len(ds) == int(g[case + "/len"])
+        gold = {str(g["%s/%d/names" % (case, j)]): j for j in range(len(ds))}
+        assert sorted(gold) == sorted(ds.framenames)
+        for k in range(len(ds)):
+            i = gold[ds.framenames[k]]
+            assert torch.equal(ds.intrinsics, torch.from_numpy(g["%s/%d/intrinsics" % (case, i)]))
+            P = np.stack(ds._loadPoses(ds.posemetas[k]["file"], ds.posemetas[k]["line_nums"]))
+            rel = o.relative_pose(np.repeat(P[:1], len(P), 0), P)
+            assert np.abs(rel - g["%s/%d/poses" % (case, i)]).max() <= 2e-6
+            tr = np.concatenate([np.eye(4, dtype=np.float32)[None], o.relative_pose(P[:-1], P[1:])])
+            assert np.abs(tr - g["%s/%d/transforms" % (case, i)]).max() <= 2e-6
+            col = np.stack([o.ingest_color(np.asarray(Image.open(p)), fx.H, fx.W, kw.get("normalize_color", False))
+                            for p in ds.colorfiles[k]])
+            dep = np.stack([o.ingest_depth(np.asarray(Image.open(p)), fx.H, fx.W, 5000.0)[..., None]
+                            for p in ds.depthfiles[k]])
+            if kw.get("channels_first"):
+                col, dep = col.transpose(0, 3, 1, 2), dep.transpose(0, 3, 1, 2)
+            assert np.array_equal(col, g["%s/%d/colors" % (case, i)])
+            assert np.array_equal(dep, g["%s/%d/depths" % (case, i)])
+    with pytest.raises(ValueError, match="should only contain trajectory folder names"):
+        ICL(root, trajectories=("kitchen",))
+    with pytest.raises(TypeError, match="seqlen must be int"):
+        ICL(root, seqlen="4")

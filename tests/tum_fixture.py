@@ -48,3 +48,39 @@ CASES = {
     "strided": dict(seqlen=2, dilation=1, stride=2, start=1, end=8, height=H, width=W, normalize_color=True,
                     channels_first=True, sequences=("rgbd_dataset_freiburg2_beta",)),
 }
+
+
+# ------------------------------------------------------------------ ICL-NUIM format
+def write_icl(root, n_frames=8, seed=11):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    for num in (0, 2):
+        name = "living_room_traj%d_frei_png" % num
+        d = os.path.join(root, name)
+        os.makedirs(os.path.join(d, "rgb"), exist_ok=True)
+        os.makedirs(os.path.join(d, "depth"), exist_ok=True)
+        assoc, sim = [], []
+        for k in range(n_frames):
+            Image.fromarray(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).save(os.path.join(d, "rgb/%d.png" % k))
+            dep = rng.integers(0, 30000, (H, W), dtype=np.uint16)
+            dep[rng.random((H, W)) < 0.05] = 0
+            Image.fromarray(dep).save(os.path.join(d, "depth/%d.png" % k))
+            assoc.append("%d depth/%d.png %d rgb/%d.png" % (k, k, k, k))
+            a = 0.03 * k + 0.2 * num
+            R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+            t = np.array([0.02 * k, -0.01 * k, 0.3 + 0.005 * k * k])
+            for r in range(3):
+                sim.append("%.6f %.6f %.6f %.6f" % (R[r, 0], R[r, 1], R[r, 2], t[r]))
+            sim.append("")
+        with open(os.path.join(d, "associations.txt"), "w") as f:
+            f.write("\n".join(assoc) + "\n")
+        with open(os.path.join(d, "livingRoom%dn.gt.sim" % num), "w") as f:
+            f.write("\n".join(sim) + "\n")
+    return root
+
+
+ICL_CASES = {
+    "default": dict(seqlen=3, height=H, width=W),
+    "strided": dict(seqlen=2, dilation=2, stride=1, start=1, end=7, height=H, width=W, normalize_color=True,
+                    channels_first=True, trajectories=("living_room_traj2_frei_png",)),
+}
