@@ -226,6 +226,37 @@ extern "C" int gs_downsample_frame_f32(const float* gvertex, const float* gnorma
                     count_out, 0, -1, scratch, gs_stream(stream));
 }
 
+// ICP source of a frame WITHOUT compaction: slot e of the [::ds, ::ds] lattice (raster order) holds the
+// global vertex R v + t of its pixel (the arithmetic of gs_global_maps_f32) or NaN when the pixel has no
+// depth.  gs_icp_*'s grid path ignores NaN source points, so the lattice can be fed to it as is: one
+// launch instead of global maps + an ordered compaction (4 launches) per frame.
+__global__ void __launch_bounds__(256) gs_lattice_source_kernel(const float* __restrict__ vertex,
+                                                                const float* __restrict__ depth,
+                                                                const float* __restrict__ pose16, int W, int ds, int Wl,
+                                                                int64_t n_lat, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_lat) return;
+  const int64_t p = (e / Wl) * ds * (int64_t)W + (e % Wl) * ds;
+  float g0 = __builtin_nanf(""), g1 = g0, g2 = g0;
+  if (depth[p] > 0.0f) {
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = pose16[i];
+    gs_rigid_fma(T, vertex[3 * p], vertex[3 * p + 1], vertex[3 * p + 2], g0, g1, g2);
+  }
+  out[3 * e] = g0; out[3 * e + 1] = g1; out[3 * e + 2] = g2;
+}
+extern "C" int gs_lattice_source_f32(const float* vertex, const float* depth, const float* pose16, int H, int W,
+                                     int ds, float* out_pts, void* stream) {
+  GS_REQUIRE(H > 0 && W > 0 && ds > 0 && vertex && depth && pose16 && out_pts, "bad arguments");
+  const int Hl = (H + ds - 1) / ds, Wl = (W + ds - 1) / ds;
+  const int64_t n_lat = (int64_t)Hl * Wl;
+  hipLaunchKernelGGL(gs_lattice_source_kernel, dim3((unsigned)gs_ceil_div(n_lat, 256)), dim3(256), 0, gs_stream(stream),
+                     vertex, depth, pose16, W, ds, Wl, n_lat, out_pts);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 // backward of gs_downsample_frame_f32 (points): scatter the compact adjoints back to their pixels
 struct EmitFrameLatticeScatter {
   int W, ds, Wl;

@@ -169,8 +169,16 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   if (lb == 0 && threadIdx.x < (int)(sizeof(IcpSmall) / 4))
     reinterpret_cast<float*>(st_out)[threadIdx.x] = reinterpret_cast<const float*>(&sm)[threadIdx.x];
 
-  // ---- search: one source point per 16-lane group, pending transform applied to the loaded point
-  if (s < n_src) {
+  // ---- search: one source point per 16-lane group, pending transform applied to the loaded point.
+  // A NaN source point (empty slot of an un-compacted lattice, gs_lattice_source_f32) is skipped: it stays
+  // NaN through every transform, is never searched and contributes no row.
+  if (s < n_src && p0 != p0) {
+    if (lane == 0) {
+      if (FULL) { src_out[3 * s] = p0; src_out[3 * s + 1] = p0; src_out[3 * s + 2] = p0; }
+      qs[slot][0] = p0; qs[slot][1] = p0; qs[slot][2] = p0;
+      keys_s[slot] = ~0ull;
+    }
+  } else if (s < n_src) {
     const float* T = FULL ? sm.T_step : sm.Tr;
     float qx, qy, qz;
     gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
@@ -205,7 +213,10 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   if (threadIdx.x < FS_QPB) {
     bool keep = false;
     float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, res = 0.0f;
-    if (r < n_src) {
+    if (r < n_src && qs[threadIdx.x][0] != qs[threadIdx.x][0]) {  // skipped (NaN) source point
+      if (FULL && out_idx) out_idx[r] = -1;
+      if (tape_idx) tape_idx[r] = -1;
+    } else if (r < n_src) {
       const unsigned long long bb = keys_s[threadIdx.x];
       int64_t j = (int64_t)(bb & 0xffffffffull);
       if (j >= n_tgt) j = 0;  // only when every distance was NaN

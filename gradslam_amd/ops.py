@@ -110,6 +110,18 @@ def downsample_frame(gvertex, gnormal, rgb, depth, ds, sync=True):
     return pts[:c], (nrm[:c] if nrm is not None else None), (col[:c] if col is not None else None)
 
 
+def lattice_source(vertex, depth, pose, ds):
+    """ICP source of a frame without compaction: (ceil(H/ds)*ceil(W/ds), 3) global vertices of the lattice
+    pixels, NaN where the pixel has no depth (ignored by icp's grid path)."""
+    vertex, depth, pose = _c(vertex), _c(depth), _c(pose)
+    dev = require_device(vertex, depth, pose)
+    H, W = depth.shape[:2]
+    out = torch.empty((-(-H // ds) * -(-W // ds), 3), dtype=f32, device=dev)
+    check(lib().gs_lattice_source_f32(ptr(vertex), ptr(depth), ptr(pose), H, W, int(ds), ptr(out), stream(dev)),
+          "gs_lattice_source_f32")
+    return out
+
+
 def project_map(points, pose, K, H, W, n_dev=None):
     """n_dev: device int64[1] holding the actual row count (points.shape[0] is then an upper bound)."""
     points, pose, K = _c(points), _c(pose), _c(K)

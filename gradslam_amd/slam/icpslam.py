@@ -100,22 +100,24 @@ class ICPSLAM(nn.Module):
             K = prev_frame.intrinsics[:, 0].contiguous().float()
             prev_poses = prev_frame.poses[:, 0].contiguous().float()
             src_pts, tgt_pts, tgt_nrm = [], [], []
-            gvm = fr.global_vertex_map
-            taped = torch.is_grad_enabled() and gvm.requires_grad and self.odom == "gradicp"
+            taped = torch.is_grad_enabled() and fr.depth_image.requires_grad and self.odom == "gradicp"
             if not taped and type(self.odomprov) in (ICPOdometryProvider, GradICPOdometryProvider):
-                # fast path: the sizes of the ICP point sets stay on the device (no host read-back between
-                # selecting the sets and solving); buffers are sized by their upper bounds
-                out = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=gvm.device)
+                # fast path: no host read-back and no compaction of the source set.  The ICP source is the
+                # frame's [::ds, ::ds] lattice of global vertices under the previous pose (NaN = no depth,
+                # skipped by the solver), built from the LOCAL vertex map in one launch; the size of the
+                # target set stays on the device.
+                out = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=fr.device)
+                vm = fr.vertex_map
                 for b in range(B):
-                    depth_b = fr.depth_image[b, 0, ..., 0]
-                    src, _, _, n_src = ops.downsample_frame(gvm[b, 0], None, None, depth_b, self.dsratio, sync=False)
+                    src = ops.lattice_source(vm[b, 0], fr.depth_image[b, 0, ..., 0], prev_poses[b], self.dsratio)
                     n_b, n_dev = pointclouds._count_of(b)
                     P, N = pointclouds._buf["points"][b][:n_b], pointclouds._buf["normals"][b][:n_b]
                     pix = ops.project_map(P, prev_poses[b], K[b], H, W, n_dev=n_dev)
                     tgt, tn, _, n_tgt = ops.select_targets(pix, W, self.dsratio, P, N, sync=False, n_dev=n_dev)
                     ops.icp(src, tgt, tn, compose=prev_poses[b], mode=self.odomprov._mode, return_idx=False,
-                            n_src_dev=n_src, n_tgt_dev=n_tgt, out=out[b, 0], **self.odomprov._kwargs())
+                            n_tgt_dev=n_tgt, out=out[b, 0], **self.odomprov._kwargs())
                 return out
+            gvm = fr.global_vertex_map
             for b in range(B):
                 # downsample_rgbdimages(live_frame): valid lattice pixels of the global vertex map
                 if taped:

@@ -298,6 +298,14 @@ GS_API int gs_append_valid_f32(float* points, float* normals, float* colors, flo
                         const float* depth, int H, int W, int64_t* new_count_out, void* scratch,
                         void* stream);
 
+/* ICP source set of a frame without compaction (the points of downsample_rgbdimages,
+ * odometry/icputils.py:654-668, computed from the LOCAL vertex map and the pose as in
+ * structures/rgbdimages.py:681-708): out_pts (ceil(H/ds) * ceil(W/ds), 3), raster order, NaN where the
+ * lattice pixel has no depth.  The grid path of gs_icp_f32 / gs_icp_dc_f32 ignores NaN source points
+ * (no search, no row, out_idx = -1), so the lattice is a valid `src` as is. */
+GS_API int gs_lattice_source_f32(const float* vertex, const float* depth, const float* pose16, int H, int W, int ds,
+                                 float* out_pts, void* stream);
+
 /* ---- dataset -> device ingest (datasets/tum.py:448-477 _preprocess_color / _preprocess_depth; the same
  * two steps in datasets/icl.py and datasets/scannet.py).  raw: the decoded PNG on the device (depth
  * uint16 (H0, W0); colour uint8 (H0, W0, 3)); out: float32 (H, W) / (H, W, 3).  Depth: cv2.INTER_NEAREST

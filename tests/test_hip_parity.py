@@ -475,3 +475,28 @@ def test_device_side_counts_batch_and_container_ops(ops):
     assert torch.equal(pc.normals_list[0][n_ref[0]:], ref.normals_list[0])
     pc = run(True)
     assert pc.has_points and pc.cpu().points_list[1].shape[0] == n_ref[1]
+
+
+def test_lattice_source_feeds_icp_like_the_compacted_set(ops):
+    """gs_lattice_source_f32: same points as global_maps + downsample_frame (bit-exact), NaN in the empty
+    slots; the ICP solve on the un-compacted lattice skips them and equals the solve on the compacted set
+    (same neighbours; transform within float64 summation-order noise)."""
+    s = make_sequence(2, 240, 320, seed=8, hole_frac=0.2)
+    K, pose = dev(s["intrinsics"][0]), dev(s["poses"][0])
+    d0, d1 = dev(s["depths"][0, ..., 0]), dev(s["depths"][1, ..., 0])
+    v0, n0, _, _ = ops.frame_maps(d0, K)
+    gv0, gn0 = ops.global_maps(v0, n0, d0, pose)
+    tgt, tn, _ = ops.downsample_frame(gv0, gn0, None, d0, 2)
+    v1, n1, _, _ = ops.frame_maps(d1, K)
+    gv1, _ = ops.global_maps(v1, n1, d1, pose)
+    src, _, _ = ops.downsample_frame(gv1, None, None, d1, 4)
+    lat = ops.lattice_source(v1, d1, pose, 4)
+    valid = ~torch.isnan(lat[:, 0])
+    assert lat.shape[0] == 60 * 80 and int(valid.sum()) == src.shape[0] < lat.shape[0]
+    assert torch.equal(lat[valid], src) and bool(torch.isnan(lat[~valid]).all())
+    n_tgt = torch.tensor([tgt.shape[0]], dtype=torch.int64, device="cuda")     # device count: grid path
+    for mode in (1, 0):
+        T_c, idx_c = ops.icp(src, tgt, tn, mode=mode, numiters=10, n_tgt_dev=n_tgt)
+        T_l, idx_l = ops.icp(lat, tgt, tn, mode=mode, numiters=10, n_tgt_dev=n_tgt)
+        assert torch.equal(idx_l[valid], idx_c) and bool((idx_l[~valid] == -1).all())
+        assert float((T_l - T_c).abs().max()) <= 1e-6 and bool(torch.isfinite(T_l).all())
