@@ -321,8 +321,12 @@ int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* gr
   while (cells_cap < GS_GRID_MAXCELL && cells_cap < want) cells_cap <<= 1;
   GsProf prof(GS_PROF_COMPACT, 28.0 * (double)n_tgt + 8.0 * (double)cells_cap, st);
   // one memset: bbox codes + unresolved counters + cell counts (contiguous in the scratch layout)
-  hipError_t e = hipMemsetAsync(m.bbox, 0, (size_t)(reinterpret_cast<char*>(m.cell_count) - reinterpret_cast<char*>(m.bbox)) +
-                                               4 * (size_t)(cells_cap + 1), st);
+  // (from the 256-byte aligned start of the scratch and rounded up to 256 bytes so that the runtime issues ONE
+  // fill kernel, not a head + body pair; the header is rewritten by the count kernel and the bytes of
+  // cell_start the round-up may touch are rewritten by the scan)
+  const size_t clear = gs_align((size_t)(reinterpret_cast<char*>(m.cell_count) - reinterpret_cast<char*>(m.g)) +
+                                4 * (size_t)(cells_cap + 1));
+  hipError_t e = hipMemsetAsync(m.g, 0, clear, st);
   if (e != hipSuccess) { gs_set_error("gs_knn_grid_build: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
   hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, GB_BLOCK * GB_ITEMS)),
                      dim3(GB_BLOCK), 0, st, tgt, n_tgt_c, m.bbox, m.unres_count);
