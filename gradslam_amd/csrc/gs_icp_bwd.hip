@@ -10,25 +10,35 @@
 // against the reference's own autograd (tests/golden/icp_grad.npz).
 //
 // Per iteration (last to first): scalar stage S1 (adjoint of T_step = exp(sigma xi), of sigma and
-// of the damping) -> point kernel P2 (look-ahead residual, scatter to targets, 12 sums for the
-// adjoint of Tr) -> scalar stage S2 (adjoint of xi through exp and the 6x6 solve) -> point kernel
-// P3 (Gauss-Newton rows, scatter to targets, 12 sums for the next S1).  All arithmetic in float64;
-// scatters are float64 atomics (order-independent to ~1e-16, rounded once at the end).
+// of the damping) -> point stage P2 (look-ahead residual, scatter to targets, 12 sums for the
+// adjoint of Tr) -> scalar stage S2 (adjoint of xi through exp and the 6x6 solve) -> point stage
+// P3 (Gauss-Newton rows, scatter to targets, 12 sums for the next S1).  As in the forward loop the
+// scalar stages are the PROLOGUE of the point kernel that follows them (every block adds up the
+// previous kernel's partial rows and evaluates the stage redundantly, block 0 records the carried
+// state), so an iteration is 2 launches, not 4; carried state and partial rows are double-buffered.
+// All arithmetic in float64; scatters are float64 atomics (order-independent to ~1e-16, rounded once
+// at the end).
 #include "gs_icp_math.h"
 
 constexpr int BW_BLOCK = 256;
 constexpr int BW_NV = 12;  // 3x3 outer-product sum + 3-vector sum
 
+struct BwdCarry {      // what one kernel hands to the next
+  double Tb[16];       // adjoint of the running transform
+  double lam_bar;      // adjoint of the damping carried to the next (earlier) iteration
+  double xi_bar[6];    // S1 -> S2
+  double e_bar;        // S1 -> P3
+};
 struct BwdState {
   double Tk[65][16];  // running transform before iteration k (Tk[K] = final)
   double Ts[64][16];  // exp(sigma_k xi_k)
   double Tr[64][16];  // exp(xi_k)
-  double Tb[16];      // adjoint of the running transform
-  double lam_bar;     // adjoint of the damping carried to the next (earlier) iteration
-  double xi_bar[6];
+  BwdCarry carry[2];  // A(k) reads [0] and writes [1]; B(k) reads [1] and writes [0]
+};
+struct BwdLocal {      // results of a prologue, shared through LDS
+  double e1_bar, e_bar;
   double g_bar[6];
   double Hs[36];
-  double e_bar, e1_bar;
 };
 
 GS_DEV void d_mm4(const double* A, const double* B, double* C) {
@@ -166,18 +176,22 @@ GS_DEV void bw_block_reduce(const double* v, double* __restrict__ partial_row) {
   }
 }
 
+// Adds up partial rows with the first wave of the block (12 values, rows strided over its 64 lanes, fixed
+// order); every thread of the block must call it (it synchronises), every thread receives G.
 GS_DEV void bw_sum_rows(const double* __restrict__ partials, int nrows, double* G) {
-  // one wave per call site is enough: 12 values, rows strided over the 64 lanes
   __shared__ double acc[BW_NV];
   const int lane = threadIdx.x;
-  for (int i = 0; i < BW_NV; ++i) {
-    double s = 0.0;
-    for (int b = lane; b < nrows; b += GS_WAVE) s += partials[(int64_t)b * BW_NV + i];
-    s = gs_wave_sum_f64(s);
-    if (lane == 0) acc[i] = s;
+  if (lane < GS_WAVE) {
+    for (int i = 0; i < BW_NV; ++i) {
+      double s = 0.0;
+      for (int b = lane; b < nrows; b += GS_WAVE) s += partials[(int64_t)b * BW_NV + i];
+      s = gs_wave_sum_f64(s);
+      if (lane == 0) acc[i] = s;
+    }
   }
   __syncthreads();
   for (int i = 0; i < BW_NV; ++i) G[i] = acc[i];
+  __syncthreads();
 }
 
 // Replays the forward transforms and seeds the adjoints.
@@ -196,21 +210,19 @@ __global__ void gs_bwd_init_kernel(BwdState* __restrict__ bs, GsIcpTape tape, co
     d_se3_exp(xs, bs->Ts[k]);
     d_mm4(bs->Ts[k], bs->Tk[k], bs->Tk[k + 1]);
   }
-  for (int i = 0; i < 16; ++i) bs->Tb[i] = (double)T_bar16[i];
-  bs->lam_bar = 0.0;
+  for (int i = 0; i < 16; ++i) bs->carry[0].Tb[i] = (double)T_bar16[i];
+  bs->carry[0].lam_bar = 0.0;
+  for (int i = 0; i < 6; ++i) bs->carry[0].xi_bar[i] = 0.0;
+  bs->carry[0].e_bar = 0.0;
 }
 
-// S1 of iteration k: needs G = sum_i sbar_next_i (x) s_k,i and h = sum_i sbar_next_i
-__global__ void __launch_bounds__(GS_WAVE) gs_bwd_s1_kernel(BwdState* __restrict__ bs, GsIcpTape tape, int k,
-                                                            const double* __restrict__ partials, int nrows,
-                                                            gs_icp_params prm) {
-  double G[BW_NV];
-  bw_sum_rows(partials, nrows, G);
-  if (threadIdx.x != 0) return;
+// S1 of iteration k (one lane): needs G = sum_i sbar_next_i (x) s_k,i and h = sum_i sbar_next_i
+GS_DEV void bw_stage_s1(const BwdState* __restrict__ bs, const GsIcpTape& tape, int k, const double* G,
+                        const gs_icp_params& prm, const BwdCarry& in, BwdCarry& out, BwdLocal& loc) {
   const double* Tk = bs->Tk[k];
   const double* Ts = bs->Ts[k];
   double Tb[16], Tsb[16];
-  for (int i = 0; i < 16; ++i) Tb[i] = bs->Tb[i];
+  for (int i = 0; i < 16; ++i) Tb[i] = in.Tb[i];
   // Ts_bar = Tb Tk^T (+ the point-cloud part)
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {
@@ -223,14 +235,12 @@ __global__ void __launch_bounds__(GS_WAVE) gs_bwd_s1_kernel(BwdState* __restrict
     Tsb[4 * i + 3] += G[9 + i];
   }
   // Tb <- Ts^T Tb
-  double nTb[16];
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {
       double acc = 0.0;
       for (int m = 0; m < 4; ++m) acc += Ts[4 * m + i] * Tb[4 * m + j];
-      nTb[4 * i + j] = acc;
+      out.Tb[4 * i + j] = acc;
     }
-  for (int i = 0; i < 16; ++i) bs->Tb[i] = nTb[i];
   double xi[6], xs[6], ub[6];
   const double sig = (double)tape.trace[12 * k + 3];
   for (int i = 0; i < 6; ++i) {
@@ -241,7 +251,7 @@ __global__ void __launch_bounds__(GS_WAVE) gs_bwd_s1_kernel(BwdState* __restrict
   double sig_bar = 0.0;
   for (int i = 0; i < 6; ++i) {
     sig_bar += ub[i] * xi[i];
-    bs->xi_bar[i] = sig * ub[i];
+    out.xi_bar[i] = sig * ub[i];
   }
   const float err = tape.trace[12 * k], new_err = tape.trace[12 * k + 1];
   const double lam = (double)tape.sys[28 * k + 27];
@@ -255,19 +265,32 @@ __global__ void __launch_bounds__(GS_WAVE) gs_bwd_s1_kernel(BwdState* __restrict
   const double q = lmin + lrange / (1 + E);
   const double dq = lrange * Bp * E / ((1 + E) * (1 + E));
   const double dsig = (B2p * E2 / nu) * pow(1 + E2, -1.0 / nu - 1.0);
-  double d_bar = sig_bar * dsig + bs->lam_bar * lam * dq;
-  bs->lam_bar = bs->lam_bar * q;
+  double d_bar = sig_bar * dsig + in.lam_bar * lam * dq;
+  out.lam_bar = in.lam_bar * q;
   if (!inside) d_bar = 0.0;
-  bs->e1_bar = d_bar;
-  bs->e_bar = -d_bar;
+  loc.e1_bar = d_bar;
+  loc.e_bar = -d_bar;
+  out.e_bar = -d_bar;
 }
 
 // P2 of iteration k: sb_mid = Rs^T sbar_next + look-ahead residual part; scatter; sums for Tr_bar
 __global__ void __launch_bounds__(BW_BLOCK) gs_bwd_p2_kernel(
-    const BwdState* __restrict__ bs, int k, const float* __restrict__ src_k, const int32_t* __restrict__ idx1,
+    BwdState* __restrict__ bs, GsIcpTape tape, int k, gs_icp_params prm, const double* __restrict__ partials_in,
+    int nrows_in, const float* __restrict__ src_k, const int32_t* __restrict__ idx1,
     int64_t n_src, const float* __restrict__ tgt, const float* __restrict__ tn, const double* __restrict__ sbar_next,
     double* __restrict__ sbar_mid, double* __restrict__ tgt_bar, double* __restrict__ tn_bar,
     double* __restrict__ partials) {
+  __shared__ BwdLocal loc;
+  {  // prologue: S1 of this iteration, identical in every block
+    double G[BW_NV];
+    bw_sum_rows(partials_in, nrows_in, G);
+    if (threadIdx.x == 0) {
+      BwdCarry out;
+      bw_stage_s1(bs, tape, k, G, prm, bs->carry[0], out, loc);
+      if (blockIdx.x == 0) bs->carry[1] = out;
+    }
+    __syncthreads();
+  }
   const int64_t i = (int64_t)blockIdx.x * BW_BLOCK + threadIdx.x;
   double v[BW_NV];
 #pragma unroll
@@ -275,7 +298,7 @@ __global__ void __launch_bounds__(BW_BLOCK) gs_bwd_p2_kernel(
   if (i < n_src) {
     const double* Ts = bs->Ts[k];
     const double* Tr = bs->Tr[k];
-    const double e1_bar = bs->e1_bar;
+    const double e1_bar = loc.e1_bar;
     const double s[3] = {(double)src_k[3 * i], (double)src_k[3 * i + 1], (double)src_k[3 * i + 2]};
     const double sn[3] = {sbar_next[3 * i], sbar_next[3 * i + 1], sbar_next[3 * i + 2]};
     double sb[3];
@@ -307,12 +330,9 @@ __global__ void __launch_bounds__(BW_BLOCK) gs_bwd_p2_kernel(
   bw_block_reduce(v, partials + (int64_t)blockIdx.x * BW_NV);
 }
 
-// S2 of iteration k: xi_bar += adjoint through Tr = exp(xi); then through xi = H^-1 g
-__global__ void __launch_bounds__(GS_WAVE) gs_bwd_s2_kernel(BwdState* __restrict__ bs, GsIcpTape tape, int k,
-                                                            const double* __restrict__ partials, int nrows) {
-  double G[BW_NV];
-  bw_sum_rows(partials, nrows, G);
-  if (threadIdx.x != 0) return;
+// S2 of iteration k (one lane): xi_bar += adjoint through Tr = exp(xi); then through xi = H^-1 g
+GS_DEV void bw_stage_s2(const GsIcpTape& tape, int k, const double* G, const BwdCarry& in, BwdCarry& out,
+                        BwdLocal& loc) {
   double Trb[16];
   for (int i = 0; i < 16; ++i) Trb[i] = 0.0;
   for (int i = 0; i < 3; ++i) {
@@ -322,7 +342,7 @@ __global__ void __launch_bounds__(GS_WAVE) gs_bwd_s2_kernel(BwdState* __restrict
   double xi[6], ub[6], xb[6], H[36], gb[6];
   for (int i = 0; i < 6; ++i) xi[i] = (double)tape.trace[12 * k + 4 + i];
   d_se3_exp_adjoint(xi, Trb, ub);
-  for (int i = 0; i < 6; ++i) xb[i] = bs->xi_bar[i] + ub[i];
+  for (int i = 0; i < 6; ++i) xb[i] = in.xi_bar[i] + ub[i];
   const float lam = tape.sys[28 * k + 27];
   int q = 0;
   for (int r = 0; r < 6; ++r)
@@ -334,20 +354,36 @@ __global__ void __launch_bounds__(GS_WAVE) gs_bwd_s2_kernel(BwdState* __restrict
   d_solve6(H, xb, gb);
   double tr = 0.0;
   for (int r = 0; r < 6; ++r) {
-    bs->g_bar[r] = gb[r];
+    loc.g_bar[r] = gb[r];
     tr += -gb[r] * xi[r];
   }
   for (int r = 0; r < 6; ++r)
-    for (int c = 0; c < 6; ++c) bs->Hs[6 * r + c] = -(gb[r] * xi[c] + gb[c] * xi[r]);
-  bs->lam_bar += tr;
+    for (int c = 0; c < 6; ++c) loc.Hs[6 * r + c] = -(gb[r] * xi[c] + gb[c] * xi[r]);
+  for (int i = 0; i < 16; ++i) out.Tb[i] = in.Tb[i];
+  for (int i = 0; i < 6; ++i) out.xi_bar[i] = 0.0;
+  out.lam_bar = in.lam_bar + tr;
+  out.e_bar = in.e_bar;
+  loc.e_bar = in.e_bar;
 }
 
 // P3 of iteration k: Gauss-Newton rows; sbar (adjoint of src_k); scatter; sums for the next S1
 __global__ void __launch_bounds__(BW_BLOCK) gs_bwd_p3_kernel(
-    const BwdState* __restrict__ bs, const float* __restrict__ src_k, const float* __restrict__ src_prev,
+    BwdState* __restrict__ bs, GsIcpTape tape, int k, const double* __restrict__ partials_in, int nrows_in,
+    const float* __restrict__ src_k, const float* __restrict__ src_prev,
     const int32_t* __restrict__ idx0, int64_t n_src, const float* __restrict__ tgt, const float* __restrict__ tn,
     const double* __restrict__ sbar_mid, double* __restrict__ sbar_out, double* __restrict__ tgt_bar,
     double* __restrict__ tn_bar, double* __restrict__ partials) {
+  __shared__ BwdLocal loc;
+  {  // prologue: S2 of this iteration, identical in every block
+    double G[BW_NV];
+    bw_sum_rows(partials_in, nrows_in, G);
+    if (threadIdx.x == 0) {
+      BwdCarry out;
+      bw_stage_s2(tape, k, G, bs->carry[1], out, loc);
+      if (blockIdx.x == 0) bs->carry[0] = out;
+    }
+    __syncthreads();
+  }
   const int64_t i = (int64_t)blockIdx.x * BW_BLOCK + threadIdx.x;
   double v[BW_NV];
 #pragma unroll
@@ -357,7 +393,7 @@ __global__ void __launch_bounds__(BW_BLOCK) gs_bwd_p3_kernel(
     double sb[3] = {sbar_mid[3 * i], sbar_mid[3 * i + 1], sbar_mid[3 * i + 2]};
     const int32_t j = idx0[i];
     if (j >= 0) {
-      const double e_bar = bs->e_bar;
+      const double e_bar = loc.e_bar;
       double n0[3], d0[3], a[6];
       for (int c = 0; c < 3; ++c) {
         n0[c] = (double)tn[3 * (int64_t)j + c];
@@ -370,10 +406,10 @@ __global__ void __launch_bounds__(BW_BLOCK) gs_bwd_p3_kernel(
       const double b = n0[0] * (d0[0] - s[0]) + n0[1] * (d0[1] - s[1]) + n0[2] * (d0[2] - s[2]);
       double ab[6], b_bar = 2 * b * e_bar;
       for (int r = 0; r < 6; ++r) {
-        double acc = bs->g_bar[r] * b;
-        for (int c = 0; c < 6; ++c) acc += bs->Hs[6 * r + c] * a[c];
+        double acc = loc.g_bar[r] * b;
+        for (int c = 0; c < 6; ++c) acc += loc.Hs[6 * r + c] * a[c];
         ab[r] = acc;
-        b_bar += a[r] * bs->g_bar[r];
+        b_bar += a[r] * loc.g_bar[r];
       }
       const double* an = ab;
       const double* ac = ab + 3;
@@ -406,8 +442,8 @@ __global__ void __launch_bounds__(GS_WAVE) gs_bwd_final_scalar_kernel(const BwdS
   bw_sum_rows(partials, nrows, G);
   if (threadIdx.x != 0 || !init_bar16) return;
   for (int i = 0; i < 3; ++i) {
-    for (int j = 0; j < 3; ++j) init_bar16[4 * i + j] = (float)(bs->Tb[4 * i + j] + G[3 * i + j]);
-    init_bar16[4 * i + 3] = (float)(bs->Tb[4 * i + 3] + G[9 + i]);
+    for (int j = 0; j < 3; ++j) init_bar16[4 * i + j] = (float)(bs->carry[0].Tb[4 * i + j] + G[3 * i + j]);
+    init_bar16[4 * i + 3] = (float)(bs->carry[0].Tb[4 * i + 3] + G[9 + i]);
   }
   for (int j = 0; j < 4; ++j) init_bar16[12 + j] = 0.0f;
 }
@@ -432,7 +468,8 @@ struct BwdScratch {
   double* sbar_b;   // [n_src][3]
   double* tgt_bar;  // [n_tgt][3]
   double* tn_bar;   // [n_tgt][3]
-  double* partials; // [nblk][12]
+  double* partials; // [nblk][12]   read by A(k) / final, written by B(k)
+  double* partials2; // [nblk][12]  written by A(k), read by B(k)
 };
 static BwdScratch bwd_carve(void* scratch, int64_t n_src, int64_t n_tgt) {
   char* p = reinterpret_cast<char*>(scratch);
@@ -442,7 +479,8 @@ static BwdScratch bwd_carve(void* scratch, int64_t n_src, int64_t n_tgt) {
   s.sbar_b = reinterpret_cast<double*>(p); p += gs_align(24 * (size_t)n_src);
   s.tgt_bar = reinterpret_cast<double*>(p); p += gs_align(24 * (size_t)n_tgt);
   s.tn_bar = reinterpret_cast<double*>(p); p += gs_align(24 * (size_t)n_tgt);
-  s.partials = reinterpret_cast<double*>(p);
+  s.partials = reinterpret_cast<double*>(p); p += gs_align(8 * BW_NV * (size_t)gs_ceil_div(n_src, BW_BLOCK));
+  s.partials2 = reinterpret_cast<double*>(p);
   return s;
 }
 
@@ -450,7 +488,7 @@ extern "C" int64_t gs_icp_backward_scratch_bytes(int64_t n_src, int64_t n_tgt) {
   if (n_src < 1) n_src = 1;
   if (n_tgt < 1) n_tgt = 1;
   return (int64_t)(gs_align(sizeof(BwdState)) + 2 * gs_align(24 * (size_t)n_src) + 2 * gs_align(24 * (size_t)n_tgt) +
-                   gs_align(8 * BW_NV * (size_t)gs_ceil_div(n_src, BW_BLOCK)) + 4096);
+                   2 * gs_align(8 * BW_NV * (size_t)gs_ceil_div(n_src, BW_BLOCK)) + 4096);
 }
 
 extern "C" int gs_icp_backward_f32(const void* tape, const float* src_in, int64_t n_src, const float* tgt,
@@ -478,13 +516,13 @@ extern "C" int gs_icp_backward_f32(const void* tape, const float* src_in, int64_
     const float* src_prev = (k > 0) ? tp.src + (size_t)(k - 1) * 3 * (size_t)n_src : src_in;
     const int32_t* idx0 = tp.idx + ((size_t)k * 2) * (size_t)n_src;
     const int32_t* idx1 = idx0 + (size_t)n_src;
-    hipLaunchKernelGGL(gs_bwd_s1_kernel, dim3(1), dim3(GS_WAVE), 0, st, sc.state, tp, k, sc.partials, nblk, *prm);
-    hipLaunchKernelGGL(gs_bwd_p2_kernel, dim3(nblk), dim3(BW_BLOCK), 0, st, sc.state, k, src_k, idx1, n_src, tgt,
-                       tgt_normals, sbar_next, sbar_mid, sc.tgt_bar, sc.tn_bar, sc.partials);
-    hipLaunchKernelGGL(gs_bwd_s2_kernel, dim3(1), dim3(GS_WAVE), 0, st, sc.state, tp, k, sc.partials, nblk);
-    // P3 overwrites sbar_next with the adjoint of src_k (it only reads sbar_mid)
-    hipLaunchKernelGGL(gs_bwd_p3_kernel, dim3(nblk), dim3(BW_BLOCK), 0, st, sc.state, src_k, src_prev, idx0, n_src, tgt,
-                       tgt_normals, sbar_mid, sbar_next, sc.tgt_bar, sc.tn_bar, sc.partials);
+    // A(k) = S1 + P2: reads partials / carry[0], writes partials2 / carry[1]
+    hipLaunchKernelGGL(gs_bwd_p2_kernel, dim3(nblk), dim3(BW_BLOCK), 0, st, sc.state, tp, k, *prm, sc.partials, nblk,
+                       src_k, idx1, n_src, tgt, tgt_normals, sbar_next, sbar_mid, sc.tgt_bar, sc.tn_bar, sc.partials2);
+    // B(k) = S2 + P3: reads partials2 / carry[1], writes partials / carry[0]; P3 overwrites sbar_next with the
+    // adjoint of src_k (it only reads sbar_mid)
+    hipLaunchKernelGGL(gs_bwd_p3_kernel, dim3(nblk), dim3(BW_BLOCK), 0, st, sc.state, tp, k, sc.partials2, nblk, src_k,
+                       src_prev, idx0, n_src, tgt, tgt_normals, sbar_mid, sbar_next, sc.tgt_bar, sc.tn_bar, sc.partials);
   }
   if (K == 0) {  // T = init: sums stay zero, Tb = T_bar
     GS_HIP(hipMemsetAsync(sc.partials, 0, 8 * BW_NV * (size_t)nblk, st));
