@@ -90,7 +90,7 @@ GS_DEV double icp_sum_col27(const double* __restrict__ partials, int nrows, doub
 constexpr int FS_BLOCK = 768;            // 12 waves; 2 blocks per CU keep all 400 blocks of a 640x480 solve resident
 constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 48 queries per block, their rows are built by wave 0
 constexpr int FS_RG = FS_QPB / 4;        // row groups of 4 in the block reduction
-static_assert(FS_QPB <= GS_WAVE && FS_QPB % 4 == 0 && FS_RG * LIN_NV <= FS_BLOCK, "block shape");
+static_assert(FS_QPB <= 2 * GS_WAVE && FS_QPB % 4 == 0 && FS_RG * LIN_NV <= FS_BLOCK, "block shape");
 
 // FULL = true : first half of iteration `it`  (prologue: LM update of iteration it-1, then search
 //               with T_step applied, full normal equations)
@@ -239,10 +239,20 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
       row[27] = rr;
     }
   }
-  if (!FULL) {  // residual only: one value, a plain wave reduction is enough
-    if (threadIdx.x < GS_WAVE) {
-      const double sum = gs_wave_sum_f64(rr);
-      if (threadIdx.x == 0) partials_out[(int64_t)lb * LIN_NV + 27] = sum;
+  if (!FULL) {  // residual only: one value per query, wave reductions of the (up to two) row-building waves
+    if (FS_QPB <= GS_WAVE) {
+      if (threadIdx.x < GS_WAVE) {
+        const double sum = gs_wave_sum_f64(rr);
+        if (threadIdx.x == 0) partials_out[(int64_t)lb * LIN_NV + 27] = sum;
+      }
+    } else {
+      double* red2 = reinterpret_cast<double*>(red);
+      if (threadIdx.x < 2 * GS_WAVE) {
+        const double sum = gs_wave_sum_f64(rr);
+        if ((threadIdx.x & (GS_WAVE - 1)) == 0) red2[threadIdx.x / GS_WAVE] = sum;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) partials_out[(int64_t)lb * LIN_NV + 27] = red2[0] + red2[1];
     }
     return;
   }

@@ -81,7 +81,7 @@ GS_DEV int grid_cell(const GsGrid& g, float x, float y, float z) {
 // segment, and finally min-reduce their packed (distance bits << 32 | index) keys -- the same
 // ordering as the brute-force engine's 64-bit atomicMin.  This turns ~100 serial dependent
 // gathers per query into ~15 wave-wide ones (the search is latency-, not bandwidth-bound).
-constexpr int GQ_G = 16;
+constexpr int GQ_G = 8;
 
 GS_DEV unsigned long long grid_key(float qx, float qy, float qz, const float4 p) {
   const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
