@@ -46,8 +46,8 @@ GS_DEV void tape_write_sys(float* __restrict__ sys, int it, const double* S, flo
 template <int BLOCK>
 GS_DEV void icp_sum_rows(const double* __restrict__ partials, int nrows, double* S, double (*sub)[32]) {
   constexpr int STEP = BLOCK / 32;
-  constexpr int CH = 18;  // rows per thread per round of independent loads: a 640x480 solve (400 rows of 48
-                          // queries, 17 per thread at 768 threads) is ONE round of memory latency; more rows
+  constexpr int CH = 18;  // rows per thread per round of independent loads: a 640x480 solve (200 rows of 96
+                          // queries, 9 per thread at 768 threads) is ONE round of memory latency; more rows
                           // in flight would push the kernel past 80 VGPRs (2 resident blocks per CU)
   const int i = threadIdx.x & 31, j = threadIdx.x >> 5;
   double s = 0.0;
@@ -87,10 +87,13 @@ GS_DEV double icp_sum_col27(const double* __restrict__ partials, int nrows, doub
 }
 
 // ---------------------------------------------------------------- grid path -------------
-constexpr int FS_BLOCK = 768;            // 12 waves; 2 blocks per CU keep all 400 blocks of a 640x480 solve resident
-constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 48 queries per block, their rows are built by wave 0
-constexpr int FS_RG = FS_QPB / 4;        // row groups of 4 in the block reduction
-static_assert(FS_QPB <= 2 * GS_WAVE && FS_QPB % 4 == 0 && FS_RG * LIN_NV <= FS_BLOCK, "block shape");
+constexpr int FS_BLOCK = 768;            // 12 waves; 2 blocks per CU keep all 200 blocks of a 640x480 solve resident
+                                         // (measured alternatives at 8 lanes per query: 512 threads 11.8 us,
+                                         // 1024 threads 11.2 us, 768 threads 10.7 us per kernel)
+constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 96 queries per block, their rows are built by the first two waves
+constexpr int FS_RPG = (FS_QPB / 4) * LIN_NV <= FS_BLOCK ? 4 : 8;  // rows per group in the block reduction
+constexpr int FS_RG = FS_QPB / FS_RPG;                            // row groups
+static_assert(FS_QPB <= 2 * GS_WAVE && FS_QPB % FS_RPG == 0 && FS_RG * LIN_NV <= FS_BLOCK, "block shape");
 
 // FULL = true : first half of iteration `it`  (prologue: LM update of iteration it-1, then search
 //               with T_step applied, full normal equations)
@@ -262,10 +265,9 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   __syncthreads();
   if (threadIdx.x < FS_RG * LIN_NV) {
     const int i = threadIdx.x % LIN_NV, part = threadIdx.x / LIN_NV;
-    double t = rows_s[4 * part][i];
-    t += rows_s[4 * part + 1][i];
-    t += rows_s[4 * part + 2][i];
-    t += rows_s[4 * part + 3][i];
+    double t = rows_s[FS_RPG * part][i];
+#pragma unroll
+    for (int u = 1; u < FS_RPG; ++u) t += rows_s[FS_RPG * part + u][i];
     sub_s[part][i] = t;
   }
   __syncthreads();
