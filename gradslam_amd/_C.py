@@ -69,6 +69,8 @@ _PROTOS = {
     "gs_append_valid_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gs_ingest_depth_u16_f32": [_vp, _i32, _i32, _vp, _i32, _i32, C.c_double, _vp],
     "gs_ingest_color_u8_f32": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
+    "gs_icp_map_dc_f32": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, C.POINTER(IcpParams), _vp, _vp,
+                          _vp],
     "gs_lattice_source_f32": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "gs_relative_pose_f32": [_vp, _vp, _i64, _vp, _vp],
     "gs_project_map_dc_f32": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp],

@@ -202,7 +202,8 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   const int nun = unres_n;  // block-uniform
   for (int u = 0; u < nun; ++u) {
     const int us = unres_q[u];
-    const unsigned long long key = block_brute_min<FS_BLOCK>(qs[us][0], qs[us][1], qs[us][2], tgt, n_tgt, red);
+    const unsigned long long key = block_brute_min_sorted<FS_BLOCK>(qs[us][0], qs[us][1], qs[us][2], sorted,
+                                                                    cell_start[g.ncell], red);
     if (threadIdx.x == 0) keys_s[us] = key;
   }
   __syncthreads();
@@ -476,7 +477,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
                    int64_t n_tgt, const float* init16, const float* compose16,
                    const gs_icp_params* prm, float* out_T16, int64_t* out_idx, void* icp_scratch,
                    void* tape, void* stream, const int64_t* n_src_dev = nullptr,
-                   const int64_t* n_tgt_dev = nullptr) {
+                   const int64_t* n_tgt_dev = nullptr, GsTargetFilter flt = GsTargetFilter{nullptr, 1, 1}) {
   GS_REQUIRE(prm, "params_host must not be NULL");
   GS_REQUIRE(n_src > 0 && n_tgt > 0, "empty point set");
   GS_REQUIRE(n_tgt < 0x7fffffffll && n_src < 0x7fffffffll, "too many points");
@@ -488,7 +489,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
   hipLaunchKernelGGL(gs_icp_init_kernel, dim3(1), dim3(64), 0, st, sc.state, init16, prm->damp, prm->numiters,
                      compose16, out_T16);
   // device-side counts (n_src / n_tgt are then upper bounds) always take the grid path
-  const bool dev_counts = n_src_dev || n_tgt_dev;
+  const bool dev_counts = n_src_dev || n_tgt_dev || flt.pix;  // a target filter exists only in the grid path
   const bool use_grid = prm->numiters > 0 && (dev_counts || (icp_grid_enabled() && gs_knn_use_grid(n_src, n_tgt)));
   const GsCount n_src_c{n_src, n_src_dev}, n_tgt_c{n_tgt, n_tgt_dev};
   float* bufs[2] = {sc.srcA, sc.srcB};
@@ -503,7 +504,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
 
   if (use_grid) {
     // the target set is fixed for all 2*numiters searches of this solve: bin it once
-    int rc = gs_knn_grid_build(tgt, n_tgt_c, n_src, sc.grid, st);
+    int rc = gs_knn_grid_build(tgt, n_tgt_c, n_src, sc.grid, st, flt);
     if (rc != GS_OK) return rc;
     GridMem gm = grid_carve(sc.grid, n_src, n_tgt);
     const int nfs = (int)icp_rows(n_src);
@@ -602,6 +603,16 @@ extern "C" int gs_icp_dc_f32(const float* src, int64_t n_src_bound, const int64_
                              int64_t* out_idx, void* icp_scratch, void* stream) {
   return icp_run(src, n_src_bound, tgt, tgt_normals, n_tgt_bound, init16, compose16, prm, out_T16, out_idx,
                  icp_scratch, nullptr, stream, n_src_dev, n_tgt_dev);
+}
+
+extern "C" int gs_icp_map_dc_f32(const float* src, int64_t n_src_bound, const int64_t* n_src_dev,
+                                 const float* map_points, const float* map_normals, const int32_t* pix,
+                                 int64_t n_map_bound, const int64_t* n_map_dev, int W, int ds, const float* init16,
+                                 const float* compose16, const gs_icp_params* prm, float* out_T16,
+                                 void* icp_scratch, void* stream) {
+  GS_REQUIRE(pix && W > 0 && ds > 0, "bad target filter");
+  return icp_run(src, n_src_bound, map_points, map_normals, n_map_bound, init16, compose16, prm, out_T16, nullptr,
+                 icp_scratch, nullptr, stream, n_src_dev, n_map_dev, GsTargetFilter{pix, W, ds});
 }
 
 extern "C" int64_t gs_icp_tape_bytes(int64_t n_src, int numiters) { return (int64_t)gs_icp_tape_size(n_src, numiters); }

@@ -30,9 +30,24 @@ struct GsGrid {
   int nx, ny, nz, ncell;
 };
 
+// Which rows of the target array take part: all of them (pix == NULL), or only the map rows whose projection
+// lands on the [::ds, ::ds] pixel lattice (the selection of gs_select_targets_f32, evaluated in place: the
+// ICP target set of the SLAM loop is then never gathered into a compact array; candidate keys carry the
+// map row index, whose order is the order of the compacted set, so ties break identically).
+struct GsTargetFilter {
+  const int32_t* pix;
+  int W, ds;
+};
+GS_DEV bool gs_is_target(const GsTargetFilter& f, int64_t n) {
+  if (!f.pix) return true;
+  const int32_t p = f.pix[n];
+  return p >= 0 && ((p / f.W) % f.ds == 0) && ((p % f.W) % f.ds == 0);
+}
+
 struct GridMem {
   GsGrid* g;
-  unsigned* bbox;    // [6] order-preserving codes of the bounding box (max of ~code(lo), code(hi)); zeroed per build
+  unsigned* bbox;    // [6] order-preserving codes of the bounding box (max of ~code(lo), code(hi)) + [6] = number
+                     // of rows that passed the target filter; zeroed per build
   int* unres_count;  // [2], ping-pong between consecutive queries
   int* cell_count;   // [MAXCELL + 1]
   int* cell_start;   // [MAXCELL + 1]
@@ -57,7 +72,8 @@ static inline GridMem grid_carve(void* scratch, int64_t n_src, int64_t n_tgt) {
 }
 
 size_t gs_knn_grid_scratch_bytes(int64_t n_src, int64_t n_tgt);
-int gs_knn_grid_build(const float* tgt, GsCount n_tgt, int64_t n_src, void* grid_scratch, hipStream_t st);
+int gs_knn_grid_build(const float* tgt, GsCount n_tgt, int64_t n_src, void* grid_scratch, hipStream_t st,
+                      GsTargetFilter filter = GsTargetFilter{nullptr, 1, 1});
 int gs_knn_grid_query(const float* src_in, const float* Tapply, float* src_out, int64_t n_src,
                       const float* tgt, int64_t n_tgt, unsigned long long* best, void* grid_scratch,
                       hipStream_t st);
@@ -231,6 +247,31 @@ GS_DEV unsigned long long grid_search16(const GsGrid& g, const int* __restrict__
     done = bd <= rb * rb;
   }
   *resolved = done;
+  return key;
+}
+
+// The same over the BINNED targets (sorted[0 .. n) = every target that passed the filter, as (x, y, z, index
+// bits)): what the fused ICP kernels use -- with a target filter the raw array holds the whole map, the binned
+// copy only the targets.  Same distance arithmetic and key order, hence the same result.
+template <int BLOCK>
+GS_DEV unsigned long long block_brute_min_sorted(float qx, float qy, float qz, const float4* __restrict__ sorted,
+                                                 int n, unsigned long long* red) {
+  unsigned long long key = ~0ull;
+  for (int j = threadIdx.x; j < n; j += BLOCK) {
+    const unsigned long long k2 = grid_key(qx, qy, qz, sorted[j]);
+    key = k2 < key ? k2 : key;
+  }
+#pragma unroll
+  for (int d = GS_WAVE / 2; d > 0; d >>= 1) {
+    const unsigned long long o = __shfl_xor(key, d, GS_WAVE);
+    key = o < key ? o : key;
+  }
+  __syncthreads();
+  if ((threadIdx.x & (GS_WAVE - 1)) == 0) red[threadIdx.x / GS_WAVE] = key;
+  __syncthreads();
+  key = red[0];
+#pragma unroll
+  for (int w = 1; w < BLOCK / GS_WAVE; ++w) key = red[w] < key ? red[w] : key;
   return key;
 }
 

@@ -143,17 +143,23 @@ GS_DEV float grid_decode(unsigned c) {
 constexpr int GB_BLOCK = 256;
 constexpr int GB_ITEMS = 8;
 __global__ void __launch_bounds__(GB_BLOCK) gs_grid_bbox_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
+                                                                 const GsTargetFilter flt,
                                                                  unsigned* __restrict__ bbox,
                                                                  int* __restrict__ unres_count) {
   const int64_t n_tgt = gs_count(n_tgt_c);
   if (blockIdx.x == 0 && threadIdx.x == 0) { unres_count[0] = 0; unres_count[1] = 0; }
   if ((int64_t)blockIdx.x * GB_BLOCK * GB_ITEMS >= n_tgt) return;
   __shared__ float red[6][GB_BLOCK / GS_WAVE];
+  __shared__ int hits_s;
+  if (threadIdx.x == 0) hits_s = 0;
+  __syncthreads();
+  int hits = 0;
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
   for (int u = 0; u < GB_ITEMS; ++u) {
     const int64_t i = ((int64_t)blockIdx.x * GB_ITEMS + u) * GB_BLOCK + threadIdx.x;
-    if (i < n_tgt) {
+    if (i < n_tgt && gs_is_target(flt, i)) {
+      ++hits;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const float v = tgt[3 * i + k];
@@ -176,7 +182,13 @@ __global__ void __launch_bounds__(GB_BLOCK) gs_grid_bbox_kernel(const float* __r
     }
     if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = b; }
   }
+  if (flt.pix) {  // number of targets (the cell-size heuristic needs it): wave sums, one atomic per block
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) hits += __shfl_down(hits, d, GS_WAVE);
+    if (lane == 0 && hits) atomicAdd(&hits_s, hits);
+  }
   __syncthreads();
+  if (flt.pix && threadIdx.x == 3 && hits_s) atomicAdd(&bbox[6], (unsigned)hits_s);
   if (threadIdx.x < 3) {
     const int k = threadIdx.x;
     float a = red[k][0], b = red[3 + k][0];
@@ -232,6 +244,7 @@ GS_DEV GsGrid grid_from_bbox(const unsigned* __restrict__ bbox, int64_t n_tgt, i
 // Every block derives the grid header from the bounding box (block 0 publishes it for the kernels
 // that follow), then counts its targets per cell.
 __global__ void __launch_bounds__(256) gs_grid_count_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
+                                                            const GsTargetFilter flt,
                                                             const unsigned* __restrict__ bbox,
                                                             GsGrid* __restrict__ gp,
                                                             int* __restrict__ cell_count, int cells_cap) {
@@ -240,11 +253,11 @@ __global__ void __launch_bounds__(256) gs_grid_count_kernel(const float* __restr
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if ((int64_t)blockIdx.x * 256 >= n_tgt && blockIdx.x != 0) return;
   if (threadIdx.x == 0) {
-    gsh = grid_from_bbox(bbox, n_tgt, cells_cap);
+    gsh = grid_from_bbox(bbox, flt.pix ? (int64_t)bbox[6] : n_tgt, cells_cap);
     if (blockIdx.x == 0) *gp = gsh;
   }
   __syncthreads();
-  if (i >= n_tgt) return;
+  if (i >= n_tgt || !gs_is_target(flt, i)) return;
   const GsGrid g = gsh;
   atomicAdd(&cell_count[grid_cell(g, tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2])], 1);
 }
@@ -293,12 +306,13 @@ __global__ void __launch_bounds__(256) gs_grid_scan_kernel(const int* __restrict
 }
 
 __global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
+                                                              const GsTargetFilter flt,
                                                               const GsGrid* __restrict__ gp,
                                                               const int* __restrict__ cell_start,
                                                               int* __restrict__ cell_count,
                                                               float4* __restrict__ sorted) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= gs_count(n_tgt_c)) return;
+  if (i >= gs_count(n_tgt_c) || !gs_is_target(flt, i)) return;
   const GsGrid g = *gp;
   const float x = tgt[3 * i], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
   const int cid = grid_cell(g, x, y, z);
@@ -308,7 +322,8 @@ __global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __res
   sorted[slot] = make_float4(x, y, z, __int_as_float((int)i));
 }
 
-int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* grid_scratch, hipStream_t st) {
+int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* grid_scratch, hipStream_t st,
+                      GsTargetFilter flt) {
   const int64_t n_tgt = n_tgt_c.host;  // upper bound: launch geometry and scratch layout
   GridMem m = grid_carve(grid_scratch, n_src, n_tgt);
   // Cells the grid of this build may use (what is cleared and scanned per build): the target density the
@@ -329,15 +344,15 @@ int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* gr
   hipError_t e = hipMemsetAsync(m.g, 0, clear, st);
   if (e != hipSuccess) { gs_set_error("gs_knn_grid_build: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
   hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, GB_BLOCK * GB_ITEMS)),
-                     dim3(GB_BLOCK), 0, st, tgt, n_tgt_c, m.bbox, m.unres_count);
+                     dim3(GB_BLOCK), 0, st, tgt, n_tgt_c, flt, m.bbox, m.unres_count);
   hipLaunchKernelGGL(gs_grid_count_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, 256)), dim3(256), 0, st,
-                     tgt, n_tgt_c, m.bbox, m.g, m.cell_count, cells_cap);
+                     tgt, n_tgt_c, flt, m.bbox, m.g, m.cell_count, cells_cap);
   const unsigned ntile = (unsigned)gs_ceil_div(cells_cap + 1, GS_GRID_TILE);
   hipLaunchKernelGGL(gs_grid_tile_sum_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums);
   hipLaunchKernelGGL(gs_grid_scan_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums,
                      m.cell_start);
   hipLaunchKernelGGL(gs_grid_scatter_kernel, dim3((unsigned)gs_ceil_div(n_tgt, 256)), dim3(256), 0, st, tgt,
-                     n_tgt_c, m.g, m.cell_start, m.cell_count, m.sorted);
+                     n_tgt_c, flt, m.g, m.cell_start, m.cell_count, m.sorted);
   return GS_OK;
 }
 

@@ -331,6 +331,26 @@ def icp(src, tgt, tgt_normals, init=None, compose=None, mode=1, numiters=20, dam
     return out[0] if len(out) == 1 else tuple(out)
 
 
+def icp_map(src, map_points, map_normals, pix, W, ds, n_map_dev=None, init=None, compose=None, mode=1, numiters=20,
+            damp=1e-8, dist_thresh=None, lambda_max=2.0, B=1.0, B2=1.0, nu=200.0, out=None):
+    """(grad)LM ICP of `src` (NaN rows are skipped) against the map rows whose projection `pix` lies on the
+    [::ds, ::ds] lattice, binned straight from the map (gs_icp_map_dc_f32): same T as select_targets + icp."""
+    src, P, N = _c(src), _c(map_points), _c(map_normals)
+    dev = require_device(src, P, N, pix)
+    init = _identity4(dev) if init is None else _c(init)
+    compose = _c(compose)
+    require_device(init, compose, n_map_dev)
+    ns, nm = src.shape[0], P.shape[0]
+    prm = _C.IcpParams(int(mode), int(numiters), float(damp), -1.0 if dist_thresh is None else float(dist_thresh),
+                       float(lambda_max), float(B), float(B2), float(nu))
+    T = torch.empty((4, 4), dtype=f32, device=dev) if out is None else out
+    assert T.shape == (4, 4) and T.dtype == f32 and T.is_contiguous() and T.device == dev
+    scratch = Workspace.get(dev).bytes("icp", lib().gs_icp_scratch_bytes(ns, nm))
+    check(lib().gs_icp_map_dc_f32(ptr(src), ns, None, ptr(P), ptr(N), ptr(pix), nm, ptr(n_map_dev), int(W), int(ds),
+                                  ptr(init), ptr(compose), prm, ptr(T), ptr(scratch), stream(dev)), "gs_icp_map_dc_f32")
+    return T
+
+
 # ----------------------------------------------------------------------------------- K5
 def similar_rows(rows, points, normals, gvertex, gnormal, dist_th, dot_th):
     rows = _c(rows, torch.int64)

@@ -240,6 +240,19 @@ GS_API int gs_icp_dc_f32(const float* src, int64_t n_src_bound, const int64_t* n
                          const float* init16, const float* compose16, const gs_icp_params* params_host,
                          float* out_T16, int64_t* out_idx, void* icp_scratch, void* stream);
 
+/* The SLAM loop's solve without gathering the target set: the targets are the rows of the surfel map
+ * (map_points / map_normals, n_map_bound rows, actual count in n_map_dev or NULL) whose projection `pix`
+ * (gs_project_map_*_f32 with the previous pose) lies on the [::ds, ::ds] pixel lattice -- the set
+ * find_active_map_points + downsample_pointclouds select (slam/icpslam.py:241-242, odometry/icputils.py:
+ * 596-597) -- binned straight from the map.  Same transform, bit for bit, as gs_icp_dc_f32 on the output of
+ * gs_select_targets_f32 (candidate order and ties follow the map row order, which is the order of the
+ * compacted set).  icp_scratch: gs_icp_scratch_bytes(n_src_bound, n_map_bound). */
+GS_API int gs_icp_map_dc_f32(const float* src, int64_t n_src_bound, const int64_t* n_src_dev,
+                             const float* map_points, const float* map_normals, const int32_t* pix,
+                             int64_t n_map_bound, const int64_t* n_map_dev, int W, int ds, const float* init16,
+                             const float* compose16, const gs_icp_params* params_host, float* out_T16,
+                             void* icp_scratch, void* stream);
+
 /* Per-iteration record kept in icp_scratch for the backward pass / diagnostics:
  * gs_icp_trace_f32 copies (numiters, 12) floats = [err, new_err, damp_after, sigmoid, xi(6), pad(2)]. */
 GS_API int gs_icp_trace_f32(const void* icp_scratch, int numiters, float* trace_out, void* stream);

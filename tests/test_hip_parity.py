@@ -500,3 +500,33 @@ def test_lattice_source_feeds_icp_like_the_compacted_set(ops):
         T_l, idx_l = ops.icp(lat, tgt, tn, mode=mode, numiters=10, n_tgt_dev=n_tgt)
         assert torch.equal(idx_l[valid], idx_c) and bool((idx_l[~valid] == -1).all())
         assert float((T_l - T_c).abs().max()) <= 1e-6 and bool(torch.isfinite(T_l).all())
+
+
+def test_icp_against_the_map_without_gathering_targets(ops):
+    """gs_icp_map_dc_f32 (targets = map rows whose projection lies on the lattice, binned straight from the
+    map) gives bit for bit the transform of select_targets + icp, with host and with device-side map counts."""
+    s = make_sequence(3, 240, 320, seed=4, hole_frac=0.1)
+    K, pose = dev(s["intrinsics"][0]), dev(s["poses"][0])
+    maps = []
+    for f in (0, 1):      # a "map" with duplicates: all valid pixels of two frames
+        d = dev(s["depths"][f, ..., 0])
+        v, n, _, _ = ops.frame_maps(d, K)
+        gv, gn = ops.global_maps(v, n, d, pose)
+        maps.append(ops.downsample_frame(gv, gn, None, d, 1)[:2])
+    P, N = torch.cat([m[0] for m in maps]), torch.cat([m[1] for m in maps])
+    d2 = dev(s["depths"][2, ..., 0])
+    v2, _, _, _ = ops.frame_maps(d2, K)
+    src = ops.lattice_source(v2, d2, pose, 4)
+    pix = ops.project_map(P, pose, K, 240, 320)
+    tgt, tn, _ = ops.select_targets(pix, 320, 4, P, N)
+    assert 2048 < tgt.shape[0] < P.shape[0] // 4
+    n_tgt = torch.tensor([tgt.shape[0]], dtype=torch.int64, device="cuda")
+    for mode in (1, 0):
+        T_ref = ops.icp(src, tgt, tn, compose=pose, mode=mode, numiters=10, n_tgt_dev=n_tgt, return_idx=False)
+        T_map = ops.icp_map(src, P, N, pix, 320, 4, compose=pose, mode=mode, numiters=10)
+        assert torch.equal(T_map, T_ref)
+        # bound-sized buffers with garbage rows behind the device-side count
+        Pb, Nb = torch.cat([P, P[:1000] + 5.0]), torch.cat([N, N[:1000]])
+        pixb = torch.cat([pix, torch.zeros(1000, dtype=torch.int32, device="cuda")])   # pixel 0 is on the lattice
+        n_map = torch.tensor([P.shape[0]], dtype=torch.int64, device="cuda")
+        assert torch.equal(ops.icp_map(src, Pb, Nb, pixb, 320, 4, n_map_dev=n_map, compose=pose, mode=mode, numiters=10), T_ref)
