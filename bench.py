@@ -142,6 +142,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
+    # A full (generation-2) pass of Python's cyclic garbage collector over the ~10^6 objects `import torch`
+    # leaves behind takes 30-40 ms; where it falls depends on the allocation count, i.e. on unrelated details
+    # (a .pyc cache hit moved it from frame 0 into the 12 timed frames and cost 5x in frames/s).  Collect now
+    # and freeze the survivors: later passes only look at objects created from here on.
+    import gc
+    gc.collect()
+    gc.freeze()
+
     # ---------------- warm-up (untimed): map init + first ICP frames, allocator, kernels
     pc = gs.Pointclouds(device=device)
     recovered = []

@@ -69,6 +69,9 @@ _PROTOS = {
     "gs_append_valid_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gs_ingest_depth_u16_f32": [_vp, _i32, _i32, _vp, _i32, _i32, C.c_double, _vp],
     "gs_ingest_color_u8_f32": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
+    "gs_update_map_scratch_bytes": [_i64, _i32, _i32],
+    "gs_update_map_fusion_dc_f32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+                                    _f, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "gs_icp_map_dc_f32": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, C.POINTER(IcpParams), _vp, _vp,
                           _vp],
     "gs_lattice_source_f32": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
@@ -82,7 +85,7 @@ _PROTOS = {
                                _vp],
 }
 _RESTYPE = {"gs_last_error": C.c_char_p, "gs_scratch_bytes": _i64, "gs_icp_scratch_bytes": _i64,
-            "gs_knn1_grid_scratch_bytes": _i64, "gs_icp_tape_bytes": _i64, "gs_icp_backward_scratch_bytes": _i64}
+            "gs_knn1_grid_scratch_bytes": _i64, "gs_update_map_scratch_bytes": _i64, "gs_icp_tape_bytes": _i64, "gs_icp_backward_scratch_bytes": _i64}
 EXPORTS = tuple(_PROTOS)
 
 

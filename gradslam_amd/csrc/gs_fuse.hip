@@ -3,6 +3,7 @@
 // structures/pointclouds.py:1117-1237).  HBM-bound: 2 x 40 B per map row (parity mode rewrites
 // every row exactly like the reference, slam/fusionutils.py:678-699) + 40 B read + 40 B write
 // per appended pixel.
+#include "gs_assoc_dev.h"
 #include "gs_compact.h"
 
 // pix_of[] = -1 and the "table is non-empty" flag = 0, in one launch
@@ -162,4 +163,191 @@ extern "C" int gs_append_valid_dc_f32(float* points, float* normals, float* colo
   GS_REQUIRE(n_map_dev && capacity >= n_map_bound + (int64_t)H * W, "device-count append needs capacity >= bound + H*W");
   return append_valid(points, normals, colors, ccounts, GsCount{n_map_bound, n_map_dev}, capacity, gvertex,
                       gnormal, rgb, alpha, depth, H, W, new_count_out, scratch, stream);
+}
+
+// ---------------------------------------------------------------- one-call map update ----
+// update_map_fusion (slam/fusionutils.py:761-789) for one sequence with the kernels regrouped by DOMAIN so
+// that the frame costs 6 launches instead of 11 (global maps 1 + projection 1 + association 3 + fuse 6);
+// every value is computed by the same arithmetic as in the separate entry points:
+//   U1 per pixel : global vertex / normal under the new pose; clear the per-pixel key and winner tables
+//   U2 per surfel: project, similarity test, per-pixel atomicMin of the (1/ccount, ray) key; pix_of = -1
+//   U3 per surfel: atomicMin of the surfel index among the rows that attain their pixel's key
+//   U4 per pixel : winner -> pix_of[winner] = pixel (+ "any match" flag); count of new pixels per tile
+//   U5 per surfel: confidence-weighted merge (parity mode rewrites every row)
+//   U6 per pixel : ordered append of the new pixels; every block derives its output offset from the tile
+//                  counts itself (no separate scan launch); block 0 also writes the new surfel count
+__global__ void __launch_bounds__(256) gs_mu_pixel_init_kernel(
+    const float* __restrict__ vertex, const float* __restrict__ normal, const float* __restrict__ depth,
+    const float* __restrict__ pose16, int64_t P, float* __restrict__ gvertex, float* __restrict__ gnormal,
+    uint64_t* __restrict__ key_pix, int32_t* __restrict__ best_pix, int32_t* __restrict__ any_flag) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p == 0) *any_flag = 0;
+  if (p >= P) return;
+  float T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = pose16[i];
+  const float validf = depth[p] > 0.0f ? 1.0f : 0.0f;
+  float g0, g1, g2;
+  gs_rigid_fma(T, vertex[3 * p], vertex[3 * p + 1], vertex[3 * p + 2], g0, g1, g2);
+  gvertex[3 * p] = g0 * validf;
+  gvertex[3 * p + 1] = g1 * validf;
+  gvertex[3 * p + 2] = g2 * validf;
+  const float n0 = normal[3 * p], n1 = normal[3 * p + 1], n2 = normal[3 * p + 2];
+  gnormal[3 * p] = gs_dot3_fma(T[0], T[1], T[2], n0, n1, n2);
+  gnormal[3 * p + 1] = gs_dot3_fma(T[4], T[5], T[6], n0, n1, n2);
+  gnormal[3 * p + 2] = gs_dot3_fma(T[8], T[9], T[10], n0, n1, n2);
+  key_pix[p] = ~0ull;
+  best_pix[p] = -1;
+}
+
+__global__ void __launch_bounds__(256) gs_mu_project_key_kernel(
+    const float* __restrict__ points, const float* __restrict__ normals, const float* __restrict__ ccounts,
+    GsCount n_map_c, const float* __restrict__ pose16, const float* __restrict__ K16, int H, int W, float u_hi,
+    float v_hi, const float* __restrict__ gvertex, const float* __restrict__ gnormal, float dist_th, float dot_th,
+    int32_t* __restrict__ pix, uint64_t* __restrict__ key_pt, unsigned long long* __restrict__ key_pix,
+    int32_t* __restrict__ pix_of) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= gs_count(n_map_c)) return;
+  const GsCamera c = gs_camera(pose16, K16);
+  const int32_t p = gs_project_point(c, points[3 * n], points[3 * n + 1], points[3 * n + 2], H, W, u_hi, v_hi);
+  uint64_t k = ~0ull;
+  if (p >= 0 && gs_is_similar(points, normals, gvertex, gnormal, n, p, dist_th, dot_th)) {
+    k = gs_assoc_key(points, ccounts, gvertex, n, p);
+    atomicMin(&key_pix[p], (unsigned long long)k);
+  }
+  pix[n] = p;
+  key_pt[n] = k;
+  pix_of[n] = -1;
+}
+
+__global__ void __launch_bounds__(256) gs_mu_pick_kernel(const int32_t* __restrict__ pix, GsCount n_map_c,
+                                                         const uint64_t* __restrict__ key_pt,
+                                                         const uint64_t* __restrict__ key_pix,
+                                                         int32_t* __restrict__ best_pix) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= gs_count(n_map_c)) return;
+  const uint64_t k = key_pt[n];
+  if (k == ~0ull) return;
+  const int32_t p = pix[n];
+  if (k == key_pix[p]) atomicMin(reinterpret_cast<unsigned*>(&best_pix[p]), (unsigned)n);
+}
+
+// per pixel tile of GS_CP_TILE pixels: inverse map of the winners + number of new pixels of the tile
+__global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_winner_count_kernel(const int32_t* __restrict__ best_pix,
+                                                                         const float* __restrict__ depth, int64_t P,
+                                                                         GsCount n_map_c, int32_t* __restrict__ pix_of,
+                                                                         int32_t* __restrict__ any_flag,
+                                                                         int32_t* __restrict__ tile_counts) {
+  __shared__ int smem[GS_CP_BLOCK / GS_WAVE + 1];
+  const int64_t n_map = gs_count(n_map_c);
+  const int64_t base = (int64_t)blockIdx.x * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < GS_CP_ITEMS; ++i) {
+    const int64_t p = base + i;
+    if (p < P) {
+      const int32_t n = best_pix[p];
+      if (n >= 0 && n < n_map) {
+        pix_of[n] = (int32_t)p;
+        *any_flag = 1;  // benign race: every writer stores the same value
+      }
+      if (depth[p] > 0.0f && n < 0) ++c;
+    }
+  }
+  int total;
+  (void)gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &total);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+}
+
+// ordered append without a scan launch: block b adds up the counts of the tiles before it (fixed order)
+__global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_append_kernel(
+    const int32_t* __restrict__ best_pix, const float* __restrict__ depth, int64_t P, int64_t ntiles,
+    const int32_t* __restrict__ tile_counts, EmitAppend emit, int64_t capacity, int64_t* __restrict__ new_count_out) {
+  __shared__ int smem[GS_CP_BLOCK / GS_WAVE + 1];
+  int before = 0, all = 0;
+  for (int64_t t = threadIdx.x; t < ntiles; t += GS_CP_BLOCK) {
+    const int v = tile_counts[t];
+    all += v;
+    if (t < (int64_t)blockIdx.x) before += v;
+  }
+  int tile_prefix, total_new, dummy;
+  (void)gs_block_excl_scan<GS_CP_BLOCK>(before, smem, &tile_prefix);
+  (void)gs_block_excl_scan<GS_CP_BLOCK>(all, smem, &total_new);
+  const int64_t n_map = gs_count(emit.n_map);
+  if (blockIdx.x == 0 && threadIdx.x == 0) new_count_out[0] = n_map + total_new;
+  const int64_t base = (int64_t)blockIdx.x * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
+  bool keep[GS_CP_ITEMS];
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < GS_CP_ITEMS; ++i) {
+    const int64_t p = base + i;
+    keep[i] = p < P && depth[p] > 0.0f && best_pix[p] < 0;
+    c += keep[i] ? 1 : 0;
+  }
+  int64_t pos = tile_prefix + gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &dummy);
+#pragma unroll
+  for (int i = 0; i < GS_CP_ITEMS; ++i) {
+    if (keep[i]) {
+      if (n_map + pos < capacity) emit(base + i, pos);
+      ++pos;
+    }
+  }
+}
+
+extern "C" int64_t gs_update_map_scratch_bytes(int64_t n_map_bound, int H, int W) {
+  const int64_t P = (int64_t)H * W;
+  return (int64_t)(256 + gs_align(8 * (size_t)P) + gs_align(4 * (size_t)gs_cp_tiles(P)) +
+                   gs_align(8 * (size_t)(n_map_bound > 0 ? n_map_bound : 1)) +
+                   2 * gs_align(4 * (size_t)(n_map_bound > 0 ? n_map_bound : 1)) + 4096);
+}
+
+extern "C" int gs_update_map_fusion_dc_f32(float* points, float* normals, float* colors, float* ccounts,
+                                           int64_t n_map_bound, const int64_t* n_map_dev, int64_t capacity,
+                                           const float* vertex, const float* normal, const float* depth,
+                                           const float* rgb, const float* alpha, const float* pose16,
+                                           const float* K16, int H, int W, float dist_th, float dot_th,
+                                           int renorm_all, float* gvertex, float* gnormal, int32_t* best_pix,
+                                           int64_t* new_count_out, void* scratch, void* stream) {
+  GS_REQUIRE(H > 0 && W > 0 && n_map_bound >= 0, "bad sizes");
+  GS_REQUIRE(capacity >= n_map_bound + (int64_t)H * W, "capacity must cover n_map_bound + H*W rows");
+  GS_REQUIRE(points && normals && colors && ccounts && vertex && normal && depth && rgb && alpha && pose16 && K16 &&
+                 gvertex && gnormal && best_pix && new_count_out && scratch,
+             "NULL pointer");
+  GS_REQUIRE(n_map_bound < 0x7fffffff && (int64_t)H * W < (1ll << 31), "too large for int32 indices");
+  hipStream_t st = gs_stream(stream);
+  const int64_t P = (int64_t)H * W, n_map = n_map_bound;
+  const GsCount n_map_c{n_map_bound, n_map_dev};
+  const int64_t ntiles = gs_cp_tiles(P);
+  char* q = reinterpret_cast<char*>(scratch);
+  int32_t* any_flag = reinterpret_cast<int32_t*>(q); q += 256;
+  uint64_t* key_pix = reinterpret_cast<uint64_t*>(q); q += gs_align(8 * (size_t)P);
+  int32_t* tile_counts = reinterpret_cast<int32_t*>(q); q += gs_align(4 * (size_t)ntiles);
+  uint64_t* key_pt = reinterpret_cast<uint64_t*>(q); q += gs_align(8 * (size_t)(n_map > 0 ? n_map : 1));
+  int32_t* pix = reinterpret_cast<int32_t*>(q); q += gs_align(4 * (size_t)(n_map > 0 ? n_map : 1));
+  int32_t* pix_of = reinterpret_cast<int32_t*>(q);
+  const float u_hi = (float)((double)W - 0.999), v_hi = (float)((double)H - 0.999);
+  const unsigned pb = (unsigned)gs_ceil_div(P, 256), nb = (unsigned)gs_ceil_div(n_map > 0 ? n_map : 1, 256);
+  {
+    GsProf prof(GS_PROF_FRAME, (double)P * 64.0, st);   // 28 B read + 24 B + 12 B written per pixel
+    hipLaunchKernelGGL(gs_mu_pixel_init_kernel, dim3(pb), dim3(256), 0, st, vertex, normal, depth, pose16, P, gvertex,
+                       gnormal, key_pix, best_pix, any_flag);
+  }
+  if (n_map > 0) {
+    GsProf prof(GS_PROF_ASSOC, 92.0 * (double)n_map, st);
+    hipLaunchKernelGGL(gs_mu_project_key_kernel, dim3(nb), dim3(256), 0, st, points, normals, ccounts, n_map_c, pose16,
+                       K16, H, W, u_hi, v_hi, gvertex, gnormal, dist_th, dot_th, pix, key_pt,
+                       reinterpret_cast<unsigned long long*>(key_pix), pix_of);
+    hipLaunchKernelGGL(gs_mu_pick_kernel, dim3(nb), dim3(256), 0, st, pix, n_map_c, key_pt, key_pix, best_pix);
+  }
+  GsProf prof(GS_PROF_FUSE, 84.0 * (double)n_map + 49.0 * (double)P, st);
+  hipLaunchKernelGGL(gs_mu_winner_count_kernel, dim3((unsigned)ntiles), dim3(GS_CP_BLOCK), 0, st, best_pix, depth, P,
+                     n_map_c, pix_of, any_flag, tile_counts);
+  if (n_map > 0)
+    hipLaunchKernelGGL(gs_fuse_merge_kernel, dim3(nb), dim3(256), 0, st, points, normals, colors, ccounts, n_map_c,
+                       pix_of, any_flag, gvertex, gnormal, rgb, alpha, renorm_all);
+  EmitAppend emit{points, normals, colors, ccounts, n_map_c, gvertex, gnormal, rgb, alpha};
+  hipLaunchKernelGGL(gs_mu_append_kernel, dim3((unsigned)ntiles), dim3(GS_CP_BLOCK), 0, st, best_pix, depth, P, ntiles,
+                     tile_counts, emit, capacity, new_count_out);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
 }

@@ -41,6 +41,15 @@ def _identity4(dev):
     return t
 
 
+def _empty_rows(n, tail, dtype, dev):
+    """torch.empty((n,) + tail) carved from an allocation whose row count is rounded up to a power of two: the
+    per-frame temporaries sized by the (growing) surfel bound then change their allocation size only when the
+    bound doubles, instead of asking the caching allocator for a slightly larger block every frame (each new
+    size is a fresh hipMalloc while the host runs ahead of the device)."""
+    cap = 1 << max(int(n) - 1, 0).bit_length() if n > 1024 else 1024
+    return torch.empty((cap,) + tuple(tail), dtype=dtype, device=dev)[:n]
+
+
 def _count(t):
     """Reads a device int64 counter back (one host sync)."""
     return int(t.item())
@@ -127,7 +136,7 @@ def project_map(points, pose, K, H, W, n_dev=None):
     points, pose, K = _c(points), _c(pose), _c(K)
     dev = require_device(points, pose, K)
     n = points.shape[0]
-    pix = torch.empty(n, dtype=torch.int32, device=dev)
+    pix = _empty_rows(n, (), torch.int32, dev)
     if n_dev is not None:
         check(lib().gs_project_map_dc_f32(ptr(points), n, ptr(n_dev), ptr(pose), ptr(K), H, W, ptr(pix), stream(dev)),
               "gs_project_map_dc_f32")
@@ -154,9 +163,9 @@ def select_targets(pix, W, ds, points, normals, colors=None, cap=None, sync=True
     dev = require_device(pix, points, normals, colors)
     n = pix.shape[0]
     cap = n if cap is None else int(cap)
-    op = torch.empty((cap, 3), dtype=f32, device=dev)
-    on = torch.empty((cap, 3), dtype=f32, device=dev) if normals is not None else None
-    oc = torch.empty((cap, 3), dtype=f32, device=dev) if colors is not None else None
+    op = _empty_rows(cap, (3,), f32, dev)
+    on = _empty_rows(cap, (3,), f32, dev) if normals is not None else None
+    oc = _empty_rows(cap, (3,), f32, dev) if colors is not None else None
     cnt = torch.empty(1, dtype=torch.int64, device=dev)
     ws = Workspace.get(dev)
     if n_dev is not None:
@@ -444,6 +453,28 @@ def fuse_append_(points, normals, colors, ccounts, n_map, best_pix, gvertex, gno
     if c > cap:
         raise _C.HipExtensionError("gs_fuse_append_f32: surfel store overflow (%d > %d)" % (c, cap))
     return c
+
+
+def update_map_fusion_(points, normals, colors, ccounts, n_map, vertex, normal, depth, rgb, alpha, pose, K, dist_th,
+                       dot_th, renorm_all=True, n_dev=None, out=None):
+    """One-call map update of a sequence (gs_update_map_fusion_dc_f32), in place on capacity-backed buffers.
+    Returns (new count as a device int64[1] tensor, gvertex, gnormal, best_pix); nothing is read back."""
+    vertex, normal, depth, rgb, alpha = _c(vertex), _c(normal), _c(depth), _c(rgb), _c(alpha)
+    pose, K = _c(pose), _c(K)
+    dev = require_device(points, normals, colors, ccounts, vertex, normal, depth, rgb, alpha, pose, K, n_dev)
+    H, W = depth.shape[:2]
+    cap = points.shape[0]
+    gv, gn = out if out is not None else (torch.empty((H, W, 3), dtype=f32, device=dev),
+                                          torch.empty((H, W, 3), dtype=f32, device=dev))
+    best = torch.empty(H * W, dtype=torch.int32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    scratch = Workspace.get(dev).bytes("map_update", lib().gs_update_map_scratch_bytes(int(n_map), H, W))
+    check(lib().gs_update_map_fusion_dc_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map), ptr(n_dev),
+                                            cap, ptr(vertex), ptr(normal), ptr(depth), ptr(rgb), ptr(alpha), ptr(pose),
+                                            ptr(K), H, W, float(dist_th), float(dot_th), 1 if renorm_all else 0, ptr(gv),
+                                            ptr(gn), ptr(best), ptr(cnt), ptr(scratch), stream(dev)),
+          "gs_update_map_fusion_dc_f32")
+    return cnt, gv, gn, best
 
 
 def append_valid_(points, normals, colors, ccounts, n_map, gvertex, gnormal, rgb, alpha, depth, n_dev=None,

@@ -287,9 +287,10 @@ def _fuse(pointclouds, rgbdimages, best_pix, sigma, inplace):
         out._init_empty_batch(B, pointclouds._buf["features"][0].shape[-1])
     for b in range(B):
         if inplace and ops.DEVICE_COUNTS:
-            # the count stays on the device: no read-back, the host only tracks an upper bound
-            n0, n_dev = pointclouds._count_of(b)
+            # the count stays on the device: no read-back, the host only tracks an upper bound.  Reserve FIRST:
+            # the bound may tighten between two look-ups, and the capacity must cover the bound that is passed on
             P, N, C, F = pointclouds._reserve(b, H * W)
+            n0, n_dev = pointclouds._count_of(b)
             if P.dtype != torch.float32 or F.shape[-1] != 1:
                 raise ValueError("map fusion needs float32 surfels with one feature column (the confidence count)")
             cnt = ops.fuse_append_(P, N, C, F, n0, best_pix[b], gv[b, 0], gn[b, 0], rgb[b, 0], alpha[b, 0, ..., 0],
@@ -353,8 +354,8 @@ def update_map_aggregate(pointclouds: Pointclouds, rgbdimages: RGBDImages, inpla
                          "(False != True)")
     for b in range(B):
         if inplace and ops.DEVICE_COUNTS:
+            P, N, C, _ = pointclouds._reserve(b, H * W)   # before _count_of: see _fuse
             n0, n_dev = pointclouds._count_of(b)
-            P, N, C, _ = pointclouds._reserve(b, H * W)
             cnt = ops.append_valid_(P, N, C, None, n0, gv[b, 0], gn[b, 0], rgb[b, 0], None, depth[b, 0, ..., 0],
                                     n_dev=n_dev, sync=False)
             pointclouds._set_count_dev(b, cnt, H * W)
@@ -375,5 +376,47 @@ def update_map_fusion(pointclouds: Pointclouds, rgbdimages: RGBDImages, dist_th:
     # a map whose counts are device-side has had frames fused into it: no read-back just for this check
     if pointclouds._dcount or pointclouds.has_points:
         _check_batch(pointclouds, rgbdimages)
+    from .. import ops
+    if inplace and ops.DEVICE_COUNTS and _one_call_update_ok(pointclouds, rgbdimages):
+        return _update_map_one_call(pointclouds, rgbdimages, dist_th, dot_th, sigma)
     best = _best_pix_per_sequence(pointclouds, rgbdimages, dist_th, dot_th)
     return _fuse(pointclouds, rgbdimages, best, sigma, inplace)
+
+
+def _one_call_update_ok(pointclouds, rgbdimages):
+    """the fused entry point covers the SLAM loop's case: float32 surfels with one feature column (or an empty
+    map), poses present, nothing on the autograd tape"""
+    if rgbdimages.poses is None or pointclouds.device != rgbdimages.device or not rgbdimages.device.type == "cuda":
+        return False
+    if torch.is_grad_enabled() and rgbdimages.depth_image.requires_grad:
+        return False
+    if len(pointclouds) == 0:
+        return True
+    if len(pointclouds) != len(rgbdimages):
+        return False
+    bufs = pointclouds._buf
+    return all(bufs[k] is not None for k in ("points", "normals", "colors", "features")) and \
+        bufs["points"][0].dtype == torch.float32 and bufs["features"][0].shape[-1] == 1
+
+
+def _update_map_one_call(pointclouds, rgbdimages, dist_th, dot_th, sigma):
+    """update_map_fusion through gs_update_map_fusion_dc_f32: global maps, association and fuse of every sequence
+    in 6 launches, surfel counts on the device.  Also fills the frame's global-map cache."""
+    from .. import ops
+    fr, K, poses = _frame(rgbdimages)
+    B, _, H, W = fr.shape
+    alpha = fr._alpha_map(sigma)
+    vm, nm = fr.vertex_map, fr.normal_map
+    rgb, depth = fr.rgb_image.contiguous().float(), fr.depth_image.contiguous().float()
+    if len(pointclouds) == 0:
+        pointclouds._init_empty_batch(B, 1)
+    gv, gn = torch.empty_like(vm), torch.empty_like(nm)
+    for b in range(B):
+        P, N, C, F = pointclouds._reserve(b, H * W)   # before _count_of: see _fuse
+        n0, n_dev = pointclouds._count_of(b)
+        cnt, _, _, _ = ops.update_map_fusion_(P, N, C, F, n0, vm[b, 0], nm[b, 0], depth[b, 0, ..., 0], rgb[b, 0],
+                                              alpha[b, 0, ..., 0], poses[b], K[b], dist_th, dot_th,
+                                              RENORMALIZE_UNMATCHED, n_dev=n_dev, out=(gv[b, 0], gn[b, 0]))
+        pointclouds._set_count_dev(b, cnt, H * W)
+    fr._global_vertex_map, fr._global_normal_map = gv, gn
+    return pointclouds

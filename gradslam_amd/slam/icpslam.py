@@ -18,10 +18,12 @@ from .fusionutils import update_map_aggregate
 
 __all__ = ["ICPSLAM"]
 
+import os as _os
+
 # Below this many surfels the ICP targets are binned straight from the map (gs_icp_map_dc_f32: three filtered
 # passes over the map instead of a compaction + a build over the compacted set: 4 launches fewer, +1.2 % frames/s
 # at 7e5 surfels); above it the gathered target set is cheaper (-4.5 % at 7e6 surfels otherwise).
-ICP_FROM_MAP_MAX_SURFELS = 2_000_000
+ICP_FROM_MAP_MAX_SURFELS = int(_os.environ.get("GRADSLAM_HIP_ICP_FROM_MAP_MAX", 2_000_000))
 
 
 class ICPSLAM(nn.Module):

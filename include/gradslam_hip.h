@@ -358,6 +358,22 @@ GS_API int gs_append_valid_dc_f32(float* points, float* normals, float* colors, 
                                   const float* alpha, const float* depth, int H, int W,
                                   int64_t* new_count_out, void* scratch, void* stream);
 
+/* update_map_fusion (slam/fusionutils.py:761-789) of one sequence as ONE call: global maps of the frame under
+ * `pose16` (structures/rgbdimages.py:681-762), projection + association of the map (fusionutils.py:198-577) and
+ * the confidence-weighted merge + ordered append (fusionutils.py:580-722), regrouped into 6 launches.  Same
+ * results, bit for bit, as gs_global_maps_f32 + gs_project_map_dc_f32 + gs_associate_dc_f32 +
+ * gs_fuse_append_dc_f32.  vertex / normal: LOCAL maps (H, W, 3); alpha (H, W); outputs gvertex / gnormal
+ * (H, W, 3), best_pix (H*W) (the correspondence table, -1 = none), new_count_out (must not alias n_map_dev;
+ * n_map_dev may be NULL = the bound is exact).  capacity >= n_map_bound + H*W. */
+GS_API int64_t gs_update_map_scratch_bytes(int64_t n_map_bound, int H, int W);
+GS_API int gs_update_map_fusion_dc_f32(float* points, float* normals, float* colors, float* ccounts,
+                                       int64_t n_map_bound, const int64_t* n_map_dev, int64_t capacity,
+                                       const float* vertex, const float* normal, const float* depth,
+                                       const float* rgb, const float* alpha, const float* pose16, const float* K16,
+                                       int H, int W, float dist_th, float dot_th, int renorm_all, float* gvertex,
+                                       float* gnormal, int32_t* best_pix, int64_t* new_count_out, void* scratch,
+                                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif
