@@ -10,6 +10,10 @@ from ._C import Workspace, check, lib, ptr, require_device, stream
 
 f32 = torch.float32
 
+# Smallest row count of the bound-sized temporaries (_empty_rows); the SLAM drivers raise it to the capacity of the
+# map they grow, so that those temporaries keep ONE allocation size for as long as the capacity lasts.
+ROW_FLOOR = 0
+
 # True: the in-place SLAM drivers keep the surfel count of the map on the device between frames
 # (the *_dc entry points) so that a frame never waits for a host read-back.  False: every count
 # is read back as soon as it is produced (exact sizes on the host at all times).
@@ -46,7 +50,7 @@ def _empty_rows(n, tail, dtype, dev):
     per-frame temporaries sized by the (growing) surfel bound then change their allocation size only when the
     bound doubles, instead of asking the caching allocator for a slightly larger block every frame (each new
     size is a fresh hipMalloc while the host runs ahead of the device)."""
-    cap = 1 << max(int(n) - 1, 0).bit_length() if n > 1024 else 1024
+    cap = max(1 << max(int(n) - 1, 0).bit_length() if n > 1024 else 1024, ROW_FLOOR)
     return torch.empty((cap,) + tuple(tail), dtype=dtype, device=dev)[:n]
 
 
@@ -322,8 +326,9 @@ def icp(src, tgt, tgt_normals, init=None, compose=None, mode=1, numiters=20, dam
     assert T.shape == (4, 4) and T.dtype == f32 and T.is_contiguous() and T.device == dev
     idx = torch.empty(ns, dtype=torch.int64, device=dev) if return_idx else None
     ws = Workspace.get(dev)
-    scratch = ws.bytes("icp", lib().gs_icp_scratch_bytes(ns, nt))
-    if n_src_dev is not None or n_tgt_dev is not None:
+    dc = n_src_dev is not None or n_tgt_dev is not None
+    scratch = ws.bytes("icp", lib().gs_icp_scratch_bytes(ns, max(nt, ROW_FLOOR) if dc else nt))
+    if dc:
         require_device(n_src_dev, n_tgt_dev)
         check(lib().gs_icp_dc_f32(ptr(src), ns, ptr(n_src_dev), ptr(tgt), ptr(tn), nt, ptr(n_tgt_dev), ptr(init),
                                   ptr(compose), prm, ptr(T), ptr(idx), ptr(scratch), stream(dev)), "gs_icp_dc_f32")
@@ -354,7 +359,7 @@ def icp_map(src, map_points, map_normals, pix, W, ds, n_map_dev=None, init=None,
                        float(lambda_max), float(B), float(B2), float(nu))
     T = torch.empty((4, 4), dtype=f32, device=dev) if out is None else out
     assert T.shape == (4, 4) and T.dtype == f32 and T.is_contiguous() and T.device == dev
-    scratch = Workspace.get(dev).bytes("icp", lib().gs_icp_scratch_bytes(ns, nm))
+    scratch = Workspace.get(dev).bytes("icp", lib().gs_icp_scratch_bytes(ns, max(nm, ROW_FLOOR)))
     check(lib().gs_icp_map_dc_f32(ptr(src), ns, None, ptr(P), ptr(N), ptr(pix), nm, ptr(n_map_dev), int(W), int(ds),
                                   ptr(init), ptr(compose), prm, ptr(T), ptr(scratch), stream(dev)), "gs_icp_map_dc_f32")
     return T
@@ -468,7 +473,7 @@ def update_map_fusion_(points, normals, colors, ccounts, n_map, vertex, normal, 
                                           torch.empty((H, W, 3), dtype=f32, device=dev))
     best = torch.empty(H * W, dtype=torch.int32, device=dev)
     cnt = torch.empty(1, dtype=torch.int64, device=dev)
-    scratch = Workspace.get(dev).bytes("map_update", lib().gs_update_map_scratch_bytes(int(n_map), H, W))
+    scratch = Workspace.get(dev).bytes("map_update", lib().gs_update_map_scratch_bytes(max(int(n_map), ROW_FLOOR), H, W))
     check(lib().gs_update_map_fusion_dc_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map), ptr(n_dev),
                                             cap, ptr(vertex), ptr(normal), ptr(depth), ptr(rgb), ptr(alpha), ptr(pose),
                                             ptr(K), H, W, float(dist_th), float(dot_th), 1 if renorm_all else 0, ptr(gv),

@@ -414,6 +414,7 @@ def _update_map_one_call(pointclouds, rgbdimages, dist_th, dot_th, sigma):
     for b in range(B):
         P, N, C, F = pointclouds._reserve(b, H * W)   # before _count_of: see _fuse
         n0, n_dev = pointclouds._count_of(b)
+        ops.ROW_FLOOR = max(ops.ROW_FLOOR, P.shape[0])   # map-sized temporaries: one size while this capacity lasts
         cnt, _, _, _ = ops.update_map_fusion_(P, N, C, F, n0, vm[b, 0], nm[b, 0], depth[b, 0, ..., 0], rgb[b, 0],
                                               alpha[b, 0, ..., 0], poses[b], K[b], dist_th, dot_th,
                                               RENORMALIZE_UNMATCHED, n_dev=n_dev, out=(gv[b, 0], gn[b, 0]))

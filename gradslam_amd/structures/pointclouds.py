@@ -321,6 +321,8 @@ class Pointclouds(object):
         self._padded_cache.clear()
         self.equisized = (len(set(self._n)) == 1) if self._n else None
 
+    RESERVE_FRAMES = 16   # initial capacity of a growing map, in units of the first append request (one frame)
+
     def _init_empty_batch(self, B, num_features, with_normals=True, with_colors=True):
         """Turns an empty map into B empty sequences with the given attribute set."""
         assert not self._n
@@ -338,7 +340,10 @@ class Pointclouds(object):
         need = n_b + int(extra)
         cap = self._buf["points"][b].shape[0]
         if need > cap:
-            new_cap = max(need, int(cap * 2), 1024)
+            # geometric growth, starting at RESERVE_FRAMES x the request: a surfel map of a few hundred MB is
+            # nothing in 288 GB of HBM, and every reallocation (and every size class the bound-sized per-frame
+            # temporaries move through) is a hipMalloc in the middle of a sequence
+            new_cap = max(need, int(cap * 2), self.RESERVE_FRAMES * int(extra), 1024)
             for k in _ATTRS:
                 if self._buf[k] is None:
                     continue
