@@ -8,7 +8,7 @@
 // Grid path (large target sets; the SLAM loop): ONE kernel per half-iteration.  Its prologue lets
 // every block redundantly finish the PREVIOUS half-iteration (add up the partial rows the previous
 // kernel left, then the scalar stage: solve + se3_exp, or LM / gradLM update) so that no separate
-// single-block kernels sit on the critical path; block 0 records the state.  Then 16 lanes per
+// single-block kernels sit on the critical path; block 0 records the state.  Then GQ_G (8) lanes per
 // source point run the grid search (gs_knn.h), the block finishes unresolved queries by brute
 // force, builds the Gauss-Newton rows and emits one partial row.  State and partial rows are
 // double-buffered between consecutive kernels.  2 x numiters + 1 launches per solve.
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   if (lb == 0 && threadIdx.x < (int)(sizeof(IcpSmall) / 4))
     reinterpret_cast<float*>(st_out)[threadIdx.x] = reinterpret_cast<const float*>(&sm)[threadIdx.x];
 
-  // ---- search: one source point per 16-lane group, pending transform applied to the loaded point.
+  // ---- search: one source point per GQ_G-lane group, pending transform applied to the loaded point.
   // A NaN source point (empty slot of an un-compacted lattice, gs_lattice_source_f32) is skipped: it stays
   // NaN through every transform, is never searched and contributes no row.
   if (s < n_src && p0 != p0) {
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
     float qx, qy, qz;
     gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
     bool done;
-    const unsigned long long key = grid_search16(g, cell_start, sorted, qx, qy, qz, lane, &done);
+    const unsigned long long key = grid_search_group(g, cell_start, sorted, qx, qy, qz, lane, &done);
     if (lane == 0) {
       if (FULL) {  // the transformed cloud of this iteration
         src_out[3 * s] = qx;
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   }
   __syncthreads();
 
-  // ---- rows: lane t < FS_QPB of wave 0 builds the row of query t; the 28 products go straight to LDS
+  // ---- rows: thread t < FS_QPB (the first two waves) builds the row of query t; the 28 products go straight to LDS
   // (held in registers they would be 56 VGPRs per lane)
   __shared__ double rows_s[FS_QPB][LIN_NV + 1];
   __shared__ double sub_s[FS_RG][LIN_NV];

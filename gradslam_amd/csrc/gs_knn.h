@@ -111,11 +111,11 @@ GS_DEV unsigned long long grid_key(float qx, float qy, float qz, const float4 p)
 }
 
 // cooperative scan of one segment list: lane `lane` holds (sb, se) of slot `lane` (se <= sb: empty)
-// The candidates of all 16 slots are treated as ONE flat list (prefix sum of the slot lengths over
-// the group); lane l takes flat positions l, l+16, ... and finds (slot, offset) of each by a
-// 4-step binary search on the prefix with shuffles.  Gather addresses therefore depend on
+// The candidates of all GQ_G slots are treated as ONE flat list (prefix sum of the slot lengths over
+// the group); lane l takes flat positions l, l+GQ_G, ... and finds (slot, offset) of each by a
+// log2(GQ_G)-step binary search on the prefix with shuffles.  Gather addresses therefore depend on
 // registers only, so the four gathers of a pass are in flight together instead of one dependent
-// global load per slot.  Every lane runs the same number of passes (shuffles need all 16 lanes).
+// global load per slot.  Every lane runs the same number of passes (shuffles need all GQ_G lanes).
 GS_DEV int grid_flat_index(int t, int sb, int excl) {
   int j = 0;
 #pragma unroll
@@ -165,10 +165,10 @@ GS_DEV unsigned long long grid_group_min(unsigned long long key) {
   return key;
 }
 
-// Shell search of one query by its 16-lane group (all 16 lanes call it with the same query).
+// Shell search of one query by its GQ_G-lane group (all lanes of the group call it with the same query).
 // Returns the packed best key (identical in all lanes); *resolved tells whether it is provably
 // the global minimum.
-GS_DEV unsigned long long grid_search16(const GsGrid& g, const int* __restrict__ cell_start,
+GS_DEV unsigned long long grid_search_group(const GsGrid& g, const int* __restrict__ cell_start,
                                         const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
                                         bool* resolved) {
   // cell of the query's projection onto the bounding box (the projection onto a convex set never

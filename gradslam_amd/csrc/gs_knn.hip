@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(GQ_BLOCK) gs_grid_query_kernel(
   const int lane = threadIdx.x & (GQ_G - 1);
   const int64_t s = ((int64_t)blockIdx.x * GQ_BLOCK + threadIdx.x) / GQ_G;
   if (blockIdx.x == 0 && threadIdx.x == 0) *unres_next = 0;  // arm the counter of the NEXT query (ping-pong)
-  if (s >= n_src) return;  // whole 16-lane groups leave together
+  if (s >= n_src) return;  // whole GQ_G-lane groups leave together
   const GsGrid g = *gp;
   float qx = src_in[3 * s], qy = src_in[3 * s + 1], qz = src_in[3 * s + 2];
   if (Tapply) {
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(GQ_BLOCK) gs_grid_query_kernel(
     src_out[3 * s + 2] = qz;
   }
   bool done;
-  const unsigned long long key = grid_search16(g, cell_start, sorted, qx, qy, qz, lane, &done);
+  const unsigned long long key = grid_search_group(g, cell_start, sorted, qx, qy, qz, lane, &done);
   if (lane == 0) {
     if (done) {
       best[s] = key;
