@@ -1,4 +1,7 @@
-// gs_icp_bwd.hip — K7: backward pass of point_to_plane_gradICP (odometry/icputils.py:479-545).
+// gs_icp_bwd.hip — K7: backward pass of point_to_plane_gradICP (odometry/icputils.py:479-545) and of the
+// hard-LM point_to_plane_ICP (odometry/icputils.py:310-367; mode 0: an accepted step applies exp(xi), a
+// rejected one nothing, the accept test and the damping schedule are constants of the differentiation, as
+// in the reference's autograd graph).
 //
 // Reverse-mode differentiation of the gradLM loop given the forward tape (gs_icp_tape_f32): the
 // gradient of any scalar loss w.r.t. the source points, the target points, the target normals and
@@ -196,12 +199,14 @@ GS_DEV void bw_sum_rows(const double* __restrict__ partials, int nrows, double* 
 
 // Replays the forward transforms and seeds the adjoints.
 __global__ void gs_bwd_init_kernel(BwdState* __restrict__ bs, GsIcpTape tape, const float* __restrict__ init16,
-                                   const float* __restrict__ T_bar16, int K) {
+                                   const float* __restrict__ T_bar16, int K, int mode) {
   if (threadIdx.x != 0) return;
   for (int i = 0; i < 16; ++i) bs->Tk[0][i] = (double)init16[i];
   for (int k = 0; k < K; ++k) {
     double xi[6], xs[6];
-    const double sig = (double)tape.trace[12 * k + 3];
+    // mode 0 (hard LM): the step is exp(xi) when the look-ahead error dropped, the identity otherwise
+    const double sig = mode == 0 ? (tape.trace[12 * k + 1] < tape.trace[12 * k] ? 1.0 : 0.0)
+                                 : (double)tape.trace[12 * k + 3];
     for (int i = 0; i < 6; ++i) {
       xi[i] = (double)tape.trace[12 * k + 4 + i];
       xs[i] = sig * xi[i];
@@ -242,6 +247,19 @@ GS_DEV void bw_stage_s1(const BwdState* __restrict__ bs, const GsIcpTape& tape, 
       out.Tb[4 * i + j] = acc;
     }
   double xi[6], xs[6], ub[6];
+  if (prm.mode == 0) {
+    // hard LM: T_step = exp(xi) if accepted (xi_bar = adjoint through exp), identity otherwise (nothing flows);
+    // neither the accept test nor the damping schedule carries a gradient
+    const bool accepted = tape.trace[12 * k + 1] < tape.trace[12 * k];
+    for (int i = 0; i < 6; ++i) xi[i] = (double)tape.trace[12 * k + 4 + i];
+    if (accepted) d_se3_exp_adjoint(xi, Tsb, ub);
+    for (int i = 0; i < 6; ++i) out.xi_bar[i] = accepted ? ub[i] : 0.0;
+    out.lam_bar = 0.0;
+    loc.e1_bar = 0.0;
+    loc.e_bar = 0.0;
+    out.e_bar = 0.0;
+    return;
+  }
   const double sig = (double)tape.trace[12 * k + 3];
   for (int i = 0; i < 6; ++i) {
     xi[i] = (double)tape.trace[12 * k + 4 + i];
@@ -497,7 +515,7 @@ extern "C" int gs_icp_backward_f32(const void* tape, const float* src_in, int64_
                                    float* normals_bar, float* init_bar16, void* scratch, void* stream) {
   GS_REQUIRE(prm && tape && src_in && tgt && tgt_normals && init16 && T_bar16 && scratch, "NULL pointer");
   GS_REQUIRE(n_src > 0 && n_tgt > 0, "empty point set");
-  GS_REQUIRE(prm->mode == 1, "backward is implemented for gradICP (mode 1)");
+  GS_REQUIRE(prm->mode == 0 || prm->mode == 1, "mode must be 0 (ICP) or 1 (gradICP)");
   GS_REQUIRE(prm->numiters >= 0 && prm->numiters <= 64, "numiters must be in [0, 64]");
   hipStream_t st = gs_stream(stream);
   const int K = prm->numiters;
@@ -508,7 +526,7 @@ extern "C" int gs_icp_backward_f32(const void* tape, const float* src_in, int64_
   GS_HIP(hipMemsetAsync(sc.tgt_bar, 0, 24 * (size_t)n_tgt, st));
   GS_HIP(hipMemsetAsync(sc.tn_bar, 0, 24 * (size_t)n_tgt, st));
   GS_HIP(hipMemsetAsync(sc.partials, 0, 8 * BW_NV * (size_t)nblk, st));  // sbar_next = 0 for the last iteration
-  hipLaunchKernelGGL(gs_bwd_init_kernel, dim3(1), dim3(64), 0, st, sc.state, tp, init16, T_bar16, K);
+  hipLaunchKernelGGL(gs_bwd_init_kernel, dim3(1), dim3(64), 0, st, sc.state, tp, init16, T_bar16, K, prm->mode);
   double* sbar_next = sc.sbar_a;  // adjoint of src_{k+1}
   double* sbar_mid = sc.sbar_b;
   for (int k = K - 1; k >= 0; --k) {

@@ -100,8 +100,9 @@ def point_to_plane_ICP(src_pc: torch.Tensor, tgt_pc: torch.Tensor, tgt_normals: 
     _icp_checks(src_pc, tgt_pc, tgt_normals, initial_transform, numiters)
     _init_checks(initial_transform)
     from .. import ops
-    T, idx = ops.icp(src_pc[0], tgt_pc[0], tgt_normals[0], init=initial_transform, mode=0, numiters=numiters,
-                     damp=damp, dist_thresh=dist_thresh)
+    # differentiable (hand-written HIP backward through the accepted LM steps) when any input requires grad
+    T, idx = ops.grad_icp(src_pc[0], tgt_pc[0], tgt_normals[0], init=initial_transform, numiters=numiters, damp=damp,
+                          dist_thresh=dist_thresh, mode=0)
     return T, idx
 
 

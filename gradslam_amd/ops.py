@@ -509,14 +509,14 @@ def append_valid_(points, normals, colors, ccounts, n_map, gvertex, gnormal, rgb
 
 # ----------------------------------------------------------------------------------- K7 (autograd)
 def icp_with_tape(src, tgt, tgt_normals, init=None, numiters=20, damp=1e-8, dist_thresh=None, lambda_max=2.0,
-                  B=1.0, B2=1.0, nu=200.0):
-    """gradICP forward that also records the tape gs_icp_backward_f32 needs.  Returns (T, idx, tape, prm)."""
+                  B=1.0, B2=1.0, nu=200.0, mode=1):
+    """(grad)ICP forward that also records the tape gs_icp_backward_f32 needs.  Returns (T, idx, tape, prm)."""
     src, tgt, tn = _c(src), _c(tgt), _c(tgt_normals)
     dev = require_device(src, tgt, tn)
     init = torch.eye(4, dtype=f32, device=dev) if init is None else _c(init)
     require_device(init)
     ns, nt = src.shape[0], tgt.shape[0]
-    prm = _C.IcpParams(1, int(numiters), float(damp), -1.0 if dist_thresh is None else float(dist_thresh),
+    prm = _C.IcpParams(int(mode), int(numiters), float(damp), -1.0 if dist_thresh is None else float(dist_thresh),
                        float(lambda_max), float(B), float(B2), float(nu))
     T = torch.empty((4, 4), dtype=f32, device=dev)
     idx = torch.empty(ns, dtype=torch.int64, device=dev)
@@ -548,9 +548,9 @@ class GradICPFunction(torch.autograd.Function):
     gs_icp_backward_f32 (hand-written reverse mode; no PyTorch ops on the tape)."""
 
     @staticmethod
-    def forward(ctx, src, tgt, tgt_normals, init, numiters, damp, dist_thresh, lambda_max, B, B2, nu):
+    def forward(ctx, src, tgt, tgt_normals, init, numiters, damp, dist_thresh, lambda_max, B, B2, nu, mode=1):
         T, idx, tape, prm = icp_with_tape(src, tgt, tgt_normals, init, numiters, damp, dist_thresh, lambda_max, B, B2,
-                                          nu)
+                                          nu, mode)
         ctx.save_for_backward(src, tgt, tgt_normals, init, tape)
         ctx.prm = prm
         ctx.mark_non_differentiable(idx)
@@ -561,17 +561,19 @@ class GradICPFunction(torch.autograd.Function):
         src, tgt, tn, init, tape = ctx.saved_tensors
         need = tuple(ctx.needs_input_grad[:4])
         gs, gt, gn, gi = icp_backward(tape, ctx.prm, src, tgt, tn, init, T_bar.contiguous(), need)
-        return (gs, gt, gn, gi) + (None,) * 7
+        return (gs, gt, gn, gi) + (None,) * 8
 
 
 def grad_icp(src, tgt, tgt_normals, init=None, numiters=20, damp=1e-8, dist_thresh=None, lambda_max=2.0, B=1.0,
-             B2=1.0, nu=200.0):
-    """Differentiable gradICP: (T (4,4), idx (Ns,)).  Uses the plain forward when nothing requires grad."""
+             B2=1.0, nu=200.0, mode=1):
+    """Differentiable gradICP (mode 1) / hard-LM ICP (mode 0): (T (4,4), idx (Ns,)).  Uses the plain forward when
+    nothing requires grad."""
     dev = src.device
     init = torch.eye(4, dtype=f32, device=dev) if init is None else init
     if torch.is_grad_enabled() and any(t.requires_grad for t in (src, tgt, tgt_normals, init)):
-        return GradICPFunction.apply(src, tgt, tgt_normals, init, numiters, damp, dist_thresh, lambda_max, B, B2, nu)
-    return icp(src, tgt, tgt_normals, init=init, mode=1, numiters=numiters, damp=damp, dist_thresh=dist_thresh,
+        return GradICPFunction.apply(src, tgt, tgt_normals, init, numiters, damp, dist_thresh, lambda_max, B, B2, nu,
+                                     mode)
+    return icp(src, tgt, tgt_normals, init=init, mode=mode, numiters=numiters, damp=damp, dist_thresh=dist_thresh,
                lambda_max=lambda_max, B=B, B2=B2, nu=nu)
 
 

@@ -210,7 +210,10 @@ GS_API int gs_global_maps_backward_f32(const float* gvertex_bar, const float* gn
 GS_API int gs_downsample_frame_backward_f32(const float* pts_bar, const float* depth, int H, int W, int ds,
                                             float* gvertex_bar, void* scratch, void* stream);
 
-/* ------------------------------------------------------------- K7: gradICP backward ----
+/* ------------------------------------------------------------- K7: (grad)ICP backward ----
+ * Both solvers are differentiable: mode 1 (gradICP, odometry/icputils.py:479-545) through the soft accept and
+ * damping functions, mode 0 (hard LM, :310-367) through the accepted steps only (the accept test and the
+ * damping schedule are constants, as in the reference's autograd graph).
  * Differentiable gradICP (config C3): gs_icp_tape_f32 is gs_icp_f32 that additionally records the
  * forward tape (caller-owned, gs_icp_tape_bytes(n_src, numiters) bytes: per-iteration source cloud,
  * neighbour indices of both searches, float32 normal equations, trace).  gs_icp_backward_f32 then

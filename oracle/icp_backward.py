@@ -13,12 +13,12 @@ from . import oracle as o
 
 
 def icp_forward_tape(src, tgt, tgt_normals, init=None, numiters=20, damp=1e-8, dist_thresh=None, lambda_max=2.0,
-                     B=1.0, B2=1.0, nu=200.0):
-    """gradICP forward through the C oracle, returning (T, tape)."""
+                     B=1.0, B2=1.0, nu=200.0, mode=1):
+    """gradICP (mode 1) / hard-LM ICP (mode 0) forward through the C oracle, returning (T, tape)."""
     src, tgt, tn = (np.ascontiguousarray(a, np.float32) for a in (src, tgt, tgt_normals))
     init = np.eye(4, dtype=np.float32) if init is None else np.ascontiguousarray(init, np.float32)
     ns = src.shape[0]
-    prm = o.IcpParams(1, numiters, damp, -1.0 if dist_thresh is None else dist_thresh, lambda_max, B, B2, nu)
+    prm = o.IcpParams(mode, numiters, damp, -1.0 if dist_thresh is None else dist_thresh, lambda_max, B, B2, nu)
     T = np.empty((4, 4), np.float32)
     idx = np.empty(ns, np.int64)
     trace = np.zeros((numiters, 12), np.float32)
@@ -31,7 +31,7 @@ def icp_forward_tape(src, tgt, tgt_normals, init=None, numiters=20, damp=1e-8, d
                            T.ctypes.data_as(f32p), idx.ctypes.data_as(C.POINTER(C.c_int64)), trace.ctypes.data_as(f32p),
                            tape_src.ctypes.data_as(f32p), tape_idx.ctypes.data_as(i32p), tape_sys.ctypes.data_as(f32p))
     tape = dict(src=tape_src, idx=tape_idx, sys=tape_sys, trace=trace, init=init,
-                prm=dict(numiters=numiters, damp=damp, lambda_max=lambda_max, B=B, B2=B2, nu=nu))
+                prm=dict(numiters=numiters, damp=damp, lambda_max=lambda_max, B=B, B2=B2, nu=nu, mode=mode))
     return T, tape
 
 
@@ -115,6 +115,8 @@ def icp_backward(tape, tgt, tgt_normals, T_bar, src_in):
     for k in range(K):
         xi = tape["trace"][k, 4:10].astype(np.float64)
         sig = float(tape["trace"][k, 3])
+        if p.get("mode", 1) == 0:   # hard LM: the step is exp(xi) when accepted, the identity otherwise
+            sig = 1.0 if np.float32(tape["trace"][k, 1]) < np.float32(tape["trace"][k, 0]) else 0.0
         Tr_list.append(se3_exp(xi))
         Ts_list.append(se3_exp(sig * xi))
         Tk.append(Ts_list[-1] @ Tk[-1])
@@ -137,6 +139,8 @@ def icp_backward(tape, tgt, tgt_normals, T_bar, src_in):
         Ts_bar[:3, 3] += sb_next.sum(0)
         Tb = Ts.T @ Tb
         sb = sb_next @ Ts[:3, :3]
+        if p.get("mode", 1) == 0:
+            sig = 1.0 if np.float32(new_err) < np.float32(err) else 0.0
         # Ts = Exp(sig * xi)
         ub = se3_exp_adjoint(sig * xi, Ts_bar)
         sig_bar = ub @ xi
@@ -151,7 +155,7 @@ def icp_backward(tape, tgt, tgt_normals, T_bar, src_in):
         dsig = (B2p * E2 / nu) * (1 + E2) ** (-1.0 / nu - 1.0)
         d_bar = sig_bar * dsig + lam_bar * lam * dq
         lam_bar = lam_bar * q
-        if not inside:
+        if not inside or p.get("mode", 1) == 0:   # hard LM: accept test and damping schedule carry no gradient
             d_bar = 0.0
         e1_bar, e_bar = d_bar, -d_bar
         # look-ahead residual: s' = Tr s, b' = n'.(d' - s')

@@ -3,6 +3,8 @@
 
     python -m oracle.make_golden_extra
 
+  icp0_grad.npz the reference's autograd gradients of the hard-LM point_to_plane_ICP (odometry/icputils.py:235-367)
+                on the clouds of icp_unit.npz: d<W,T>/d(src, tgt, normals) for K = 1, 5, 20 and with dist_thresh.
   gt_odom.npz   GroundTruthOdometryProvider.provide / relative_transformation on seeded poses
                 (odometry/groundtruth.py:74-78, geometry/geometryutils.py:413-478).
   icl_items.npz the same for the reference's ICL loader (datasets/icl.py) on tests/tum_fixture.py:write_icl.
@@ -91,6 +93,27 @@ def tum_items():
     print("icl_items.npz", {k: int(out[k]) for k in out if k.endswith("/len")})
 
 
+def icp0_grad():
+    refimport.import_reference()
+    import torch
+    from gradslam.odometry import icputils
+    gi = np.load(os.path.join(OUT, "icp_unit.npz"))
+    W = np.load(os.path.join(OUT, "icp_grad.npz"))["W"]
+    out = dict(W=W)
+    for K, thr in ((1, None), (5, None), (20, None), (5, 1e-4)):
+        leaf = [torch.from_numpy(gi[k]).clone().requires_grad_(True) for k in ("src", "tgt", "tgt_normals")]
+        T, _ = icputils.point_to_plane_ICP(leaf[0][None], leaf[1][None], leaf[2][None], torch.eye(4), numiters=K,
+                                           dist_thresh=thr)
+        (T * torch.from_numpy(W)).sum().backward()
+        tag = "K%d%s" % (K, "" if thr is None else "_thr")
+        out[tag + "_T"] = T.detach().numpy()
+        for name, t in zip(("src", "tgt", "tn"), leaf):
+            out[tag + "_" + name] = t.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "icp0_grad.npz"), **out)
+    print("icp0_grad.npz", sorted(k for k in out if k.endswith("_T")))
+
+
 if __name__ == "__main__":
     main()
     tum_items()
+    icp0_grad()

@@ -168,3 +168,36 @@ def test_pointfusion_driver_pose_gradient_wrt_live_depth(golden):
     (rp[0, 1] * dev(g["chain_W"])).sum().backward()
     got, ref = dd.grad[0, 1, ..., 0].cpu().numpy(), g["slam_depth1_grad"]
     assert rel(got, ref) < 5e-3 and (got != 0).sum() == (ref != 0).sum()
+
+
+# ------------------------------------------------------------------------------------------ hard-LM ICP (mode 0)
+@pytest.mark.parametrize("K,thr,tag", CASES)
+def test_numpy_backward_oracle_matches_reference_autograd_hard_lm(golden, K, thr, tag):
+    """point_to_plane_ICP: accepted steps carry the gradient, rejected ones and the accept test do not."""
+    g, u = golden("icp0_grad"), golden("icp_unit")
+    T, tape = ib.icp_forward_tape(u["src"], u["tgt"], u["tgt_normals"], numiters=K, dist_thresh=thr, mode=0)
+    np.testing.assert_allclose(T, g[tag + "_T"], atol=2e-5, rtol=0)
+    if K >= 5:   # the fixture exercises both branches
+        acc = [bool(tape["trace"][k, 1] < tape["trace"][k, 0]) for k in range(K)]
+        assert any(acc) and not all(acc)
+    sb, tb, nb, _ = ib.icp_backward(tape, u["tgt"], u["tgt_normals"], g["W"], u["src"])
+    assert rel(sb, g[tag + "_src"]) < 5e-4 and rel(tb, g[tag + "_tgt"]) < 5e-4 and rel(nb, g[tag + "_tn"]) < 5e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,thr,tag", CASES)
+def test_hip_backward_hard_lm_matches_oracle_and_reference(golden, K, thr, tag):
+    from gradslam_amd.odometry import icputils
+    g, u = golden("icp0_grad"), golden("icp_unit")
+    leaf = [dev(u[k]).requires_grad_(True) for k in ("src", "tgt", "tgt_normals")]
+    init = torch.eye(4, device="cuda", requires_grad=True)
+    T, idx = icputils.point_to_plane_ICP(leaf[0][None], leaf[1][None], leaf[2][None], init, numiters=K, dist_thresh=thr)
+    assert T.requires_grad and not idx.requires_grad
+    (T * dev(g["W"])).sum().backward()
+    np.testing.assert_allclose(T.detach().cpu().numpy(), g[tag + "_T"], atol=2e-5, rtol=0)
+    _, tape = ib.icp_forward_tape(u["src"], u["tgt"], u["tgt_normals"], numiters=K, dist_thresh=thr, mode=0)
+    sb, tb, nb, ibar = ib.icp_backward(tape, u["tgt"], u["tgt_normals"], g["W"], u["src"])
+    for have, orc, name in zip([t.grad.cpu().numpy() for t in leaf], (sb, tb, nb), ("src", "tgt", "tn")):
+        assert rel(have, orc) < 2e-4, name
+        assert rel(have, g[tag + "_" + name]) < 5e-4, name
+    assert rel(init.grad.cpu().numpy(), ibar) < 2e-4
