@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <memory>
+
 #include "gs_icp_math.h"
 #include "gs_knn.h"
 
@@ -514,8 +516,8 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
     // one event pair around the 2 x numiters half-iteration kernels.  Compulsory bytes of a half-iteration:
     // source in (+out), 27 cell bounds (8 B) per query, matched target + normal gather, partial rows, one
     // pass over the binned targets: 271 B (full) / 259 B (look-ahead) per query + 16 B per target
-    GsProf* prof_loop = new GsProf(GS_PROF_ICP_FUSED, (double)prm->numiters * ((double)n_src * 530.0 + 32.0 * (double)n_tgt),
-                                   st, 2 * prm->numiters);
+    std::unique_ptr<GsProf> prof_loop(new GsProf(
+        GS_PROF_ICP_FUSED, (double)prm->numiters * ((double)n_src * 530.0 + 32.0 * (double)n_tgt), st, 2 * prm->numiters));
     for (int it = 0; it < prm->numiters; ++it) {
       float* cur = cloud(it);
       {
@@ -540,7 +542,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
       ++h;
       cur_in = cur;
     }
-    delete prof_loop;  // closing event right behind the last half-iteration kernel
+    prof_loop.reset();  // closing event right behind the last half-iteration kernel
     if (prm->numiters > 0) {
       GsProf prof(GS_PROF_SOLVE, 1.0, st);
       hipLaunchKernelGGL(gs_icp_finish_kernel, dim3(1), dim3(FS_BLOCK), 0, st, sc.partials[(h + 1) & 1], n_src_c,
