@@ -69,6 +69,8 @@ _PROTOS = {
     "gs_append_valid_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gs_ingest_depth_u16_f32": [_vp, _i32, _i32, _vp, _i32, _i32, C.c_double, _vp],
     "gs_ingest_color_u8_f32": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
+    "gs_fuse_append_backward_f32": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp,
+                                    _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gs_update_map_scratch_bytes": [_i64, _i32, _i32],
     "gs_update_map_fusion_dc_f32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
                                     _f, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp],

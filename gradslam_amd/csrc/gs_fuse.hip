@@ -165,6 +165,130 @@ extern "C" int gs_append_valid_dc_f32(float* points, float* normals, float* colo
                       gnormal, rgb, alpha, depth, H, W, new_count_out, scratch, stream);
 }
 
+// ---------------------------------------------------------------- K7: backward of the fuse ----
+// Reverse mode of fuse_with_map (slam/fusionutils.py:653-720) for one sequence: given the adjoints of the
+// fused map (points / normals / colours / confidence counts, n_new rows), the adjoints of the OLD map rows and
+// of the frame's global vertex / normal maps, colours and alpha.  Correspondences are constants (index ops).
+// Per old row n with matched pixel p (alpha = 0, frame value = 0 when unmatched):
+//   u = cc x + alpha f,  cc' = cc + alpha,  x' = u / where(cc' == 0, 1, cc')           (three attributes)
+// Every pixel is written by at most one row (its winner) or by one appended row: plain stores, no atomics.
+__global__ void __launch_bounds__(256) gs_fuse_bwd_rows_kernel(
+    const float* __restrict__ points, const float* __restrict__ normals, const float* __restrict__ colors,
+    const float* __restrict__ ccounts, int64_t n_old, const int32_t* __restrict__ pix_of,
+    const int32_t* __restrict__ any_flag, const float* __restrict__ gvertex, const float* __restrict__ gnormal,
+    const float* __restrict__ rgb, const float* __restrict__ alpha, int renorm_all,
+    const float* __restrict__ P_bar, const float* __restrict__ N_bar, const float* __restrict__ C_bar,
+    const float* __restrict__ F_bar, float* __restrict__ oP_bar, float* __restrict__ oN_bar,
+    float* __restrict__ oC_bar, float* __restrict__ oF_bar, float* __restrict__ gv_bar, float* __restrict__ gn_bar,
+    float* __restrict__ rgb_bar, float* __restrict__ alpha_bar) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_old) return;
+  const int32_t p = (*any_flag != 0) ? pix_of[n] : -1;
+  if (*any_flag == 0 || (p < 0 && !renorm_all)) {  // the row was not rewritten: identity
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      oP_bar[3 * n + k] = P_bar[3 * n + k];
+      oN_bar[3 * n + k] = N_bar[3 * n + k];
+      oC_bar[3 * n + k] = C_bar[3 * n + k];
+    }
+    oF_bar[n] = F_bar[n];
+    return;
+  }
+  const double a = p >= 0 ? (double)alpha[p] : 0.0;
+  const double cc = (double)ccounts[n];
+  const double cc2 = cc + a;
+  const double inv = 1.0 / (cc2 == 0.0 ? 1.0 : cc2);
+  double inv_bar = 0.0, cc_bar = 0.0, a_bar = 0.0;
+  const float* olds[3] = {points, normals, colors};
+  const float* frames[3] = {gvertex, gnormal, rgb};
+  const float* bars[3] = {P_bar, N_bar, C_bar};
+  float* obars[3] = {oP_bar, oN_bar, oC_bar};
+  float* fbars[3] = {gv_bar, gn_bar, rgb_bar};
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double x = (double)olds[t][3 * n + k];
+      const double f = p >= 0 ? (double)frames[t][3 * (int64_t)p + k] : 0.0;
+      const double xb = (double)bars[t][3 * n + k];
+      const double ub = xb * inv;
+      inv_bar += xb * (cc * x + a * f);
+      obars[t][3 * n + k] = (float)(cc * ub);
+      if (p >= 0) fbars[t][3 * (int64_t)p + k] = (float)(a * ub);
+      cc_bar += x * ub;
+      a_bar += f * ub;
+    }
+  }
+  const double cc2_bar = (double)F_bar[n] + (cc2 != 0.0 ? -inv * inv * inv_bar : 0.0);
+  oF_bar[n] = (float)(cc_bar + cc2_bar);
+  if (p >= 0) alpha_bar[p] = (float)(a_bar + cc2_bar);
+}
+
+struct EmitAppendBackward {
+  const float* P_bar;
+  const float* N_bar;
+  const float* C_bar;
+  const float* F_bar;
+  int64_t n_old;
+  float* gv_bar;
+  float* gn_bar;
+  float* rgb_bar;
+  float* alpha_bar;
+  __device__ void operator()(int64_t p, int64_t pos) const {
+    const int64_t r = n_old + pos;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      gv_bar[3 * p + k] = P_bar[3 * r + k];
+      gn_bar[3 * p + k] = N_bar[3 * r + k];
+      rgb_bar[3 * p + k] = C_bar[3 * r + k];
+    }
+    alpha_bar[p] = F_bar[r];
+  }
+};
+
+extern "C" int gs_fuse_append_backward_f32(const float* points, const float* normals, const float* colors,
+                                           const float* ccounts, int64_t n_old, const int32_t* best_pix,
+                                           const float* gvertex, const float* gnormal, const float* rgb,
+                                           const float* alpha, const float* depth, int H, int W, int renorm_all,
+                                           const float* P_bar, const float* N_bar, const float* C_bar,
+                                           const float* F_bar, int64_t n_new, float* old_points_bar,
+                                           float* old_normals_bar, float* old_colors_bar, float* old_ccounts_bar,
+                                           float* gvertex_bar, float* gnormal_bar, float* rgb_bar, float* alpha_bar,
+                                           void* scratch, void* stream) {
+  GS_REQUIRE(H > 0 && W > 0 && n_old >= 0 && n_new >= n_old, "bad sizes");
+  GS_REQUIRE(best_pix && gvertex && gnormal && rgb && alpha && depth && P_bar && N_bar && C_bar && F_bar && gvertex_bar &&
+                 gnormal_bar && rgb_bar && alpha_bar && scratch,
+             "NULL pointer");
+  hipStream_t st = gs_stream(stream);
+  const int64_t P = (int64_t)H * W;
+  GS_HIP(hipMemsetAsync(gvertex_bar, 0, 12 * (size_t)P, st));
+  GS_HIP(hipMemsetAsync(gnormal_bar, 0, 12 * (size_t)P, st));
+  GS_HIP(hipMemsetAsync(rgb_bar, 0, 12 * (size_t)P, st));
+  GS_HIP(hipMemsetAsync(alpha_bar, 0, 4 * (size_t)P, st));
+  char* base = reinterpret_cast<char*>(scratch) + gs_cp_scratch_bytes(P > n_old ? P : n_old);
+  int32_t* any_flag = reinterpret_cast<int32_t*>(base);
+  int32_t* pix_of = reinterpret_cast<int32_t*>(base + 256);
+  if (n_old > 0) {
+    GS_REQUIRE(points && normals && colors && ccounts && old_points_bar && old_normals_bar && old_colors_bar &&
+                   old_ccounts_bar,
+               "NULL pointer");
+    const GsCount n_old_c{n_old, nullptr};
+    hipLaunchKernelGGL(gs_fuse_init_kernel, dim3((unsigned)gs_ceil_div(n_old, 256)), dim3(256), 0, st, pix_of, n_old,
+                       any_flag);
+    hipLaunchKernelGGL(gs_fuse_scatter_kernel, dim3((unsigned)gs_ceil_div(P, 256)), dim3(256), 0, st, best_pix, P,
+                       n_old_c, pix_of, any_flag);
+    hipLaunchKernelGGL(gs_fuse_bwd_rows_kernel, dim3((unsigned)gs_ceil_div(n_old, 256)), dim3(256), 0, st, points,
+                       normals, colors, ccounts, n_old, pix_of, any_flag, gvertex, gnormal, rgb, alpha, renorm_all, P_bar,
+                       N_bar, C_bar, F_bar, old_points_bar, old_normals_bar, old_colors_bar, old_ccounts_bar,
+                       gvertex_bar, gnormal_bar, rgb_bar, alpha_bar);
+    GS_LAUNCH_CHECK();
+  }
+  // appended rows: row n_old + k is the k-th new pixel in raster order (the forward's ordered compaction)
+  EmitAppendBackward emit{P_bar, N_bar, C_bar, F_bar, n_old, gvertex_bar, gnormal_bar, rgb_bar, alpha_bar};
+  int64_t* cnt = reinterpret_cast<int64_t*>(base + 128);
+  return gs_compact(P, PredNewPixel{depth, best_pix}, emit, cnt, 0, n_new - n_old, scratch, st);
+}
+
 // ---------------------------------------------------------------- one-call map update ----
 // update_map_fusion (slam/fusionutils.py:761-789) for one sequence with the kernels regrouped by DOMAIN so
 // that the frame costs 6 launches instead of 11 (global maps 1 + projection 1 + association 3 + fuse 6);

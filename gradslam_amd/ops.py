@@ -577,6 +577,46 @@ def grad_icp(src, tgt, tgt_normals, init=None, numiters=20, damp=1e-8, dist_thre
                lambda_max=lambda_max, B=B, B2=B2, nu=nu)
 
 
+class FuseAppendFunction(torch.autograd.Function):
+    """fuse_with_map of one sequence as a differentiable op (out of place): old map rows + frame maps -> fused map.
+    forward = gs_fuse_append_f32 on a copy, backward = gs_fuse_append_backward_f32.  Correspondences (best_pix)
+    and depth (validity only) are constants."""
+
+    @staticmethod
+    def forward(ctx, points, normals, colors, ccounts, gvertex, gnormal, rgb, alpha, depth, best_pix, renorm_all):
+        n0 = points.shape[0]
+        H, W = depth.shape[:2]
+        dev = gvertex.device
+        bufs = [torch.empty((n0 + H * W, c), dtype=f32, device=dev) for c in (3, 3, 3, 1)]
+        for dst, src in zip(bufs, (points, normals, colors, ccounts)):
+            dst[:n0] = src
+        n1 = fuse_append_(*bufs, n0, best_pix, gvertex, gnormal, rgb, alpha, depth, renorm_all)
+        ctx.save_for_backward(points, normals, colors, ccounts, gvertex, gnormal, rgb, alpha, depth, best_pix)
+        ctx.renorm_all, ctx.n1 = bool(renorm_all), n1
+        return tuple(b[:n1] for b in bufs)
+
+    @staticmethod
+    def backward(ctx, P_bar, N_bar, C_bar, F_bar):
+        points, normals, colors, ccounts, gvertex, gnormal, rgb, alpha, depth, best_pix = ctx.saved_tensors
+        dev = gvertex.device
+        n0, n1 = points.shape[0], ctx.n1
+        H, W = depth.shape[:2]
+        bars = [_c(t) if t is not None else torch.zeros((n1, c), dtype=f32, device=dev)
+                for t, c in zip((P_bar, N_bar, C_bar, F_bar), (3, 3, 3, 1))]
+        old = [torch.empty((n0, c), dtype=f32, device=dev) for c in (3, 3, 3, 1)]
+        gv_b, gn_b, rgb_b = (torch.empty((H, W, 3), dtype=f32, device=dev) for _ in range(3))
+        a_b = torch.empty((H, W), dtype=f32, device=dev)
+        ws = Workspace.get(dev)
+        check(lib().gs_fuse_append_backward_f32(ptr(_c(points)), ptr(_c(normals)), ptr(_c(colors)), ptr(_c(ccounts)), n0,
+                                                ptr(best_pix), ptr(_c(gvertex)), ptr(_c(gnormal)), ptr(_c(rgb)),
+                                                ptr(_c(alpha)), ptr(_c(depth)), H, W, 1 if ctx.renorm_all else 0,
+                                                ptr(bars[0]), ptr(bars[1]), ptr(bars[2]), ptr(bars[3]), n1, ptr(old[0]),
+                                                ptr(old[1]), ptr(old[2]), ptr(old[3]), ptr(gv_b), ptr(gn_b), ptr(rgb_b),
+                                                ptr(a_b), ptr(ws.scratch(n0, H * W)), stream(dev)),
+              "gs_fuse_append_backward_f32")
+        return old[0], old[1], old[2], old[3], gv_b, gn_b, rgb_b, a_b, None, None, None
+
+
 class FrameMapsFunction(torch.autograd.Function):
     """depth (H,W) -> (vertex, normal, alpha); differentiable w.r.t. depth (gs_frame_maps_backward_f32)."""
 

@@ -377,10 +377,64 @@ def update_map_fusion(pointclouds: Pointclouds, rgbdimages: RGBDImages, dist_th:
     if pointclouds._dcount or pointclouds.has_points:
         _check_batch(pointclouds, rgbdimages)
     from .. import ops
+    if _wants_map_grad(pointclouds, rgbdimages):
+        return _fuse_differentiable(pointclouds, rgbdimages, dist_th, dot_th, sigma, inplace)
     if inplace and ops.DEVICE_COUNTS and _one_call_update_ok(pointclouds, rgbdimages):
         return _update_map_one_call(pointclouds, rgbdimages, dist_th, dot_th, sigma)
     best = _best_pix_per_sequence(pointclouds, rgbdimages, dist_th, dot_th)
     return _fuse(pointclouds, rgbdimages, best, sigma, inplace)
+
+
+def _wants_map_grad(pointclouds, rgbdimages):
+    """the fused map has to stay on the autograd tape: a frame input or the map itself requires grad"""
+    if not torch.is_grad_enabled() or rgbdimages.device.type != "cuda":
+        return False
+    if rgbdimages.depth_image.requires_grad or rgbdimages.rgb_image.requires_grad:
+        return True
+    bufs = pointclouds._buf
+    return any(bufs[k] is not None and any(t.requires_grad for t in bufs[k]) for k in bufs)
+
+
+def _fuse_differentiable(pointclouds, rgbdimages, dist_th, dot_th, sigma, inplace):
+    """update_map_fusion on the autograd tape (FuseAppendFunction per sequence, out of place as autograd requires):
+    depth -> vertex / normal / alpha -> global maps -> merge + append; correspondences are constants.  With
+    inplace=True the new tensors replace the buffers of the given object (as the reference's padded setters do)."""
+    from .. import ops
+    fr, K, poses = _frame(rgbdimages)
+    B, _, H, W = fr.shape
+    alpha = fr._alpha_map(sigma)
+    gv, gn = fr.global_vertex_map, fr.global_normal_map
+    rgb, depth = fr.rgb_image.float(), fr.depth_image.float()
+    out = pointclouds if inplace else Pointclouds(device=pointclouds.device)
+    if len(pointclouds) == 0 and inplace:
+        pointclouds._init_empty_batch(B, 1)
+    new = {k: [] for k in ("points", "normals", "colors", "features")}
+    for b in range(B):
+        if len(pointclouds) == 0:
+            old = [torch.empty((0, c), dtype=torch.float32, device=fr.device) for c in (3, 3, 3, 1)]
+        else:
+            n_b = pointclouds._n[b]
+            old = [pointclouds._buf[k][b][:n_b] for k in ("points", "normals", "colors", "features")]
+        with torch.no_grad():
+            if old[0].shape[0]:
+                pix = ops.project_map(old[0], poses[b], K[b], H, W)
+                best = ops.associate(pix, old[0], old[1], old[3][:, :1], gv[b, 0], gn[b, 0], dist_th, dot_th)
+            else:
+                best = torch.full((H * W,), -1, dtype=torch.int32, device=fr.device)
+        fused = ops.FuseAppendFunction.apply(old[0], old[1], old[2], old[3], gv[b, 0], gn[b, 0], rgb[b, 0],
+                                             alpha[b, 0, ..., 0], depth[b, 0, ..., 0].detach(), best,
+                                             RENORMALIZE_UNMATCHED)
+        for k, t in zip(new, fused):
+            new[k].append(t)
+    if not inplace and len(pointclouds) == 0:
+        out._init_empty_batch(B, 1)
+    elif not inplace:
+        out._init_empty_batch(B, 1)
+    for k in new:
+        out._buf[k] = new[k]
+    out._n = [t.shape[0] for t in new["points"]]
+    out._invalidate()
+    return out
 
 
 def _one_call_update_ok(pointclouds, rgbdimages):

@@ -361,6 +361,21 @@ GS_API int gs_append_valid_dc_f32(float* points, float* normals, float* colors, 
                                   const float* alpha, const float* depth, int H, int W,
                                   int64_t* new_count_out, void* scratch, void* stream);
 
+/* Backward of gs_fuse_append_f32 = reverse mode of fuse_with_map (slam/fusionutils.py:653-720): adjoints of
+ * the fused map (n_new rows; the first n_old are the merged old rows, the rest the appended pixels in raster
+ * order) -> adjoints of the old map rows (values BEFORE the merge are passed in) and of the frame's global
+ * vertex / normal maps, colours (H, W, 3) and alpha (H, W).  best_pix: the correspondence table used in the
+ * forward.  scratch: gs_scratch_bytes(n_old, H * W). */
+GS_API int gs_fuse_append_backward_f32(const float* points, const float* normals, const float* colors,
+                                       const float* ccounts, int64_t n_old, const int32_t* best_pix,
+                                       const float* gvertex, const float* gnormal, const float* rgb,
+                                       const float* alpha, const float* depth, int H, int W, int renorm_all,
+                                       const float* P_bar, const float* N_bar, const float* C_bar,
+                                       const float* F_bar, int64_t n_new, float* old_points_bar,
+                                       float* old_normals_bar, float* old_colors_bar, float* old_ccounts_bar,
+                                       float* gvertex_bar, float* gnormal_bar, float* rgb_bar, float* alpha_bar,
+                                       void* scratch, void* stream);
+
 /* update_map_fusion (slam/fusionutils.py:761-789) of one sequence as ONE call: global maps of the frame under
  * `pose16` (structures/rgbdimages.py:681-762), projection + association of the map (fusionutils.py:198-577) and
  * the confidence-weighted merge + ordered append (fusionutils.py:580-722), regrouped into 6 launches.  Same

@@ -5,6 +5,9 @@
 
   icp0_grad.npz the reference's autograd gradients of the hard-LM point_to_plane_ICP (odometry/icputils.py:235-367)
                 on the clouds of icp_unit.npz: d<W,T>/d(src, tgt, normals) for K = 1, 5, 20 and with dist_thresh.
+  fusion_grad.npz the reference's autograd through PointFusion(odom="gt") over 3 frames of a 32x40 synthetic
+                sequence: d<W, final map (points, normals, colours, confidence counts)>/d(depth, rgb) -- the
+                differentiable mapping path (slam/fusionutils.py:653-720 through structures/rgbdimages.py maps).
   gt_odom.npz   GroundTruthOdometryProvider.provide / relative_transformation on seeded poses
                 (odometry/groundtruth.py:74-78, geometry/geometryutils.py:413-478).
   icl_items.npz the same for the reference's ICL loader (datasets/icl.py) on tests/tum_fixture.py:write_icl.
@@ -113,7 +116,35 @@ def icp0_grad():
     print("icp0_grad.npz", sorted(k for k in out if k.endswith("_T")))
 
 
+def fusion_grad():
+    refimport.import_reference()
+    import torch
+    import gradslam
+    from gradslam_amd.datasets.synthetic import make_sequence
+    s = make_sequence(3, 32, 40, seed=3, hole_frac=0.1)
+    depth = torch.from_numpy(s["depths"][None]).clone().requires_grad_(True)
+    rgb = torch.from_numpy(s["colors"][None]).clone().requires_grad_(True)
+    frames = gradslam.RGBDImages(rgb, depth, torch.from_numpy(s["intrinsics"][None]), torch.from_numpy(s["poses"][None]))
+    slam = gradslam.slam.PointFusion(odom="gt", dsratio=4)
+    pc, _ = slam(frames)
+    rng = np.random.default_rng(1)
+    n = pc.points_list[0].shape[0]
+    W = {k: rng.standard_normal((n, c)).astype(np.float32) for k, c in (("points", 3), ("normals", 3), ("colors", 3),
+                                                                     ("features", 1))}
+    loss = sum((getattr(pc, k + "_list")[0] * torch.from_numpy(W[k])).sum() for k in W)
+    loss.backward()
+    out = dict(colors=s["colors"], depths=s["depths"], intrinsics=s["intrinsics"], poses=s["poses"],
+               depth_grad=depth.grad[0].numpy(), rgb_grad=rgb.grad[0].numpy(), n=np.array(n))
+    for k in W:
+        out["W_" + k] = W[k]
+        out["map_" + k] = getattr(pc, k + "_list")[0].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "fusion_grad.npz"), **out)
+    print("fusion_grad.npz: %d surfels, |d depth| max %.3e, |d rgb| max %.3e"
+          % (n, np.abs(out["depth_grad"]).max(), np.abs(out["rgb_grad"]).max()))
+
+
 if __name__ == "__main__":
     main()
     tum_items()
     icp0_grad()
+    fusion_grad()

@@ -179,3 +179,44 @@ def test_relative_pose_matches_reference(golden):
     rel = o.relative_pose(g["T1"], g["T2"])
     assert np.abs(rel - g["rel"][:, 0]).max() <= 2e-6
     assert np.array_equal(rel[:, 3], np.tile(np.array([0, 0, 0, 1], np.float32), (rel.shape[0], 1)))
+
+
+def test_fuse_adjoint_by_finite_differences():
+    """oracle/fusion_backward.py: the reverse mode of merge + append against central differences of its own
+    float64 forward (matched, unmatched and zero-confidence rows, appended pixels)."""
+    from oracle import fusion_backward as fb
+    rng = np.random.default_rng(0)
+    n, P = 12, 20
+    old = [rng.standard_normal((n, 3)) for _ in range(3)]
+    cc = rng.random(n) + 0.1
+    cc[3] = 0.0
+    frame = [rng.standard_normal((P, 3)) for _ in range(3)]
+    alpha = rng.random(P)
+    pix_of = np.full(n, -1)
+    pix_of[[0, 2, 3, 5, 9]] = [4, 7, 1, 15, 11]
+    new_pix = np.array([0, 2, 3, 8, 19])
+    W = [rng.standard_normal((n + len(new_pix), 3)) for _ in range(3)]
+    Wc = rng.standard_normal(n + len(new_pix))
+
+    def loss(old, cc, frame, alpha):
+        out, c2 = fb.fuse_forward(old, cc, frame, alpha, pix_of, new_pix)
+        return sum((o_ * w).sum() for o_, w in zip(out, W)) + (c2 * Wc).sum()
+
+    ob, cb, fbar, ab = fb.fuse_backward(old, cc, frame, alpha, pix_of, new_pix, W, Wc)
+    h = 1e-6
+
+    def fd(arr, idx, rebuild):
+        e = np.zeros_like(arr)
+        e[idx] = h
+        return (rebuild(arr + e) - rebuild(arr - e)) / (2 * h)
+    for t in range(3):
+        for idx in ((0, 1), (3, 0), (7, 2)):
+            assert abs(fd(old[t], idx, lambda v: loss([v if k == t else old[k] for k in range(3)], cc, frame, alpha))
+                       - ob[t][idx]) < 1e-6
+        for idx in ((4, 0), (1, 2), (8, 1), (5, 0)):
+            assert abs(fd(frame[t], idx, lambda v: loss(old, cc, [v if k == t else frame[k] for k in range(3)], alpha))
+                       - fbar[t][idx]) < 1e-6
+    for i in (0, 1, 5):      # (row 3 has cc' = alpha != 0 here; a zero cc' row has a zero derivative by the guard)
+        assert abs(fd(cc, i, lambda v: loss(old, v, frame, alpha)) - cb[i]) < 1e-6
+    for p in (4, 7, 1, 0, 19, 6):
+        assert abs(fd(alpha, p, lambda v: loss(old, cc, frame, v)) - ab[p]) < 1e-6
