@@ -141,13 +141,19 @@ class ICPSLAM(nn.Module):
                 # find_active_map_points(pointclouds, prev_frame) + downsample_pointclouds, without tables
                 P, N = pointclouds.points_list[b], pointclouds.normals_list[b]
                 pix = ops.project_map(P, prev_poses[b], K[b], H, W)
-                tp, tn, _ = ops.select_targets(pix, W, self.dsratio, P, N)
+                if taped and (P.requires_grad or N.requires_grad):
+                    # the map is on the tape (differentiable mapping): gather the targets by row index so that the
+                    # pose gradient also reaches the earlier frames through the map (same rows, same order)
+                    rows = ops.active_table(pix, W)
+                    idx = rows[(rows[:, 2] % self.dsratio == 0) & (rows[:, 3] % self.dsratio == 0), 1]
+                    tp, tn = P[idx], N[idx]
+                else:
+                    tp, tn, _ = ops.select_targets(pix, W, self.dsratio, P, N)
                 tgt_pts.append(tp)
                 tgt_nrm.append(tn)
             if taped and isinstance(self.odomprov, GradICPOdometryProvider):
-                # differentiable pose path: depth -> vertex -> global vertex -> ICP source -> gradICP -> pose.
-                # The map (ICP target) is a constant here; the reference additionally differentiates
-                # through the map built from EARLIER frames (not implemented: fusion has no backward yet).
+                # differentiable pose path: depth -> vertex -> global vertex -> ICP source -> gradICP -> pose, and,
+                # when the map is on the tape, earlier frames -> map -> ICP targets / normals -> pose.
                 o = self.odomprov
                 out = []
                 for b in range(B):

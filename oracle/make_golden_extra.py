@@ -8,6 +8,8 @@
   fusion_grad.npz the reference's autograd through PointFusion(odom="gt") over 3 frames of a 32x40 synthetic
                 sequence: d<W, final map (points, normals, colours, confidence counts)>/d(depth, rgb) -- the
                 differentiable mapping path (slam/fusionutils.py:653-720 through structures/rgbdimages.py maps).
+  slam_grad0.npz the reference's d<W, pose_1>/d depth_0 for the 64x64 two-frame PointFusion(odom="gradicp") run of
+                depth_grad.npz: frame 0 reaches pose_1 only through the MAP (the ICP target set).
   gt_odom.npz   GroundTruthOdometryProvider.provide / relative_transformation on seeded poses
                 (odometry/groundtruth.py:74-78, geometry/geometryutils.py:413-478).
   icl_items.npz the same for the reference's ICL loader (datasets/icl.py) on tests/tum_fixture.py:write_icl.
@@ -143,8 +145,26 @@ def fusion_grad():
           % (n, np.abs(out["depth_grad"]).max(), np.abs(out["rgb_grad"]).max()))
 
 
+def slam_grad0():
+    refimport.import_reference()
+    import torch
+    import gradslam
+    g = np.load(os.path.join(OUT, "depth_grad.npz"))
+    dd = torch.from_numpy(g["slam_depths"][None]).clone().requires_grad_(True)
+    pp = torch.from_numpy(g["slam_poses"][None]).clone()
+    pp[:, 1:] = pp[:, :1]
+    frames = gradslam.RGBDImages(torch.from_numpy(g["slam_colors"][None]), dd,
+                                 torch.from_numpy(g["slam_intrinsics"][None, None]), pp)
+    _, rp = gradslam.slam.PointFusion(odom="gradicp")(frames)
+    (rp[0, 1] * torch.from_numpy(g["chain_W"])).sum().backward()
+    assert np.array_equal(dd.grad[0, 1, ..., 0].numpy(), g["slam_depth1_grad"])   # same run as depth_grad.npz (c)
+    np.savez_compressed(os.path.join(OUT, "slam_grad0.npz"), depth0_grad=dd.grad[0, 0, ..., 0].numpy().copy())
+    print("slam_grad0.npz: |d depth0| max %.3e, nonzero %d" % (np.abs(dd.grad[0, 0]).max(), int((dd.grad[0, 0] != 0).sum())))
+
+
 if __name__ == "__main__":
     main()
     tum_items()
     icp0_grad()
     fusion_grad()
+    slam_grad0()

@@ -168,6 +168,13 @@ def test_pointfusion_driver_pose_gradient_wrt_live_depth(golden):
     (rp[0, 1] * dev(g["chain_W"])).sum().backward()
     got, ref = dd.grad[0, 1, ..., 0].cpu().numpy(), g["slam_depth1_grad"]
     assert rel(got, ref) < 5e-3 and (got != 0).sum() == (ref != 0).sum()
+    # frame 0 reaches pose_1 only through the map it was fused into (the ICP targets and their normals)
+    got0, ref0 = dd.grad[0, 0, ..., 0].cpu().numpy(), golden("slam_grad0")["depth0_grad"]
+    err0 = np.abs(got0 - ref0)
+    # (the supports agree up to a few pixels whose reference gradient is float32 round-off of an exact zero)
+    assert abs(int((got0 != 0).sum()) - int((ref0 != 0).sum())) <= 0.01 * (ref0 != 0).sum()
+    assert np.median(err0[ref0 != 0]) < 1e-3 * np.abs(ref0).max()
+    assert (err0 < 1e-2 * np.abs(ref0).max()).mean() > 0.999
 
 
 # ------------------------------------------------------------------------------------------ hard-LM ICP (mode 0)
