@@ -69,6 +69,8 @@ _PROTOS = {
     "gs_append_valid_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gs_ingest_depth_u16_f32": [_vp, _i32, _i32, _vp, _i32, _i32, C.c_double, _vp],
     "gs_ingest_color_u8_f32": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
+    "gs_global_maps_pose_backward_scratch_bytes": [_i32, _i32],
+    "gs_global_maps_pose_backward_f32": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gs_fuse_append_backward_f32": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp,
                                     _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gs_update_map_scratch_bytes": [_i64, _i32, _i32],
@@ -87,7 +89,7 @@ _PROTOS = {
                                _vp],
 }
 _RESTYPE = {"gs_last_error": C.c_char_p, "gs_scratch_bytes": _i64, "gs_icp_scratch_bytes": _i64,
-            "gs_knn1_grid_scratch_bytes": _i64, "gs_update_map_scratch_bytes": _i64, "gs_icp_tape_bytes": _i64, "gs_icp_backward_scratch_bytes": _i64}
+            "gs_knn1_grid_scratch_bytes": _i64, "gs_update_map_scratch_bytes": _i64, "gs_global_maps_pose_backward_scratch_bytes": _i64, "gs_icp_tape_bytes": _i64, "gs_icp_backward_scratch_bytes": _i64}
 EXPORTS = tuple(_PROTOS)
 
 

@@ -480,6 +480,61 @@ __global__ void __launch_bounds__(BW_BLOCK) gs_bwd_cast_kernel(const double* __r
   if (i < n) out[i] = (float)in[i];
 }
 
+// ---------------------------------------------------------------- pose adjoint of the global maps ----
+// gvertex = (R v + t) * valid, gnormal = R n (structures/rgbdimages.py:681-762):
+//   R_bar = sum_p valid_p gv_bar_p (x) v_p + sum_p gn_bar_p (x) n_p,   t_bar = sum_p valid_p gv_bar_p
+// 12 sums over the pixels: block partial rows, then one wave adds them up (fixed order, float64).
+__global__ void __launch_bounds__(BW_BLOCK) gs_pose_bar_partial_kernel(
+    const float* __restrict__ vertex, const float* __restrict__ normal, const float* __restrict__ depth,
+    const float* __restrict__ gv_bar, const float* __restrict__ gn_bar, int64_t P, double* __restrict__ partials) {
+  const int64_t p = (int64_t)blockIdx.x * BW_BLOCK + threadIdx.x;
+  double v[BW_NV];
+#pragma unroll
+  for (int q = 0; q < BW_NV; ++q) v[q] = 0.0;
+  if (p < P) {
+    const bool valid = depth[p] > 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double gb = (gv_bar && valid) ? (double)gv_bar[3 * p + a] : 0.0;
+      const double nb = gn_bar ? (double)gn_bar[3 * p + a] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        v[3 * a + c] = gb * (double)vertex[3 * p + c] + nb * (normal ? (double)normal[3 * p + c] : 0.0);
+      v[9 + a] = gb;
+    }
+  }
+  bw_block_reduce(v, partials + (int64_t)blockIdx.x * BW_NV);
+}
+__global__ void __launch_bounds__(GS_WAVE) gs_pose_bar_final_kernel(const double* __restrict__ partials, int nrows,
+                                                                    float* __restrict__ pose_bar16) {
+  double G[BW_NV];
+  bw_sum_rows(partials, nrows, G);
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) pose_bar16[4 * i + j] = (float)G[3 * i + j];
+    pose_bar16[4 * i + 3] = (float)G[9 + i];
+  }
+  for (int j = 0; j < 4; ++j) pose_bar16[12 + j] = 0.0f;
+}
+extern "C" int64_t gs_global_maps_pose_backward_scratch_bytes(int H, int W) {
+  return (int64_t)(gs_align(8 * BW_NV * (size_t)gs_ceil_div((int64_t)H * W, BW_BLOCK)) + 256);
+}
+extern "C" int gs_global_maps_pose_backward_f32(const float* vertex, const float* normal, const float* depth,
+                                                const float* gvertex_bar, const float* gnormal_bar, int H, int W,
+                                                float* pose_bar16, void* scratch, void* stream) {
+  GS_REQUIRE(H > 0 && W > 0 && vertex && depth && pose_bar16 && scratch && (gvertex_bar || gnormal_bar), "bad arguments");
+  GS_REQUIRE(!gnormal_bar || normal, "gnormal_bar needs the normal map");
+  hipStream_t st = gs_stream(stream);
+  const int64_t P = (int64_t)H * W;
+  const int nblk = (int)gs_ceil_div(P, BW_BLOCK);
+  double* partials = reinterpret_cast<double*>(scratch);
+  hipLaunchKernelGGL(gs_pose_bar_partial_kernel, dim3(nblk), dim3(BW_BLOCK), 0, st, vertex, normal, depth, gvertex_bar,
+                     gnormal_bar, P, partials);
+  hipLaunchKernelGGL(gs_pose_bar_final_kernel, dim3(1), dim3(GS_WAVE), 0, st, partials, nblk, pose_bar16);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 struct BwdScratch {
   BwdState* state;
   double* sbar_a;   // [n_src][3]

@@ -643,17 +643,17 @@ class FrameMapsFunction(torch.autograd.Function):
 
 
 class GlobalMapsFunction(torch.autograd.Function):
-    """(vertex, normal) + pose -> (gvertex, gnormal); differentiable w.r.t. the local maps."""
+    """(vertex, normal) + pose -> (gvertex, gnormal); differentiable w.r.t. the local maps and the pose."""
 
     @staticmethod
     def forward(ctx, vertex, normal, depth, pose):
         gv, gn = global_maps(vertex, normal, depth, pose)
-        ctx.save_for_backward(depth, pose)
+        ctx.save_for_backward(depth, pose, vertex, normal)
         return gv, gn
 
     @staticmethod
     def backward(ctx, gv_bar, gn_bar):
-        depth, pose = ctx.saved_tensors
+        depth, pose, vertex, normal = ctx.saved_tensors
         depth_c, pose_c = _c(depth), _c(pose)
         dev = require_device(depth_c, pose_c)
         H, W = depth_c.shape[:2]
@@ -662,7 +662,14 @@ class GlobalMapsFunction(torch.autograd.Function):
         n_bar = torch.empty((H, W, 3), dtype=f32, device=dev) if gn_bar is not None else None
         check(lib().gs_global_maps_backward_f32(ptr(gv_bar), ptr(gn_bar), ptr(depth_c), ptr(pose_c), H, W, ptr(v_bar),
                                                 ptr(n_bar), stream(dev)), "gs_global_maps_backward_f32")
-        return v_bar, n_bar, None, None
+        pose_bar = None
+        if ctx.needs_input_grad[3]:
+            pose_bar = torch.empty((4, 4), dtype=f32, device=dev)
+            scratch = Workspace.get(dev).bytes("pose_bar", lib().gs_global_maps_pose_backward_scratch_bytes(H, W))
+            check(lib().gs_global_maps_pose_backward_f32(ptr(_c(vertex)), ptr(_c(normal)), ptr(depth_c), ptr(gv_bar),
+                                                         ptr(gn_bar), H, W, ptr(pose_bar), ptr(scratch), stream(dev)),
+                  "gs_global_maps_pose_backward_f32")
+        return v_bar, n_bar, None, pose_bar
 
 
 class DownsampleFramePointsFunction(torch.autograd.Function):

@@ -391,6 +391,8 @@ def _wants_map_grad(pointclouds, rgbdimages):
         return False
     if rgbdimages.depth_image.requires_grad or rgbdimages.rgb_image.requires_grad:
         return True
+    if rgbdimages.poses is not None and rgbdimages.poses.requires_grad:
+        return True
     bufs = pointclouds._buf
     return any(bufs[k] is not None and any(t.requires_grad for t in bufs[k]) for k in bufs)
 

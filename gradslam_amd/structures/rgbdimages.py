@@ -215,7 +215,7 @@ class RGBDImages(object):
             return
         depth = self._cl(self._depth_image)
         poses = self._poses.contiguous().float()
-        if torch.is_grad_enabled() and (vm.requires_grad or nm.requires_grad):
+        if torch.is_grad_enabled() and (vm.requires_grad or nm.requires_grad or poses.requires_grad):
             rows = [[ops.GlobalMapsFunction.apply(vm[b, s], nm[b, s], depth[b, s, ..., 0], poses[b, s]) for s in range(L)]
                     for b in range(B)]
             gv = torch.stack([torch.stack([r[0] for r in row]) for row in rows])

@@ -205,6 +205,13 @@ GS_API int gs_frame_maps_backward_f32(const float* depth, const float* K16, int 
 GS_API int gs_global_maps_backward_f32(const float* gvertex_bar, const float* gnormal_bar, const float* depth,
                                        const float* pose16, int H, int W, float* vertex_bar, float* normal_bar,
                                        void* stream);
+/* ... and w.r.t. the pose: pose_bar (4x4, last row zero) with R_bar = sum_p valid_p gvertex_bar_p (x) v_p +
+ * sum_p gnormal_bar_p (x) n_p and t_bar = sum_p valid_p gvertex_bar_p (the recovered pose of a frame feeds the
+ * global maps that are fused into the map: this is the link map -> pose -> ICP of the reference's graph). */
+GS_API int64_t gs_global_maps_pose_backward_scratch_bytes(int H, int W);
+GS_API int gs_global_maps_pose_backward_f32(const float* vertex, const float* normal, const float* depth,
+                                            const float* gvertex_bar, const float* gnormal_bar, int H, int W,
+                                            float* pose_bar16, void* scratch, void* stream);
 /* Reverse mode of gs_downsample_frame_f32 (points): gvertex_bar (H,W,3) = zeros with the compact
  * adjoints pts_bar scattered back to the valid lattice pixels (odometry/icputils.py:654-660). */
 GS_API int gs_downsample_frame_backward_f32(const float* pts_bar, const float* depth, int H, int W, int ds,

@@ -126,7 +126,8 @@ def fusion_grad():
     s = make_sequence(3, 32, 40, seed=3, hole_frac=0.1)
     depth = torch.from_numpy(s["depths"][None]).clone().requires_grad_(True)
     rgb = torch.from_numpy(s["colors"][None]).clone().requires_grad_(True)
-    frames = gradslam.RGBDImages(rgb, depth, torch.from_numpy(s["intrinsics"][None]), torch.from_numpy(s["poses"][None]))
+    poses = torch.from_numpy(s["poses"][None]).clone().requires_grad_(True)
+    frames = gradslam.RGBDImages(rgb, depth, torch.from_numpy(s["intrinsics"][None]), poses)
     slam = gradslam.slam.PointFusion(odom="gt", dsratio=4)
     pc, _ = slam(frames)
     rng = np.random.default_rng(1)
@@ -136,7 +137,8 @@ def fusion_grad():
     loss = sum((getattr(pc, k + "_list")[0] * torch.from_numpy(W[k])).sum() for k in W)
     loss.backward()
     out = dict(colors=s["colors"], depths=s["depths"], intrinsics=s["intrinsics"], poses=s["poses"],
-               depth_grad=depth.grad[0].numpy(), rgb_grad=rgb.grad[0].numpy(), n=np.array(n))
+               depth_grad=depth.grad[0].numpy(), rgb_grad=rgb.grad[0].numpy(), poses_grad=poses.grad[0].numpy(),
+               n=np.array(n))
     for k in W:
         out["W_" + k] = W[k]
         out["map_" + k] = getattr(pc, k + "_list")[0].detach().numpy()

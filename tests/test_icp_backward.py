@@ -259,7 +259,8 @@ def test_differentiable_mapping_matches_reference_autograd(golden):
     g = golden("fusion_grad")
     depth = dev(g["depths"][None]).requires_grad_(True)
     rgb = dev(g["colors"][None]).requires_grad_(True)
-    frames = gs.RGBDImages(rgb, depth, dev(g["intrinsics"][None]), dev(g["poses"][None]))
+    poses = dev(g["poses"][None]).requires_grad_(True)
+    frames = gs.RGBDImages(rgb, depth, dev(g["intrinsics"][None]), poses)
     pc, _ = gs.slam.PointFusion(odom="gt", dsratio=4, device="cuda")(frames)
     assert pc.points_list[0].shape[0] == int(g["n"]) and pc.points_list[0].requires_grad
     loss = 0
@@ -269,6 +270,8 @@ def test_differentiable_mapping_matches_reference_autograd(golden):
         loss = loss + (t * dev(g["W_" + k])).sum()
     loss.backward()
     assert rel(rgb.grad[0].cpu().numpy(), g["rgb_grad"]) < 1e-4
+    # the poses reach the map through the global maps (R v + t, R n): 12 sums per frame, last row untouched
+    assert rel(poses.grad[0].cpu().numpy(), g["poses_grad"]) < 1e-4 and np.all(poses.grad[0, :, 3].cpu().numpy() == 0)
     # depth: as in test_depth_gradients_through_frame_maps, the reference's float32 normal normalisation amplifies
     # rounding on the few near-degenerate pixels next to depth holes (4 of 3840 here): compare robustly
     got, ref = depth.grad[0].cpu().numpy(), g["depth_grad"]
