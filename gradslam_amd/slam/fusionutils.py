@@ -341,6 +341,8 @@ def update_map_aggregate(pointclouds: Pointclouds, rgbdimages: RGBDImages, inpla
     _check_rgbd(rgbdimages)
     _check_seq1(rgbdimages)
     from .. import ops
+    if _wants_map_grad(pointclouds, rgbdimages):
+        return _aggregate_differentiable(pointclouds, rgbdimages, inplace)
     fr = rgbdimages.to_channels_last()
     B, _, H, W = fr.shape
     if not inplace:
@@ -365,6 +367,41 @@ def update_map_aggregate(pointclouds: Pointclouds, rgbdimages: RGBDImages, inpla
                                depth[b, 0, ..., 0])
         pointclouds._set_count(b, n1)
     return pointclouds
+
+
+def _aggregate_differentiable(pointclouds, rgbdimages, inplace):
+    """update_map_aggregate on the autograd tape: FuseAppendFunction with an empty correspondence table (old rows
+    pass through untouched, every valid pixel is appended); the confidence column it carries is dropped."""
+    from .. import ops
+    fr = rgbdimages.to_channels_last()
+    B, _, H, W = fr.shape
+    gv, gn = fr.global_vertex_map, fr.global_normal_map
+    rgb, depth = fr.rgb_image.float(), fr.depth_image.float()
+    if len(pointclouds) and pointclouds.has_features:
+        raise ValueError("pointclouds to append and to be appended must either both have or not have features: "
+                         "(False != True)")
+    new = {k: [] for k in ("points", "normals", "colors")}
+    none = torch.full((H * W,), -1, dtype=torch.int32, device=fr.device)
+    zeros_a = torch.zeros((H, W), dtype=torch.float32, device=fr.device)
+    for b in range(B):
+        if len(pointclouds) == 0:
+            old = [torch.empty((0, 3), dtype=torch.float32, device=fr.device) for _ in range(3)]
+        else:
+            n_b = pointclouds._n[b]
+            old = [pointclouds._buf[k][b][:n_b] for k in ("points", "normals", "colors")]
+        cc = torch.zeros((old[0].shape[0], 1), dtype=torch.float32, device=fr.device)
+        fused = ops.FuseAppendFunction.apply(old[0], old[1], old[2], cc, gv[b, 0], gn[b, 0], rgb[b, 0], zeros_a,
+                                             depth[b, 0, ..., 0].detach(), none, False)
+        for k, t in zip(new, fused[:3]):
+            new[k].append(t)
+    out = pointclouds if inplace else Pointclouds(device=pointclouds.device)
+    if len(out) == 0:
+        out._init_empty_batch(B, 0)
+    for k in new:
+        out._buf[k] = new[k]
+    out._n = [t.shape[0] for t in new["points"]]
+    out._invalidate()
+    return out
 
 
 def update_map_fusion(pointclouds: Pointclouds, rgbdimages: RGBDImages, dist_th: Union[float, int],

@@ -142,6 +142,15 @@ def fusion_grad():
     for k in W:
         out["W_" + k] = W[k]
         out["map_" + k] = getattr(pc, k + "_list")[0].detach().numpy()
+    # the same for ICPSLAM's aggregate map (update_map_aggregate, slam/fusionutils.py:725-758): 2 frames
+    d2 = torch.from_numpy(s["depths"][None, :2]).clone().requires_grad_(True)
+    fr2 = gradslam.RGBDImages(torch.from_numpy(s["colors"][None, :2]), d2, torch.from_numpy(s["intrinsics"][None]),
+                              torch.from_numpy(s["poses"][None, :2]))
+    pca, _ = gradslam.slam.ICPSLAM(odom="gt", dsratio=4)(fr2)
+    na = pca.points_list[0].shape[0]
+    Wa = rng.standard_normal((na, 3)).astype(np.float32)
+    ((pca.points_list[0] * torch.from_numpy(Wa)).sum() + (pca.normals_list[0] * torch.from_numpy(Wa[::-1].copy())).sum()).backward()
+    out["agg_W"], out["agg_n"], out["agg_depth_grad"] = Wa, np.array(na), d2.grad[0].numpy()
     np.savez_compressed(os.path.join(OUT, "fusion_grad.npz"), **out)
     print("fusion_grad.npz: %d surfels, |d depth| max %.3e, |d rgb| max %.3e"
           % (n, np.abs(out["depth_grad"]).max(), np.abs(out["rgb_grad"]).max()))
