@@ -289,7 +289,7 @@ def _fuse(pointclouds, rgbdimages, best_pix, sigma, inplace):
         if inplace and ops.DEVICE_COUNTS:
             # the count stays on the device: no read-back, the host only tracks an upper bound.  Reserve FIRST:
             # the bound may tighten between two look-ups, and the capacity must cover the bound that is passed on
-            P, N, C, F = pointclouds._reserve(b, H * W)
+            P, N, C, F = pointclouds._reserve(b, H * W, pointclouds.RESERVE_FRAMES)
             n0, n_dev = pointclouds._count_of(b)
             if P.dtype != torch.float32 or F.shape[-1] != 1:
                 raise ValueError("map fusion needs float32 surfels with one feature column (the confidence count)")
@@ -356,7 +356,7 @@ def update_map_aggregate(pointclouds: Pointclouds, rgbdimages: RGBDImages, inpla
                          "(False != True)")
     for b in range(B):
         if inplace and ops.DEVICE_COUNTS:
-            P, N, C, _ = pointclouds._reserve(b, H * W)   # before _count_of: see _fuse
+            P, N, C, _ = pointclouds._reserve(b, H * W, pointclouds.RESERVE_FRAMES)   # before _count_of: see _fuse
             n0, n_dev = pointclouds._count_of(b)
             cnt = ops.append_valid_(P, N, C, None, n0, gv[b, 0], gn[b, 0], rgb[b, 0], None, depth[b, 0, ..., 0],
                                     n_dev=n_dev, sync=False)
@@ -505,9 +505,10 @@ def _update_map_one_call(pointclouds, rgbdimages, dist_th, dot_th, sigma):
         pointclouds._init_empty_batch(B, 1)
     gv, gn = torch.empty_like(vm), torch.empty_like(nm)
     for b in range(B):
-        P, N, C, F = pointclouds._reserve(b, H * W)   # before _count_of: see _fuse
+        P, N, C, F = pointclouds._reserve(b, H * W, pointclouds.RESERVE_FRAMES)   # before _count_of: see _fuse
         n0, n_dev = pointclouds._count_of(b)
-        ops.ROW_FLOOR = max(ops.ROW_FLOOR, P.shape[0])   # map-sized temporaries: one size while this capacity lasts
+        # map-sized temporaries: one allocation size while this capacity lasts (follows the map being grown)
+        ops.ROW_FLOOR = P.shape[0] if b == 0 else max(ops.ROW_FLOOR, P.shape[0])
         cnt, _, _, _ = ops.update_map_fusion_(P, N, C, F, n0, vm[b, 0], nm[b, 0], depth[b, 0, ..., 0], rgb[b, 0],
                                               alpha[b, 0, ..., 0], poses[b], K[b], dist_th, dot_th,
                                               RENORMALIZE_UNMATCHED, n_dev=n_dev, out=(gv[b, 0], gn[b, 0]))

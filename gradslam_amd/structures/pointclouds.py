@@ -321,7 +321,7 @@ class Pointclouds(object):
         self._padded_cache.clear()
         self.equisized = (len(set(self._n)) == 1) if self._n else None
 
-    RESERVE_FRAMES = 16   # initial capacity of a growing map, in units of the first append request (one frame)
+    RESERVE_FRAMES = 16   # capacity a SLAM driver asks for up front, in frames (see _reserve)
 
     def _init_empty_batch(self, B, num_features, with_normals=True, with_colors=True):
         """Turns an empty map into B empty sequences with the given attribute set."""
@@ -333,9 +333,10 @@ class Pointclouds(object):
         self._buf["colors"] = mk(3) if with_colors else None
         self._buf["features"] = mk(num_features) if num_features else None
 
-    def _reserve(self, b, extra):
+    def _reserve(self, b, extra, frames_ahead=1):
         """Guarantees room for `extra` more rows in sequence b (geometric growth) and returns the
-        capacity-backed buffers (points, normals, colors, features)."""
+        capacity-backed buffers (points, normals, colors, features).  `frames_ahead`: the SLAM drivers, which
+        append up to `extra` rows per frame for many frames, ask for several frames of room at once."""
         n_b = self._count_of(b)[0]
         need = n_b + int(extra)
         cap = self._buf["points"][b].shape[0]
@@ -343,7 +344,7 @@ class Pointclouds(object):
             # geometric growth, starting at RESERVE_FRAMES x the request: a surfel map of a few hundred MB is
             # nothing in 288 GB of HBM, and every reallocation (and every size class the bound-sized per-frame
             # temporaries move through) is a hipMalloc in the middle of a sequence
-            new_cap = max(need, int(cap * 2), self.RESERVE_FRAMES * int(extra), 1024)
+            new_cap = max(need, int(cap * 2), int(frames_ahead) * int(extra), 1024)
             for k in _ATTRS:
                 if self._buf[k] is None:
                     continue

@@ -359,3 +359,20 @@ def test_icl_loader_host_logic_matches_reference(tmp_path, golden):
         ICL(root, trajectories=("kitchen",))
     with pytest.raises(TypeError, match="seqlen must be int"):
         ICL(root, seqlen="4")
+
+
+def test_surfel_store_capacity_policy():
+    """_reserve: geometric growth; only the SLAM drivers ask for several frames of room up front."""
+    pc = gs.Pointclouds(device="cpu")
+    pc._init_empty_batch(1, 1)
+    P, N, C, F = pc._reserve(0, 1000)
+    assert P.shape == (1024, 3) and F.shape == (1024, 1)          # plain append: no look-ahead
+    pc._set_count(0, 1000)
+    assert pc._reserve(0, 100)[0].shape[0] == 2048                 # doubling
+    pc2 = gs.Pointclouds(device="cpu")
+    pc2._init_empty_batch(1, 1)
+    assert pc2._reserve(0, 1000, pc2.RESERVE_FRAMES)[0].shape[0] == 16000
+    big = gs.Pointclouds(points=[torch.zeros(5000, 3)], normals=[torch.zeros(5000, 3)])
+    base = gs.Pointclouds(points=[torch.zeros(10, 3)], normals=[torch.zeros(10, 3)])
+    base.append_points(big)
+    assert base.points_list[0].shape[0] == 5010 and base._buf["points"][0].shape[0] < 3 * 5010
