@@ -1,35 +1,38 @@
 #!/usr/bin/env python
-"""bench.py — frames/sec of PointFusion on synthetic 640x480 RGB-D (BASELINE.json metric).
+"""bench.py -- frames/sec of PointFusion on B = 8 synthetic 640x480 RGB-D sequences (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without WORLD_SIZE: spawns the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One process per GPU; rank r tracks its own independent sequence (seed r) with
-gradslam_amd.slam.PointFusion(odom="gradicp") — the drop-in API, `step()` per frame.  A step =
-one frame through the whole hot path: back-projection/normals, target selection, 20 gradLM
-point-to-plane ICP iterations (40 exact 1-NN searches), projective association, fuse + append.
-Frames are resident in HBM before the timed region.  Weak scaling: per-GPU work is fixed
-(one sequence per GPU), value = total frames of all ranks / max-over-ranks time.
+One process per GPU.  The B (= --batch, default 8) independent sequences (seeds 0..B-1) are sharded over the ranks
+(rank r owns multigpu.shard_sequences(B, N, r): 8 / 4 / 2 / 1 sequences per GPU at N = 1 / 2 / 4 / 8) and every rank
+tracks ITS sequences as one batch with gradslam_amd.slam.PointFusion(odom="gradicp").step(): every kernel of a frame
+serves all sequences of the rank at once (workgroup -> sequence), which is how one GPU is filled -- one 640x480
+sequence alone is a chain of ~50 dependent launches.  A step = one frame of every sequence through the
+whole hot path: back-projection / normals, target selection, 20 gradLM point-to-plane ICP iterations (40 exact 1-NN
+searches), projective association, fuse + append.  Frames are resident in HBM before the timed region.  Total work
+is fixed (B sequences x K frames) as N grows: "scaling": "strong".  value = B * K / max-over-ranks time.
 
 The JSON line also carries
-  roofline      the dominant kernel (fused exact grid 1-NN + Gauss-Newton linearisation): compulsory
-                bytes / its mean launch duration measured with HIP events on the launch stream
-                inside the library, in a second pass over the SAME frames from the same map state
-                (so event overhead never touches `value`);
-  roofline_hbm  the HBM-bound kernel groups (K1 frame maps, K5 projection+association, K6 fuse);
-  roofline_bruteforce  the brute-force 1-NN engine (fp32-VALU bound, 8 flop per pair distance);
-  cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/) on the host cores
-                for a bounded sample of the same workload, rank 0, N=1 only.
+  roofline      the dominant kernel (fused exact grid 1-NN + Gauss-Newton linearisation, batched over the
+                sequences): algorithmic bytes / its mean launch duration, measured with HIP events on the launch
+                stream inside the library in a second pass over the SAME frames from the same map state (event
+                overhead never touches `value`); `traffic` = HBM bytes per launch from the committed PMC passes;
+  roofline_hbm  the HBM-bound kernel groups (K1 frame maps, grid build, K5 association, K6 fuse) and ms per step;
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/) on the host cores for a bounded
+                sample of the same workload, rank 0, N = 1 only, next to the RECORDED timing of the unmodified
+                reference (tests/golden/cpu_ref_timing.json, build container); parity of the timed GPU poses
+                against both (ate_vs_oracle_m, ate_vs_reference_golden_m).
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -43,31 +46,71 @@ H, W = 480, 640
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=8, help="independent sequences in total (sharded over the GPUs)")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--odom", default="gradicp", choices=["gradicp", "icp", "gt"])
+    ap.add_argument("--workload", default="c4", choices=["c4", "c5"],
+                    help="c4: B x 640x480 PointFusion (BASELINE configs[1]/[3]); c5: one 1296x968 sequence, growing map")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2, help="full steps of the CPU oracle sample")
     ap.add_argument("--no-roofline-pass", action="store_true")
     return ap.parse_args()
 
 
-def frames_on_device(gs, seq, device):
-    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
-    poses = seq["poses"].copy()
-    poses[1:] = poses[:1]  # only the first pose is given; the rest is recovered by ICP
-    return gs.RGBDImages(T(seq["colors"][None]), T(seq["depths"][None]), T(seq["intrinsics"][None]), T(poses[None]))
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, RCCL rendezvous on
+    127.0.0.1) and relay rank 0's JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    sys.exit(max(rcs))
 
 
-def run_steps(slam, pc, frames, prev, first, last, poses_out=None):
+def _make(a):
+    from gradslam_amd.datasets.synthetic import make_sequence
+    return make_sequence(*a[:3], seed=a[3])
+
+
+def make_sequences(seeds, L, Hh, Ww):
+    """the seeded synthetic sequences of this rank, generated in parallel on the host cores"""
+    if len(seeds) == 1:
+        return [_make((L, Hh, Ww, seeds[0]))]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(len(seeds), os.cpu_count() or 1)) as pool:
+        return pool.map(_make, [(L, Hh, Ww, s) for s in seeds])
+
+
+def frames_on_device(gs, seqs, device):
+    import torch
+    st = lambda k: torch.from_numpy(np.stack([s[k] for s in seqs])).to(device)  # noqa: E731
+    poses = st("poses")
+    poses[:, 1:] = poses[:, :1]  # only the first pose is given; the rest is recovered by ICP
+    return gs.RGBDImages(st("colors"), st("depths"), st("intrinsics"), poses)
+
+
+def run_steps(slam, pc, frames, prev, first, last, poses_out=None, after_step=None):
     for s in range(first, last):
         live = frames[:, s]
         pc, pose = slam.step(pc, live, prev, inplace=True)
         if poses_out is not None:
             poses_out.append(pose[:, 0])
         prev = live
+        if after_step is not None:
+            after_step(pc)
     return pc, prev
 
 
@@ -75,7 +118,7 @@ def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of a kernel from the newest committed profiles/*_pmc_hbm_traffic.txt (produced by
     tools/collect_profiles.sh + tools/summarize_profiles.py from separate PMC passes); (None, None) if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_hbm_traffic.txt")))
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_hbm_traffic.txt")))
     if not files:
         return None, None
     tot, calls = 0.0, 0
@@ -96,31 +139,42 @@ def read_profile(lib, kind):
 
 def cpu_baseline(seq, n_full_steps, odom):
     """Oracle (port of the reference's algorithm) on the host cores: frame 0 initialises the map
-    (untimed, like the warm-up), the next `n_full_steps` frames are timed."""
+    (untimed, like the warm-up), the next `n_full_steps` frames are timed.  Returns (dict, oracle poses)."""
     from oracle import slam as oslam
     L = 1 + n_full_steps
     poses = seq["poses"][:L].copy()
     poses[1:] = poses[:1]
     marks = []
     t0 = time.perf_counter()
-    oslam.run_sequence(seq["colors"][:L], seq["depths"][:L], seq["intrinsics"][0], poses, odom=odom,
-                       per_frame=lambda s, m, p: marks.append(time.perf_counter()))
+    _, op = oslam.run_sequence(seq["colors"][:L], seq["depths"][:L], seq["intrinsics"][0], poses, odom=odom,
+                               per_frame=lambda s, m, p: marks.append(time.perf_counter()))
     dt = marks[-1] - marks[0]
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
-    return {"value": n_full_steps / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "oracle/ (C restatement of gradslam's CPU path, OpenMP) on frames 1..%d of the same "
-                      "640x480 sequence after an untimed map-init frame; %.1f s of CPU work" % (n_full_steps, dt),
-            "total_s": time.perf_counter() - t0}
+    out = {"value": n_full_steps / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "oracle/ (C restatement of gradslam's CPU path, OpenMP) on frames 1..%d of sequence 0 of the same "
+                     "workload after an untimed map-init frame; %.1f s of CPU work" % (n_full_steps, dt),
+           "total_s": time.perf_counter() - t0}
+    rec = os.path.join(REPO, "tests", "golden", "cpu_ref_timing.json")
+    if os.path.exists(rec):   # the unmodified reference, timed once in the build container (oracle/make_golden_640.py)
+        r = json.load(open(rec))
+        out["reference_recorded"] = {"value": r["frames_per_s_steady"], "unit": "frames/s", "cores": r["cores"],
+                                     "what": r["what"], "machine": r["machine"],
+                                     "source": "tests/golden/cpu_ref_timing.json"}
+    return out, op
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+    import torch
+
     import gradslam_amd as gs
     from gradslam_amd import _C, multigpu
-    from gradslam_amd.datasets.synthetic import make_sequence
+    from tests.conftest import ate as ate_np
 
     rank, world, local = multigpu.init_from_env()
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
@@ -128,11 +182,17 @@ def main():
     device = torch.device("cuda", local)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    if args.workload == "c5":   # BASELINE configs[4]: one ScanNet-resolution sequence, dynamic map growth
+        args.batch, args.height, args.width = world, 968, 1296
+    Hh, Ww = args.height, args.width
 
     K, Wm = args.steps, max(args.warmup, 1)  # frame 0 only initialises the map: it is always warm-up
     L = Wm + K
-    seq = make_sequence(L, args.height, args.width, seed=rank)
-    frames = frames_on_device(gs, seq, device)
+    mine = multigpu.shard_sequences(args.batch, world, rank)
+    assert mine, "more GPUs than sequences"
+    seqs = make_sequences(mine, L, Hh, Ww)
+    frames = frames_on_device(gs, seqs, device)
+    B_local = len(mine)
     slam = gs.slam.PointFusion(odom=args.odom, device=device)
     lib = _C.lib()
 
@@ -143,9 +203,8 @@ def main():
         torch.cuda.synchronize(device)
 
     # A full (generation-2) pass of Python's cyclic garbage collector over the ~10^6 objects `import torch`
-    # leaves behind takes 30-40 ms; where it falls depends on the allocation count, i.e. on unrelated details
-    # (a .pyc cache hit moved it from frame 0 into the 12 timed frames and cost 5x in frames/s).  Collect now
-    # and freeze the survivors: later passes only look at objects created from here on.
+    # leaves behind takes 30-40 ms; where it falls depends on the allocation count, i.e. on unrelated details.
+    # Collect now and freeze the survivors: later passes only look at objects created from here on.
     import gc
     gc.collect()
     gc.freeze()
@@ -157,19 +216,20 @@ def main():
     torch.cuda.synchronize(device)
     snapshot = (pc.clone(), prev) if not args.no_roofline_pass else None
 
-    # ---------------- timed region: exactly K steps
+    # ---------------- timed region: exactly K steps (one frame of every sequence each)
     barrier()
     t0 = time.perf_counter()
     pc, prev_end = run_steps(slam, pc, frames, prev, Wm, L, recovered)
+    t_enq = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    n_map = pc.points_list[0].shape[0]
-    poses_local = torch.stack(recovered, 1)  # (1, L, 4, 4) recovered trajectory of this rank's sequence
-    ate_gt = gs.metrics.ate_rmse(poses_local[0].cpu(), torch.from_numpy(seq["poses"]))
+    n_map = [int(p.shape[0]) for p in pc.points_list]
+    poses_local = torch.stack(recovered, 1)  # (B_local, L, 4, 4) recovered trajectories of this rank's sequences
+    ate_gt = max(ate_np(poses_local[b].cpu().numpy(), seqs[b]["poses"]) for b in range(B_local))
 
     # ---------------- the only exchange step: final pose (+ map) gather over RCCL
     barrier()
@@ -178,92 +238,85 @@ def main():
     all_maps = multigpu.gather_maps(pc) if world > 1 else pc
     barrier()
     gather_ms = (time.perf_counter() - g0) * 1e3
-    assert all_poses.shape[0] == world and len(all_maps) == world
+    assert all_poses.shape[0] == args.batch and len(all_maps) == args.batch
 
     # ---------------- roofline pass: same frames from the same map state, HIP events inside the library
-    roofline, roofline_hbm, roofline_brute = None, None, None
+    roofline, roofline_hbm = None, None
     if snapshot is not None and rank == 0:
         pc2, prev2 = snapshot
-        from gradslam_amd import ops as _ops
-        dc_mode, _ops.DEVICE_COUNTS = _ops.DEVICE_COUNTS, False  # exact host counts -> exact algorithmic bytes
         _C.check(lib.gs_profile_begin(64 * K + 1024), "gs_profile_begin")
-        run_steps(slam, pc2, frames, prev2, Wm, L)
+        # exact surfel counts on the host in this pass (one read-back per step): exact algorithmic bytes
+        run_steps(slam, pc2, frames, prev2, Wm, L, after_step=lambda p: p._tighten_counts())
         _C.check(lib.gs_profile_end(), "gs_profile_end")
-        _ops.DEVICE_COUNTS = dc_mode
         ms, n, nbytes = read_profile(lib, 8)
         if n > 0:  # dominant kernel by GPU time: the fused exact-NN search + Gauss-Newton linearisation
             gbs = nbytes / (ms * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic("gs_icp_half_kernel")
-            roofline = {"kernel": "gs_icp_half_kernel<FULL> (K3+K4 fused: prologue = row sums + 6x6 solve / LM update of the "
-                                  "previous half-iteration, then exact grid 1-NN + GN rows + one partial row per block), "
-                                  "%d launches per frame" % (n // K),
+            traffic, traffic_src = pmc_traffic("gs_icp_half_batch_kernel")
+            per_launch = nbytes / n
+            roofline = {"kernel": "gs_icp_half_batch_kernel<FULL> (K3+K4 fused, %d sequences per launch: prologue = row sums "
+                                  "+ 6x6 solve / LM update of the previous half-iteration, then exact grid 1-NN + GN rows + "
+                                  "one partial row per block), %d launches per step" % (B_local, n // K),
                         "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                        "launches": n, "avg_launch_us": ms * 1e3 / n, "alg_bytes_per_launch": nbytes / n,
-                        "note": "latency-bound, not bandwidth-bound: a launch is ~4.5 us of dispatch floor + one "
-                                "memory round trip for the partial rows + a one-wave float64 scalar stage + ~19k "
-                                "queries x 3 dependent L2 gathers; compulsory bytes = Ns*(24 src io + 216 cell bounds + "
-                                "24 match gather + 7 partials) + 16*Nt. `traffic` = HBM bytes per launch from separate "
-                                "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH x2 per MI355X_MICROARCH.md), "
-                                "averaged over the two kernel variants. The same search as brute force is the "
-                                "fp32-VALU-bound kernel in roofline_bruteforce."}
+                        "launches": n, "avg_launch_us": ms * 1e3 / n, "alg_bytes_per_launch": per_launch,
+                        "alg_le_traffic": None if traffic is None else bool(per_launch <= traffic),
+                        "note": "latency-bound, not bandwidth-bound.  Algorithmic bytes per launch and sequence (exact "
+                                "device counts read back in this pass): 12 B per lattice slot read, per searched "
+                                "query 12 B cloud written (first half) + 24 B matched target point and normal, one "
+                                "partial row per 96 queries, one 16 B pass over the binned targets; cell-bound "
+                                "look-ups and extra candidate gathers are traffic, not algorithmic bytes.  `traffic` = "
+                                "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                "(FETCH x2 per MI355X_MICROARCH.md)."}
         groups = {}
-        for kind, name in ((2, "K1 frame maps"), (3, "K5a map projection"), (4, "K5 association"),
-                           (5, "K6 fuse+append"), (1, "K4 linearise")):
+        for kind, name in ((2, "K1 frame maps + global maps"), (6, "K2/K3 lattice + projection + grid build"),
+                           (4, "K5 association"), (5, "K6 fuse+append")):
             gms, gn, gbytes = read_profile(lib, kind)
             if gn > 0:
                 gbs = gbytes / (gms * 1e-3) / 1e9
-                groups[name] = {"achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "launch_groups": gn,
-                                "avg_us": gms * 1e3 / gn, "alg_bytes_per_group": gbytes / gn}
-        roofline_hbm = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "groups": groups}
+                groups[name] = {"achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "launches": gn,
+                                "avg_us_per_launch": gms * 1e3 / gn, "alg_bytes_per_launch": gbytes / gn}
         tot = {k: read_profile(lib, k)[0] for k in range(9)}
-        roofline_hbm["gpu_ms_per_frame_by_group"] = {
-            n_: tot[k] / K for k, n_ in ((8, "icp_search_linearise"), (7, "icp_solve_update"), (6, "grid_build"),
-                                         (2, "frame_maps"), (3, "project"), (4, "associate"), (5, "fuse"))}
-        # the brute-force engine (API-level knn_points, fallback of the grid): fp32-VALU roofline on the
-        # ICP point sets of the last frame
-        from gradslam_amd import ops
-        lastf = frames[:, L - 1].to_channels_last()
-        lastf.poses = recovered[-1][:, None]
-        src, _, _ = ops.downsample_frame(lastf.global_vertex_map[0, 0], None, None, lastf.depth_image[0, 0, ..., 0], 4)
-        pix = ops.project_map(pc.points_list[0], recovered[-1][0], lastf.intrinsics[0, 0], args.height, args.width)
-        tgt, _, _ = ops.select_targets(pix, args.width, 4, pc.points_list[0], pc.normals_list[0])
-        ops.knn1(src, tgt)
-        _C.check(lib.gs_profile_begin(64), "gs_profile_begin")
-        for _ in range(10):
-            ops.knn1(src, tgt)
-        _C.check(lib.gs_profile_end(), "gs_profile_end")
-        bms, bn, pairs = read_profile(lib, 0)
-        tf = KNN_FLOP_PER_PAIR * pairs / (bms * 1e-3) / 1e12
-        roofline_brute = {"kernel": "gs_knn1_kernel (brute-force exact 1-NN)", "bound": "valu_fp32",
-                          "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
-                          "avg_launch_us": bms * 1e3 / bn, "pairs_per_launch": pairs / bn,
-                          "flop_per_pair": KNN_FLOP_PER_PAIR,
-                          "grid_engine_speedup_vs_this": (bms / bn) / (ms / n) if n else None}
+        step_ms = {n_: tot[k] / K for k, n_ in ((8, "icp_search_linearise"), (7, "icp_finish"), (6, "prep_project_grid_build"),
+                                                (2, "frame_maps_global_maps"), (4, "associate"), (5, "fuse"))}
+        roofline_hbm = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "groups": groups,
+                        "gpu_ms_per_step_by_group": step_ms,
+                        "hbm_frac_whole_step": (sum(read_profile(lib, k)[2] for k in (2, 4, 5, 6, 8)) / K) /
+                                               (elapsed / K) / 1e9 / PEAK_HBM_GBS}
 
-    cpu = None
+    cpu, ate_oracle, ate_ref = None, None, None
+    if rank == 0:
+        gp = os.path.join(REPO, "tests", "golden", "pf640.npz")
+        if os.path.exists(gp) and mine[0] == 0 and (Hh, Ww) == (480, 640) and args.odom == "gradicp":
+            g = np.load(gp)   # the REAL reference's poses on sequence 0 (oracle/make_golden_640.py)
+            nfr = min(L, g["poses"].shape[0])
+            ate_ref = {"value_m": ate_np(poses_local[0, :nfr].cpu().numpy(), g["poses"][:nfr]), "frames": nfr,
+                       "source": "tests/golden/pf640.npz (unmodified gradslam PointFusion on the same sequence)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(make_sequence(1 + args.cpu_frames, args.height, args.width, seed=0), args.cpu_frames,
-                           args.odom)
+        cpu, op = cpu_baseline(seqs[0], args.cpu_frames, args.odom)
+        ate_oracle = ate_np(poses_local[0, :op.shape[0]].cpu().numpy(), op)
 
     if rank == 0:
-        value = world * K / elapsed
+        value = args.batch * K / elapsed
         out = {
             "metric": "frames/sec PointFusion 640x480 RGB-D", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "PointFusion(odom=%s, dsratio=4, numiters=20) forward, %dx%d, one sequence "
-                                   "(B=1) per GPU, frames resident in HBM (BASELINE configs[1]; configs[3] at "
-                                   "N=8)" % (args.odom, args.width, args.height),
-                       "sequences_per_gpu": 1, "frames_timed_per_gpu": K, "map_surfels_end": n_map,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PointFusion(odom=%s, dsratio=4, numiters=20) forward, B=%d independent %dx%d "
+                                   "sequences sharded over %d GPU(s) (%d per GPU, batched: every kernel serves all "
+                                   "sequences of the GPU), frames resident in HBM (BASELINE configs[%s])"
+                                   % (args.odom, args.batch, Ww, Hh, world, B_local, "4" if args.workload == "c5" else "3"),
+                       "sequences_total": args.batch, "sequences_per_gpu": B_local, "frames_timed_per_sequence": K,
+                       "map_surfels_end_rank0": n_map,
                        "parity_mode": "renormalize_unmatched=True (reference-identical merge)",
                        "final_gather_ms": gather_ms, "api": "gradslam_amd.slam.PointFusion.step",
+                       "host_enqueue_ms_per_step": t_enq / K * 1e3,
                        "host_readbacks_per_frame": 0 if gs.ops.DEVICE_COUNTS else 3,
-                       "ate_vs_ground_truth_m_rank0": ate_gt},
-            "roofline": roofline, "roofline_hbm": roofline_hbm, "roofline_bruteforce": roofline_brute,
-            "cpu_baseline": cpu,
+                       "ate_vs_ground_truth_m_rank0_max": ate_gt, "ate_vs_oracle_m": ate_oracle,
+                       "ate_vs_reference_golden": ate_ref},
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgradslam_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -22,6 +22,24 @@ class IcpParams(C.Structure):
     _fields_ = [("mode", C.c_int), ("numiters", C.c_int), ("damp", C.c_float),
                 ("dist_thresh", C.c_float), ("lambda_max", C.c_float), ("B", C.c_float),
                 ("B2", C.c_float), ("nu", C.c_float)]
+
+
+class MapView(C.Structure):
+    """gs_map_view: one sequence's capacity-backed surfel store as the batched entry points see it."""
+    _fields_ = [("points", C.c_void_p), ("normals", C.c_void_p), ("colors", C.c_void_p), ("ccounts", C.c_void_p),
+                ("capacity", C.c_int64), ("n_bound", C.c_int64), ("n_dev", C.c_void_p)]
+
+
+class LocalizeSeq(C.Structure):
+    _fields_ = [("vertex", C.c_void_p), ("depth", C.c_void_p), ("K16", C.c_void_p), ("prev_pose16", C.c_void_p),
+                ("map", MapView), ("out_pose16", C.c_void_p), ("scratch", C.c_void_p)]
+
+
+class UpdateSeq(C.Structure):
+    _fields_ = [("map", MapView), ("vertex", C.c_void_p), ("normal", C.c_void_p), ("depth", C.c_void_p),
+                ("rgb", C.c_void_p), ("alpha", C.c_void_p), ("pose16", C.c_void_p), ("K16", C.c_void_p),
+                ("gvertex", C.c_void_p), ("gnormal", C.c_void_p), ("best_pix", C.c_void_p),
+                ("new_count_out", C.c_void_p), ("scratch", C.c_void_p)]
 
 
 # name -> argtypes (return type is int unless listed in _RESTYPE)
@@ -87,9 +105,14 @@ _PROTOS = {
                               _vp, _vp, _vp],
     "gs_append_valid_dc_f32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
                                _vp],
+    "gs_frame_maps_batch_f32": [_vp, _vp, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp],
+    "gs_localize_scratch_bytes": [_i32, _i32, _i32, _i64],
+    "gs_localize_batch_f32": [C.POINTER(LocalizeSeq), _i32, _i32, _i32, _i32, C.POINTER(IcpParams), _vp],
+    "gs_update_map_fusion_batch_f32": [C.POINTER(UpdateSeq), _i32, _i32, _i32, _f, _f, _i32, _vp],
 }
 _RESTYPE = {"gs_last_error": C.c_char_p, "gs_scratch_bytes": _i64, "gs_icp_scratch_bytes": _i64,
-            "gs_knn1_grid_scratch_bytes": _i64, "gs_update_map_scratch_bytes": _i64, "gs_global_maps_pose_backward_scratch_bytes": _i64, "gs_icp_tape_bytes": _i64, "gs_icp_backward_scratch_bytes": _i64}
+            "gs_knn1_grid_scratch_bytes": _i64, "gs_update_map_scratch_bytes": _i64, "gs_global_maps_pose_backward_scratch_bytes": _i64, "gs_icp_tape_bytes": _i64, "gs_icp_backward_scratch_bytes": _i64,
+            "gs_localize_scratch_bytes": _i64}
 EXPORTS = tuple(_PROTOS)
 
 

@@ -12,7 +12,10 @@
 
 #include "../../include/gradslam_hip.h"
 
-#define GS_ABI_VERSION 1
+#define GS_ABI_VERSION 2
+
+// sequences per launch of the batched (multi-sequence) kernels; larger batches run in chunks of this size
+constexpr int GS_MAX_BATCH = 8;
 
 // ---------------------------------------------------------------- error plumbing -------
 void gs_set_error(const char* fmt, ...);

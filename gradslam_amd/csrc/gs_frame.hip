@@ -126,10 +126,9 @@ GS_DEV void fm_vertex(float d, int h, int w, const GsKinv& k, float& x, float& y
   z = (az * d) * validf;
 }
 
-__global__ void __launch_bounds__(256) gs_frame_maps_kernel(
-    const float* __restrict__ depth, const float* __restrict__ K16, int H, int W, float two_sigma_sq,
-    float* __restrict__ vertex, float* __restrict__ normal, float* __restrict__ alpha,
-    uint8_t* __restrict__ valid) {
+GS_DEV void frame_maps_body(const float* __restrict__ depth, const float* __restrict__ K16, int H, int W,
+                            float two_sigma_sq, float* __restrict__ vertex, float* __restrict__ normal,
+                            float* __restrict__ alpha, uint8_t* __restrict__ valid) {
   __shared__ float tile[FM_LH][FM_LW];
   const int w_base = blockIdx.x * FM_TW, h_base = blockIdx.y * FM_TH;
   // stage depth tile with a one-pixel halo on every side (coordinates clamped into the image;
@@ -189,6 +188,21 @@ __global__ void __launch_bounds__(256) gs_frame_maps_kernel(
   }
 }
 
+__global__ void __launch_bounds__(256) gs_frame_maps_kernel(
+    const float* __restrict__ depth, const float* __restrict__ K16, int H, int W, float two_sigma_sq,
+    float* __restrict__ vertex, float* __restrict__ normal, float* __restrict__ alpha,
+    uint8_t* __restrict__ valid) {
+  frame_maps_body(depth, K16, H, W, two_sigma_sq, vertex, normal, alpha, valid);
+}
+// blockIdx.z = frame of a contiguous (n_frames, H, W) stack
+__global__ void __launch_bounds__(256) gs_frame_maps_batch_kernel(
+    const float* __restrict__ depth, const float* __restrict__ K16, int frames_per_K, int H, int W, float two_sigma_sq,
+    float* __restrict__ vertex, float* __restrict__ normal, float* __restrict__ alpha) {
+  const size_t f = blockIdx.z, P = (size_t)H * W;
+  frame_maps_body(depth + f * P, K16 + 16 * (f / frames_per_K), H, W, two_sigma_sq, vertex + 3 * f * P,
+                  normal ? normal + 3 * f * P : nullptr, alpha ? alpha + f * P : nullptr, nullptr);
+}
+
 extern "C" int gs_frame_maps_f32(const float* depth, const float* K16, int H, int W,
                                  float two_sigma_sq, float* vertex, float* normal, float* alpha,
                                  uint8_t* valid, void* stream) {
@@ -199,6 +213,21 @@ extern "C" int gs_frame_maps_f32(const float* depth, const float* K16, int H, in
   GsProf prof(GS_PROF_FRAME, bytes, gs_stream(stream));
   hipLaunchKernelGGL(gs_frame_maps_kernel, grid, dim3(256), 0, gs_stream(stream), depth, K16, H, W,
                      two_sigma_sq, vertex, normal, alpha, valid);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_frame_maps_batch_f32(const float* depth, const float* K16, int n_frames, int frames_per_K, int H,
+                                       int W, float two_sigma_sq, float* vertex, float* normal, float* alpha,
+                                       void* stream) {
+  GS_REQUIRE(depth && K16 && vertex, "depth, K16 and vertex must not be NULL");
+  GS_REQUIRE(H >= 2 && W >= 2, "image must be at least 2x2");
+  GS_REQUIRE(n_frames > 0 && n_frames <= 65535 && frames_per_K > 0, "bad frame count");
+  dim3 grid((unsigned)gs_ceil_div(W, FM_TW), (unsigned)gs_ceil_div(H, FM_TH), (unsigned)n_frames);
+  const double bytes = (double)n_frames * H * W * (4.0 + 12.0 + (normal ? 12 : 0) + (alpha ? 4 : 0));
+  GsProf prof(GS_PROF_FRAME, bytes, gs_stream(stream));
+  hipLaunchKernelGGL(gs_frame_maps_batch_kernel, grid, dim3(256), 0, gs_stream(stream), depth, K16, frames_per_K, H, W,
+                     two_sigma_sq, vertex, normal, alpha);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

@@ -290,9 +290,10 @@ extern "C" int gs_fuse_append_backward_f32(const float* points, const float* nor
 }
 
 // ---------------------------------------------------------------- one-call map update ----
-// update_map_fusion (slam/fusionutils.py:761-789) for one sequence with the kernels regrouped by DOMAIN so
-// that the frame costs 6 launches instead of 11 (global maps 1 + projection 1 + association 3 + fuse 6);
-// every value is computed by the same arithmetic as in the separate entry points:
+// update_map_fusion (slam/fusionutils.py:761-789) with the kernels regrouped by DOMAIN so that a frame costs 6
+// launches instead of 11 (global maps 1 + projection 1 + association 3 + fuse 6), for B independent sequences per
+// launch (block b -> sequence b % B on its block b / B); every value is computed by the same arithmetic as in the
+// separate entry points:
 //   U1 per pixel : global vertex / normal under the new pose; clear the per-pixel key and winner tables
 //   U2 per surfel: project, similarity test, per-pixel atomicMin of the (1/ccount, ray) key; pix_of = -1
 //   U3 per surfel: atomicMin of the surfel index among the rows that attain their pixel's key
@@ -300,119 +301,170 @@ extern "C" int gs_fuse_append_backward_f32(const float* points, const float* nor
 //   U5 per surfel: confidence-weighted merge (parity mode rewrites every row)
 //   U6 per pixel : ordered append of the new pixels; every block derives its output offset from the tile
 //                  counts itself (no separate scan launch); block 0 also writes the new surfel count
-__global__ void __launch_bounds__(256) gs_mu_pixel_init_kernel(
-    const float* __restrict__ vertex, const float* __restrict__ normal, const float* __restrict__ depth,
-    const float* __restrict__ pose16, int64_t P, float* __restrict__ gvertex, float* __restrict__ gnormal,
-    uint64_t* __restrict__ key_pix, int32_t* __restrict__ best_pix, int32_t* __restrict__ any_flag) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p == 0) *any_flag = 0;
-  if (p >= P) return;
+struct MuSeq {
+  float* points; float* normals; float* colors; float* ccounts;
+  GsCount n_map;
+  int64_t capacity;
+  const float* vertex; const float* normal; const float* depth; const float* rgb; const float* alpha;
+  const float* pose16; const float* K16;
+  float* gvertex; float* gnormal;
+  int32_t* best_pix;
+  int64_t* new_count_out;
+  // scratch
+  int32_t* any_flag;
+  uint64_t* key_pix;
+  int32_t* tile_counts;
+  uint64_t* key_pt;
+  int32_t* pix;
+  int32_t* pix_of;
+};
+struct MuBatch {
+  int B, H, W, renorm_all;
+  int64_t P, ntiles;
+  float u_hi, v_hi, dist_th, dot_th;
+  MuSeq s[GS_MAX_BATCH];
+};
+
+__global__ void __launch_bounds__(256) gs_mu_pixel_init_kernel(const MuBatch mb) {
+  const MuSeq& q = mb.s[blockIdx.x % mb.B];
+  const int64_t p = (int64_t)(blockIdx.x / mb.B) * 256 + threadIdx.x;
+  if (p == 0) *q.any_flag = 0;
+  if (p >= mb.P) return;
   float T[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) T[i] = pose16[i];
-  const float validf = depth[p] > 0.0f ? 1.0f : 0.0f;
+  for (int i = 0; i < 12; ++i) T[i] = q.pose16[i];
+  const float validf = q.depth[p] > 0.0f ? 1.0f : 0.0f;
   float g0, g1, g2;
-  gs_rigid_fma(T, vertex[3 * p], vertex[3 * p + 1], vertex[3 * p + 2], g0, g1, g2);
-  gvertex[3 * p] = g0 * validf;
-  gvertex[3 * p + 1] = g1 * validf;
-  gvertex[3 * p + 2] = g2 * validf;
-  const float n0 = normal[3 * p], n1 = normal[3 * p + 1], n2 = normal[3 * p + 2];
-  gnormal[3 * p] = gs_dot3_fma(T[0], T[1], T[2], n0, n1, n2);
-  gnormal[3 * p + 1] = gs_dot3_fma(T[4], T[5], T[6], n0, n1, n2);
-  gnormal[3 * p + 2] = gs_dot3_fma(T[8], T[9], T[10], n0, n1, n2);
-  key_pix[p] = ~0ull;
-  best_pix[p] = -1;
+  gs_rigid_fma(T, q.vertex[3 * p], q.vertex[3 * p + 1], q.vertex[3 * p + 2], g0, g1, g2);
+  q.gvertex[3 * p] = g0 * validf;
+  q.gvertex[3 * p + 1] = g1 * validf;
+  q.gvertex[3 * p + 2] = g2 * validf;
+  const float n0 = q.normal[3 * p], n1 = q.normal[3 * p + 1], n2 = q.normal[3 * p + 2];
+  q.gnormal[3 * p] = gs_dot3_fma(T[0], T[1], T[2], n0, n1, n2);
+  q.gnormal[3 * p + 1] = gs_dot3_fma(T[4], T[5], T[6], n0, n1, n2);
+  q.gnormal[3 * p + 2] = gs_dot3_fma(T[8], T[9], T[10], n0, n1, n2);
+  q.key_pix[p] = ~0ull;
+  q.best_pix[p] = -1;
 }
 
-__global__ void __launch_bounds__(256) gs_mu_project_key_kernel(
-    const float* __restrict__ points, const float* __restrict__ normals, const float* __restrict__ ccounts,
-    GsCount n_map_c, const float* __restrict__ pose16, const float* __restrict__ K16, int H, int W, float u_hi,
-    float v_hi, const float* __restrict__ gvertex, const float* __restrict__ gnormal, float dist_th, float dot_th,
-    int32_t* __restrict__ pix, uint64_t* __restrict__ key_pt, unsigned long long* __restrict__ key_pix,
-    int32_t* __restrict__ pix_of) {
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= gs_count(n_map_c)) return;
-  const GsCamera c = gs_camera(pose16, K16);
-  const int32_t p = gs_project_point(c, points[3 * n], points[3 * n + 1], points[3 * n + 2], H, W, u_hi, v_hi);
+__global__ void __launch_bounds__(256) gs_mu_project_key_kernel(const MuBatch mb) {
+  const MuSeq& q = mb.s[blockIdx.x % mb.B];
+  const int64_t n = (int64_t)(blockIdx.x / mb.B) * 256 + threadIdx.x;
+  if (n >= gs_count(q.n_map)) return;
+  const GsCamera c = gs_camera(q.pose16, q.K16);
+  const int32_t p = gs_project_point(c, q.points[3 * n], q.points[3 * n + 1], q.points[3 * n + 2], mb.H, mb.W, mb.u_hi,
+                                     mb.v_hi);
   uint64_t k = ~0ull;
-  if (p >= 0 && gs_is_similar(points, normals, gvertex, gnormal, n, p, dist_th, dot_th)) {
-    k = gs_assoc_key(points, ccounts, gvertex, n, p);
-    atomicMin(&key_pix[p], (unsigned long long)k);
+  if (p >= 0 && gs_is_similar(q.points, q.normals, q.gvertex, q.gnormal, n, p, mb.dist_th, mb.dot_th)) {
+    k = gs_assoc_key(q.points, q.ccounts, q.gvertex, n, p);
+    atomicMin(reinterpret_cast<unsigned long long*>(&q.key_pix[p]), (unsigned long long)k);
   }
-  pix[n] = p;
-  key_pt[n] = k;
-  pix_of[n] = -1;
+  q.pix[n] = p;
+  q.key_pt[n] = k;
+  q.pix_of[n] = -1;
 }
 
-__global__ void __launch_bounds__(256) gs_mu_pick_kernel(const int32_t* __restrict__ pix, GsCount n_map_c,
-                                                         const uint64_t* __restrict__ key_pt,
-                                                         const uint64_t* __restrict__ key_pix,
-                                                         int32_t* __restrict__ best_pix) {
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= gs_count(n_map_c)) return;
-  const uint64_t k = key_pt[n];
+__global__ void __launch_bounds__(256) gs_mu_pick_kernel(const MuBatch mb) {
+  const MuSeq& q = mb.s[blockIdx.x % mb.B];
+  const int64_t n = (int64_t)(blockIdx.x / mb.B) * 256 + threadIdx.x;
+  if (n >= gs_count(q.n_map)) return;
+  const uint64_t k = q.key_pt[n];
   if (k == ~0ull) return;
-  const int32_t p = pix[n];
-  if (k == key_pix[p]) atomicMin(reinterpret_cast<unsigned*>(&best_pix[p]), (unsigned)n);
+  const int32_t p = q.pix[n];
+  if (k == q.key_pix[p]) atomicMin(reinterpret_cast<unsigned*>(&q.best_pix[p]), (unsigned)n);
 }
 
 // per pixel tile of GS_CP_TILE pixels: inverse map of the winners + number of new pixels of the tile
-__global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_winner_count_kernel(const int32_t* __restrict__ best_pix,
-                                                                         const float* __restrict__ depth, int64_t P,
-                                                                         GsCount n_map_c, int32_t* __restrict__ pix_of,
-                                                                         int32_t* __restrict__ any_flag,
-                                                                         int32_t* __restrict__ tile_counts) {
+__global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_winner_count_kernel(const MuBatch mb) {
   __shared__ int smem[GS_CP_BLOCK / GS_WAVE + 1];
-  const int64_t n_map = gs_count(n_map_c);
-  const int64_t base = (int64_t)blockIdx.x * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
+  const MuSeq& q = mb.s[blockIdx.x % mb.B];
+  const unsigned blk = blockIdx.x / mb.B;
+  const int64_t n_map = gs_count(q.n_map);
+  const int64_t base = (int64_t)blk * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
   int c = 0;
 #pragma unroll
   for (int i = 0; i < GS_CP_ITEMS; ++i) {
     const int64_t p = base + i;
-    if (p < P) {
-      const int32_t n = best_pix[p];
+    if (p < mb.P) {
+      const int32_t n = q.best_pix[p];
       if (n >= 0 && n < n_map) {
-        pix_of[n] = (int32_t)p;
-        *any_flag = 1;  // benign race: every writer stores the same value
+        q.pix_of[n] = (int32_t)p;
+        *q.any_flag = 1;  // benign race: every writer stores the same value
       }
-      if (depth[p] > 0.0f && n < 0) ++c;
+      if (q.depth[p] > 0.0f && n < 0) ++c;
     }
   }
   int total;
   (void)gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &total);
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+  if (threadIdx.x == 0) q.tile_counts[blk] = total;
+}
+
+// slam/fusionutils.py:678-699 applied to rows [0, n_map) (the arithmetic of gs_fuse_merge_kernel)
+GS_DEV void fuse_merge_row(float* __restrict__ points, float* __restrict__ normals, float* __restrict__ colors,
+                           float* __restrict__ ccounts, const int64_t n, const int32_t p,
+                           const float* __restrict__ gvertex, const float* __restrict__ gnormal,
+                           const float* __restrict__ rgb, const float* __restrict__ alpha) {
+  const float a = p >= 0 ? alpha[p] : 0.0f;
+  const float cc = ccounts[n];
+  const float cc2 = cc + a;
+  const float inv = 1.0f / (cc2 == 0.0f ? 1.0f : cc2);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float fp = p >= 0 ? gvertex[3 * (int64_t)p + k] : 0.0f;
+    const float fn = p >= 0 ? gnormal[3 * (int64_t)p + k] : 0.0f;
+    const float fc = p >= 0 ? rgb[3 * (int64_t)p + k] : 0.0f;
+    points[3 * n + k] = ((cc * points[3 * n + k]) + (a * fp)) * inv;
+    normals[3 * n + k] = ((cc * normals[3 * n + k]) + (a * fn)) * inv;
+    colors[3 * n + k] = ((cc * colors[3 * n + k]) + (a * fc)) * inv;
+  }
+  ccounts[n] = cc2;
+}
+__global__ void __launch_bounds__(256) gs_mu_merge_kernel(const MuBatch mb) {
+  const MuSeq& q = mb.s[blockIdx.x % mb.B];
+  const int64_t n = (int64_t)(blockIdx.x / mb.B) * 256 + threadIdx.x;
+  if (n >= gs_count(q.n_map)) return;
+  // :659 -- the reference skips the whole merge only when the correspondence table of the WHOLE batch is empty
+  // (pc2im_bnhw.shape[0] != 0 is a batch-level test): a sequence without matches is still renormalised when
+  // another sequence of the same call has some
+  bool any = false;
+  for (int b = 0; b < mb.B; ++b) any = any || (*mb.s[b].any_flag != 0);
+  if (!any) return;
+  const int32_t p = q.pix_of[n];
+  if (p < 0 && !mb.renorm_all) return;
+  fuse_merge_row(q.points, q.normals, q.colors, q.ccounts, n, p, q.gvertex, q.gnormal, q.rgb, q.alpha);
 }
 
 // ordered append without a scan launch: block b adds up the counts of the tiles before it (fixed order)
-__global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_append_kernel(
-    const int32_t* __restrict__ best_pix, const float* __restrict__ depth, int64_t P, int64_t ntiles,
-    const int32_t* __restrict__ tile_counts, EmitAppend emit, int64_t capacity, int64_t* __restrict__ new_count_out) {
+__global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_append_kernel(const MuBatch mb) {
   __shared__ int smem[GS_CP_BLOCK / GS_WAVE + 1];
+  const MuSeq& q = mb.s[blockIdx.x % mb.B];
+  const unsigned blk = blockIdx.x / mb.B;
   int before = 0, all = 0;
-  for (int64_t t = threadIdx.x; t < ntiles; t += GS_CP_BLOCK) {
-    const int v = tile_counts[t];
+  for (int64_t t = threadIdx.x; t < mb.ntiles; t += GS_CP_BLOCK) {
+    const int v = q.tile_counts[t];
     all += v;
-    if (t < (int64_t)blockIdx.x) before += v;
+    if (t < (int64_t)blk) before += v;
   }
   int tile_prefix, total_new, dummy;
   (void)gs_block_excl_scan<GS_CP_BLOCK>(before, smem, &tile_prefix);
   (void)gs_block_excl_scan<GS_CP_BLOCK>(all, smem, &total_new);
-  const int64_t n_map = gs_count(emit.n_map);
-  if (blockIdx.x == 0 && threadIdx.x == 0) new_count_out[0] = n_map + total_new;
-  const int64_t base = (int64_t)blockIdx.x * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
+  const int64_t n_map = gs_count(q.n_map);
+  if (blk == 0 && threadIdx.x == 0) q.new_count_out[0] = n_map + total_new;
+  const int64_t base = (int64_t)blk * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
   bool keep[GS_CP_ITEMS];
   int c = 0;
 #pragma unroll
   for (int i = 0; i < GS_CP_ITEMS; ++i) {
     const int64_t p = base + i;
-    keep[i] = p < P && depth[p] > 0.0f && best_pix[p] < 0;
+    keep[i] = p < mb.P && q.depth[p] > 0.0f && q.best_pix[p] < 0;
     c += keep[i] ? 1 : 0;
   }
   int64_t pos = tile_prefix + gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &dummy);
+  const EmitAppend emit{q.points, q.normals, q.colors, q.ccounts, q.n_map, q.gvertex, q.gnormal, q.rgb, q.alpha};
 #pragma unroll
   for (int i = 0; i < GS_CP_ITEMS; ++i) {
     if (keep[i]) {
-      if (n_map + pos < capacity) emit(base + i, pos);
+      if (n_map + pos < q.capacity) emit(base + i, pos);
       ++pos;
     }
   }
@@ -425,6 +477,78 @@ extern "C" int64_t gs_update_map_scratch_bytes(int64_t n_map_bound, int H, int W
                    2 * gs_align(4 * (size_t)(n_map_bound > 0 ? n_map_bound : 1)) + 4096);
 }
 
+static int update_chunk(const gs_update_seq* seqs, int B, int H, int W, float dist_th, float dot_th, int renorm_all,
+                        hipStream_t st) {
+  MuBatch mb;
+  mb.B = B; mb.H = H; mb.W = W; mb.renorm_all = renorm_all;
+  mb.P = (int64_t)H * W;
+  mb.ntiles = gs_cp_tiles(mb.P);
+  mb.u_hi = (float)((double)W - 0.999); mb.v_hi = (float)((double)H - 0.999);
+  mb.dist_th = dist_th; mb.dot_th = dot_th;
+  int64_t n_max = 0;
+  double bytes_assoc = 0.0, bytes_fuse = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const gs_update_seq& u = seqs[b];
+    const int64_t n_map = u.map.n_bound;
+    n_max = n_map > n_max ? n_map : n_max;
+    char* q = reinterpret_cast<char*>(u.scratch);
+    MuSeq& m = mb.s[b];
+    m.points = u.map.points; m.normals = u.map.normals; m.colors = u.map.colors; m.ccounts = u.map.ccounts;
+    m.n_map = GsCount{u.map.n_bound, u.map.n_dev};
+    m.capacity = u.map.capacity;
+    m.vertex = u.vertex; m.normal = u.normal; m.depth = u.depth; m.rgb = u.rgb; m.alpha = u.alpha;
+    m.pose16 = u.pose16; m.K16 = u.K16;
+    m.gvertex = u.gvertex; m.gnormal = u.gnormal; m.best_pix = u.best_pix; m.new_count_out = u.new_count_out;
+    m.any_flag = reinterpret_cast<int32_t*>(q); q += 256;
+    m.key_pix = reinterpret_cast<uint64_t*>(q); q += gs_align(8 * (size_t)mb.P);
+    m.tile_counts = reinterpret_cast<int32_t*>(q); q += gs_align(4 * (size_t)mb.ntiles);
+    m.key_pt = reinterpret_cast<uint64_t*>(q); q += gs_align(8 * (size_t)(n_map > 0 ? n_map : 1));
+    m.pix = reinterpret_cast<int32_t*>(q); q += gs_align(4 * (size_t)(n_map > 0 ? n_map : 1));
+    m.pix_of = reinterpret_cast<int32_t*>(q);
+    bytes_assoc += 92.0 * (double)n_map;
+    bytes_fuse += 84.0 * (double)n_map + 49.0 * (double)mb.P;
+  }
+  const unsigned uB = (unsigned)B;
+  const unsigned pb = uB * (unsigned)gs_ceil_div(mb.P, 256), nb = uB * (unsigned)gs_ceil_div(n_max > 0 ? n_max : 1, 256);
+  {
+    GsProf prof(GS_PROF_FRAME, (double)B * (double)mb.P * 64.0, st);   // 28 B read + 24 B + 12 B written per pixel
+    hipLaunchKernelGGL(gs_mu_pixel_init_kernel, dim3(pb), dim3(256), 0, st, mb);
+  }
+  if (n_max > 0) {
+    GsProf prof(GS_PROF_ASSOC, bytes_assoc, st, 2);
+    hipLaunchKernelGGL(gs_mu_project_key_kernel, dim3(nb), dim3(256), 0, st, mb);
+    hipLaunchKernelGGL(gs_mu_pick_kernel, dim3(nb), dim3(256), 0, st, mb);
+  }
+  GsProf prof(GS_PROF_FUSE, bytes_fuse, st, n_max > 0 ? 3 : 2);
+  hipLaunchKernelGGL(gs_mu_winner_count_kernel, dim3(uB * (unsigned)mb.ntiles), dim3(GS_CP_BLOCK), 0, st, mb);
+  if (n_max > 0) hipLaunchKernelGGL(gs_mu_merge_kernel, dim3(nb), dim3(256), 0, st, mb);
+  hipLaunchKernelGGL(gs_mu_append_kernel, dim3(uB * (unsigned)mb.ntiles), dim3(GS_CP_BLOCK), 0, st, mb);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_update_map_fusion_batch_f32(const gs_update_seq* seqs_host, int B, int H, int W, float dist_th,
+                                              float dot_th, int renorm_all, void* stream) {
+  GS_REQUIRE(seqs_host && B > 0 && H > 0 && W > 0, "bad arguments");
+  GS_REQUIRE((int64_t)H * W < (1ll << 31), "too large for int32 indices");
+  for (int b = 0; b < B; ++b) {
+    const gs_update_seq& u = seqs_host[b];
+    GS_REQUIRE(u.map.n_bound >= 0 && u.map.n_bound < 0x7fffffff, "bad map size");
+    GS_REQUIRE(u.map.capacity >= u.map.n_bound + (int64_t)H * W, "capacity must cover n_bound + H*W rows");
+    GS_REQUIRE(u.map.points && u.map.normals && u.map.colors && u.map.ccounts && u.vertex && u.normal && u.depth && u.rgb &&
+                   u.alpha && u.pose16 && u.K16 && u.gvertex && u.gnormal && u.best_pix && u.new_count_out && u.scratch,
+               "NULL pointer");
+    GS_REQUIRE(u.new_count_out != u.map.n_dev, "new_count_out must not alias the map's device count");
+  }
+  hipStream_t st = gs_stream(stream);
+  for (int c0 = 0; c0 < B; c0 += GS_MAX_BATCH) {
+    const int nb = B - c0 < GS_MAX_BATCH ? B - c0 : GS_MAX_BATCH;
+    const int rc = update_chunk(seqs_host + c0, nb, H, W, dist_th, dot_th, renorm_all, st);
+    if (rc != GS_OK) return rc;
+  }
+  return GS_OK;
+}
+
 extern "C" int gs_update_map_fusion_dc_f32(float* points, float* normals, float* colors, float* ccounts,
                                            int64_t n_map_bound, const int64_t* n_map_dev, int64_t capacity,
                                            const float* vertex, const float* normal, const float* depth,
@@ -432,46 +556,10 @@ extern "C" int gs_update_map_fusion_dc_f32(float* points, float* normals, float*
                                            const float* K16, int H, int W, float dist_th, float dot_th,
                                            int renorm_all, float* gvertex, float* gnormal, int32_t* best_pix,
                                            int64_t* new_count_out, void* scratch, void* stream) {
-  GS_REQUIRE(H > 0 && W > 0 && n_map_bound >= 0, "bad sizes");
-  GS_REQUIRE(capacity >= n_map_bound + (int64_t)H * W, "capacity must cover n_map_bound + H*W rows");
-  GS_REQUIRE(points && normals && colors && ccounts && vertex && normal && depth && rgb && alpha && pose16 && K16 &&
-                 gvertex && gnormal && best_pix && new_count_out && scratch,
-             "NULL pointer");
-  GS_REQUIRE(n_map_bound < 0x7fffffff && (int64_t)H * W < (1ll << 31), "too large for int32 indices");
-  hipStream_t st = gs_stream(stream);
-  const int64_t P = (int64_t)H * W, n_map = n_map_bound;
-  const GsCount n_map_c{n_map_bound, n_map_dev};
-  const int64_t ntiles = gs_cp_tiles(P);
-  char* q = reinterpret_cast<char*>(scratch);
-  int32_t* any_flag = reinterpret_cast<int32_t*>(q); q += 256;
-  uint64_t* key_pix = reinterpret_cast<uint64_t*>(q); q += gs_align(8 * (size_t)P);
-  int32_t* tile_counts = reinterpret_cast<int32_t*>(q); q += gs_align(4 * (size_t)ntiles);
-  uint64_t* key_pt = reinterpret_cast<uint64_t*>(q); q += gs_align(8 * (size_t)(n_map > 0 ? n_map : 1));
-  int32_t* pix = reinterpret_cast<int32_t*>(q); q += gs_align(4 * (size_t)(n_map > 0 ? n_map : 1));
-  int32_t* pix_of = reinterpret_cast<int32_t*>(q);
-  const float u_hi = (float)((double)W - 0.999), v_hi = (float)((double)H - 0.999);
-  const unsigned pb = (unsigned)gs_ceil_div(P, 256), nb = (unsigned)gs_ceil_div(n_map > 0 ? n_map : 1, 256);
-  {
-    GsProf prof(GS_PROF_FRAME, (double)P * 64.0, st);   // 28 B read + 24 B + 12 B written per pixel
-    hipLaunchKernelGGL(gs_mu_pixel_init_kernel, dim3(pb), dim3(256), 0, st, vertex, normal, depth, pose16, P, gvertex,
-                       gnormal, key_pix, best_pix, any_flag);
-  }
-  if (n_map > 0) {
-    GsProf prof(GS_PROF_ASSOC, 92.0 * (double)n_map, st);
-    hipLaunchKernelGGL(gs_mu_project_key_kernel, dim3(nb), dim3(256), 0, st, points, normals, ccounts, n_map_c, pose16,
-                       K16, H, W, u_hi, v_hi, gvertex, gnormal, dist_th, dot_th, pix, key_pt,
-                       reinterpret_cast<unsigned long long*>(key_pix), pix_of);
-    hipLaunchKernelGGL(gs_mu_pick_kernel, dim3(nb), dim3(256), 0, st, pix, n_map_c, key_pt, key_pix, best_pix);
-  }
-  GsProf prof(GS_PROF_FUSE, 84.0 * (double)n_map + 49.0 * (double)P, st);
-  hipLaunchKernelGGL(gs_mu_winner_count_kernel, dim3((unsigned)ntiles), dim3(GS_CP_BLOCK), 0, st, best_pix, depth, P,
-                     n_map_c, pix_of, any_flag, tile_counts);
-  if (n_map > 0)
-    hipLaunchKernelGGL(gs_fuse_merge_kernel, dim3(nb), dim3(256), 0, st, points, normals, colors, ccounts, n_map_c,
-                       pix_of, any_flag, gvertex, gnormal, rgb, alpha, renorm_all);
-  EmitAppend emit{points, normals, colors, ccounts, n_map_c, gvertex, gnormal, rgb, alpha};
-  hipLaunchKernelGGL(gs_mu_append_kernel, dim3((unsigned)ntiles), dim3(GS_CP_BLOCK), 0, st, best_pix, depth, P, ntiles,
-                     tile_counts, emit, capacity, new_count_out);
-  GS_LAUNCH_CHECK();
-  return GS_OK;
+  gs_update_seq u;
+  u.map = gs_map_view{points, normals, colors, ccounts, capacity, n_map_bound, n_map_dev};
+  u.vertex = vertex; u.normal = normal; u.depth = depth; u.rgb = rgb; u.alpha = alpha;
+  u.pose16 = pose16; u.K16 = K16;
+  u.gvertex = gvertex; u.gnormal = gnormal; u.best_pix = best_pix; u.new_count_out = new_count_out; u.scratch = scratch;
+  return gs_update_map_fusion_batch_f32(&u, 1, H, W, dist_th, dot_th, renorm_all, stream);
 }

@@ -23,9 +23,10 @@
 #include "gs_icp_math.h"
 #include "gs_knn.h"
 
+constexpr int GS_ICP_MAX_ITERS = 1024;  // rows of the per-iteration trace kept in the scratch
 struct GsIcpState {
-  IcpSmall s[2];          // double-buffered by the grid path; the brute-force path uses s[0]
-  float trace[64 * 12];   // up to 64 iterations
+  IcpSmall s[2];                        // double-buffered by the grid path; the brute-force path uses s[0]
+  float trace[GS_ICP_MAX_ITERS * 12];   // [err, new_err, damp, sigmoid, xi(6), 0, 0] per iteration
 };
 
 // Optional forward tape for gs_icp_backward_f32 (layout: gs_icp_math.h:GsIcpTape).
@@ -107,19 +108,51 @@ static_assert(FS_QPB <= 2 * GS_WAVE && FS_QPB % FS_RPG == 0 && FS_RG * LIN_NV <=
 // target set an XCD touches is an eighth of the whole (+ halo) and stays resident in its L2 across
 // the 2 x numiters kernels of a solve (the full set of a 1296x968 frame is larger than one L2).
 constexpr unsigned GS_XCDS = 8;
-GS_DEV unsigned gs_xcd_block(unsigned b, unsigned nb) {
-  const unsigned q = nb / GS_XCDS, r = nb % GS_XCDS, x = b % GS_XCDS;
-  return x * q + (x < r ? x : r) + b / GS_XCDS;
+// b-th of nb blocks that are dealt round-robin to X XCDs -> logical block such that every XCD owns one contiguous
+// range of logical blocks
+GS_DEV unsigned gs_xcd_block(unsigned b, unsigned nb, unsigned X = GS_XCDS) {
+  const unsigned q = nb / X, r = nb % X, x = b % X;
+  return x * q + (x < r ? x : r) + b / X;
 }
 
+// What one sequence contributes to a half-iteration launch (the batched launch carries up to GS_MAX_BATCH of them).
+struct IcpHalfSeq {
+  const float* src_in;
+  float* src_out;
+  const float* tgt;
+  const float* tn;
+  GsCount n_tgt;
+  const GsGrid* gp;
+  const int* cell_start;
+  const float4* sorted;
+  const double* partials_in;
+  double* partials_out;
+  const IcpSmall* st_in;
+  IcpSmall* st_out;
+  float* trace;
+  int64_t* out_idx;
+  int32_t* tape_idx;
+  float* tape_sys;
+};
+
 template <bool FULL>
-__global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
-    const float* __restrict__ src_in, float* __restrict__ src_out, GsCount n_src_c, const float* __restrict__ tgt,
-    const float* __restrict__ tn, GsCount n_tgt_c, const GsGrid* __restrict__ gp, const int* __restrict__ cell_start,
-    const float4* __restrict__ sorted, float dist_thresh, const double* __restrict__ partials_in,
-    double* __restrict__ partials_out, const IcpSmall* __restrict__ st_in, IcpSmall* __restrict__ st_out,
-    float* __restrict__ trace, gs_icp_params prm, int it, int64_t* __restrict__ out_idx,
-    int32_t* __restrict__ tape_idx, float* __restrict__ tape_sys, int rows_in_reduced) {
+GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const float dist_thresh, const gs_icp_params& prm,
+                          const int it, const int rows_in_reduced, const unsigned lb) {
+  const float* __restrict__ src_in = q.src_in;
+  float* __restrict__ src_out = q.src_out;
+  const float* __restrict__ tgt = q.tgt;
+  const float* __restrict__ tn = q.tn;
+  const GsGrid* __restrict__ gp = q.gp;
+  const int* __restrict__ cell_start = q.cell_start;
+  const float4* __restrict__ sorted = q.sorted;
+  const double* __restrict__ partials_in = q.partials_in;
+  double* __restrict__ partials_out = q.partials_out;
+  const IcpSmall* __restrict__ st_in = q.st_in;
+  IcpSmall* __restrict__ st_out = q.st_out;
+  float* __restrict__ trace = q.trace;
+  int64_t* __restrict__ out_idx = q.out_idx;
+  int32_t* __restrict__ tape_idx = q.tape_idx;
+  float* __restrict__ tape_sys = q.tape_sys;
   __shared__ IcpSmall sm;
   __shared__ double S[32];
   __shared__ double sub[FS_BLOCK / 32][32];
@@ -129,10 +162,10 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   __shared__ int unres_n;
   __shared__ unsigned long long red[FS_BLOCK / GS_WAVE];
 
-  const int64_t n_src = gs_count(n_src_c), n_tgt = gs_count(n_tgt_c);
+  const int64_t n_src = gs_count(n_src_c), n_tgt = gs_count(q.n_tgt);
   // rows the previous kernel produced (already added up to one row by gs_icp_reduce_rows_kernel for large solves)
   const int nrows_in = rows_in_reduced ? 1 : (int)((n_src + FS_QPB - 1) / FS_QPB);
-  const unsigned lb = gs_xcd_block(blockIdx.x, gridDim.x);  // logical block: which FS_QPB queries this block owns
+  // lb = logical block: which FS_QPB queries this block owns
   if ((int64_t)lb * FS_QPB >= n_src && lb != 0) return;  // beyond the actual count (bound-sized grid)
   // the source point of this group does not depend on the prologue: issue its load first so that
   // the global-memory latency hides behind the scalar stage
@@ -157,7 +190,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
     if (it > 0) e1 = icp_sum_col27<FS_BLOCK>(partials_in, nrows_in, reinterpret_cast<double*>(red));
     else __syncthreads();
     if (threadIdx.x == 0) {  // scalar stage, in place on the LDS copy of the state
-      if (it > 0) icp_update_math((float)e1, sm, prm, (lb == 0 && it - 1 < 64) ? trace + 12 * (it - 1) : nullptr);
+      if (it > 0) icp_update_math((float)e1, sm, prm, (lb == 0 && it - 1 < GS_ICP_MAX_ITERS) ? trace + 12 * (it - 1) : nullptr);
       unres_n = 0;
     }
   } else {
@@ -282,6 +315,28 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(
   }
 }
 
+template <bool FULL>
+__global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(const IcpHalfSeq q, GsCount n_src_c, float dist_thresh,
+                                                                  gs_icp_params prm, int it, int rows_in_reduced) {
+  icp_half_body<FULL>(q, n_src_c, dist_thresh, prm, it, rows_in_reduced, gs_xcd_block(blockIdx.x, gridDim.x));
+}
+
+// Batched: block b works for sequence b % B (with B = 8 a sequence lives on one XCD: its binned targets, cell table
+// and partial rows stay in that XCD's L2) on that sequence's block b / B; when B divides 8 the 8 / B XCDs of a
+// sequence each own a contiguous range of its query rows.
+struct IcpHalfBatch {
+  int B;
+  IcpHalfSeq s[GS_MAX_BATCH];
+};
+template <bool FULL>
+__global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_batch_kernel(const IcpHalfBatch hb, GsCount n_src_c,
+                                                                        float dist_thresh, gs_icp_params prm, int it,
+                                                                        int rows_in_reduced) {
+  const unsigned B = (unsigned)hb.B, blk = blockIdx.x / B, nblk = gridDim.x / B;
+  const unsigned X = (GS_XCDS % B == 0) ? GS_XCDS / B : 1u;
+  icp_half_body<FULL>(hb.s[blockIdx.x % B], n_src_c, dist_thresh, prm, it, rows_in_reduced, gs_xcd_block(blk, nblk, X));
+}
+
 // Large solves (more rows than FS_REDUCE_ROWS): every block of the next kernel adding up all rows is
 // O(rows^2) L2 traffic (1634 rows of a 1296x968 frame: 366 KB per block, 600 MB per launch).  One
 // extra single-block launch adds them up once, in the same order, into a one-row buffer.
@@ -306,7 +361,7 @@ __global__ void __launch_bounds__(FS_BLOCK) gs_icp_finish_kernel(const double* _
   if (threadIdx.x != 0) return;
   IcpSmall sm = st->s[buf];
   const int it = prm.numiters - 1;
-  icp_update_math((float)e1, sm, prm, it < 64 ? st->trace + 12 * it : nullptr);
+  icp_update_math((float)e1, sm, prm, it < GS_ICP_MAX_ITERS ? st->trace + 12 * it : nullptr);
   st->s[buf ^ 1] = sm;
   icp_write_result(sm, compose16, out_T16);
 }
@@ -400,7 +455,7 @@ __global__ void __launch_bounds__(SUM_BLOCK) gs_icp_update_kernel(const double* 
   const double e1 = icp_sum_col27<SUM_BLOCK>(partials, nrows, red);
   if (threadIdx.x != 0) return;
   IcpSmall sm = st->s[0];
-  icp_update_math((float)e1, sm, prm, it < 64 ? st->trace + 12 * it : nullptr);
+  icp_update_math((float)e1, sm, prm, it < GS_ICP_MAX_ITERS ? st->trace + 12 * it : nullptr);
   st->s[0] = sm;
   if (it == prm.numiters - 1) icp_write_result(sm, compose16, out_T16);
 }
@@ -475,6 +530,17 @@ static int icp_tape_finish(void* tape, const GsIcpState* state, int64_t n_src, i
   return GS_OK;
 }
 
+// Algorithmic (compulsory) bytes of the 2 x numiters half-iteration kernels of one solve: per slot of
+// the source array 12 B read; per searched query 12 B written (first half: the transformed cloud) + 24 B matched target
+// point and normal; one partial row (28 / 1 doubles) per FS_QPB queries; one 16 B pass over the binned targets
+// per half-iteration.  Cell-bound look-ups and candidate gathers beyond that are traffic, not compulsory bytes.
+static double icp_alg_bytes(int numiters, int64_t n_slots, int64_t n_queries, int64_t n_binned) {
+  const double rows = (double)gs_ceil_div(n_slots, FS_QPB);
+  const double full = 12.0 * n_slots + 36.0 * n_queries + 8.0 * LIN_NV * rows + 16.0 * n_binned;
+  const double look = 12.0 * n_slots + 24.0 * n_queries + 8.0 * rows + 16.0 * n_binned;
+  return (double)numiters * (full + look);
+}
+
 static int icp_run(const float* src, int64_t n_src, const float* tgt, const float* tgt_normals,
                    int64_t n_tgt, const float* init16, const float* compose16,
                    const gs_icp_params* prm, float* out_T16, int64_t* out_idx, void* icp_scratch,
@@ -484,7 +550,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
   GS_REQUIRE(n_src > 0 && n_tgt > 0, "empty point set");
   GS_REQUIRE(n_tgt < 0x7fffffffll && n_src < 0x7fffffffll, "too many points");
   GS_REQUIRE(src && tgt && tgt_normals && init16 && out_T16 && icp_scratch, "NULL pointer");
-  GS_REQUIRE(prm->numiters >= 0 && prm->numiters <= 64, "numiters must be in [0, 64]");
+  GS_REQUIRE(prm->numiters >= 0 && prm->numiters <= GS_ICP_MAX_ITERS, "numiters must be in [0, 1024]");
   GS_REQUIRE(prm->mode == 0 || prm->mode == 1, "mode must be 0 (ICP) or 1 (gradICP)");
   hipStream_t st = gs_stream(stream);
   IcpScratch sc = icp_carve(icp_scratch, n_src);
@@ -513,18 +579,28 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
     const bool reduce_rows = nfs > FS_REDUCE_ROWS;
     const float* cur_in = src;  // cloud before the pending transform of the half-iteration
     int h = 0;                  // half-iteration index: kernel h reads s[h&1] / partials[(h+1)&1], writes the others
-    // one event pair around the 2 x numiters half-iteration kernels.  Compulsory bytes of a half-iteration:
-    // source in (+out), 27 cell bounds (8 B) per query, matched target + normal gather, partial rows, one
-    // pass over the binned targets: 271 B (full) / 259 B (look-ahead) per query + 16 B per target
-    std::unique_ptr<GsProf> prof_loop(new GsProf(
-        GS_PROF_ICP_FUSED, (double)prm->numiters * ((double)n_src * 530.0 + 32.0 * (double)n_tgt), st, 2 * prm->numiters));
+    // one event pair around the 2 x numiters half-iteration kernels; work = algorithmic bytes (icp_alg_bytes).
+    // With a target filter n_tgt is the whole map: the binned count is read back (profile passes only).
+    double prof_bytes = 0.0;
+    if (g_gs_prof_on) {
+      int64_t n_binned = n_tgt;
+      if (flt.pix) {
+        unsigned hits = 0;
+        GS_HIP(hipMemcpyAsync(&hits, gm.bbox + 6, 4, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+        n_binned = hits;
+      }
+      prof_bytes = icp_alg_bytes(prm->numiters, n_src, n_src, n_binned);
+    }
+    std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
     for (int it = 0; it < prm->numiters; ++it) {
       float* cur = cloud(it);
       {
-        hipLaunchKernelGGL((gs_icp_half_kernel<true>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur_in, cur, n_src_c, tgt,
-                           tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
-                           sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
-                           &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, out_idx, tidx(it, 0), nullptr, 0);
+        const IcpHalfSeq q{cur_in, cur, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted,
+                           sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1], &sc.state->s[(h + 1) & 1],
+                           sc.state->trace, out_idx, tidx(it, 0), nullptr};
+        hipLaunchKernelGGL((gs_icp_half_kernel<true>), dim3(nfs), dim3(FS_BLOCK), 0, st, q, n_src_c, prm->dist_thresh,
+                           *prm, it, 0);
       }
       ++h;
       if (reduce_rows) {
@@ -533,11 +609,11 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
                            sc.rowred);
       }
       {
-        hipLaunchKernelGGL((gs_icp_half_kernel<false>), dim3(nfs), dim3(FS_BLOCK), 0, st, cur, nullptr, n_src_c, tgt,
-                           tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, prm->dist_thresh,
+        const IcpHalfSeq q{cur, nullptr, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted,
                            reduce_rows ? sc.rowred : sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
-                           &sc.state->s[(h + 1) & 1], sc.state->trace, *prm, it, nullptr, tidx(it, 1), tp.sys,
-                           reduce_rows ? 1 : 0);
+                           &sc.state->s[(h + 1) & 1], sc.state->trace, nullptr, tidx(it, 1), tp.sys};
+        hipLaunchKernelGGL((gs_icp_half_kernel<false>), dim3(nfs), dim3(FS_BLOCK), 0, st, q, n_src_c, prm->dist_thresh,
+                           *prm, it, reduce_rows ? 1 : 0);
       }
       ++h;
       cur_in = cur;
@@ -617,6 +693,252 @@ extern "C" int gs_icp_map_dc_f32(const float* src, int64_t n_src_bound, const in
                  icp_scratch, nullptr, stream, n_src_dev, n_map_dev, GsTargetFilter{pix, W, ds});
 }
 
+// ---------------------------------------------------------------- batched localisation -----
+// ICPSLAM._localize (slam/icpslam.py:238-247) for B independent sequences in ONE chain of launches: every kernel
+// below runs for all sequences at once (block b -> sequence b % B), so the dependent-launch floor of the 2 x numiters
+// half-iteration kernels, which bounds a single 640x480 sequence, is paid once per B frames and the chip
+// is filled by B x the blocks.  Per sequence the arithmetic is that of gs_lattice_source_f32 + gs_project_map_dc_f32
+// + gs_icp_map_dc_f32, bit for bit (same device functions).
+struct LocSeq {
+  const float* vertex;
+  const float* depth;
+  const float* pose16;   // previous pose: lattice transform, projection and the composed result
+  float* lattice;        // [n_lat][3] ICP source (NaN = no depth)
+  GsIcpState* state;
+  float* out_pose16;
+  char* clear_ptr;       // grid scratch bytes that must be zero before the build
+  int64_t* n_valid;      // number of lattice slots with depth (profiling / roofline accounting)
+};
+struct LocBatch {
+  int B, W, ds, Wl;
+  int64_t n_lat;
+  size_t clear_bytes;
+  float damp;
+  int numiters;
+  int count_valid;       // profile passes: count the lattice slots with depth
+  LocSeq s[GS_MAX_BATCH];
+};
+constexpr int LP_CLEAR_ITEMS = 8;  // 16-byte stores per thread of a clearing block (32 KB per block)
+
+// lattice source (gs_lattice_source_kernel) + solver state (gs_icp_init_kernel) + zeroing of the grid scratch
+__global__ void __launch_bounds__(256) gs_loc_prep_kernel(const LocBatch lb, unsigned nb_lat) {
+  const LocSeq& q = lb.s[blockIdx.x % lb.B];
+  const unsigned blk = blockIdx.x / lb.B;
+  if (blk < nb_lat) {
+    const int64_t e = (int64_t)blk * 256 + threadIdx.x;
+    int valid = 0;
+    if (e < lb.n_lat) {
+      const int64_t p = (e / lb.Wl) * lb.ds * (int64_t)lb.W + (e % lb.Wl) * lb.ds;
+      float g0 = __builtin_nanf(""), g1 = g0, g2 = g0;
+      if (q.depth[p] > 0.0f) {
+        float T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = q.pose16[i];
+        gs_rigid_fma(T, q.vertex[3 * p], q.vertex[3 * p + 1], q.vertex[3 * p + 2], g0, g1, g2);
+        valid = 1;
+      }
+      q.lattice[3 * e] = g0; q.lattice[3 * e + 1] = g1; q.lattice[3 * e + 2] = g2;
+    }
+    const unsigned long long m = lb.count_valid ? __ballot(valid) : 0ull;
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(reinterpret_cast<unsigned long long*>(q.n_valid), (unsigned long long)__popcll(m));
+    if (blk == 0 && threadIdx.x == 0) {  // gs_icp_init_kernel with init = identity
+      IcpSmall sm;
+      for (int i = 0; i < 16; ++i) {
+        const float id = (i % 5 == 0) ? 1.0f : 0.0f;
+        sm.T_total[i] = id; sm.T_step[i] = id; sm.Tr[i] = id;
+      }
+      for (int i = 0; i < 8; ++i) sm.xi[i] = 0.0f;
+      sm.damp = lb.damp;
+      sm.err = 0.0f;
+      sm.pad[0] = sm.pad[1] = 0.0f;
+      q.state->s[0] = sm;
+      q.state->s[1] = sm;
+      if (lb.numiters == 0) icp_write_result(sm, q.pose16, q.out_pose16);
+    }
+    return;
+  }
+  float4* dst = reinterpret_cast<float4*>(q.clear_ptr);
+  const size_t n16 = lb.clear_bytes / 16;
+  const size_t base = (size_t)(blk - nb_lat) * 256 * LP_CLEAR_ITEMS + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < LP_CLEAR_ITEMS; ++u) {
+    const size_t i = base + (size_t)u * 256;
+    if (i < n16) dst[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+}
+
+struct IcpRowsBatch {
+  int B;
+  const double* in[GS_MAX_BATCH];
+  double* out[GS_MAX_BATCH];
+};
+__global__ void __launch_bounds__(FS_BLOCK) gs_icp_reduce_rows_batch_kernel(const IcpRowsBatch rb, GsCount n_src_c) {
+  __shared__ double S[32];
+  __shared__ double sub[FS_BLOCK / 32][32];
+  const int nrows = (int)((gs_count(n_src_c) + FS_QPB - 1) / FS_QPB);
+  icp_sum_rows<FS_BLOCK>(rb.in[blockIdx.x], nrows, S, sub);
+  if (threadIdx.x < LIN_NV) rb.out[blockIdx.x][threadIdx.x] = S[threadIdx.x];
+}
+
+struct IcpFinishBatch {
+  int B;
+  const double* partials_in[GS_MAX_BATCH];
+  GsIcpState* st[GS_MAX_BATCH];
+  const float* compose16[GS_MAX_BATCH];
+  float* out_T16[GS_MAX_BATCH];
+};
+__global__ void __launch_bounds__(FS_BLOCK) gs_icp_finish_batch_kernel(const IcpFinishBatch fb, GsCount n_src_c, int buf,
+                                                                       gs_icp_params prm) {
+  __shared__ double red[FS_BLOCK / GS_WAVE];
+  const int b = blockIdx.x;
+  const int nrows_in = (int)((gs_count(n_src_c) + FS_QPB - 1) / FS_QPB);
+  const double e1 = icp_sum_col27<FS_BLOCK>(fb.partials_in[b], nrows_in, red);
+  if (threadIdx.x != 0) return;
+  GsIcpState* st = fb.st[b];
+  IcpSmall sm = st->s[buf];
+  const int it = prm.numiters - 1;
+  icp_update_math((float)e1, sm, prm, it < GS_ICP_MAX_ITERS ? st->trace + 12 * it : nullptr);
+  st->s[buf ^ 1] = sm;
+  icp_write_result(sm, fb.compose16[b], fb.out_T16[b]);
+}
+
+static int64_t loc_lattice(int H, int W, int ds) { return (int64_t)((H + ds - 1) / ds) * ((W + ds - 1) / ds); }
+
+extern "C" int64_t gs_localize_scratch_bytes(int H, int W, int ds, int64_t n_map_bound) {
+  if (H < 1 || W < 1 || ds < 1) return 0;
+  const int64_t n_lat = loc_lattice(H, W, ds);
+  return (int64_t)(gs_align(12 * (size_t)n_lat) + gs_align(4 * (size_t)(n_map_bound > 0 ? n_map_bound : 1)) + 256) +
+         gs_icp_scratch_bytes(n_lat, n_map_bound);
+}
+
+static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int ds, const gs_icp_params* prm,
+                          hipStream_t st) {
+  const int64_t n_lat = loc_lattice(H, W, ds);
+  const int Wl = (W + ds - 1) / ds;
+  LocBatch lb;
+  GsGridBatch gb;
+  IcpScratch sc[GS_MAX_BATCH];
+  GridMem gm[GS_MAX_BATCH];
+  lb.B = gb.B = B;
+  lb.W = gb.W = W; gb.H = H;
+  lb.ds = gb.ds = ds;
+  lb.Wl = Wl; lb.n_lat = n_lat; lb.damp = prm->damp; lb.numiters = prm->numiters;
+  gb.cells_cap = gs_knn_grid_cells_cap(n_lat);
+  for (int b = 0; b < B; ++b) {
+    const gs_localize_seq& q = seqs[b];
+    char* p = reinterpret_cast<char*>(q.scratch);
+    float* lattice = reinterpret_cast<float*>(p); p += gs_align(12 * (size_t)n_lat);
+    int32_t* pix = reinterpret_cast<int32_t*>(p); p += gs_align(4 * (size_t)q.map.n_bound);
+    int64_t* n_valid = reinterpret_cast<int64_t*>(p); p += 256;
+    sc[b] = icp_carve(p, n_lat);
+    gm[b] = grid_carve(sc[b].grid, n_lat, q.map.n_bound);
+    lb.s[b] = LocSeq{q.vertex, q.depth, q.prev_pose16, lattice, sc[b].state, q.out_pose16,
+                     reinterpret_cast<char*>(gm[b].g), n_valid};
+    gb.s[b] = GsGridSeq{q.map.points, GsCount{q.map.n_bound, q.map.n_dev}, pix, q.prev_pose16, q.K16, gm[b]};
+    if (g_gs_prof_on) GS_HIP(hipMemsetAsync(n_valid, 0, 8, st));
+  }
+  lb.count_valid = g_gs_prof_on ? 1 : 0;
+  lb.clear_bytes = gs_knn_grid_clear_bytes(gm[0], gb.cells_cap);  // same layout offsets for every sequence
+  const unsigned nb_lat = (unsigned)gs_ceil_div(n_lat, 256);
+  const unsigned nb_clear = (unsigned)gs_ceil_div((int64_t)(lb.clear_bytes / 16), 256 * LP_CLEAR_ITEMS);
+  {
+    double bytes = 0.0;  // lattice 28 B per slot; projection 16 B + two filter passes 4 B per map row; cell table
+    for (int b = 0; b < B; ++b) bytes += 28.0 * n_lat + 24.0 * seqs[b].map.n_bound + 16.0 * gb.cells_cap;
+    GsProf prof(GS_PROF_COMPACT, bytes, st, 6);
+    hipLaunchKernelGGL(gs_loc_prep_kernel, dim3((unsigned)B * (nb_lat + nb_clear)), dim3(256), 0, st, lb, nb_lat);
+    int rc = gs_knn_grid_build_batch(gb, st);
+    if (rc != GS_OK) return rc;
+  }
+  if (prm->numiters == 0) { GS_LAUNCH_CHECK(); return GS_OK; }
+
+  const int nfs = (int)icp_rows(n_lat);
+  const bool reduce_rows = nfs > FS_REDUCE_ROWS;
+  const GsCount n_src_c{n_lat, nullptr};
+  double prof_bytes = 0.0;
+  if (g_gs_prof_on) {  // exact counts for the roofline line (profile passes only: one sync)
+    for (int b = 0; b < B; ++b) {
+      unsigned hits = 0;
+      int64_t nv = 0;
+      GS_HIP(hipMemcpyAsync(&hits, gm[b].bbox + 6, 4, hipMemcpyDeviceToHost, st));
+      GS_HIP(hipMemcpyAsync(&nv, lb.s[b].n_valid, 8, hipMemcpyDeviceToHost, st));
+      GS_HIP(hipStreamSynchronize(st));
+      prof_bytes += icp_alg_bytes(prm->numiters, n_lat, nv, hits);
+    }
+  }
+  std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
+  IcpHalfBatch hb;
+  hb.B = B;
+  int h = 0;
+  for (int it = 0; it < prm->numiters; ++it) {
+    for (int b = 0; b < B; ++b) {
+      const gs_localize_seq& q = seqs[b];
+      const float* cur_in = it == 0 ? lb.s[b].lattice : (((it - 1) & 1) ? sc[b].srcB : sc[b].srcA);
+      float* cur = (it & 1) ? sc[b].srcB : sc[b].srcA;
+      hb.s[b] = IcpHalfSeq{cur_in, cur, q.map.points, q.map.normals, GsCount{q.map.n_bound, q.map.n_dev}, gm[b].g,
+                           gm[b].cell_start, gm[b].sorted, sc[b].partials[(h + 1) & 1], sc[b].partials[h & 1],
+                           &sc[b].state->s[h & 1], &sc[b].state->s[(h + 1) & 1], sc[b].state->trace, nullptr, nullptr,
+                           nullptr};
+    }
+    hipLaunchKernelGGL((gs_icp_half_batch_kernel<true>), dim3((unsigned)(B * nfs)), dim3(FS_BLOCK), 0, st, hb, n_src_c,
+                       prm->dist_thresh, *prm, it, 0);
+    ++h;
+    if (reduce_rows) {
+      IcpRowsBatch rb;
+      rb.B = B;
+      for (int b = 0; b < B; ++b) { rb.in[b] = sc[b].partials[(h + 1) & 1]; rb.out[b] = sc[b].rowred; }
+      hipLaunchKernelGGL(gs_icp_reduce_rows_batch_kernel, dim3((unsigned)B), dim3(FS_BLOCK), 0, st, rb, n_src_c);
+    }
+    for (int b = 0; b < B; ++b) {
+      IcpHalfSeq& u = hb.s[b];
+      u.src_in = (it & 1) ? sc[b].srcB : sc[b].srcA;
+      u.src_out = nullptr;
+      u.partials_in = reduce_rows ? sc[b].rowred : sc[b].partials[(h + 1) & 1];
+      u.partials_out = sc[b].partials[h & 1];
+      u.st_in = &sc[b].state->s[h & 1];
+      u.st_out = &sc[b].state->s[(h + 1) & 1];
+    }
+    hipLaunchKernelGGL((gs_icp_half_batch_kernel<false>), dim3((unsigned)(B * nfs)), dim3(FS_BLOCK), 0, st, hb, n_src_c,
+                       prm->dist_thresh, *prm, it, reduce_rows ? 1 : 0);
+    ++h;
+  }
+  prof_loop.reset();
+  {
+    GsProf prof(GS_PROF_SOLVE, 1.0, st);
+    IcpFinishBatch fb;
+    fb.B = B;
+    for (int b = 0; b < B; ++b) {
+      fb.partials_in[b] = sc[b].partials[(h + 1) & 1];
+      fb.st[b] = sc[b].state;
+      fb.compose16[b] = seqs[b].prev_pose16;
+      fb.out_T16[b] = seqs[b].out_pose16;
+    }
+    hipLaunchKernelGGL(gs_icp_finish_batch_kernel, dim3((unsigned)B), dim3(FS_BLOCK), 0, st, fb, n_src_c, h & 1, *prm);
+  }
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_localize_batch_f32(const gs_localize_seq* seqs_host, int B, int H, int W, int ds,
+                                     const gs_icp_params* prm, void* stream) {
+  GS_REQUIRE(seqs_host && prm && B > 0 && H > 0 && W > 0 && ds > 0, "bad arguments");
+  GS_REQUIRE(prm->numiters >= 0 && prm->numiters <= GS_ICP_MAX_ITERS, "numiters must be in [0, 1024]");
+  GS_REQUIRE(prm->mode == 0 || prm->mode == 1, "mode must be 0 (ICP) or 1 (gradICP)");
+  GS_REQUIRE((int64_t)H * W < (1ll << 31), "image too large for int32 pixel ids");
+  for (int b = 0; b < B; ++b) {
+    const gs_localize_seq& q = seqs_host[b];
+    GS_REQUIRE(q.vertex && q.depth && q.K16 && q.prev_pose16 && q.out_pose16 && q.scratch, "NULL pointer");
+    GS_REQUIRE(q.map.points && q.map.normals && q.map.n_bound > 0 && q.map.n_bound < 0x7fffffffll,
+               "every sequence needs a non-empty map (points + normals)");
+  }
+  hipStream_t st = gs_stream(stream);
+  for (int c0 = 0; c0 < B; c0 += GS_MAX_BATCH) {
+    const int nb = B - c0 < GS_MAX_BATCH ? B - c0 : GS_MAX_BATCH;
+    const int rc = localize_chunk(seqs_host + c0, nb, H, W, ds, prm, st);
+    if (rc != GS_OK) return rc;
+  }
+  return GS_OK;
+}
+
 extern "C" int64_t gs_icp_tape_bytes(int64_t n_src, int numiters) { return (int64_t)gs_icp_tape_size(n_src, numiters); }
 
 extern "C" int gs_icp_tape_f32(const float* src, int64_t n_src, const float* tgt, const float* tgt_normals,
@@ -629,7 +951,7 @@ extern "C" int gs_icp_tape_f32(const float* src, int64_t n_src, const float* tgt
 }
 
 extern "C" int gs_icp_trace_f32(const void* icp_scratch, int numiters, float* trace_out, void* stream) {
-  GS_REQUIRE(icp_scratch && trace_out && numiters >= 0 && numiters <= 64, "bad arguments");
+  GS_REQUIRE(icp_scratch && trace_out && numiters >= 0 && numiters <= GS_ICP_MAX_ITERS, "bad arguments");
   const GsIcpState* st = reinterpret_cast<const GsIcpState*>(icp_scratch);
   GS_HIP(hipMemcpyAsync(trace_out, st->trace, sizeof(float) * 12 * (size_t)numiters, hipMemcpyDeviceToDevice,
                         gs_stream(stream)));

@@ -72,6 +72,30 @@ static inline GridMem grid_carve(void* scratch, int64_t n_src, int64_t n_tgt) {
 }
 
 size_t gs_knn_grid_scratch_bytes(int64_t n_src, int64_t n_tgt);
+
+// ---- batched build: B independent target sets per launch (block b of a launch works for sequence b % B, so
+// that with B = 8 every sequence stays on one XCD and its binned targets in that XCD's L2) ----
+struct GsGridSeq {
+  const float* tgt;      // target rows (the whole map when a filter is given)
+  GsCount n_tgt;
+  int32_t* pix;          // target filter (with W, ds of the batch); when pose16 != NULL it is WRITTEN first:
+  const float* pose16;   //   pix[n] = projection of row n under (pose16, K16) (gs_project_map_f32)
+  const float* K16;
+  GridMem m;             // grid_carve(scratch, n_src, n_tgt.host)
+};
+struct GsGridBatch {
+  int B, H, W, ds;
+  int cells_cap;
+  GsGridSeq s[GS_MAX_BATCH];
+};
+// cells_cap of a build for n_src queries (device-side target counts)
+int gs_knn_grid_cells_cap(int64_t n_src);
+// bytes from the start of the grid scratch that must be ZERO before a build (header, bbox, counters, cell counts)
+size_t gs_knn_grid_clear_bytes(const GridMem& m, int cells_cap);
+// projection (optional) + bbox, count, tile sums, scan, scatter: 5 launches for all B sequences; the caller has
+// cleared gs_knn_grid_clear_bytes() of every scratch
+int gs_knn_grid_build_batch(const GsGridBatch& gb, hipStream_t st);
+
 int gs_knn_grid_build(const float* tgt, GsCount n_tgt, int64_t n_src, void* grid_scratch, hipStream_t st,
                       GsTargetFilter filter = GsTargetFilter{nullptr, 1, 1});
 int gs_knn_grid_query(const float* src_in, const float* Tapply, float* src_out, int64_t n_src,

@@ -22,6 +22,8 @@
 
 #include <stdlib.h>
 
+#include "gs_assoc_dev.h"
+
 constexpr int KNN_BLOCK = 256;
 constexpr int KNN_TCHUNK = 512;
 
@@ -142,13 +144,14 @@ GS_DEV float grid_decode(unsigned c) {
 }
 constexpr int GB_BLOCK = 256;
 constexpr int GB_ITEMS = 8;
-__global__ void __launch_bounds__(GB_BLOCK) gs_grid_bbox_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
-                                                                 const GsTargetFilter flt,
-                                                                 unsigned* __restrict__ bbox,
-                                                                 int* __restrict__ unres_count) {
-  const int64_t n_tgt = gs_count(n_tgt_c);
-  if (blockIdx.x == 0 && threadIdx.x == 0) { unres_count[0] = 0; unres_count[1] = 0; }
-  if ((int64_t)blockIdx.x * GB_BLOCK * GB_ITEMS >= n_tgt) return;
+// Body shared by the single-sequence and the batched kernels (blk = block index within the sequence).
+// cam != NULL: pix[] is an OUTPUT (projection of every row under the camera, gs_project_map_f32) and the
+// filter is evaluated on the value just computed.
+GS_DEV void grid_bbox_body(const float* __restrict__ tgt, const int64_t n_tgt, const GsTargetFilter flt,
+                           const GsCamera* cam, int H, float u_hi, float v_hi, int32_t* __restrict__ pix_out,
+                           unsigned* __restrict__ bbox, int* __restrict__ unres_count, const unsigned blk) {
+  if (blk == 0 && threadIdx.x == 0) { unres_count[0] = 0; unres_count[1] = 0; }
+  if ((int64_t)blk * GB_BLOCK * GB_ITEMS >= n_tgt) return;
   __shared__ float red[6][GB_BLOCK / GS_WAVE];
   __shared__ int hits_s;
   if (threadIdx.x == 0) hits_s = 0;
@@ -157,12 +160,24 @@ __global__ void __launch_bounds__(GB_BLOCK) gs_grid_bbox_kernel(const float* __r
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
   for (int u = 0; u < GB_ITEMS; ++u) {
-    const int64_t i = ((int64_t)blockIdx.x * GB_ITEMS + u) * GB_BLOCK + threadIdx.x;
-    if (i < n_tgt && gs_is_target(flt, i)) {
+    const int64_t i = ((int64_t)blk * GB_ITEMS + u) * GB_BLOCK + threadIdx.x;
+    if (i >= n_tgt) continue;
+    bool is_t;
+    float v3[3];
+    if (cam) {
+      v3[0] = tgt[3 * i]; v3[1] = tgt[3 * i + 1]; v3[2] = tgt[3 * i + 2];
+      const int32_t p = gs_project_point(*cam, v3[0], v3[1], v3[2], H, flt.W, u_hi, v_hi);
+      pix_out[i] = p;
+      is_t = p >= 0 && ((p / flt.W) % flt.ds == 0) && ((p % flt.W) % flt.ds == 0);
+    } else {
+      is_t = gs_is_target(flt, i);
+      if (is_t) { v3[0] = tgt[3 * i]; v3[1] = tgt[3 * i + 1]; v3[2] = tgt[3 * i + 2]; }
+    }
+    if (is_t) {
       ++hits;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float v = tgt[3 * i + k];
+        const float v = v3[k];
         if (v > -3.0e38f && v < 3.0e38f) {  // finite
           lo[k] = v < lo[k] ? v : lo[k];
           hi[k] = v > hi[k] ? v : hi[k];
@@ -182,13 +197,14 @@ __global__ void __launch_bounds__(GB_BLOCK) gs_grid_bbox_kernel(const float* __r
     }
     if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = b; }
   }
-  if (flt.pix) {  // number of targets (the cell-size heuristic needs it): wave sums, one atomic per block
+  const bool filtered = flt.pix != nullptr || cam != nullptr;
+  if (filtered) {  // number of targets (the cell-size heuristic needs it): wave sums, one atomic per block
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) hits += __shfl_down(hits, d, GS_WAVE);
     if (lane == 0 && hits) atomicAdd(&hits_s, hits);
   }
   __syncthreads();
-  if (flt.pix && threadIdx.x == 3 && hits_s) atomicAdd(&bbox[6], (unsigned)hits_s);
+  if (filtered && threadIdx.x == 3 && hits_s) atomicAdd(&bbox[6], (unsigned)hits_s);
   if (threadIdx.x < 3) {
     const int k = threadIdx.x;
     float a = red[k][0], b = red[3 + k][0];
@@ -201,6 +217,12 @@ __global__ void __launch_bounds__(GB_BLOCK) gs_grid_bbox_kernel(const float* __r
       atomicMax(&bbox[3 + k], grid_code(b));
     }
   }
+}
+__global__ void __launch_bounds__(GB_BLOCK) gs_grid_bbox_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
+                                                                 const GsTargetFilter flt,
+                                                                 unsigned* __restrict__ bbox,
+                                                                 int* __restrict__ unres_count) {
+  grid_bbox_body(tgt, gs_count(n_tgt_c), flt, nullptr, 0, 0.0f, 0.0f, nullptr, bbox, unres_count, blockIdx.x);
 }
 
 // Cell size from the bounding box.  Heuristic: targets are a sampled surface (spacing ~ sqrt(area / n))
@@ -243,53 +265,59 @@ GS_DEV GsGrid grid_from_bbox(const unsigned* __restrict__ bbox, int64_t n_tgt, i
 
 // Every block derives the grid header from the bounding box (block 0 publishes it for the kernels
 // that follow), then counts its targets per cell.
-__global__ void __launch_bounds__(256) gs_grid_count_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
-                                                            const GsTargetFilter flt,
-                                                            const unsigned* __restrict__ bbox,
-                                                            GsGrid* __restrict__ gp,
-                                                            int* __restrict__ cell_count, int cells_cap) {
+GS_DEV void grid_count_body(const float* __restrict__ tgt, const int64_t n_tgt, const GsTargetFilter flt,
+                            const unsigned* __restrict__ bbox, GsGrid* __restrict__ gp, int* __restrict__ cell_count,
+                            int cells_cap, const unsigned blk) {
   __shared__ GsGrid gsh;
-  const int64_t n_tgt = gs_count(n_tgt_c);
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if ((int64_t)blockIdx.x * 256 >= n_tgt && blockIdx.x != 0) return;
+  const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+  if ((int64_t)blk * 256 >= n_tgt && blk != 0) return;
   if (threadIdx.x == 0) {
     gsh = grid_from_bbox(bbox, flt.pix ? (int64_t)bbox[6] : n_tgt, cells_cap);
-    if (blockIdx.x == 0) *gp = gsh;
+    if (blk == 0) *gp = gsh;
   }
   __syncthreads();
   if (i >= n_tgt || !gs_is_target(flt, i)) return;
   const GsGrid g = gsh;
   atomicAdd(&cell_count[grid_cell(g, tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2])], 1);
 }
+__global__ void __launch_bounds__(256) gs_grid_count_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
+                                                            const GsTargetFilter flt,
+                                                            const unsigned* __restrict__ bbox,
+                                                            GsGrid* __restrict__ gp,
+                                                            int* __restrict__ cell_count, int cells_cap) {
+  grid_count_body(tgt, gs_count(n_tgt_c), flt, bbox, gp, cell_count, cells_cap, blockIdx.x);
+}
 
 // exclusive scan of cell_count[0 .. ncell] (ncell + 1 entries, the last one is the end sentinel)
-__global__ void __launch_bounds__(256) gs_grid_tile_sum_kernel(const int* __restrict__ cell_count,
-                                                               const GsGrid* __restrict__ gp,
-                                                               int* __restrict__ tile_sums) {
+GS_DEV void grid_tile_sum_body(const int* __restrict__ cell_count, const GsGrid* __restrict__ gp,
+                               int* __restrict__ tile_sums, const unsigned blk) {
   __shared__ int smem[256 / GS_WAVE + 1];
   const int n = gp->ncell + 1;
-  const int base = blockIdx.x * GS_GRID_TILE + threadIdx.x * 4;
-  if (blockIdx.x * GS_GRID_TILE >= n) return;
+  const int base = blk * GS_GRID_TILE + threadIdx.x * 4;
+  if ((int)(blk * GS_GRID_TILE) >= n) return;
   int c = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) c += (base + i < n) ? cell_count[base + i] : 0;
   int total;
   (void)gs_block_excl_scan<256>(c, smem, &total);
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+  if (threadIdx.x == 0) tile_sums[blk] = total;
 }
-__global__ void __launch_bounds__(256) gs_grid_scan_kernel(const int* __restrict__ cell_count,
-                                                           const GsGrid* __restrict__ gp,
-                                                           const int* __restrict__ tile_sums,
-                                                           int* __restrict__ cell_start) {
+__global__ void __launch_bounds__(256) gs_grid_tile_sum_kernel(const int* __restrict__ cell_count,
+                                                               const GsGrid* __restrict__ gp,
+                                                               int* __restrict__ tile_sums) {
+  grid_tile_sum_body(cell_count, gp, tile_sums, blockIdx.x);
+}
+GS_DEV void grid_scan_body(const int* __restrict__ cell_count, const GsGrid* __restrict__ gp,
+                           const int* __restrict__ tile_sums, int* __restrict__ cell_start, const unsigned blk) {
   __shared__ int smem[256 / GS_WAVE + 1];
   const int n = gp->ncell + 1;
-  if (blockIdx.x * GS_GRID_TILE >= n) return;
+  if ((int)(blk * GS_GRID_TILE) >= n) return;
   // prefix of the tiles before this one
   int pre = 0;
-  for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) pre += tile_sums[t];
+  for (int t = threadIdx.x; t < (int)blk; t += 256) pre += tile_sums[t];
   int tile_prefix;
   (void)gs_block_excl_scan<256>(pre, smem, &tile_prefix);
-  const int base = blockIdx.x * GS_GRID_TILE + threadIdx.x * 4;
+  const int base = blk * GS_GRID_TILE + threadIdx.x * 4;
   int v[4], c = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -304,15 +332,18 @@ __global__ void __launch_bounds__(256) gs_grid_scan_kernel(const int* __restrict
     run += v[i];
   }
 }
+__global__ void __launch_bounds__(256) gs_grid_scan_kernel(const int* __restrict__ cell_count,
+                                                           const GsGrid* __restrict__ gp,
+                                                           const int* __restrict__ tile_sums,
+                                                           int* __restrict__ cell_start) {
+  grid_scan_body(cell_count, gp, tile_sums, cell_start, blockIdx.x);
+}
 
-__global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
-                                                              const GsTargetFilter flt,
-                                                              const GsGrid* __restrict__ gp,
-                                                              const int* __restrict__ cell_start,
-                                                              int* __restrict__ cell_count,
-                                                              float4* __restrict__ sorted) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= gs_count(n_tgt_c) || !gs_is_target(flt, i)) return;
+GS_DEV void grid_scatter_body(const float* __restrict__ tgt, const int64_t n_tgt, const GsTargetFilter flt,
+                              const GsGrid* __restrict__ gp, const int* __restrict__ cell_start,
+                              int* __restrict__ cell_count, float4* __restrict__ sorted, const unsigned blk) {
+  const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+  if (i >= n_tgt || !gs_is_target(flt, i)) return;
   const GsGrid g = *gp;
   const float x = tgt[3 * i], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
   const int cid = grid_cell(g, x, y, z);
@@ -321,26 +352,93 @@ __global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __res
   const int slot = cell_start[cid] + atomicSub(&cell_count[cid], 1) - 1;
   sorted[slot] = make_float4(x, y, z, __int_as_float((int)i));
 }
+__global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
+                                                              const GsTargetFilter flt,
+                                                              const GsGrid* __restrict__ gp,
+                                                              const int* __restrict__ cell_start,
+                                                              int* __restrict__ cell_count,
+                                                              float4* __restrict__ sorted) {
+  grid_scatter_body(tgt, gs_count(n_tgt_c), flt, gp, cell_start, cell_count, sorted, blockIdx.x);
+}
+
+// ---- batched build: block b of a launch works for sequence b % B on its block b / B ----
+__global__ void __launch_bounds__(GB_BLOCK) gs_gridb_bbox_kernel(const GsGridBatch gb, float u_hi, float v_hi) {
+  const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
+  const unsigned blk = blockIdx.x / gb.B;
+  const GsTargetFilter flt{q.pix, gb.W, gb.ds};
+  if (q.pose16) {
+    __shared__ GsCamera cam;
+    if (threadIdx.x == 0) cam = gs_camera(q.pose16, q.K16);
+    __syncthreads();
+    grid_bbox_body(q.tgt, gs_count(q.n_tgt), flt, &cam, gb.H, u_hi, v_hi, q.pix, q.m.bbox, q.m.unres_count, blk);
+  } else {
+    grid_bbox_body(q.tgt, gs_count(q.n_tgt), flt, nullptr, 0, 0.0f, 0.0f, nullptr, q.m.bbox, q.m.unres_count, blk);
+  }
+}
+__global__ void __launch_bounds__(256) gs_gridb_count_kernel(const GsGridBatch gb) {
+  const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
+  grid_count_body(q.tgt, gs_count(q.n_tgt), GsTargetFilter{q.pix, gb.W, gb.ds}, q.m.bbox, q.m.g, q.m.cell_count,
+                  gb.cells_cap, blockIdx.x / gb.B);
+}
+__global__ void __launch_bounds__(256) gs_gridb_tile_sum_kernel(const GsGridBatch gb) {
+  const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
+  grid_tile_sum_body(q.m.cell_count, q.m.g, q.m.tile_sums, blockIdx.x / gb.B);
+}
+__global__ void __launch_bounds__(256) gs_gridb_scan_kernel(const GsGridBatch gb) {
+  const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
+  grid_scan_body(q.m.cell_count, q.m.g, q.m.tile_sums, q.m.cell_start, blockIdx.x / gb.B);
+}
+__global__ void __launch_bounds__(256) gs_gridb_scatter_kernel(const GsGridBatch gb) {
+  const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
+  grid_scatter_body(q.tgt, gs_count(q.n_tgt), GsTargetFilter{q.pix, gb.W, gb.ds}, q.m.g, q.m.cell_start, q.m.cell_count,
+                    q.m.sorted, blockIdx.x / gb.B);
+}
+
+// Cells the grid of a build may use (what is cleared and scanned per build): the target density the
+// cell size has to follow grows with the query lattice (the targets are map surfels seen on the same
+// lattice, several per pixel in a mature map), so the budget is tied to n_src; a host-exact n_tgt
+// (API calls) may raise it.  1M cells for a 640x480 frame, 4M for 1296x968.
+static int grid_cells_cap(int64_t n_src, int64_t n_tgt_exact) {
+  int64_t want = 48 * n_src;
+  if (16 * n_tgt_exact > want) want = 16 * n_tgt_exact;
+  int cells_cap = 1 << 20;
+  while (cells_cap < GS_GRID_MAXCELL && cells_cap < want) cells_cap <<= 1;
+  return cells_cap;
+}
+int gs_knn_grid_cells_cap(int64_t n_src) { return grid_cells_cap(n_src, 0); }
+size_t gs_knn_grid_clear_bytes(const GridMem& m, int cells_cap) {
+  // from the 256-byte aligned start of the scratch and rounded up to 256 bytes (the header is rewritten by the
+  // count kernel and the bytes of cell_start the round-up may touch are rewritten by the scan)
+  return gs_align((size_t)(reinterpret_cast<char*>(m.cell_count) - reinterpret_cast<char*>(m.g)) +
+                  4 * (size_t)(cells_cap + 1));
+}
+
+int gs_knn_grid_build_batch(const GsGridBatch& gb, hipStream_t st) {
+  int64_t n_max = 1;
+  for (int b = 0; b < gb.B; ++b) n_max = gb.s[b].n_tgt.host > n_max ? gb.s[b].n_tgt.host : n_max;
+  const unsigned B = (unsigned)gb.B;
+  const float u_hi = (float)((double)gb.W - 0.999), v_hi = (float)((double)gb.H - 0.999);
+  hipLaunchKernelGGL(gs_gridb_bbox_kernel, dim3(B * (unsigned)gs_ceil_div(n_max, GB_BLOCK * GB_ITEMS)), dim3(GB_BLOCK), 0,
+                     st, gb, u_hi, v_hi);
+  hipLaunchKernelGGL(gs_gridb_count_kernel, dim3(B * (unsigned)gs_ceil_div(n_max, 256)), dim3(256), 0, st, gb);
+  const unsigned ntile = (unsigned)gs_ceil_div(gb.cells_cap + 1, GS_GRID_TILE);
+  hipLaunchKernelGGL(gs_gridb_tile_sum_kernel, dim3(B * ntile), dim3(256), 0, st, gb);
+  hipLaunchKernelGGL(gs_gridb_scan_kernel, dim3(B * ntile), dim3(256), 0, st, gb);
+  hipLaunchKernelGGL(gs_gridb_scatter_kernel, dim3(B * (unsigned)gs_ceil_div(n_max, 256)), dim3(256), 0, st, gb);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { gs_set_error("gs_knn_grid_build_batch: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
+  return GS_OK;
+}
 
 int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* grid_scratch, hipStream_t st,
                       GsTargetFilter flt) {
   const int64_t n_tgt = n_tgt_c.host;  // upper bound: launch geometry and scratch layout
   GridMem m = grid_carve(grid_scratch, n_src, n_tgt);
-  // Cells the grid of this build may use (what is cleared and scanned per build): the target density the
-  // cell size has to follow grows with the query lattice (the targets are map surfels seen on the same
-  // lattice, several per pixel in a mature map), so the budget is tied to n_src; a host-exact n_tgt
-  // (API calls) may raise it.  1M cells for a 640x480 frame, 4M for 1296x968.
-  int64_t want = 48 * n_src;
-  if (!n_tgt_c.dev && 16 * n_tgt > want) want = 16 * n_tgt;
-  int cells_cap = 1 << 20;
-  while (cells_cap < GS_GRID_MAXCELL && cells_cap < want) cells_cap <<= 1;
+  const int cells_cap = grid_cells_cap(n_src, n_tgt_c.dev ? 0 : n_tgt);
   GsProf prof(GS_PROF_COMPACT, 28.0 * (double)n_tgt + 8.0 * (double)cells_cap, st);
-  // one memset: bbox codes + unresolved counters + cell counts (contiguous in the scratch layout)
-  // (from the 256-byte aligned start of the scratch and rounded up to 256 bytes so that the runtime issues ONE
-  // fill kernel, not a head + body pair; the header is rewritten by the count kernel and the bytes of
-  // cell_start the round-up may touch are rewritten by the scan)
-  const size_t clear = gs_align((size_t)(reinterpret_cast<char*>(m.cell_count) - reinterpret_cast<char*>(m.g)) +
-                                4 * (size_t)(cells_cap + 1));
+  // one memset: bbox codes + unresolved counters + cell counts (contiguous in the scratch layout; 256-byte
+  // aligned and rounded so that the runtime issues ONE fill kernel, not a head + body pair)
+  const size_t clear = gs_knn_grid_clear_bytes(m, cells_cap);
   hipError_t e = hipMemsetAsync(m.g, 0, clear, st);
   if (e != hipSuccess) { gs_set_error("gs_knn_grid_build: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
   hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, GB_BLOCK * GB_ITEMS)),

@@ -47,10 +47,17 @@ class ICPOdometryProvider(OdometryProvider):
         from .. import ops
         transforms = []
         for b in range(len(maps_pointclouds)):
-            T = ops.icp(frames_pointclouds.points_list[b], maps_pointclouds.points_list[b],
-                        maps_pointclouds.normals_list[b], init=None,
-                        compose=None if compose_with is None else compose_with[b], mode=self._mode,
-                        return_idx=False, **self._kwargs())
+            src, tgt, tn = (frames_pointclouds.points_list[b], maps_pointclouds.points_list[b],
+                            maps_pointclouds.normals_list[b])
+            if torch.is_grad_enabled() and (src.requires_grad or tgt.requires_grad or tn.requires_grad):
+                # differentiable like the reference's providers (hand-written HIP backward, both solvers)
+                T, _ = ops.grad_icp(src, tgt, tn, None, mode=self._mode, **self._kwargs())
+                if compose_with is not None:
+                    from ..slam.icpslam import _compose
+                    T = _compose(T, compose_with[b])
+            else:
+                T = ops.icp(src, tgt, tn, init=None, compose=None if compose_with is None else compose_with[b],
+                            mode=self._mode, return_idx=False, **self._kwargs())
             transforms.append(T)
         return torch.stack(transforms).unsqueeze(1)
 

@@ -10,14 +10,18 @@ from ._C import Workspace, check, lib, ptr, require_device, stream
 
 f32 = torch.float32
 
-# Smallest row count of the bound-sized temporaries (_empty_rows); the SLAM drivers raise it to the capacity of the
-# map they grow, so that those temporaries keep ONE allocation size for as long as the capacity lasts.
-ROW_FLOOR = 0
-
 # True: the in-place SLAM drivers keep the surfel count of the map on the device between frames
 # (the *_dc entry points) so that a frame never waits for a host read-back.  False: every count
 # is read back as soon as it is produced (exact sizes on the host at all times).
 DEVICE_COUNTS = os.environ.get("GRADSLAM_HIP_DEVICE_COUNTS", "1") != "0"
+
+
+def _thresh(dist_thresh):
+    """C-ABI encoding of dist_thresh: < 0 means None (no filter).  A negative USER threshold keeps no pair in the
+    reference (squared distances are never below it, odometry/icputils.py:203-208); 0 has the same effect."""
+    if dist_thresh is None:
+        return -1.0
+    return max(float(dist_thresh), 0.0)
 
 
 def two_sigma_sq(sigma):
@@ -50,8 +54,17 @@ def _empty_rows(n, tail, dtype, dev):
     per-frame temporaries sized by the (growing) surfel bound then change their allocation size only when the
     bound doubles, instead of asking the caching allocator for a slightly larger block every frame (each new
     size is a fresh hipMalloc while the host runs ahead of the device)."""
-    cap = max(1 << max(int(n) - 1, 0).bit_length() if n > 1024 else 1024, ROW_FLOOR)
+    cap = 1 << max(int(n) - 1, 0).bit_length() if n > 1024 else 1024
     return torch.empty((cap,) + tuple(tail), dtype=dtype, device=dev)[:n]
+
+
+def _warn_detached(name, *tensors):
+    """API functions without a backward kernel return detached tensors; say so instead of silently cutting the
+    autograd graph (the reference's torch ops would have recorded it)."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        import warnings
+        warnings.warn("gradslam_amd.%s has no backward kernel: the result is detached from the autograd graph"
+                      % name, RuntimeWarning, stacklevel=3)
 
 
 def _count(t):
@@ -93,6 +106,7 @@ def global_maps(vertex, normal, depth, pose, out=None):
 
 
 def alpha_of_points(points, sigma, eps=1e-7):
+    _warn_detached("get_alpha", points)
     points = _c(points)
     dev = require_device(points)
     out = torch.empty(points.shape[:-1], dtype=f32, device=dev)
@@ -243,7 +257,7 @@ def gauss_newton_rows(src, tgt, tgt_normals, dist_thresh=None):
     keep = torch.empty(ns, dtype=torch.uint8, device=dev)
     best = torch.empty(ns, dtype=torch.int64, device=dev)
     check(lib().gs_gauss_newton_rows_f32(ptr(src), ns, ptr(tgt), ptr(tn), tgt.shape[0],
-                                         -1.0 if dist_thresh is None else float(dist_thresh), ptr(A), ptr(b),
+                                         _thresh(dist_thresh), ptr(A), ptr(b),
                                          ptr(idx), ptr(keep), ptr(best), stream(dev)), "gs_gauss_newton_rows_f32")
     return A, b, idx, keep.view(torch.bool)
 
@@ -259,6 +273,7 @@ def solve_normal_eq(A, b, damp=1e-8, keep=None):
 
 
 def se3_exp(xi):
+    _warn_detached("se3_exp", xi)
     xi = _c(xi).reshape(6)
     dev = require_device(xi)
     T = torch.empty((4, 4), dtype=f32, device=dev)
@@ -299,6 +314,7 @@ def relative_pose(T01, T02):
 
 
 def transform_points(pts, T):
+    _warn_detached("transform_pointcloud", pts, T)
     pts, T = _c(pts), _c(T)
     dev = require_device(pts, T)
     out = torch.empty_like(pts)
@@ -320,14 +336,14 @@ def icp(src, tgt, tgt_normals, init=None, compose=None, mode=1, numiters=20, dam
     compose = _c(compose)
     require_device(init, compose)
     ns, nt = src.shape[0], tgt.shape[0]
-    prm = _C.IcpParams(int(mode), int(numiters), float(damp), -1.0 if dist_thresh is None else float(dist_thresh),
+    prm = _C.IcpParams(int(mode), int(numiters), float(damp), _thresh(dist_thresh),
                        float(lambda_max), float(B), float(B2), float(nu))
     T = torch.empty((4, 4), dtype=f32, device=dev) if out is None else out
     assert T.shape == (4, 4) and T.dtype == f32 and T.is_contiguous() and T.device == dev
     idx = torch.empty(ns, dtype=torch.int64, device=dev) if return_idx else None
     ws = Workspace.get(dev)
     dc = n_src_dev is not None or n_tgt_dev is not None
-    scratch = ws.bytes("icp", lib().gs_icp_scratch_bytes(ns, max(nt, ROW_FLOOR) if dc else nt))
+    scratch = ws.bytes("icp", lib().gs_icp_scratch_bytes(ns, nt))
     if dc:
         require_device(n_src_dev, n_tgt_dev)
         check(lib().gs_icp_dc_f32(ptr(src), ns, ptr(n_src_dev), ptr(tgt), ptr(tn), nt, ptr(n_tgt_dev), ptr(init),
@@ -355,11 +371,11 @@ def icp_map(src, map_points, map_normals, pix, W, ds, n_map_dev=None, init=None,
     compose = _c(compose)
     require_device(init, compose, n_map_dev)
     ns, nm = src.shape[0], P.shape[0]
-    prm = _C.IcpParams(int(mode), int(numiters), float(damp), -1.0 if dist_thresh is None else float(dist_thresh),
+    prm = _C.IcpParams(int(mode), int(numiters), float(damp), _thresh(dist_thresh),
                        float(lambda_max), float(B), float(B2), float(nu))
     T = torch.empty((4, 4), dtype=f32, device=dev) if out is None else out
     assert T.shape == (4, 4) and T.dtype == f32 and T.is_contiguous() and T.device == dev
-    scratch = Workspace.get(dev).bytes("icp", lib().gs_icp_scratch_bytes(ns, max(nm, ROW_FLOOR)))
+    scratch = Workspace.get(dev).bytes("icp", lib().gs_icp_scratch_bytes(ns, nm))
     check(lib().gs_icp_map_dc_f32(ptr(src), ns, None, ptr(P), ptr(N), ptr(pix), nm, ptr(n_map_dev), int(W), int(ds),
                                   ptr(init), ptr(compose), prm, ptr(T), ptr(scratch), stream(dev)), "gs_icp_map_dc_f32")
     return T
@@ -473,7 +489,7 @@ def update_map_fusion_(points, normals, colors, ccounts, n_map, vertex, normal, 
                                           torch.empty((H, W, 3), dtype=f32, device=dev))
     best = torch.empty(H * W, dtype=torch.int32, device=dev)
     cnt = torch.empty(1, dtype=torch.int64, device=dev)
-    scratch = Workspace.get(dev).bytes("map_update", lib().gs_update_map_scratch_bytes(max(int(n_map), ROW_FLOOR), H, W))
+    scratch = Workspace.get(dev).bytes("map_update", lib().gs_update_map_scratch_bytes(int(n_map), H, W))
     check(lib().gs_update_map_fusion_dc_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map), ptr(n_dev),
                                             cap, ptr(vertex), ptr(normal), ptr(depth), ptr(rgb), ptr(alpha), ptr(pose),
                                             ptr(K), H, W, float(dist_th), float(dot_th), 1 if renorm_all else 0, ptr(gv),
@@ -507,6 +523,101 @@ def append_valid_(points, normals, colors, ccounts, n_map, gvertex, gnormal, rgb
     return c
 
 
+# ----------------------------------------------------------------------------------- batched frame loop
+def frame_maps_batch(depth, K, frames_per_K, sigma=None, out=None):
+    """K1 for a stack of frames in one launch: depth (n, H, W), K (n // frames_per_K, 4, 4) ->
+    vertex (n, H, W, 3), normal (n, H, W, 3), alpha (n, H, W) or None (sigma None)."""
+    depth, K = _c(depth), _c(K)
+    dev = require_device(depth, K)
+    n, H, W = depth.shape
+    ov, on, oa = out if out is not None else (None, None, None)
+    vertex = ov if ov is not None else torch.empty((n, H, W, 3), dtype=f32, device=dev)
+    normal = on if on is not None else torch.empty((n, H, W, 3), dtype=f32, device=dev)
+    alpha = oa if oa is not None else (torch.empty((n, H, W), dtype=f32, device=dev) if sigma is not None else None)
+    require_device(vertex, normal, alpha)
+    L, tss = int(frames_per_K), two_sigma_sq(0.6 if sigma is None else sigma)
+    step = max(32768 // L, 1) * L if n > 32768 and L <= 32768 else n   # gridDim.z limit: whole K groups per launch
+    for f0 in range(0, n, step):
+        m = min(step, n - f0)
+        check(lib().gs_frame_maps_batch_f32(ptr(depth[f0:]), ptr(K[f0 // L:]), m, L, H, W, tss, ptr(vertex[f0:]),
+                                            ptr(normal[f0:]), None if alpha is None else ptr(alpha[f0:]),
+                                            stream(dev)), "gs_frame_maps_batch_f32")
+    return vertex, normal, alpha
+
+
+def _map_view(bufs, cap, n_bound, n_dev):
+    P, N, Cc, F = bufs
+    return _C.MapView(P.data_ptr(), N.data_ptr(), 0 if Cc is None else Cc.data_ptr(), 0 if F is None else F.data_ptr(),
+                      int(cap), int(n_bound), 0 if n_dev is None else n_dev.data_ptr())
+
+
+def localize_batch(vertex, depth, K, prev_poses, maps, ds, mode=1, numiters=20, damp=1e-8, dist_thresh=None,
+                   lambda_max=2.0, B=1.0, B2=1.0, nu=200.0, out=None):
+    """ICPSLAM._localize for all sequences of a batch in one chain of launches (gs_localize_batch_f32).
+    vertex (B, H, W, 3) LOCAL vertex maps of the live frames, depth (B, H, W), K / prev_poses (B, 4, 4);
+    maps: per sequence (points, normals, n_bound, n_dev) with capacity-backed buffers (n_dev None: n_bound exact).
+    Returns the recovered poses (B, 4, 4) = T_icp @ prev_pose."""
+    vertex, depth, K, prev_poses = _c(vertex), _c(depth), _c(K), _c(prev_poses)
+    dev = require_device(vertex, depth, K, prev_poses)
+    Bn, H, W = depth.shape
+    T = torch.empty((Bn, 4, 4), dtype=f32, device=dev) if out is None else out
+    assert T.shape == (Bn, 4, 4) and T.dtype == f32 and T.is_contiguous() and T.device == dev
+    prm = _C.IcpParams(int(mode), int(numiters), float(damp), _thresh(dist_thresh), float(lambda_max), float(B),
+                       float(B2), float(nu))
+    ws = Workspace.get(dev)
+    seqs = (_C.LocalizeSeq * Bn)()
+    L = lib()
+    P3, P1 = H * W * 3 * 4, H * W * 4
+    v0, d0, k0, p0, t0 = vertex.data_ptr(), depth.data_ptr(), K.data_ptr(), prev_poses.data_ptr(), T.data_ptr()
+    for b in range(Bn):
+        P, N, n_bound, n_dev = maps[b]
+        require_device(P, N, n_dev)
+        cap = P.shape[0]
+        scratch = ws.bytes("localize%d" % b, L.gs_localize_scratch_bytes(H, W, int(ds), cap))
+        q = seqs[b]
+        q.vertex, q.depth, q.K16, q.prev_pose16 = v0 + b * P3, d0 + b * P1, k0 + b * 64, p0 + b * 64
+        q.map = _map_view((P, N, None, None), cap, n_bound, n_dev)
+        q.out_pose16, q.scratch = t0 + b * 64, scratch.data_ptr()
+    check(L.gs_localize_batch_f32(seqs, Bn, H, W, int(ds), prm, stream(dev)), "gs_localize_batch_f32")
+    return T
+
+
+def update_map_fusion_batch_(maps, vertex, normal, depth, rgb, alpha, poses, K, dist_th, dot_th, renorm_all=True,
+                             out=None):
+    """update_map_fusion of all sequences of a batch, in place on their capacity-backed buffers
+    (gs_update_map_fusion_batch_f32: 6 launches for the whole batch).  maps: per sequence
+    (points, normals, colors, ccounts, n_bound, n_dev).  vertex / normal / rgb (B, H, W, 3), depth / alpha (B, H, W),
+    poses / K (B, 4, 4).  Returns (counts int64 (B,) on the device, gvertex, gnormal, best_pix (B, H*W))."""
+    vertex, normal, depth, rgb, alpha = _c(vertex), _c(normal), _c(depth), _c(rgb), _c(alpha)
+    poses, K = _c(poses), _c(K)
+    dev = require_device(vertex, normal, depth, rgb, alpha, poses, K)
+    Bn, H, W = depth.shape
+    gv, gn = out if out is not None else (torch.empty_like(vertex), torch.empty_like(normal))
+    require_device(gv, gn)
+    best = torch.empty((Bn, H * W), dtype=torch.int32, device=dev)
+    cnt = torch.empty(Bn, dtype=torch.int64, device=dev)
+    ws = Workspace.get(dev)
+    seqs = (_C.UpdateSeq * Bn)()
+    L = lib()
+    P3, P1 = H * W * 3 * 4, H * W * 4
+    base = [t.data_ptr() for t in (vertex, normal, depth, rgb, alpha, poses, K, gv, gn, best, cnt)]
+    for b in range(Bn):
+        P, N, Cc, F, n_bound, n_dev = maps[b]
+        require_device(P, N, Cc, F, n_dev)
+        cap = P.shape[0]
+        scratch = ws.bytes("map_update%d" % b, L.gs_update_map_scratch_bytes(cap, H, W))
+        u = seqs[b]
+        u.map = _map_view((P, N, Cc, F), cap, n_bound, n_dev)
+        u.vertex, u.normal, u.depth, u.rgb, u.alpha = (base[0] + b * P3, base[1] + b * P3, base[2] + b * P1,
+                                                       base[3] + b * P3, base[4] + b * P1)
+        u.pose16, u.K16 = base[5] + b * 64, base[6] + b * 64
+        u.gvertex, u.gnormal, u.best_pix = base[7] + b * P3, base[8] + b * P3, base[9] + b * P1
+        u.new_count_out, u.scratch = base[10] + b * 8, scratch.data_ptr()
+    check(L.gs_update_map_fusion_batch_f32(seqs, Bn, H, W, float(dist_th), float(dot_th), 1 if renorm_all else 0,
+                                           stream(dev)), "gs_update_map_fusion_batch_f32")
+    return cnt, gv, gn, best
+
+
 # ----------------------------------------------------------------------------------- K7 (autograd)
 def icp_with_tape(src, tgt, tgt_normals, init=None, numiters=20, damp=1e-8, dist_thresh=None, lambda_max=2.0,
                   B=1.0, B2=1.0, nu=200.0, mode=1):
@@ -516,7 +627,7 @@ def icp_with_tape(src, tgt, tgt_normals, init=None, numiters=20, damp=1e-8, dist
     init = torch.eye(4, dtype=f32, device=dev) if init is None else _c(init)
     require_device(init)
     ns, nt = src.shape[0], tgt.shape[0]
-    prm = _C.IcpParams(int(mode), int(numiters), float(damp), -1.0 if dist_thresh is None else float(dist_thresh),
+    prm = _C.IcpParams(int(mode), int(numiters), float(damp), _thresh(dist_thresh),
                        float(lambda_max), float(B), float(B2), float(nu))
     T = torch.empty((4, 4), dtype=f32, device=dev)
     idx = torch.empty(ns, dtype=torch.int64, device=dev)

@@ -414,6 +414,14 @@ def update_map_fusion(pointclouds: Pointclouds, rgbdimages: RGBDImages, dist_th:
     if pointclouds._dcount or pointclouds.has_points:
         _check_batch(pointclouds, rgbdimages)
     from .. import ops
+    if pointclouds._dcount or pointclouds.has_points:
+        # the checks find_correspondences (fusionutils.py:568-575) and fuse_with_map (:641-653) would run
+        if not pointclouds.has_normals:
+            raise ValueError("Pointclouds must have normals for finding similar map points, but did not.")
+        if not pointclouds.has_features:
+            raise ValueError("Pointclouds must have features for finding best unique correspondences, but did not.")
+        if not pointclouds.has_colors:
+            raise ValueError("Pointclouds must have colors for map fusion, but did not.")
     if _wants_map_grad(pointclouds, rgbdimages):
         return _fuse_differentiable(pointclouds, rgbdimages, dist_th, dot_th, sigma, inplace)
     if inplace and ops.DEVICE_COUNTS and _one_call_update_ok(pointclouds, rgbdimages):
@@ -493,8 +501,9 @@ def _one_call_update_ok(pointclouds, rgbdimages):
 
 
 def _update_map_one_call(pointclouds, rgbdimages, dist_th, dot_th, sigma):
-    """update_map_fusion through gs_update_map_fusion_dc_f32: global maps, association and fuse of every sequence
-    in 6 launches, surfel counts on the device.  Also fills the frame's global-map cache."""
+    """update_map_fusion through gs_update_map_fusion_batch_f32: global maps, association and fuse of EVERY sequence
+    of the batch in 6 launches (workgroup -> sequence), surfel counts on the device.  Also fills the frame's
+    global-map cache."""
     from .. import ops
     fr, K, poses = _frame(rgbdimages)
     B, _, H, W = fr.shape
@@ -504,14 +513,15 @@ def _update_map_one_call(pointclouds, rgbdimages, dist_th, dot_th, sigma):
     if len(pointclouds) == 0:
         pointclouds._init_empty_batch(B, 1)
     gv, gn = torch.empty_like(vm), torch.empty_like(nm)
+    maps = []
     for b in range(B):
         P, N, C, F = pointclouds._reserve(b, H * W, pointclouds.RESERVE_FRAMES)   # before _count_of: see _fuse
         n0, n_dev = pointclouds._count_of(b)
-        # map-sized temporaries: one allocation size while this capacity lasts (follows the map being grown)
-        ops.ROW_FLOOR = P.shape[0] if b == 0 else max(ops.ROW_FLOOR, P.shape[0])
-        cnt, _, _, _ = ops.update_map_fusion_(P, N, C, F, n0, vm[b, 0], nm[b, 0], depth[b, 0, ..., 0], rgb[b, 0],
-                                              alpha[b, 0, ..., 0], poses[b], K[b], dist_th, dot_th,
-                                              RENORMALIZE_UNMATCHED, n_dev=n_dev, out=(gv[b, 0], gn[b, 0]))
-        pointclouds._set_count_dev(b, cnt, H * W)
+        maps.append((P, N, C, F, n0, n_dev))
+    cnt, _, _, _ = ops.update_map_fusion_batch_(maps, vm[:, 0], nm[:, 0], depth[:, 0, ..., 0], rgb[:, 0],
+                                                alpha[:, 0, ..., 0], poses, K, dist_th, dot_th, RENORMALIZE_UNMATCHED,
+                                                out=(gv[:, 0], gn[:, 0]))
+    for b in range(B):
+        pointclouds._set_count_dev(b, cnt[b:b + 1], H * W)
     fr._global_vertex_map, fr._global_normal_map = gv, gn
     return pointclouds

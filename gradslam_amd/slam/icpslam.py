@@ -18,13 +18,6 @@ from .fusionutils import update_map_aggregate
 
 __all__ = ["ICPSLAM"]
 
-import os as _os
-
-# Below this many surfels the ICP targets are binned straight from the map (gs_icp_map_dc_f32: three filtered
-# passes over the map instead of a compaction + a build over the compacted set: 4 launches fewer, +1.2 % frames/s
-# at 7e5 surfels); above it the gathered target set is cheaper (-4.5 % at 7e6 surfels otherwise).
-ICP_FROM_MAP_MAX_SURFELS = int(_os.environ.get("GRADSLAM_HIP_ICP_FROM_MAP_MAX", 2_000_000))
-
 
 class ICPSLAM(nn.Module):
     r"""Point-to-plane ICP odometry + aggregate mapping (every valid pixel is appended)."""
@@ -107,32 +100,32 @@ class ICPSLAM(nn.Module):
             K = prev_frame.intrinsics[:, 0].contiguous().float()
             prev_poses = prev_frame.poses[:, 0].contiguous().float()
             src_pts, tgt_pts, tgt_nrm = [], [], []
-            taped = torch.is_grad_enabled() and fr.depth_image.requires_grad and self.odom == "gradicp"
-            if not taped and type(self.odomprov) in (ICPOdometryProvider, GradICPOdometryProvider):
+            # on the autograd tape whenever the reference's graph would be: the live depth, the previous pose or the
+            # map (points / normals) requires grad -- for BOTH solvers (the hard-LM ICP back-propagates through its
+            # accepted steps, gs_icp_backward_f32 mode 0)
+            builtin = type(self.odomprov) in (ICPOdometryProvider, GradICPOdometryProvider)
+            taped = torch.is_grad_enabled() and builtin and (
+                fr.depth_image.requires_grad or prev_frame.poses.requires_grad or _map_requires_grad(pointclouds))
+            if not taped and builtin:
                 # fast path: no host read-back and no compaction of the source set.  The ICP source is the
                 # frame's [::ds, ::ds] lattice of global vertices under the previous pose (NaN = no depth,
                 # skipped by the solver), built from the LOCAL vertex map in one launch; the size of the
                 # target set stays on the device.
+                # All sequences of the batch go through ONE chain of launches (gs_localize_batch_f32).
                 out = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=fr.device)
-                vm = fr.vertex_map
+                maps = []
                 for b in range(B):
-                    src = ops.lattice_source(vm[b, 0], fr.depth_image[b, 0, ..., 0], prev_poses[b], self.dsratio)
                     n_b, n_dev = pointclouds._count_of(b)
-                    P, N = pointclouds._buf["points"][b][:n_b], pointclouds._buf["normals"][b][:n_b]
-                    pix = ops.project_map(P, prev_poses[b], K[b], H, W, n_dev=n_dev)
-                    if n_b <= ICP_FROM_MAP_MAX_SURFELS:
-                        # targets = map rows seen on the lattice, binned straight from the map (never gathered)
-                        ops.icp_map(src, P, N, pix, W, self.dsratio, n_map_dev=n_dev, compose=prev_poses[b],
-                                    mode=self.odomprov._mode, out=out[b, 0], **self.odomprov._kwargs())
-                    else:
-                        tgt, tn, _, n_tgt = ops.select_targets(pix, W, self.dsratio, P, N, sync=False, n_dev=n_dev)
-                        ops.icp(src, tgt, tn, compose=prev_poses[b], mode=self.odomprov._mode, return_idx=False,
-                                n_tgt_dev=n_tgt, out=out[b, 0], **self.odomprov._kwargs())
-                return out
+                    maps.append((pointclouds._buf["points"][b], pointclouds._buf["normals"][b], n_b, n_dev))
+                if all(m[2] > 0 for m in maps):
+                    ops.localize_batch(fr.vertex_map[:, 0], fr.depth_image[:, 0, ..., 0], K, prev_poses, maps,
+                                       self.dsratio, mode=self.odomprov._mode, out=out.view(B, 4, 4),
+                                       **self.odomprov._kwargs())
+                    return out
             gvm = fr.global_vertex_map
             for b in range(B):
                 # downsample_rgbdimages(live_frame): valid lattice pixels of the global vertex map
-                if taped:
+                if taped and gvm.requires_grad:
                     p = ops.DownsampleFramePointsFunction.apply(gvm[b, 0], fr.depth_image[b, 0, ..., 0].detach(),
                                                                 self.dsratio)
                 else:
@@ -151,14 +144,13 @@ class ICPSLAM(nn.Module):
                     tp, tn, _ = ops.select_targets(pix, W, self.dsratio, P, N)
                 tgt_pts.append(tp)
                 tgt_nrm.append(tn)
-            if taped and isinstance(self.odomprov, GradICPOdometryProvider):
-                # differentiable pose path: depth -> vertex -> global vertex -> ICP source -> gradICP -> pose, and,
+            if taped:
+                # differentiable pose path: depth -> vertex -> global vertex -> ICP source -> (grad)ICP -> pose, and,
                 # when the map is on the tape, earlier frames -> map -> ICP targets / normals -> pose.
-                o = self.odomprov
                 out = []
                 for b in range(B):
-                    T, _ = ops.grad_icp(src_pts[b], tgt_pts[b], tgt_nrm[b], None, o.numiters, o.damp, o.dist_thresh,
-                                        o.lambda_max, o.B, o.B2, o.nu)
+                    T, _ = ops.grad_icp(src_pts[b], tgt_pts[b], tgt_nrm[b], None, mode=self.odomprov._mode,
+                                        **self.odomprov._kwargs())
                     out.append(T)
                 return _compose(torch.stack(out), prev_poses).unsqueeze(1)
             maps_pc = Pointclouds(points=tgt_pts, normals=tgt_nrm)
@@ -171,6 +163,11 @@ class ICPSLAM(nn.Module):
 
     def _map(self, pointclouds: Pointclouds, live_frame: RGBDImages, inplace: bool = False):
         return update_map_aggregate(pointclouds, live_frame, inplace)
+
+
+def _map_requires_grad(pointclouds):
+    bufs = pointclouds._buf
+    return any(bufs[k] is not None and any(t.requires_grad for t in bufs[k]) for k in ("points", "normals"))
 
 
 def _compose(trans_01, trans_12):

@@ -367,6 +367,10 @@ class Pointclouds(object):
         dc.poll()
         return dc.bound, dc.dev
 
+    def _tighten_counts(self):
+        """Reads the device-side counts back (one sync): host counts exact again (used by profiling passes)."""
+        return list(self._n)
+
     def _set_count_dev(self, b, dev_count, max_growth):
         """The kernels wrote the new count of sequence b to `dev_count`; at most `max_growth` rows
         were added.  Nothing is read back (see _DeviceCount)."""

@@ -174,14 +174,13 @@ class RGBDImages(object):
             self._vertex_map, self._normal_map = self._from_cl(vm), self._from_cl(nm)
             self._alpha_cache = (sg, torch.stack([torch.stack([r[2] for r in row]) for row in rows]).unsqueeze(-1))
             return
+        # every (b, l) frame in ONE launch (gs_frame_maps_batch_f32)
         vm = torch.empty((B, L, H, W, 3), dtype=torch.float32, device=self.device)
         nm = torch.empty_like(vm)
         am = torch.empty((B, L, H, W, 1), dtype=torch.float32, device=self.device) if sigma is not None else None
-        for b in range(B):
-            for s in range(L):
-                ops.frame_maps(depth[b, s, ..., 0], K[b, 0], 0.6 if sigma is None else sigma,
-                               want_alpha=sigma is not None, want_valid=False,
-                               out=(vm[b, s], nm[b, s], None if am is None else am[b, s, ..., 0]))
+        ops.frame_maps_batch(depth.view(B * L, H, W), K.view(B, 4, 4), L, sigma,
+                             out=(vm.view(B * L, H, W, 3), nm.view(B * L, H, W, 3),
+                                  None if am is None else am.view(B * L, H, W)))
         self._vertex_map, self._normal_map = self._from_cl(vm), self._from_cl(nm)
         if am is not None:
             self._alpha_cache = (float(sigma), am)

@@ -14,8 +14,8 @@
  *   - nothing here allocates: the caller (torch) owns every buffer, scratch included;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*), no host sync
  *     unless the function name ends in _sync;
- *   - one call handles ONE sequence of the batch (the reference's batch index b is a
- *     host-side loop / one sequence per GPU);
+ *   - one call handles ONE sequence of the batch (the reference's batch index b is a host-side loop) except
+ *     the *_batch_* entry points at the end, which run the frame loop of B sequences per launch;
  *   - images are channels-last row-major (H, W, C) float32; map attributes are (N, 3)
  *     or (N, 1) float32 row-major; index tables are int64 (rows, 4) = [b, n, h, w];
  *   - 4x4 matrices are 16 contiguous float32, row-major, on the device.
@@ -398,6 +398,70 @@ GS_API int gs_update_map_fusion_dc_f32(float* points, float* normals, float* col
                                        int H, int W, float dist_th, float dot_th, int renorm_all, float* gvertex,
                                        float* gnormal, int32_t* best_pix, int64_t* new_count_out, void* scratch,
                                        void* stream);
+
+/* ---- the frame loop for B INDEPENDENT sequences per call -----------------------------------------------
+ * The reference loops `for b in range(B)` over the sequences of a batch (odometry/gradicp.py:105,
+ * odometry/icp.py:84, slam/fusionutils.py:710-713); one 640x480 sequence cannot fill an MI355X (its frame is a
+ * chain of ~50 dependent launches).  These entry points run EVERY kernel of a frame for all B
+ * sequences at once (workgroup b serves sequence b mod B, so with B = 8 every sequence lives on one XCD), which
+ * pays the dependent-launch floor once per B frames.  Per sequence the results are bit-identical to the
+ * one-sequence entry points they are named after (same device functions).  The descriptor arrays are HOST arrays
+ * of device pointers; nothing is read back. */
+typedef struct gs_map_view {
+  float* points;        /* (capacity, 3) */
+  float* normals;       /* (capacity, 3) */
+  float* colors;        /* (capacity, 3); may be NULL where only points / normals are read */
+  float* ccounts;       /* (capacity, 1); idem */
+  int64_t capacity;     /* rows the buffers hold */
+  int64_t n_bound;      /* host-side upper bound of the surfel count (launch geometry, scratch sizing) */
+  const int64_t* n_dev; /* device int64[1]: the actual count, or NULL when n_bound is exact */
+} gs_map_view;
+
+/* K1 for n_frames frames in one launch: depth (n_frames, H, W), frame f uses K16 + 16 * (f / frames_per_K)
+ * (an RGBDImages of B sequences x L frames: frames_per_K = L); vertex / normal (n_frames, H, W, 3),
+ * alpha (n_frames, H, W); normal / alpha may be NULL.  Same arithmetic as gs_frame_maps_f32. */
+GS_API int gs_frame_maps_batch_f32(const float* depth, const float* K16, int n_frames, int frames_per_K, int H, int W,
+                                   float two_sigma_sq, float* vertex, float* normal, float* alpha, void* stream);
+
+/* ICPSLAM._localize (slam/icpslam.py:238-247) for B sequences: ICP source = the live frame's [::ds, ::ds] lattice
+ * under the previous pose (gs_lattice_source_f32), targets = the map rows that project onto that lattice in the
+ * previous frame (gs_project_map_dc_f32 + the selection of gs_select_targets_f32, binned straight from the map),
+ * numiters (grad)LM iterations, result composed with the previous pose: out_pose16 = T_icp * prev_pose16
+ * (the transform gs_icp_map_dc_f32 returns).  scratch: gs_localize_scratch_bytes(H, W, ds, map.n_bound) bytes per
+ * sequence (after the call it holds the solver state / trace at the offset gs_icp_trace_f32 expects + the
+ * projection table). */
+typedef struct gs_localize_seq {
+  const float* vertex;      /* live frame, LOCAL vertex map (H, W, 3) */
+  const float* depth;       /* live frame depth (H, W) */
+  const float* K16;         /* intrinsics of the previous frame */
+  const float* prev_pose16; /* pose of the previous frame (initial guess and composition) */
+  gs_map_view map;          /* points + normals are read; n_bound > 0 */
+  float* out_pose16;        /* recovered pose of the live frame */
+  void* scratch;
+} gs_localize_seq;
+GS_API int64_t gs_localize_scratch_bytes(int H, int W, int ds, int64_t n_map_bound);
+GS_API int gs_localize_batch_f32(const gs_localize_seq* seqs_host, int B, int H, int W, int ds,
+                                 const gs_icp_params* params_host, void* stream);
+
+/* update_map_fusion (slam/fusionutils.py:761-789) for B sequences: gs_update_map_fusion_dc_f32 per sequence, 6
+ * launches for the whole batch.  scratch: gs_update_map_scratch_bytes(map.n_bound, H, W) per sequence. */
+typedef struct gs_update_seq {
+  gs_map_view map;          /* all four attributes, capacity >= n_bound + H*W */
+  const float* vertex;      /* LOCAL vertex / normal maps (H, W, 3) */
+  const float* normal;
+  const float* depth;       /* (H, W) */
+  const float* rgb;         /* (H, W, 3) */
+  const float* alpha;       /* (H, W) */
+  const float* pose16;      /* the frame's (recovered) pose */
+  const float* K16;
+  float* gvertex;           /* out: global maps (H, W, 3) */
+  float* gnormal;
+  int32_t* best_pix;        /* out: correspondence table (H*W), -1 = none */
+  int64_t* new_count_out;   /* out: device int64[1]; must not alias map.n_dev */
+  void* scratch;
+} gs_update_seq;
+GS_API int gs_update_map_fusion_batch_f32(const gs_update_seq* seqs_host, int B, int H, int W, float dist_th,
+                                          float dot_th, int renorm_all, void* stream);
 
 #ifdef __cplusplus
 }

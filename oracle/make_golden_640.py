@@ -1,0 +1,91 @@
+"""End-to-end golden of the REAL reference at the benchmarked resolution (BASELINE configs[1]): runs
+gradslam.slam.PointFusion(odom="gradicp") of /root/reference (oracle/refimport.py + shims, OpenMP brute-force
+stand-in for chamferdist's knn_points) on the seeded synthetic 640x480 sequence bench.py uses (seed 0) and records
+the recovered poses, the surfel count after every frame, per-frame float64 checksums of the fused points and
+the wall time of every frame on this container's host cores.
+
+    python -m oracle.make_golden_640 [--frames 12]
+
+Build-container only (minutes of CPU).  Outputs (committed, travel to the GPU box):
+  tests/golden/pf640.npz             poses (L,4,4), counts (L,), point / normal / colour / ccount sums per frame,
+                                     a checksum of the input depths (the inputs are regenerated from the seed)
+  tests/golden/cpu_ref_timing.json   seconds per frame of the unmodified reference on `cores` host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+from oracle import refimport  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=12)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--tag", default="pf640")
+    args = ap.parse_args()
+    refimport.import_reference()
+    import torch
+    from gradslam.slam.pointfusion import PointFusion
+    from gradslam.structures.pointclouds import Pointclouds
+    from gradslam.structures.rgbdimages import RGBDImages
+    from gradslam_amd.datasets.synthetic import make_sequence
+
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    L, H, W = args.frames, args.height, args.width
+    s = make_sequence(L, H, W, seed=args.seed)
+    T = torch.from_numpy
+    poses = T(s["poses"][None]).clone()
+    poses[:, 1:] = poses[:, :1]
+    frames = RGBDImages(T(s["colors"][None]), T(s["depths"][None]), T(s["intrinsics"][None]), poses)
+    slam = PointFusion(odom="gradicp")
+    pc = Pointclouds()
+    prev = None
+    rec = np.zeros((L, 4, 4), np.float32)
+    counts = np.zeros(L, np.int64)
+    sums = {k: np.zeros((L, c), np.float64) for k, c in (("points", 3), ("normals", 3), ("colors", 3), ("ccounts", 1))}
+    secs = np.zeros(L)
+    with torch.no_grad():
+        for f in range(L):   # slam/icpslam.py:124-137, one step() per frame so that every frame can be recorded
+            live = frames[:, f]
+            t0 = time.perf_counter()
+            pc, live.poses = slam.step(pc, live, prev, inplace=True)
+            secs[f] = time.perf_counter() - t0
+            prev = live
+            rec[f] = live.poses[0, 0].numpy()
+            counts[f] = pc.points_list[0].shape[0]
+            for k, lst in (("points", pc.points_list), ("normals", pc.normals_list), ("colors", pc.colors_list),
+                           ("ccounts", pc.features_list)):
+                sums[k][f] = lst[0].double().sum(0).numpy()
+            print("frame %2d  %.2f s  %d surfels" % (f, secs[f], counts[f]), flush=True)
+    np.savez_compressed(os.path.join(OUT, args.tag + ".npz"), poses=rec, counts=counts, gt_poses=s["poses"],
+                        depth_sum=np.float64(s["depths"].astype(np.float64).sum()),
+                        color_sum=np.float64(s["colors"].astype(np.float64).sum()),
+                        seed=np.int64(args.seed), H=np.int64(H), W=np.int64(W),
+                        last_points=pc.points_list[0][-4096:].numpy(), **{"sum_" + k: v for k, v in sums.items()})
+    timing = {"what": "unmodified gradslam v0.1.0 PointFusion(odom='gradicp').step on CPU (torch %s), synthetic %dx%d "
+                      "sequence seed %d; chamferdist.knn_points replaced by an OpenMP brute-force stand-in "
+                      "(oracle/shims), everything else is the reference's own PyTorch code" % (torch.__version__, W, H,
+                                                                                             args.seed),
+              "cores": cores, "frames": L, "seconds_per_frame": [float(x) for x in secs],
+              "frames_per_s_steady": float((L - 2) / secs[2:].sum()) if L > 3 else None,
+              "machine": "build container (not the GPU box's host)"}
+    with open(os.path.join(OUT, "cpu_ref_timing" + ("" if args.tag == "pf640" else "_" + args.tag) + ".json"), "w") as f:
+        json.dump(timing, f, indent=1)
+    print(json.dumps(timing))
+
+
+if __name__ == "__main__":
+    main()
