@@ -19,6 +19,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
+# extra compiler flags for debugging builds, e.g. GRADSLAM_HIP_BUILD_FLAGS="-DGS_ICP_TIMELINE" (tools/icp_timeline.py)
+FLAGS += os.environ.get("GRADSLAM_HIP_BUILD_FLAGS", "").split()
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.sep not in c or os.path.exists(c)):

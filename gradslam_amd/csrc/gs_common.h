@@ -153,7 +153,12 @@ struct GsCount {
 };
 GS_DEV int64_t gs_count(const GsCount c) {
   if (!c.dev) return c.host;
-  const int64_t v = *c.dev;
+  // the count is the same for every lane: keep it in scalar registers (a vector load would pin two VGPRs for the
+  // whole kernel; the fused ICP kernel is register-bound)
+  const int64_t raw = *c.dev;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)raw);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)raw >> 32));
+  const int64_t v = (int64_t)(((uint64_t)hi << 32) | lo);
   return v < c.host ? (v < 0 ? 0 : v) : c.host;
 }
 

@@ -37,7 +37,10 @@ __global__ void __launch_bounds__(256) gs_fuse_merge_kernel(
     int renorm_all) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= gs_count(n_map_c)) return;
-  if (*any_flag == 0) return;  // :659 — empty table: the reference skips the whole merge
+  // :659 — empty table: the reference skips the whole merge.  Its test is on the table of the WHOLE batch, so a
+  // caller that handles the sequences of a batch one call at a time passes renorm_all = 2 ("another sequence has
+  // matches": rewrite every row even though this table is empty)
+  if (*any_flag == 0 && renorm_all != 2) return;
   const int32_t p = pix_of[n];
   if (p < 0 && !renorm_all) return;
   const float a = p >= 0 ? alpha[p] : 0.0f;

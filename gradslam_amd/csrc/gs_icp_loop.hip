@@ -96,6 +96,7 @@ constexpr int FS_BLOCK = 768;            // 12 waves; 2 blocks per CU keep all 2
 constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 96 queries per block, their rows are built by the first two waves
 constexpr int FS_RPG = (FS_QPB / 4) * LIN_NV <= FS_BLOCK ? 4 : 8;  // rows per group in the block reduction
 constexpr int FS_RG = FS_QPB / FS_RPG;                            // row groups
+constexpr int FS_HG = 16;  // lanes per query of the shell search for queries the 2x2x2 stage leaves open
 static_assert(FS_QPB <= 2 * GS_WAVE && FS_QPB % FS_RPG == 0 && FS_RG * LIN_NV <= FS_BLOCK, "block shape");
 
 // FULL = true : first half of iteration `it`  (prologue: LM update of iteration it-1, then search
@@ -135,54 +136,72 @@ struct IcpHalfSeq {
   float* tape_sys;
 };
 
-template <bool FULL>
+// index pairs (into [a0..a5, res]) of the 28 accumulated products: 21 upper-triangular a_i a_k, 6 a_i res, res res
+__constant__ unsigned char FS_PA[LIN_NV] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6};
+__constant__ unsigned char FS_PB[LIN_NV] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6};
+
+// One half-iteration for one sequence.  G lanes serve a query, so a block holds NQ = FS_BLOCK / G query slots =
+// NU row units of FS_QPB (96) queries.  Every unit produces ONE partial row, always with the same fixed-order sums,
+// so the normal equations do not depend on G, on the number of blocks or on which block works on which unit: a
+// block owns the contiguous units [lb * upb, (lb + 1) * upb) and walks them NU at a time (grids smaller than the
+// unit count are how a GPU shared by 8 sequences keeps every block resident and pays the prologue once per block).
+template <bool FULL, int G>
 GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const float dist_thresh, const gs_icp_params& prm,
-                          const int it, const int rows_in_reduced, const unsigned lb) {
+                          const int it, const int rows_in_reduced, const unsigned lb, const int upb,
+                          unsigned long long* __restrict__ tl_arg = nullptr) {
+#ifdef GS_ICP_TIMELINE
+  unsigned long long* __restrict__ tl = tl_arg;
+#else
+  constexpr unsigned long long* tl = nullptr;  // per-block timeline stamps: debugging builds only (-DGS_ICP_TIMELINE)
+#endif
+  constexpr int NQ = FS_BLOCK / G, NU = NQ / FS_QPB;
+  static_assert(NQ % FS_QPB == 0 && 2 * NU <= FS_BLOCK / GS_WAVE, "block shape");
   const float* __restrict__ src_in = q.src_in;
   float* __restrict__ src_out = q.src_out;
   const float* __restrict__ tgt = q.tgt;
   const float* __restrict__ tn = q.tn;
-  const GsGrid* __restrict__ gp = q.gp;
   const int* __restrict__ cell_start = q.cell_start;
   const float4* __restrict__ sorted = q.sorted;
   const double* __restrict__ partials_in = q.partials_in;
   double* __restrict__ partials_out = q.partials_out;
-  const IcpSmall* __restrict__ st_in = q.st_in;
-  IcpSmall* __restrict__ st_out = q.st_out;
-  float* __restrict__ trace = q.trace;
   int64_t* __restrict__ out_idx = q.out_idx;
   int32_t* __restrict__ tape_idx = q.tape_idx;
-  float* __restrict__ tape_sys = q.tape_sys;
+
   __shared__ IcpSmall sm;
   __shared__ double S[32];
   __shared__ double sub[FS_BLOCK / 32][32];
-  __shared__ unsigned long long keys_s[FS_QPB];
-  __shared__ float qs[FS_QPB][3];
-  __shared__ int unres_q[FS_QPB];
-  __shared__ int unres_n;
+  __shared__ unsigned long long keys_s[NQ];
+  __shared__ float qs[NQ][3];
+  __shared__ float qa_s[NQ][8];   // a0..a5, residual of every query of the block (zero when filtered out)
+  __shared__ double sub_s[NU][FS_RG][LIN_NV];
+  __shared__ int unres_q[NQ], hard_q[NQ];
+  __shared__ int unres_n, hard_n;
   __shared__ unsigned long long red[FS_BLOCK / GS_WAVE];
 
   const int64_t n_src = gs_count(n_src_c), n_tgt = gs_count(q.n_tgt);
+  const int nunits = (int)((n_src + FS_QPB - 1) / FS_QPB);
   // rows the previous kernel produced (already added up to one row by gs_icp_reduce_rows_kernel for large solves)
-  const int nrows_in = rows_in_reduced ? 1 : (int)((n_src + FS_QPB - 1) / FS_QPB);
-  // lb = logical block: which FS_QPB queries this block owns
-  if ((int64_t)lb * FS_QPB >= n_src && lb != 0) return;  // beyond the actual count (bound-sized grid)
-  // the source point of this group does not depend on the prologue: issue its load first so that
+  const int nrows_in = rows_in_reduced ? 1 : nunits;
+  const int u_first = (int)lb * upb, u_last = (u_first + upb < nunits) ? u_first + upb : nunits;
+  if (u_first >= nunits && lb != 0) return;  // beyond the actual count (bound-sized grid)
+  // the source point of the first slot does not depend on the prologue: issue its load first so that
   // the global-memory latency hides behind the scalar stage
-  const int lane = threadIdx.x & (GQ_G - 1), slot = threadIdx.x / GQ_G;
-  const int64_t s = (int64_t)lb * FS_QPB + slot;
+  const int lane = threadIdx.x & (G - 1), slot = threadIdx.x / G;
   float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
-  if (s < n_src) {
-    p0 = src_in[3 * s];
-    p1 = src_in[3 * s + 1];
-    p2 = src_in[3 * s + 2];
+  {
+    const int64_t s = (int64_t)u_first * FS_QPB + slot;
+    if (slot / FS_QPB + u_first < u_last && s < n_src) {
+      p0 = src_in[3 * s];
+      p1 = src_in[3 * s + 1];
+      p2 = src_in[3 * s + 2];
+    }
   }
 
   // the state of the previous half and the grid header are fetched while the partial rows are summed
   // (their latency is off the critical path; the sums' __syncthreads publish sm)
-  const GsGrid g = *gp;
+  const GsGrid g = *q.gp;
   if (threadIdx.x >= GS_WAVE && threadIdx.x < GS_WAVE + (int)(sizeof(IcpSmall) / 4))
-    reinterpret_cast<float*>(&sm)[threadIdx.x - GS_WAVE] = reinterpret_cast<const float*>(st_in)[threadIdx.x - GS_WAVE];
+    reinterpret_cast<float*>(&sm)[threadIdx.x - GS_WAVE] = reinterpret_cast<const float*>(q.st_in)[threadIdx.x - GS_WAVE];
 
   // ---- prologue: finish the previous half-iteration (identical in every block)
   if (FULL) {
@@ -190,151 +209,283 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
     if (it > 0) e1 = icp_sum_col27<FS_BLOCK>(partials_in, nrows_in, reinterpret_cast<double*>(red));
     else __syncthreads();
     if (threadIdx.x == 0) {  // scalar stage, in place on the LDS copy of the state
-      if (it > 0) icp_update_math((float)e1, sm, prm, (lb == 0 && it - 1 < GS_ICP_MAX_ITERS) ? trace + 12 * (it - 1) : nullptr);
+      if (it > 0)
+        icp_update_math((float)e1, sm, prm, (lb == 0 && it - 1 < GS_ICP_MAX_ITERS) ? q.trace + 12 * (it - 1) : nullptr);
       unres_n = 0;
+      hard_n = 0;
     }
   } else {
     icp_sum_rows<FS_BLOCK>(partials_in, nrows_in, S, sub);
     if (threadIdx.x < GS_WAVE) gs_solve_spd6_wave(S, sm.damp, sm.xi);  // 6x6 solve across the lanes of wave 0
     __syncthreads();
     if (threadIdx.x == 0) {
-      if (tape_sys && lb == 0) tape_write_sys(tape_sys, it, S, sm.damp);
+      if (q.tape_sys && lb == 0) tape_write_sys(q.tape_sys, it, S, sm.damp);
       icp_solve_finish(S, sm);
       unres_n = 0;
+      hard_n = 0;
     }
   }
   __syncthreads();
   if (lb == 0 && threadIdx.x < (int)(sizeof(IcpSmall) / 4))
-    reinterpret_cast<float*>(st_out)[threadIdx.x] = reinterpret_cast<const float*>(&sm)[threadIdx.x];
+    reinterpret_cast<float*>(q.st_out)[threadIdx.x] = reinterpret_cast<const float*>(&sm)[threadIdx.x];
+  if (tl && threadIdx.x == 0) { tl[4] = wall_clock64(); tl[7] = 0; tl[2] = 0; }
 
-  // ---- search: one source point per GQ_G-lane group, pending transform applied to the loaded point.
-  // A NaN source point (empty slot of an un-compacted lattice, gs_lattice_source_f32) is skipped: it stays
-  // NaN through every transform, is never searched and contributes no row.
-  if (s < n_src && p0 != p0) {
-    if (lane == 0) {
-      if (FULL) { src_out[3 * s] = p0; src_out[3 * s + 1] = p0; src_out[3 * s + 2] = p0; }
-      qs[slot][0] = p0; qs[slot][1] = p0; qs[slot][2] = p0;
-      keys_s[slot] = ~0ull;
-    }
-  } else if (s < n_src) {
-    const float* T = FULL ? sm.T_step : sm.Tr;
-    float qx, qy, qz;
-    gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
-    bool done;
-    const unsigned long long key = grid_search_group(g, cell_start, sorted, qx, qy, qz, lane, &done);
-    if (lane == 0) {
-      if (FULL) {  // the transformed cloud of this iteration
-        src_out[3 * s] = qx;
-        src_out[3 * s + 1] = qy;
-        src_out[3 * s + 2] = qz;
+  for (int u0 = u_first; u0 < u_last; u0 += NU) {
+    const int64_t s = (int64_t)u0 * FS_QPB + slot;
+    const bool live = (u0 + slot / FS_QPB < u_last) && s < n_src;  // this slot holds a source point
+    if (u0 != u_first) {
+      p0 = p1 = p2 = 0.0f;
+      if (live) {
+        p0 = src_in[3 * s];
+        p1 = src_in[3 * s + 1];
+        p2 = src_in[3 * s + 2];
       }
-      qs[slot][0] = qx; qs[slot][1] = qy; qs[slot][2] = qz;
-      keys_s[slot] = key;
-      if (!done) unres_q[atomicAdd(&unres_n, 1)] = slot;
     }
-  }
-  __syncthreads();
-  const int nun = unres_n;  // block-uniform
-  for (int u = 0; u < nun; ++u) {
-    const int us = unres_q[u];
-    const unsigned long long key = block_brute_min_sorted<FS_BLOCK>(qs[us][0], qs[us][1], qs[us][2], sorted,
-                                                                    cell_start[g.ncell], red);
-    if (threadIdx.x == 0) keys_s[us] = key;
-  }
-  __syncthreads();
+    // ---- search: one source point per G-lane group, pending transform applied to the loaded point.
+    // A NaN source point (empty slot of an un-compacted lattice, gs_lattice_source_f32) is skipped: it stays
+    // NaN through every transform, is never searched and contributes no row.
+    if (live && p0 != p0) {
+      if (lane == 0) {
+        if (FULL) { src_out[3 * s] = p0; src_out[3 * s + 1] = p0; src_out[3 * s + 2] = p0; }
+        qs[slot][0] = p0; qs[slot][1] = p0; qs[slot][2] = p0;
+        keys_s[slot] = ~0ull;
+      }
+    } else if (live) {
+      const float* T = FULL ? sm.T_step : sm.Tr;
+      float qx, qy, qz;
+      gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
+      bool done;
+      const unsigned long long key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, &done);
+      if (lane == 0) {
+        if (FULL) {  // the transformed cloud of this iteration
+          src_out[3 * s] = qx;
+          src_out[3 * s + 1] = qy;
+          src_out[3 * s + 2] = qz;
+        }
+        qs[slot][0] = qx; qs[slot][1] = qy; qs[slot][2] = qz;
+        keys_s[slot] = key;
+        if (!done) hard_q[atomicAdd(&hard_n, 1)] = slot;
+      }
+    }
+    __syncthreads();
+    // ---- the few queries the 2x2x2 stage did not resolve (neighbour farther than ~half a cell): Chebyshev shells
+    // by groups of FS_HG lanes, so that they do not hold up the waves of the common case
+    const int nh = hard_n;  // block-uniform
+    for (int i = threadIdx.x / FS_HG; i < nh; i += FS_BLOCK / FS_HG) {
+      const int hs = hard_q[i];
+      bool done;
+      const unsigned long long key = grid_search_rings<FS_HG>(g, cell_start, sorted, qs[hs][0], qs[hs][1], qs[hs][2],
+                                                              threadIdx.x & (FS_HG - 1), keys_s[hs], &done);
+      if ((threadIdx.x & (FS_HG - 1)) == 0) {
+        keys_s[hs] = key;
+        if (!done) unres_q[atomicAdd(&unres_n, 1)] = hs;
+      }
+    }
+    if (nh) {
+      __syncthreads();
+      if (threadIdx.x == 0) hard_n = 0;
+      __syncthreads();
+    }
+    if (tl && threadIdx.x == 0 && u0 == u_first) { tl[5] = wall_clock64(); tl[2] += (unsigned long long)nh; }
+    const int nun = unres_n;  // block-uniform
+    if (tl && threadIdx.x == 0) { tl[7] += (unsigned long long)nun; if (u0 == u_first) tl[6] = wall_clock64(); }
+    for (int u = 0; u < nun; ++u) {
+      const int us = unres_q[u];
+      const unsigned long long key = block_brute_min_sorted<FS_BLOCK>(qs[us][0], qs[us][1], qs[us][2], sorted,
+                                                                      cell_start[g.ncell], red);
+      if (threadIdx.x == 0) keys_s[us] = key;
+    }
+    if (nun) {
+      __syncthreads();
+      if (threadIdx.x == 0) unres_n = 0;
+      __syncthreads();
+    }
 
-  // ---- rows: thread t < FS_QPB (the first two waves) builds the row of query t; the 28 products go straight to LDS
-  // (held in registers they would be 56 VGPRs per lane)
-  __shared__ double rows_s[FS_QPB][LIN_NV + 1];
-  __shared__ double sub_s[FS_RG][LIN_NV];
-  const int64_t r = (int64_t)lb * FS_QPB + threadIdx.x;
-  double rr = 0.0;
-  if (threadIdx.x < FS_QPB) {
-    bool keep = false;
-    float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, res = 0.0f;
-    if (r < n_src && qs[threadIdx.x][0] != qs[threadIdx.x][0]) {  // skipped (NaN) source point
-      if (FULL && out_idx) out_idx[r] = -1;
-      if (tape_idx) tape_idx[r] = -1;
-    } else if (r < n_src) {
-      const unsigned long long bb = keys_s[threadIdx.x];
-      int64_t j = (int64_t)(bb & 0xffffffffull);
-      if (j >= n_tgt) j = 0;  // only when every distance was NaN
-      const float d2 = __uint_as_float((uint32_t)(bb >> 32));
-      keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
-      gn_row(qs[threadIdx.x][0], qs[threadIdx.x][1], qs[threadIdx.x][2], tgt, tn, j, a, res);
-      if (FULL && out_idx) out_idx[r] = j;
-      if (tape_idx) tape_idx[r] = keep ? (int32_t)j : -1;
-    }
-    if (keep) rr = (double)res * (double)res;
-    if (FULL) {
-      double* row = rows_s[threadIdx.x];
-      int q = 0;
+    // ---- Gauss-Newton row of every query: its own group's first lane gathers the match and leaves [a, res] in LDS
+    if (lane == 0) {
+      float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, res = 0.0f;
+      if (live && qs[slot][0] != qs[slot][0]) {  // skipped (NaN) source point
+        if (FULL && out_idx) out_idx[s] = -1;
+        if (tape_idx) tape_idx[s] = -1;
+      } else if (live) {
+        const unsigned long long bb = keys_s[slot];
+        int64_t j = (int64_t)(bb & 0xffffffffull);
+        if (j >= n_tgt) j = 0;  // only when every distance was NaN
+        const float d2 = __uint_as_float((uint32_t)(bb >> 32));
+        const bool keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
+        gn_row(qs[slot][0], qs[slot][1], qs[slot][2], tgt, tn, j, a, res);
+        if (FULL && out_idx) out_idx[s] = j;
+        if (tape_idx) tape_idx[s] = keep ? (int32_t)j : -1;
+        if (!keep) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int k = i; k < 6; ++k) row[q++] = keep ? (double)a[i] * (double)a[k] : 0.0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) row[21 + i] = keep ? (double)a[i] * (double)res : 0.0;
-      row[27] = rr;
-    }
-  }
-  if (!FULL) {  // residual only: one value per query, wave reductions of the (up to two) row-building waves
-    if (FS_QPB <= GS_WAVE) {
-      if (threadIdx.x < GS_WAVE) {
-        const double sum = gs_wave_sum_f64(rr);
-        if (threadIdx.x == 0) partials_out[(int64_t)lb * LIN_NV + 27] = sum;
+          for (int i = 0; i < 6; ++i) a[i] = 0.0f;
+          res = 0.0f;
+        }
       }
-    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) qa_s[slot][i] = a[i];
+      qa_s[slot][6] = res;
+    }
+    __syncthreads();
+    if (!FULL) {  // residual only: per unit the wave-sum tree over its 96 values (64 + 32), then the two wave sums
       double* red2 = reinterpret_cast<double*>(red);
-      if (threadIdx.x < 2 * GS_WAVE) {
+      const int wave = threadIdx.x / GS_WAVE, wl = threadIdx.x & (GS_WAVE - 1);
+      if (wave < 2 * NU) {
+        const int r = (wave & 1) * GS_WAVE + wl;   // row within the unit
+        double rr = 0.0;
+        if (r < FS_QPB) {
+          const float res = qa_s[(wave >> 1) * FS_QPB + r][6];
+          rr = (double)res * (double)res;
+        }
         const double sum = gs_wave_sum_f64(rr);
-        if ((threadIdx.x & (GS_WAVE - 1)) == 0) red2[threadIdx.x / GS_WAVE] = sum;
+        if (wl == 0) red2[wave] = sum;
       }
       __syncthreads();
-      if (threadIdx.x == 0) partials_out[(int64_t)lb * LIN_NV + 27] = red2[0] + red2[1];
+      if (threadIdx.x < NU && u0 + (int)threadIdx.x < u_last)
+        partials_out[(int64_t)(u0 + threadIdx.x) * LIN_NV + 27] = red2[2 * threadIdx.x] + red2[2 * threadIdx.x + 1];
+      __syncthreads();
+      continue;
     }
-    return;
-  }
-  // FS_QPB rows x 28 values through LDS (a 28-fold wave shuffle reduction costs ~6 us of dependent
-  // cross-lane traffic in one wave): FS_RG groups of 28 threads add 4 rows each, then 28 threads
-  // add the sub-sums, always in index order.
-  __syncthreads();
-  if (threadIdx.x < FS_RG * LIN_NV) {
-    const int i = threadIdx.x % LIN_NV, part = threadIdx.x / LIN_NV;
-    double t = rows_s[FS_RPG * part][i];
+    // FS_QPB rows x 28 values per unit: FS_RG groups of 28 threads add the products of 4 rows each, then 28
+    // threads add the sub-sums, always in index order.
+    for (int w = threadIdx.x; w < NU * FS_RG * LIN_NV; w += FS_BLOCK) {
+      const int i = w % LIN_NV, part = (w / LIN_NV) % FS_RG, un = w / (LIN_NV * FS_RG);
+      const int ia = FS_PA[i], ib = FS_PB[i];
+      const float* r0 = qa_s[un * FS_QPB + FS_RPG * part];
+      double t = (double)r0[ia] * (double)r0[ib];
 #pragma unroll
-    for (int u = 1; u < FS_RPG; ++u) t += rows_s[FS_RPG * part + u][i];
-    sub_s[part][i] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x < LIN_NV) {
-    double t = sub_s[0][threadIdx.x];
+      for (int u = 1; u < FS_RPG; ++u) t += (double)r0[8 * u + ia] * (double)r0[8 * u + ib];
+      sub_s[un][part][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NU * LIN_NV) {
+      const int i = threadIdx.x % LIN_NV, un = threadIdx.x / LIN_NV;
+      if (u0 + un < u_last) {
+        double t = sub_s[un][0][i];
 #pragma unroll
-    for (int k = 1; k < FS_RG; ++k) t += sub_s[k][threadIdx.x];
-    partials_out[(int64_t)lb * LIN_NV + threadIdx.x] = t;
+        for (int k = 1; k < FS_RG; ++k) t += sub_s[un][k][i];
+        partials_out[(int64_t)(u0 + un) * LIN_NV + i] = t;
+      }
+    }
+    __syncthreads();
   }
-}
-
-template <bool FULL>
-__global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_kernel(const IcpHalfSeq q, GsCount n_src_c, float dist_thresh,
-                                                                  gs_icp_params prm, int it, int rows_in_reduced) {
-  icp_half_body<FULL>(q, n_src_c, dist_thresh, prm, it, rows_in_reduced, gs_xcd_block(blockIdx.x, gridDim.x));
 }
 
 // Batched: block b works for sequence b % B (with B = 8 a sequence lives on one XCD: its binned targets, cell table
-// and partial rows stay in that XCD's L2) on that sequence's block b / B; when B divides 8 the 8 / B XCDs of a
+// and partial rows stay in that XCD's L2) as that sequence's block b / B; when B divides 8 the 8 / B XCDs of a
 // sequence each own a contiguous range of its query rows.
 struct IcpHalfBatch {
   int B;
+  int upb;  // row units per block
+  int rot;  // experiment: sequence of block b = (b + rot) % B
+  unsigned long long* timeline;  // debugging aid (GRADSLAM_HIP_ICP_TIMELINE): per block [start, end, hw id, xcc id]
   IcpHalfSeq s[GS_MAX_BATCH];
 };
-template <bool FULL>
+template <bool FULL, int G>
 __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_batch_kernel(const IcpHalfBatch hb, GsCount n_src_c,
                                                                         float dist_thresh, gs_icp_params prm, int it,
                                                                         int rows_in_reduced) {
   const unsigned B = (unsigned)hb.B, blk = blockIdx.x / B, nblk = gridDim.x / B;
   const unsigned X = (GS_XCDS % B == 0) ? GS_XCDS / B : 1u;
-  icp_half_body<FULL>(hb.s[blockIdx.x % B], n_src_c, dist_thresh, prm, it, rows_in_reduced, gs_xcd_block(blk, nblk, X));
+#ifdef GS_ICP_TIMELINE
+  unsigned long long t0 = 0;
+  if (hb.timeline && threadIdx.x == 0) t0 = wall_clock64();
+#endif
+  icp_half_body<FULL, G>(hb.s[(blockIdx.x + hb.rot) % B], n_src_c, dist_thresh, prm, it, rows_in_reduced,
+                         gs_xcd_block(blk, nblk, X), hb.upb, hb.timeline ? hb.timeline + 72 * (size_t)blockIdx.x : nullptr);
+#ifdef GS_ICP_TIMELINE
+  if (hb.timeline && threadIdx.x == 0) {
+    unsigned long long* r = hb.timeline + 72 * (size_t)blockIdx.x;
+    r[0] = t0;
+    r[1] = wall_clock64();
+  }
+#endif
+}
+
+static size_t icp_rows(int64_t n_src) { return (size_t)gs_ceil_div(n_src, FS_QPB); }  // >= ceil(n_src / LIN_BLOCK)
+
+// Launch geometry of a half-iteration: lanes per query G, blocks per sequence nb and row units per block upb.
+// Every sequence of the batch gets an equal share of the resident blocks (2 per CU at 768 threads); the largest G
+// whose blocks all fit that share wins (more lanes per query = shorter searches, but only while every query of the
+// sequence is in flight at once); if not even G = 2 fits, blocks walk several unit groups.
+// GRADSLAM_HIP_ICP_LANES = 2 | 4 | 8 forces G (A/B runs: the results do not depend on it).
+struct IcpHalfPlan {
+  int G, nb, upb;
+};
+static IcpHalfPlan icp_half_plan(int64_t n_src, int B) {
+  static int cus = 0, forced = -1, per_cu = 2;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+    else
+      cus = 256;
+  }
+  if (forced < 0) {
+    const char* e = getenv("GRADSLAM_HIP_ICP_LANES");
+    forced = e ? atoi(e) : 0;
+    const char* f = getenv("GRADSLAM_HIP_ICP_BLOCKS_PER_CU");  // resident-block budget per CU (experiments)
+    if (f && atoi(f) > 0) per_cu = atoi(f);
+  }
+  const int nunits = (int)icp_rows(n_src);
+  const int budget = (per_cu * cus) / B > 0 ? (per_cu * cus) / B : 1;
+  IcpHalfPlan pl{2, 1, 1};
+  for (int G = 8; G >= 2; G >>= 1) {
+    const int NU = FS_BLOCK / G / FS_QPB, need = (nunits + NU - 1) / NU;
+    if ((forced == 0 && need <= budget) || forced == G || (forced == 0 && G == 2)) {
+      pl.G = G;
+      pl.nb = need <= budget ? need : budget;
+      pl.upb = NU * ((nunits + NU * pl.nb - 1) / (NU * pl.nb));
+      pl.nb = (nunits + pl.upb - 1) / pl.upb;
+      break;
+    }
+  }
+  return pl;
+}
+template <bool FULL>
+static void icp_half_launch(const IcpHalfPlan& pl, IcpHalfBatch& hb, GsCount n_src_c, const gs_icp_params* prm, int it,
+                            int rows_in_reduced, hipStream_t st) {
+  hb.upb = pl.upb;
+  static const int rot_env = getenv("GRADSLAM_HIP_SEQ_ROT") ? atoi(getenv("GRADSLAM_HIP_SEQ_ROT")) : 0;
+  hb.rot = rot_env;
+  static const char* tl_path = getenv("GRADSLAM_HIP_ICP_TIMELINE");
+  static unsigned long long* tl_buf = nullptr;
+  hb.timeline = nullptr;
+  const size_t tl_n = 72 * (size_t)hb.B * pl.nb;
+  const bool tl = tl_path && FULL && it == prm->numiters - 1;  // record the last full half-iteration of a solve
+  if (tl) {
+    if (!tl_buf && hipMalloc(&tl_buf, 8 * 64 * 8192) != hipSuccess) tl_buf = nullptr;
+    if (tl_buf && tl_n <= 72 * 7000) {
+      hb.timeline = tl_buf;
+      (void)hipMemsetAsync(tl_buf, 0, 8 * tl_n, st);
+    }
+  }
+  const dim3 grid((unsigned)(hb.B * pl.nb)), block(FS_BLOCK);
+  if (pl.G == 8)
+    hipLaunchKernelGGL((gs_icp_half_batch_kernel<FULL, 8>), grid, block, 0, st, hb, n_src_c, prm->dist_thresh, *prm, it,
+                       rows_in_reduced);
+  else if (pl.G == 4)
+    hipLaunchKernelGGL((gs_icp_half_batch_kernel<FULL, 4>), grid, block, 0, st, hb, n_src_c, prm->dist_thresh, *prm, it,
+                       rows_in_reduced);
+  else
+    hipLaunchKernelGGL((gs_icp_half_batch_kernel<FULL, 2>), grid, block, 0, st, hb, n_src_c, prm->dist_thresh, *prm, it,
+                       rows_in_reduced);
+  if (hb.timeline) {  // debugging aid: synchronous dump of this launch's block records
+    std::unique_ptr<unsigned long long[]> h(new unsigned long long[tl_n]);
+    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.get(), tl_buf, 8 * tl_n, hipMemcpyDeviceToHost) == hipSuccess) {
+      FILE* f = fopen(tl_path, "w");
+      if (f) {
+        fprintf(f, "# B=%d G=%d nb=%d upb=%d: block start end(100MHz ticks) hw_id xcc_id after_prologue after_search after_unres n_unres\n", hb.B, pl.G, pl.nb, pl.upb);
+        for (size_t i = 0; i < tl_n / 72; ++i) {
+          fprintf(f, "%zu", i);
+          for (int k = 0; k < 72; ++k) fprintf(f, " %llu", h[72 * i + k]);
+          fprintf(f, "\n");
+        }
+        fclose(f);
+      }
+    }
+    hb.timeline = nullptr;
+  }
 }
 
 // Large solves (more rows than FS_REDUCE_ROWS): every block of the next kernel adding up all rows is
@@ -488,7 +639,6 @@ struct IcpScratch {
   double* partials[2];
   void* grid;
 };
-static size_t icp_rows(int64_t n_src) { return (size_t)gs_ceil_div(n_src, FS_QPB); }  // >= ceil(n_src / LIN_BLOCK)
 static IcpScratch icp_carve(void* scratch, int64_t n_src) {
   char* p = reinterpret_cast<char*>(scratch);
   IcpScratch s;
@@ -593,28 +743,25 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
       prof_bytes = icp_alg_bytes(prm->numiters, n_src, n_src, n_binned);
     }
     std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
+    const IcpHalfPlan plan = icp_half_plan(n_src, 1);
+    IcpHalfBatch hb;
+    hb.B = 1;
     for (int it = 0; it < prm->numiters; ++it) {
       float* cur = cloud(it);
-      {
-        const IcpHalfSeq q{cur_in, cur, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted,
+      hb.s[0] = IcpHalfSeq{cur_in, cur, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted,
                            sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1], &sc.state->s[(h + 1) & 1],
                            sc.state->trace, out_idx, tidx(it, 0), nullptr};
-        hipLaunchKernelGGL((gs_icp_half_kernel<true>), dim3(nfs), dim3(FS_BLOCK), 0, st, q, n_src_c, prm->dist_thresh,
-                           *prm, it, 0);
-      }
+      icp_half_launch<true>(plan, hb, n_src_c, prm, it, 0, st);
       ++h;
       if (reduce_rows) {
         GsProf prof(GS_PROF_SOLVE, 1.0, st);
         hipLaunchKernelGGL(gs_icp_reduce_rows_kernel, dim3(1), dim3(FS_BLOCK), 0, st, sc.partials[(h + 1) & 1], n_src_c,
                            sc.rowred);
       }
-      {
-        const IcpHalfSeq q{cur, nullptr, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted,
+      hb.s[0] = IcpHalfSeq{cur, nullptr, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted,
                            reduce_rows ? sc.rowred : sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
                            &sc.state->s[(h + 1) & 1], sc.state->trace, nullptr, tidx(it, 1), tp.sys};
-        hipLaunchKernelGGL((gs_icp_half_kernel<false>), dim3(nfs), dim3(FS_BLOCK), 0, st, q, n_src_c, prm->dist_thresh,
-                           *prm, it, reduce_rows ? 1 : 0);
-      }
+      icp_half_launch<false>(plan, hb, n_src_c, prm, it, reduce_rows ? 1 : 0, st);
       ++h;
       cur_in = cur;
     }
@@ -866,6 +1013,7 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
     }
   }
   std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
+  const IcpHalfPlan plan = icp_half_plan(n_lat, B);
   IcpHalfBatch hb;
   hb.B = B;
   int h = 0;
@@ -879,8 +1027,7 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
                            &sc[b].state->s[h & 1], &sc[b].state->s[(h + 1) & 1], sc[b].state->trace, nullptr, nullptr,
                            nullptr};
     }
-    hipLaunchKernelGGL((gs_icp_half_batch_kernel<true>), dim3((unsigned)(B * nfs)), dim3(FS_BLOCK), 0, st, hb, n_src_c,
-                       prm->dist_thresh, *prm, it, 0);
+    icp_half_launch<true>(plan, hb, n_src_c, prm, it, 0, st);
     ++h;
     if (reduce_rows) {
       IcpRowsBatch rb;
@@ -897,8 +1044,7 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
       u.st_in = &sc[b].state->s[h & 1];
       u.st_out = &sc[b].state->s[(h + 1) & 1];
     }
-    hipLaunchKernelGGL((gs_icp_half_batch_kernel<false>), dim3((unsigned)(B * nfs)), dim3(FS_BLOCK), 0, st, hb, n_src_c,
-                       prm->dist_thresh, *prm, it, reduce_rows ? 1 : 0);
+    icp_half_launch<false>(plan, hb, n_src_c, prm, it, reduce_rows ? 1 : 0, st);
     ++h;
   }
   prof_loop.reset();

@@ -116,14 +116,16 @@ GS_DEV int grid_cell(const GsGrid& g, float x, float y, float z) {
   return (iz * g.ny + iy) * g.nx + ix;
 }
 
-// A query is served by a group of GQ_G = 8 lanes (8 queries per wave; 16 lanes halve the work per lane but
-// double the waves every kernel has to launch, which costs more than it saves: measured 12.6 -> 10.7 us
-// per ICP half-iteration kernel going from 16 to 8, 11.5 us with 4): the lanes first fetch the
+// A query is served by a group of G lanes (G = 8, 4 or 2; 64 / G queries per wave): the lanes first fetch the
 // [begin, end) bounds of the row segments of a shell in parallel, then stride together over every
 // segment, and finally min-reduce their packed (distance bits << 32 | index) keys -- the same
-// ordering as the brute-force engine's 64-bit atomicMin.  This turns ~100 serial dependent
-// gathers per query into ~15 wave-wide ones (the search is latency-, not bandwidth-bound).
-constexpr int GQ_G = 8;
+// ordering as the brute-force engine's 64-bit atomicMin, so the result does not depend on G.  This turns ~100
+// serial dependent gathers per query into ~15 wave-wide ones (the search is latency-, not bandwidth-bound).
+// Which G is fastest depends on how many queries have to share the chip: ONE 640x480 sequence per GPU (19 200
+// queries on 256 CUs) is served best by 8 lanes per query (measured 12.6 / 10.7 / 11.5 us per ICP half-iteration
+// with 16 / 8 / 4 lanes: every dependent launch pays for the waves it has to start); with 8 sequences per GPU a
+// sequence owns one XCD (32 CUs x 24 waves), where only 2 lanes per query keep all its queries in flight at once.
+constexpr int GQ_G = 8;  // group size of the API-level query kernel and of one-sequence-per-GPU solves
 
 GS_DEV unsigned long long grid_key(float qx, float qy, float qz, const float4 p) {
   const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
@@ -134,136 +136,127 @@ GS_DEV unsigned long long grid_key(float qx, float qy, float qz, const float4 p)
   return d == d ? knn_pack(d, (uint32_t)__float_as_int(p.w)) : ~0ull;
 }
 
-// cooperative scan of one segment list: lane `lane` holds (sb, se) of slot `lane` (se <= sb: empty)
-// The candidates of all GQ_G slots are treated as ONE flat list (prefix sum of the slot lengths over
-// the group); lane l takes flat positions l, l+GQ_G, ... and finds (slot, offset) of each by a
-// log2(GQ_G)-step binary search on the prefix with shuffles.  Gather addresses therefore depend on
-// registers only, so the four gathers of a pass are in flight together instead of one dependent
-// global load per slot.  Every lane runs the same number of passes (shuffles need all GQ_G lanes).
-GS_DEV int grid_flat_index(int t, int sb, int excl) {
-  int j = 0;
-#pragma unroll
-  for (int step = GQ_G / 2; step > 0; step >>= 1) {
-    const int e = __shfl(excl, j + step, GQ_G);
-    j = (e <= t) ? j + step : j;
-  }
-  return __shfl(sb, j, GQ_G) + (t - __shfl(excl, j, GQ_G));
-}
-
-GS_DEV unsigned long long grid_scan_slots(int sb, int se, int lane, float qx, float qy, float qz,
-                                          const float4* __restrict__ sorted, unsigned long long key) {
-  const int len = se > sb ? se - sb : 0;
-  int incl = len;
-#pragma unroll
-  for (int d = 1; d < GQ_G; d <<= 1) {
-    const int t = __shfl_up(incl, d, GQ_G);
-    if (lane >= d) incl += t;
-  }
-  const int excl = incl - len;
-  const int total = __shfl(incl, GQ_G - 1, GQ_G);
-  for (int t0 = 0; t0 < total; t0 += 4 * GQ_G) {  // four independent gathers in flight per lane
-    int t[4], ix[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      t[u] = t0 + u * GQ_G + lane;
-      ix[u] = grid_flat_index(t[u] < total ? t[u] : 0, sb, excl);  // total > 0: position 0 is always valid
-    }
-    float4 p[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) p[u] = sorted[ix[u]];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned long long k2 = t[u] < total ? grid_key(qx, qy, qz, p[u]) : ~0ull;
-      key = k2 < key ? k2 : key;
-    }
-  }
-  return key;
-}
-
+template <int G>
 GS_DEV unsigned long long grid_group_min(unsigned long long key) {
 #pragma unroll
-  for (int d = GQ_G / 2; d > 0; d >>= 1) {
-    const unsigned long long o = __shfl_xor(key, d, GQ_G);
+  for (int d = G / 2; d > 0; d >>= 1) {
+    const unsigned long long o = __shfl_xor(key, d, G);
     key = o < key ? o : key;
   }
   return key;
 }
 
-// Shell search of one query by its GQ_G-lane group (all lanes of the group call it with the same query).
-// Returns the packed best key (identical in all lanes); *resolved tells whether it is provably
-// the global minimum.
-GS_DEV unsigned long long grid_search_group(const GsGrid& g, const int* __restrict__ cell_start,
-                                        const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
-                                        bool* resolved) {
+// Search of one query by a group of G lanes (all lanes of the group call with the same query), in two parts:
+//   grid_search_stage0: the 2x2x2 block of cells whose centre is nearest to the query -- resolves almost every ICP
+//                       query (its neighbour sits within a fraction of a cell);
+//   grid_search_rings : cubes of Chebyshev radius 1 .. GS_GRID_RINGS around the query's cell for the rest (a few % of the
+//                       queries of a frame whose border looks at surface the map has not seen: distances of 0.5 - 2
+//                       cells); the fused ICP kernels run this part with wider groups on the collected leftovers so
+//                       that a handful of far queries does not hold up whole waves.
+// Both return the packed best key (identical in all lanes); *resolved tells whether it is provably the global
+// minimum.  grid_search_group = stage 0, then the rings if needed, with the same group.
+struct GsQueryCell {
+  float px, py, pz;  // projection of the query onto the bounding box
+  int cx, cy, cz;
+};
+GS_DEV GsQueryCell grid_query_cell(const GsGrid& g, float qx, float qy, float qz) {
   // cell of the query's projection onto the bounding box (the projection onto a convex set never
   // increases the distance to points inside it, so shell bounds around it stay valid)
-  const float px = fminf(fmaxf(qx, g.ox), g.mx), py = fminf(fmaxf(qy, g.oy), g.my), pz = fminf(fmaxf(qz, g.oz), g.mz);
-  const int cx = grid_axis(px, g.ox, g.inv_c, g.nx), cy = grid_axis(py, g.oy, g.inv_c, g.ny),
-            cz = grid_axis(pz, g.oz, g.inv_c, g.nz);
+  GsQueryCell c;
+  c.px = fminf(fmaxf(qx, g.ox), g.mx); c.py = fminf(fmaxf(qy, g.oy), g.my); c.pz = fminf(fmaxf(qz, g.oz), g.mz);
+  c.cx = grid_axis(c.px, g.ox, g.inv_c, g.nx); c.cy = grid_axis(c.py, g.oy, g.inv_c, g.ny);
+  c.cz = grid_axis(c.pz, g.oz, g.inv_c, g.nz);
+  return c;
+}
+
+template <int G>
+GS_DEV unsigned long long grid_search_stage0(const GsGrid& g, const int* __restrict__ cell_start,
+                                             const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
+                                             bool* resolved) {
+  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
+  const float px = qc.px, py = qc.py, pz = qc.pz;
+  const int cx = qc.cx, cy = qc.cy, cz = qc.cz;
   unsigned long long key = ~0ull;
-  bool done = false;
+  // The 2x2x2 block of cells whose centre is nearest to the (projected) query.  Every target
+  // outside that box is at least as far as the nearest box face that has cells behind it (>= half a cell
+  // by construction); ICP queries sit within a fraction of a cell of their neighbour, so most searches
+  // end here with 8 cells (4 row segments) instead of 27.
+  const float fx = (px - g.ox) * g.inv_c - (float)cx, fy = (py - g.oy) * g.inv_c - (float)cy,
+              fz = (pz - g.oz) * g.inv_c - (float)cz;
+  const int x0 = (fx < 0.5f) ? cx - 1 : cx, y0 = (fy < 0.5f) ? cy - 1 : cy, z0 = (fz < 0.5f) ? cz - 1 : cz;
+  // distance (in cells) from the query to the nearest box face with cells behind it, per axis
+  const float BIG = 3.0e38f;
+  const float ax = fminf(x0 >= 1 ? fx + (float)(cx - x0) : BIG, x0 + 2 < g.nx ? (float)(x0 + 2 - cx) - fx : BIG);
+  const float ay = fminf(y0 >= 1 ? fy + (float)(cy - y0) : BIG, y0 + 2 < g.ny ? (float)(y0 + 2 - cy) - fy : BIG);
+  const float az = fminf(z0 >= 1 ? fz + (float)(cz - z0) : BIG, z0 + 2 < g.nz ? (float)(z0 + 2 - cz) - fz : BIG);
+  const float amin = fminf(ax, fminf(ay, az));
+  // The 4 row segments of the box (2 cells each) as ONE flat candidate list.  Every lane of the group fetches all
+  // 8 segment bounds itself (the lanes' addresses coincide, so this costs one round trip and no cross-lane
+  // traffic), then lane l takes the flat positions l, l + G, ...: position -> (segment, offset) is three
+  // compares on registers.  No shuffles until the final min.
+  int sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, e1 = 0, e2 = 0, e3 = 0, total = 0;
   {
-    // Stage 0: the 2x2x2 block of cells whose centre is nearest to the (projected) query.  Every target
-    // outside that box is at least as far as the nearest box face that has cells behind it (>= half a cell
-    // by construction); ICP queries sit within a fraction of a cell of their neighbour, so most searches
-    // end here with 8 cells (4 row segments) instead of 27.
-    const float fx = (px - g.ox) * g.inv_c - (float)cx, fy = (py - g.oy) * g.inv_c - (float)cy,
-                fz = (pz - g.oz) * g.inv_c - (float)cz;
-    const int x0 = (fx < 0.5f) ? cx - 1 : cx, y0 = (fy < 0.5f) ? cy - 1 : cy, z0 = (fz < 0.5f) ? cz - 1 : cz;
-    // distance (in cells) from the query to the nearest box face with cells behind it, per axis
-    const float BIG = 3.0e38f;
-    const float ax = fminf(x0 >= 1 ? fx + (float)(cx - x0) : BIG, x0 + 2 < g.nx ? (float)(x0 + 2 - cx) - fx : BIG);
-    const float ay = fminf(y0 >= 1 ? fy + (float)(cy - y0) : BIG, y0 + 2 < g.ny ? (float)(y0 + 2 - cy) - fy : BIG);
-    const float az = fminf(z0 >= 1 ? fz + (float)(cz - z0) : BIG, z0 + 2 < g.nz ? (float)(z0 + 2 - cz) - fz : BIG);
-    const float amin = fminf(ax, fminf(ay, az));
-    int sb = 0, se = 0;
-    if (lane < 4) {
-      const int zz = z0 + (lane >> 1), yy = y0 + (lane & 1);
-      if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
-        const int xa = x0 < 0 ? 0 : x0, xb = x0 + 1 >= g.nx ? g.nx - 1 : x0 + 1;
-        const int row = (zz * g.ny + yy) * g.nx;
-        sb = cell_start[row + xa];
-        se = cell_start[row + xb + 1];
-      }
-    }
-    key = grid_group_min(grid_scan_slots(sb, se, lane, qx, qy, qz, sorted, key));
-    // 0.1 % of a cell is orders of magnitude above the float rounding of the cell assignment
-    const float rb = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
-    const float bd = __uint_as_float((uint32_t)(key >> 32));  // NaN while nothing was found
-    done = rb > 0.0f && (rb >= 1.0e30f ? bd == bd : bd <= rb * rb);
+    const int xa = x0 < 0 ? 0 : x0, xb = x0 + 1 >= g.nx ? g.nx - 1 : x0 + 1;
+    const bool zl = z0 >= 0, zh = z0 + 1 < g.nz, yl = y0 >= 0, yh = y0 + 1 < g.ny;  // z0 + 1 >= 0, y0 + 1 >= 0 always
+    const int r0 = (z0 * g.ny + y0) * g.nx, r1 = r0 + g.nx, r2 = r0 + g.ny * g.nx, r3 = r2 + g.nx;
+    int se0 = 0, se1 = 0, se2 = 0, se3 = 0;
+    if (zl && yl) { sb0 = cell_start[r0 + xa]; se0 = cell_start[r0 + xb + 1]; }
+    if (zl && yh) { sb1 = cell_start[r1 + xa]; se1 = cell_start[r1 + xb + 1]; }
+    if (zh && yl) { sb2 = cell_start[r2 + xa]; se2 = cell_start[r2 + xb + 1]; }
+    if (zh && yh) { sb3 = cell_start[r3 + xa]; se3 = cell_start[r3 + xb + 1]; }
+    e1 = se0 - sb0;
+    e2 = e1 + (se1 - sb1);
+    e3 = e2 + (se2 - sb2);
+    total = e3 + (se3 - sb3);
   }
-  for (int k = 1; k <= GS_GRID_RINGS && !done; ++k) {
-    // k == 1: the full 3x3x3 block (shells 0 and 1) as 9 rows of up to 3 cells;
-    // k >= 2: shell k only -- border rows are one run of 2k+1 cells, interior rows contribute
-    // their two end cells.  Two slots per row, GQ_G slots per pass.
-    const int side = 2 * k + 1, per_row = (k == 1) ? 1 : 2, nslot = per_row * side * side;
-    for (int s0 = 0; s0 < nslot; s0 += GQ_G) {
-      const int slot = s0 + lane;
-      int sb = 0, se = 0;
-      if (slot < nslot) {
-        const int rowi = (k == 1) ? slot : (slot >> 1), second = (k == 1) ? 0 : (slot & 1);
-        const int dz = rowi / side - k, dy = rowi % side - k;
-        const int zz = cz + dz, yy = cy + dy;
-        if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
-          const int row = (zz * g.ny + yy) * g.nx;
-          const bool full_row = (k == 1) || dz == -k || dz == k || dy == -k || dy == k;
-          int x0, x1;
-          if (full_row) {
-            x0 = second ? 1 : (cx - k < 0 ? 0 : cx - k);
-            x1 = second ? 0 : (cx + k >= g.nx ? g.nx - 1 : cx + k);
-          } else {
-            x0 = x1 = second ? cx + k : cx - k;
-            if (x0 < 0 || x0 >= g.nx) { x0 = 1; x1 = 0; }
-          }
-          if (x0 <= x1) {
-            sb = cell_start[row + x0];
-            se = cell_start[row + x1 + 1];
-          }
-        }
-      }
-      key = grid_scan_slots(sb, se, lane, qx, qy, qz, sorted, key);
+  for (int t0 = lane; t0 < total; t0 += 4 * G) {  // four independent gathers in flight per lane
+    float4 p[4];
+    bool in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * G;
+      in[u] = t < total;
+      const int tt = in[u] ? t : 0;  // total > 0 here: position 0 is valid
+      const int ix = tt < e1 ? sb0 + tt : (tt < e2 ? sb1 + (tt - e1) : (tt < e3 ? sb2 + (tt - e2) : sb3 + (tt - e3)));
+      p[u] = sorted[ix];
     }
-    key = grid_group_min(key);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned long long k2 = in[u] ? grid_key(qx, qy, qz, p[u]) : ~0ull;
+      key = k2 < key ? k2 : key;
+    }
+  }
+  key = grid_group_min<G>(key);
+  // 0.1 % of a cell is orders of magnitude above the float rounding of the cell assignment
+  const float rb = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
+  const float bd = __uint_as_float((uint32_t)(key >> 32));  // NaN while nothing was found
+  *resolved = rb > 0.0f && (rb >= 1.0e30f ? bd == bd : bd <= rb * rb);
+  return key;
+}
+
+// Cubes of Chebyshev radius 1 .. GS_GRID_RINGS around the query's cell: lane l of the group scans the rows
+// l, l + G, ... of the cube (2k+1 cells each) on its own.  Deliberately simple (a few registers, no cross-lane traffic
+// but the final min): it serves the few queries per frame whose neighbour is farther than half a cell.
+template <int G>
+GS_DEV unsigned long long grid_search_rings(const GsGrid& g, const int* __restrict__ cell_start,
+                                            const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
+                                            unsigned long long key, bool* resolved) {
+  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
+  bool done = false;
+  for (int k = 1; k <= GS_GRID_RINGS && !done; ++k) {
+    const int side = 2 * k + 1, nrow = side * side;
+    const int xa = qc.cx - k < 0 ? 0 : qc.cx - k, xb = qc.cx + k >= g.nx ? g.nx - 1 : qc.cx + k;
+    for (int r = lane; r < nrow; r += G) {
+      const int zz = qc.cz + r / side - k, yy = qc.cy + r % side - k;
+      if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
+      const int row = (zz * g.ny + yy) * g.nx;
+      const int je = cell_start[row + xb + 1];
+      for (int j = cell_start[row + xa]; j < je; ++j) {
+        const unsigned long long k2 = grid_key(qx, qy, qz, sorted[j]);
+        key = k2 < key ? k2 : key;
+      }
+    }
+    key = grid_group_min<G>(key);
     // every unvisited target is farther than k cells from the projected query; 0.1 % of a cell is
     // orders of magnitude above the float rounding of the cell assignment
     const float rb = (float)k * g.c * 0.999f;
@@ -271,6 +264,15 @@ GS_DEV unsigned long long grid_search_group(const GsGrid& g, const int* __restri
     done = bd <= rb * rb;
   }
   *resolved = done;
+  return key;
+}
+
+template <int G = GQ_G>
+GS_DEV unsigned long long grid_search_group(const GsGrid& g, const int* __restrict__ cell_start,
+                                        const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
+                                        bool* resolved) {
+  unsigned long long key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, resolved);
+  if (!*resolved) key = grid_search_rings<G>(g, cell_start, sorted, qx, qy, qz, lane, key, resolved);
   return key;
 }
 

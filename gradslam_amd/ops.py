@@ -461,12 +461,12 @@ def fuse_append_(points, normals, colors, ccounts, n_map, best_pix, gvertex, gno
     if n_dev is not None:
         check(lib().gs_fuse_append_dc_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map),
                                           ptr(n_dev), cap, ptr(best_pix), ptr(gvertex), ptr(gnormal), ptr(rgb),
-                                          ptr(alpha), ptr(depth), H, W, 1 if renorm_all else 0, ptr(cnt),
+                                          ptr(alpha), ptr(depth), H, W, int(renorm_all), ptr(cnt),
                                           ptr(ws.scratch(n_map, H * W)), stream(dev)), "gs_fuse_append_dc_f32")
     else:
         check(lib().gs_fuse_append_f32(ptr(points), ptr(normals), ptr(colors), ptr(ccounts), int(n_map), cap,
                                        ptr(best_pix), ptr(gvertex), ptr(gnormal), ptr(rgb), ptr(alpha), ptr(depth),
-                                       H, W, 1 if renorm_all else 0, ptr(cnt), ptr(ws.scratch(n_map, H * W)),
+                                       H, W, int(renorm_all), ptr(cnt), ptr(ws.scratch(n_map, H * W)),
                                        stream(dev)), "gs_fuse_append_f32")
     if not sync:
         return cnt

@@ -285,6 +285,11 @@ def _fuse(pointclouds, rgbdimages, best_pix, sigma, inplace):
     out = pointclouds if inplace else Pointclouds(device=pointclouds.device)
     if not inplace:
         out._init_empty_batch(B, pointclouds._buf["features"][0].shape[-1])
+    # fusionutils.py:659 skips the merge only when the table of the WHOLE batch is empty: with B > 1 a sequence
+    # without matches is still renormalised when another one has some (mode 2 of gs_fuse_append_f32)
+    renorm = RENORMALIZE_UNMATCHED
+    if renorm and B > 1 and any(bool((bp >= 0).any()) for bp in best_pix):
+        renorm = 2
     for b in range(B):
         if inplace and ops.DEVICE_COUNTS:
             # the count stays on the device: no read-back, the host only tracks an upper bound.  Reserve FIRST:
@@ -294,7 +299,7 @@ def _fuse(pointclouds, rgbdimages, best_pix, sigma, inplace):
             if P.dtype != torch.float32 or F.shape[-1] != 1:
                 raise ValueError("map fusion needs float32 surfels with one feature column (the confidence count)")
             cnt = ops.fuse_append_(P, N, C, F, n0, best_pix[b], gv[b, 0], gn[b, 0], rgb[b, 0], alpha[b, 0, ..., 0],
-                                   depth[b, 0, ..., 0], RENORMALIZE_UNMATCHED, n_dev=n_dev, sync=False)
+                                   depth[b, 0, ..., 0], renorm, n_dev=n_dev, sync=False)
             pointclouds._set_count_dev(b, cnt, H * W)
             continue
         n0 = pointclouds._n[b]
@@ -302,7 +307,7 @@ def _fuse(pointclouds, rgbdimages, best_pix, sigma, inplace):
         if P.dtype != torch.float32 or F.shape[-1] != 1:
             raise ValueError("map fusion needs float32 surfels with one feature column (the confidence count)")
         n1 = ops.fuse_append_(P, N, C, F, n0, best_pix[b], gv[b, 0], gn[b, 0], rgb[b, 0], alpha[b, 0, ..., 0],
-                              depth[b, 0, ..., 0], RENORMALIZE_UNMATCHED)
+                              depth[b, 0, ..., 0], renorm)
         if inplace:
             pointclouds._set_count(b, n1)
         else:

@@ -302,7 +302,10 @@ GS_API int gs_rows_to_best_pix(const int64_t* rows, int64_t n_rows, int H, int W
  * (structures/pointclouds.py:1117-1237) on a capacity-backed surfel store:
  *   matched rows n = best_pix[p]:  cc' = cc + a;  x' = (cc*x + a*f) * (1/cc')  for points,
  *   normals, colours;  every other row is rewritten as (cc*x)*(1/cc) exactly as the
- *   reference does (renorm_all != 0; 0 skips that and leaves unmatched rows untouched);
+ *   reference does (renorm_all != 0; 0 skips that and leaves unmatched rows untouched).  The reference skips
+ *   the merge when the correspondence table OF THE WHOLE BATCH is empty (:659); this call sees one sequence, so
+ *   renorm_all = 1 skips it when this sequence's table is empty and renorm_all = 2 never skips it (the caller knows
+ *   that another sequence of the batch has matches);
  *   unmatched valid pixels are appended in raster order at rows n_map .. n_map+n_new-1.
  * The arrays must have room for n_map + H*W rows.  n_map_host is the current size;
  * new_count_out: device int64[1] receives n_map + n_new. */
