@@ -69,7 +69,8 @@ _PROTOS = {
     "gs_icp_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, C.POINTER(IcpParams), _vp, _vp, _vp, _vp],
     "gs_icp_trace_f32": [_vp, _i32, _vp, _vp],
     "gs_icp_dc_f32": [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, C.POINTER(IcpParams), _vp, _vp, _vp, _vp],
-    "gs_frame_maps_backward_f32": [_vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gs_frame_maps_backward_f32": [_vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gs_frame_maps_backward_kbar_scratch_bytes": [_i32, _i32],
     "gs_global_maps_backward_f32": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gs_downsample_frame_backward_f32": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "gs_icp_tape_bytes": [_i64, _i32],
@@ -105,14 +106,14 @@ _PROTOS = {
                               _vp, _vp, _vp],
     "gs_append_valid_dc_f32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
                                _vp],
-    "gs_frame_maps_batch_f32": [_vp, _vp, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp],
+    "gs_frame_maps_batch_f32": [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp],
     "gs_localize_scratch_bytes": [_i32, _i32, _i32, _i64],
     "gs_localize_batch_f32": [C.POINTER(LocalizeSeq), _i32, _i32, _i32, _i32, C.POINTER(IcpParams), _vp],
     "gs_update_map_fusion_batch_f32": [C.POINTER(UpdateSeq), _i32, _i32, _i32, _f, _f, _i32, _vp],
 }
 _RESTYPE = {"gs_last_error": C.c_char_p, "gs_scratch_bytes": _i64, "gs_icp_scratch_bytes": _i64,
             "gs_knn1_grid_scratch_bytes": _i64, "gs_update_map_scratch_bytes": _i64, "gs_global_maps_pose_backward_scratch_bytes": _i64, "gs_icp_tape_bytes": _i64, "gs_icp_backward_scratch_bytes": _i64,
-            "gs_localize_scratch_bytes": _i64}
+            "gs_localize_scratch_bytes": _i64, "gs_frame_maps_backward_kbar_scratch_bytes": _i64}
 EXPORTS = tuple(_PROTOS)
 
 

@@ -196,10 +196,12 @@ __global__ void __launch_bounds__(256) gs_frame_maps_kernel(
 }
 // blockIdx.z = frame of a contiguous (n_frames, H, W) stack
 __global__ void __launch_bounds__(256) gs_frame_maps_batch_kernel(
-    const float* __restrict__ depth, const float* __restrict__ K16, int frames_per_K, int H, int W, float two_sigma_sq,
-    float* __restrict__ vertex, float* __restrict__ normal, float* __restrict__ alpha) {
+    const float* __restrict__ depth, int64_t stride_seq, int64_t stride_frame, const float* __restrict__ K16,
+    int frames_per_K, int H, int W, float two_sigma_sq, float* __restrict__ vertex, float* __restrict__ normal,
+    float* __restrict__ alpha) {
   const size_t f = blockIdx.z, P = (size_t)H * W;
-  frame_maps_body(depth + f * P, K16 + 16 * (f / frames_per_K), H, W, two_sigma_sq, vertex + 3 * f * P,
+  const size_t b = f / frames_per_K, l = f % frames_per_K;
+  frame_maps_body(depth + b * stride_seq + l * stride_frame, K16 + 16 * b, H, W, two_sigma_sq, vertex + 3 * f * P,
                   normal ? normal + 3 * f * P : nullptr, alpha ? alpha + f * P : nullptr, nullptr);
 }
 
@@ -217,17 +219,18 @@ extern "C" int gs_frame_maps_f32(const float* depth, const float* K16, int H, in
   return GS_OK;
 }
 
-extern "C" int gs_frame_maps_batch_f32(const float* depth, const float* K16, int n_frames, int frames_per_K, int H,
-                                       int W, float two_sigma_sq, float* vertex, float* normal, float* alpha,
-                                       void* stream) {
+extern "C" int gs_frame_maps_batch_f32(const float* depth, int64_t depth_stride_seq, int64_t depth_stride_frame,
+                                       const float* K16, int n_frames, int frames_per_K, int H, int W,
+                                       float two_sigma_sq, float* vertex, float* normal, float* alpha, void* stream) {
   GS_REQUIRE(depth && K16 && vertex, "depth, K16 and vertex must not be NULL");
   GS_REQUIRE(H >= 2 && W >= 2, "image must be at least 2x2");
-  GS_REQUIRE(n_frames > 0 && n_frames <= 65535 && frames_per_K > 0, "bad frame count");
+  GS_REQUIRE(n_frames > 0 && n_frames <= 65535 && frames_per_K > 0 && n_frames % frames_per_K == 0, "bad frame count");
+  GS_REQUIRE(depth_stride_frame >= (int64_t)H * W && depth_stride_seq >= 0, "bad depth strides");
   dim3 grid((unsigned)gs_ceil_div(W, FM_TW), (unsigned)gs_ceil_div(H, FM_TH), (unsigned)n_frames);
   const double bytes = (double)n_frames * H * W * (4.0 + 12.0 + (normal ? 12 : 0) + (alpha ? 4 : 0));
   GsProf prof(GS_PROF_FRAME, bytes, gs_stream(stream));
-  hipLaunchKernelGGL(gs_frame_maps_batch_kernel, grid, dim3(256), 0, gs_stream(stream), depth, K16, frames_per_K, H, W,
-                     two_sigma_sq, vertex, normal, alpha);
+  hipLaunchKernelGGL(gs_frame_maps_batch_kernel, grid, dim3(256), 0, gs_stream(stream), depth, depth_stride_seq,
+                     depth_stride_frame, K16, frames_per_K, H, W, two_sigma_sq, vertex, normal, alpha);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }
@@ -355,62 +358,127 @@ __global__ void __launch_bounds__(256) gs_frame_bwd_diff_kernel(const float* __r
   o[5] = nb[0] * dh[1] - nb[1] * dh[0];
 }
 
+// KBAR: additionally reduce, per block, the adjoints of the four inverse-intrinsics entries the vertex depends on
+// (x = (k00 u + k02) d, y = (k11 v + k12) d): [k00, k02, k11, k12]_bar = sum_p vb_x u d, vb_x d, vb_y v d, vb_y d.
+template <bool KBAR>
 __global__ void __launch_bounds__(256) gs_frame_bwd_depth_kernel(
     const float* __restrict__ depth, const float* __restrict__ K16, int H, int W, float two_sigma_sq,
     const float* __restrict__ vertex_bar, const float* __restrict__ alpha_bar, const float* __restrict__ dhdv_bar,
-    float* __restrict__ depth_bar) {
+    float* __restrict__ depth_bar, double* __restrict__ kbar_partials) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= (int64_t)H * W) return;
-  const int h = (int)(p / W), w = (int)(p % W);
-  const GsKinv k = gs_kinv(K16);
-  float vb[3] = {0.0f, 0.0f, 0.0f};
-  if (vertex_bar)
-    for (int c = 0; c < 3; ++c) vb[c] = vertex_bar[3 * p + c];
-  const float d = depth[p];
-  const float m = d > 0.0f ? 1.0f : 0.0f;
-  float rx, ry;
-  fb_ray(h, w, k, rx, ry);
-  if (alpha_bar) {  // alpha = clamp(exp(-|v|^2 / (2 sigma^2)), 1e-7, 1.01)
-    const float v[3] = {rx * d * m, ry * d * m, d * m};
-    const float a = gs_alpha_of(v[0], v[1], v[2], two_sigma_sq, 1e-7f);
-    if (a > 1e-7f && a < 1.01f) {
-      const float f = alpha_bar[p] * a * (-2.0f / two_sigma_sq);
-      for (int c = 0; c < 3; ++c) vb[c] += f * v[c];
+  const bool in = p < (int64_t)H * W;
+  double kb[4] = {0.0, 0.0, 0.0, 0.0};
+  if (in) {
+    const int h = (int)(p / W), w = (int)(p % W);
+    const GsKinv k = gs_kinv(K16);
+    float vb[3] = {0.0f, 0.0f, 0.0f};
+    if (vertex_bar)
+      for (int c = 0; c < 3; ++c) vb[c] = vertex_bar[3 * p + c];
+    const float d = depth[p];
+    const float m = d > 0.0f ? 1.0f : 0.0f;
+    float rx, ry;
+    fb_ray(h, w, k, rx, ry);
+    if (alpha_bar) {  // alpha = clamp(exp(-|v|^2 / (2 sigma^2)), 1e-7, 1.01)
+      const float v[3] = {rx * d * m, ry * d * m, d * m};
+      const float a = gs_alpha_of(v[0], v[1], v[2], two_sigma_sq, 1e-7f);
+      if (a > 1e-7f && a < 1.01f) {
+        const float f = alpha_bar[p] * a * (-2.0f / two_sigma_sq);
+        for (int c = 0; c < 3; ++c) vb[c] += f * v[c];
+      }
+    }
+    if (dhdv_bar) {
+      auto DH = [&](int hh, int ww, int c) { return dhdv_bar[6 * ((int64_t)hh * W + ww) + c]; };
+      auto DV = [&](int hh, int ww, int c) { return dhdv_bar[6 * ((int64_t)hh * W + ww) + 3 + c]; };
+      for (int c = 0; c < 3; ++c) {
+        float acc = 0.0f;
+        // horizontal difference of pixel (h, w'): a1 = (h, min(w', W-2) + 1), a0 = (h, min(w', W-2))
+        if (w >= 1) acc += DH(h, w - 1, c);
+        if (w == W - 1) acc += DH(h, W - 1, c);
+        if (w <= W - 2) acc -= DH(h, w, c);
+        if (w == W - 2) acc -= DH(h, W - 1, c);
+        // vertical difference of pixel (h', w)
+        if (h >= 1) acc += DV(h - 1, w, c);
+        if (h == H - 1) acc += DV(H - 1, w, c);
+        if (h <= H - 2) acc -= DV(h, w, c);
+        if (h == H - 2) acc -= DV(H - 1, w, c);
+        vb[c] += acc;
+      }
+    }
+    if (depth_bar) depth_bar[p] = m * (vb[0] * rx + vb[1] * ry + vb[2]);
+    if (KBAR) {
+      const double dm = (double)d * (double)m;
+      kb[0] = (double)vb[0] * (double)w * dm; kb[1] = (double)vb[0] * dm;
+      kb[2] = (double)vb[1] * (double)h * dm; kb[3] = (double)vb[1] * dm;
     }
   }
-  if (dhdv_bar) {
-    auto DH = [&](int hh, int ww, int c) { return dhdv_bar[6 * ((int64_t)hh * W + ww) + c]; };
-    auto DV = [&](int hh, int ww, int c) { return dhdv_bar[6 * ((int64_t)hh * W + ww) + 3 + c]; };
-    for (int c = 0; c < 3; ++c) {
-      float acc = 0.0f;
-      // horizontal difference of pixel (h, w'): a1 = (h, min(w', W-2) + 1), a0 = (h, min(w', W-2))
-      if (w >= 1) acc += DH(h, w - 1, c);
-      if (w == W - 1) acc += DH(h, W - 1, c);
-      if (w <= W - 2) acc -= DH(h, w, c);
-      if (w == W - 2) acc -= DH(h, W - 1, c);
-      // vertical difference of pixel (h', w)
-      if (h >= 1) acc += DV(h - 1, w, c);
-      if (h == H - 1) acc += DV(H - 1, w, c);
-      if (h <= H - 2) acc -= DV(h, w, c);
-      if (h == H - 2) acc -= DV(H - 1, w, c);
-      vb[c] += acc;
+  if (KBAR) {  // fixed-order block sums (wave tree, then the 4 waves in order)
+    __shared__ double red[4][256 / GS_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double sum = gs_wave_sum_f64(kb[i]);
+      if (lane == 0) red[i][wave] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      const int i = threadIdx.x;
+      kbar_partials[(int64_t)blockIdx.x * 4 + i] = ((red[i][0] + red[i][1]) + red[i][2]) + red[i][3];
     }
   }
-  depth_bar[p] = m * (vb[0] * rx + vb[1] * ry + vb[2]);
+}
+
+// K_bar (4x4) from the block partials: inverse_intrinsics (geometry/projutils.py:437-449) has k00 = 1 / (fx + eps),
+// k02 = -cx / (fx + eps) (same for y), so fx_bar = -k00_bar / f'^2 + k02_bar cx / f'^2, cx_bar = -k02_bar / f'.
+__global__ void __launch_bounds__(256) gs_frame_bwd_kbar_kernel(const double* __restrict__ partials, int nblocks,
+                                                                const float* __restrict__ K16,
+                                                                float* __restrict__ K_bar16) {
+  __shared__ double red[4][256];
+  for (int i = 0; i < 4; ++i) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partials[(int64_t)b * 4 + i];
+    red[i][threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double kb[4];
+  for (int i = 0; i < 4; ++i) {
+    double s = 0.0;
+    for (int t = 0; t < 256; ++t) s += red[i][t];
+    kb[i] = s;
+  }
+  const double eps = 1e-6, fx = (double)K16[0] + eps, fy = (double)K16[5] + eps, cx = K16[2], cy = K16[6];
+  for (int i = 0; i < 16; ++i) K_bar16[i] = 0.0f;
+  K_bar16[0] = (float)((-kb[0] + kb[1] * cx) / (fx * fx));
+  K_bar16[2] = (float)(-kb[1] / fx);
+  K_bar16[5] = (float)((-kb[2] + kb[3] * cy) / (fy * fy));
+  K_bar16[6] = (float)(-kb[3] / fy);
+}
+
+extern "C" int64_t gs_frame_maps_backward_kbar_scratch_bytes(int H, int W) {
+  return (int64_t)gs_align(8 * 4 * (size_t)gs_ceil_div((int64_t)H * W, 256));
 }
 
 extern "C" int gs_frame_maps_backward_f32(const float* depth, const float* K16, int H, int W, float two_sigma_sq,
                                           const float* vertex_bar, const float* normal_bar, const float* alpha_bar,
-                                          float* depth_bar, float* scratch_6hw, void* stream) {
-  GS_REQUIRE(depth && K16 && depth_bar, "NULL pointer");
+                                          float* depth_bar, float* scratch_6hw, float* K_bar16, void* kbar_scratch,
+                                          void* stream) {
+  GS_REQUIRE(depth && K16 && (depth_bar || K_bar16), "NULL pointer");
   GS_REQUIRE(H >= 2 && W >= 2, "image must be at least 2x2");
   GS_REQUIRE(!normal_bar || scratch_6hw, "normal_bar needs scratch of 6*H*W floats");
+  GS_REQUIRE(!K_bar16 || kbar_scratch, "K_bar16 needs gs_frame_maps_backward_kbar_scratch_bytes() of scratch");
   hipStream_t st = gs_stream(stream);
   const unsigned nb = (unsigned)gs_ceil_div((int64_t)H * W, 256);
   if (normal_bar)
     hipLaunchKernelGGL(gs_frame_bwd_diff_kernel, dim3(nb), dim3(256), 0, st, depth, K16, H, W, normal_bar, scratch_6hw);
-  hipLaunchKernelGGL(gs_frame_bwd_depth_kernel, dim3(nb), dim3(256), 0, st, depth, K16, H, W, two_sigma_sq, vertex_bar,
-                     alpha_bar, normal_bar ? scratch_6hw : nullptr, depth_bar);
+  if (K_bar16) {
+    double* partials = reinterpret_cast<double*>(kbar_scratch);
+    hipLaunchKernelGGL((gs_frame_bwd_depth_kernel<true>), dim3(nb), dim3(256), 0, st, depth, K16, H, W, two_sigma_sq,
+                       vertex_bar, alpha_bar, normal_bar ? scratch_6hw : nullptr, depth_bar, partials);
+    hipLaunchKernelGGL(gs_frame_bwd_kbar_kernel, dim3(1), dim3(256), 0, st, partials, (int)nb, K16, K_bar16);
+  } else {
+    hipLaunchKernelGGL((gs_frame_bwd_depth_kernel<false>), dim3(nb), dim3(256), 0, st, depth, K16, H, W, two_sigma_sq,
+                       vertex_bar, alpha_bar, normal_bar ? scratch_6hw : nullptr, depth_bar, nullptr);
+  }
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

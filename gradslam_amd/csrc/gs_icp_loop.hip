@@ -377,7 +377,6 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
 struct IcpHalfBatch {
   int B;
   int upb;  // row units per block
-  int rot;  // experiment: sequence of block b = (b + rot) % B
   unsigned long long* timeline;  // debugging aid (GRADSLAM_HIP_ICP_TIMELINE): per block [start, end, hw id, xcc id]
   IcpHalfSeq s[GS_MAX_BATCH];
 };
@@ -391,7 +390,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_batch_kernel(const Ic
   unsigned long long t0 = 0;
   if (hb.timeline && threadIdx.x == 0) t0 = wall_clock64();
 #endif
-  icp_half_body<FULL, G>(hb.s[(blockIdx.x + hb.rot) % B], n_src_c, dist_thresh, prm, it, rows_in_reduced,
+  icp_half_body<FULL, G>(hb.s[blockIdx.x % B], n_src_c, dist_thresh, prm, it, rows_in_reduced,
                          gs_xcd_block(blk, nblk, X), hb.upb, hb.timeline ? hb.timeline + 72 * (size_t)blockIdx.x : nullptr);
 #ifdef GS_ICP_TIMELINE
   if (hb.timeline && threadIdx.x == 0) {
@@ -446,8 +445,6 @@ template <bool FULL>
 static void icp_half_launch(const IcpHalfPlan& pl, IcpHalfBatch& hb, GsCount n_src_c, const gs_icp_params* prm, int it,
                             int rows_in_reduced, hipStream_t st) {
   hb.upb = pl.upb;
-  static const int rot_env = getenv("GRADSLAM_HIP_SEQ_ROT") ? atoi(getenv("GRADSLAM_HIP_SEQ_ROT")) : 0;
-  hb.rot = rot_env;
   static const char* tl_path = getenv("GRADSLAM_HIP_ICP_TIMELINE");
   static unsigned long long* tl_buf = nullptr;
   hb.timeline = nullptr;

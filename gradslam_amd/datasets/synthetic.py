@@ -30,14 +30,18 @@ def _scene_depth_at(x_w, y_w):
     return 2.0 + 0.3 * np.sin(3.0 * x_w + 0.4) * np.cos(2.5 * y_w) + 0.2 * x_w
 
 
-def make_sequence(L, H, W, seed=0, hole_frac=0.05, yaw_per_frame=0.002, tx_per_frame=0.005):
+def make_sequence(L, H, W, seed=0, hole_frac=0.05, yaw_per_frame=0.002, tx_per_frame=0.005, first=0):
     """Returns dict(colors (L,H,W,3) f32 in [0,255), depths (L,H,W,1) f32 metres with
     `hole_frac` pixels zeroed, intrinsics (1,4,4), poses (L,4,4) ground truth).
 
     Depth is the ray-cast (fixed-point iteration) of a static height-field scene seen from the
     moving camera, so consecutive frames are geometrically consistent and ICP converges to the
-    ground-truth motion."""
-    rng = np.random.default_rng(seed)
+    ground-truth motion.
+
+    first > 0: frames first .. first + L - 1 of the same camera path with their own random stream (holes, colours),
+    so that a long sequence can be generated in parallel chunks (bench.py --workload c5); first = 0 is the sequence the
+    parity tests and goldens use."""
+    rng = np.random.default_rng(seed if first == 0 else [seed, first])
     K = tum_intrinsics(H, W)
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
     u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
@@ -47,7 +51,7 @@ def make_sequence(L, H, W, seed=0, hole_frac=0.05, yaw_per_frame=0.002, tx_per_f
     poses = np.empty((L, 4, 4), np.float32)
     phase = 0.1 * seed
     for s in range(L):
-        T = gt_pose(s, yaw_per_frame, tx_per_frame).astype(np.float64)
+        T = gt_pose(first + s, yaw_per_frame, tx_per_frame).astype(np.float64)
         poses[s] = T.astype(np.float32)
         R, t = T[:3, :3], T[:3, 3]
         d = np.full((H, W), 2.0)

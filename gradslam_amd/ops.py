@@ -524,25 +524,51 @@ def append_valid_(points, normals, colors, ccounts, n_map, gvertex, gnormal, rgb
 
 
 # ----------------------------------------------------------------------------------- batched frame loop
-def frame_maps_batch(depth, K, frames_per_K, sigma=None, out=None):
-    """K1 for a stack of frames in one launch: depth (n, H, W), K (n // frames_per_K, 4, 4) ->
-    vertex (n, H, W, 3), normal (n, H, W, 3), alpha (n, H, W) or None (sigma None)."""
-    depth, K = _c(depth), _c(K)
-    dev = require_device(depth, K)
-    n, H, W = depth.shape
+def frame_maps_batch(depth, K, sigma=None, out=None):
+    """K1 for every frame of a (B, L, H, W) depth stack in one launch (its (H, W) images must be contiguous; the
+    sequence / frame strides are free, so a slice frames[:, s] of a longer stack is read in place): K (B, 4, 4) ->
+    vertex (B, L, H, W, 3), normal (B, L, H, W, 3), alpha (B, L, H, W) or None (sigma None)."""
+    K = _c(K)
+    if depth.dtype != f32:
+        depth = depth.to(f32)
+    Bn, L, H, W = depth.shape
+    if depth.stride(3) != 1 or depth.stride(2) != W or (L > 1 and depth.stride(1) < H * W) or \
+            (Bn > 1 and depth.stride(0) < H * W):
+        depth = depth.contiguous()
+    dev = require_device(K)
+    if depth.device != dev:
+        raise _C.HipExtensionError("gradslam_amd kernels run on the GPU only; all tensors on one device")
     ov, on, oa = out if out is not None else (None, None, None)
-    vertex = ov if ov is not None else torch.empty((n, H, W, 3), dtype=f32, device=dev)
-    normal = on if on is not None else torch.empty((n, H, W, 3), dtype=f32, device=dev)
-    alpha = oa if oa is not None else (torch.empty((n, H, W), dtype=f32, device=dev) if sigma is not None else None)
+    vertex = ov if ov is not None else torch.empty((Bn, L, H, W, 3), dtype=f32, device=dev)
+    normal = on if on is not None else torch.empty((Bn, L, H, W, 3), dtype=f32, device=dev)
+    alpha = oa if oa is not None else (torch.empty((Bn, L, H, W), dtype=f32, device=dev) if sigma is not None else None)
     require_device(vertex, normal, alpha)
-    L, tss = int(frames_per_K), two_sigma_sq(0.6 if sigma is None else sigma)
-    step = max(32768 // L, 1) * L if n > 32768 and L <= 32768 else n   # gridDim.z limit: whole K groups per launch
-    for f0 in range(0, n, step):
-        m = min(step, n - f0)
-        check(lib().gs_frame_maps_batch_f32(ptr(depth[f0:]), ptr(K[f0 // L:]), m, L, H, W, tss, ptr(vertex[f0:]),
-                                            ptr(normal[f0:]), None if alpha is None else ptr(alpha[f0:]),
-                                            stream(dev)), "gs_frame_maps_batch_f32")
+    tss = two_sigma_sq(0.6 if sigma is None else sigma)
+    sb, sl = (depth.stride(0) if Bn > 1 else L * H * W), (depth.stride(1) if L > 1 else H * W)
+    step = max(32768 // L, 1) if Bn * L > 32768 and L <= 32768 else Bn   # gridDim.z limit: whole sequences per launch
+    for b0 in range(0, Bn, step):
+        m = min(step, Bn - b0)
+        check(lib().gs_frame_maps_batch_f32(depth.data_ptr() + 4 * b0 * sb, sb, sl, ptr(K[b0:]), m * L, L, H, W, tss,
+                                            ptr(vertex[b0:]), ptr(normal[b0:]),
+                                            None if alpha is None else ptr(alpha[b0:]), stream(dev)),
+              "gs_frame_maps_batch_f32")
     return vertex, normal, alpha
+
+
+def _batch_view(t, inner_ndim):
+    """(B, ...) float32 tensor whose per-sequence slices t[b] are contiguous -> (tensor kept alive, base pointer,
+    batch stride in bytes).  A slice frames[:, s] of a (B, L, ...) stack qualifies as is (its batch stride is L
+    frames): no copy; anything else is made contiguous first."""
+    if t.dtype != f32:
+        t = t.to(f32)
+    inner = t.shape[t.ndim - inner_ndim:]
+    want, acc = [], 1
+    for d in reversed(inner):
+        want.append(acc)
+        acc *= int(d)
+    if tuple(t.stride()[t.ndim - inner_ndim:]) != tuple(reversed(want)) or (t.shape[0] > 1 and t.stride(0) < acc):
+        t = t.contiguous()
+    return t, t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else acc) * 4
 
 
 def _map_view(bufs, cap, n_bound, n_dev):
@@ -557,9 +583,13 @@ def localize_batch(vertex, depth, K, prev_poses, maps, ds, mode=1, numiters=20, 
     vertex (B, H, W, 3) LOCAL vertex maps of the live frames, depth (B, H, W), K / prev_poses (B, 4, 4);
     maps: per sequence (points, normals, n_bound, n_dev) with capacity-backed buffers (n_dev None: n_bound exact).
     Returns the recovered poses (B, 4, 4) = T_icp @ prev_pose."""
-    vertex, depth, K, prev_poses = _c(vertex), _c(depth), _c(K), _c(prev_poses)
-    dev = require_device(vertex, depth, K, prev_poses)
+    K, prev_poses = _c(K), _c(prev_poses)
     Bn, H, W = depth.shape
+    vertex, v0, vs = _batch_view(vertex, 3)
+    depth, d0, dstr = _batch_view(depth, 2)
+    dev = require_device(K, prev_poses)
+    if vertex.device != dev or depth.device != dev or not vertex.is_cuda:
+        raise _C.HipExtensionError("gradslam_amd kernels run on the GPU only; all tensors on one device")
     T = torch.empty((Bn, 4, 4), dtype=f32, device=dev) if out is None else out
     assert T.shape == (Bn, 4, 4) and T.dtype == f32 and T.is_contiguous() and T.device == dev
     prm = _C.IcpParams(int(mode), int(numiters), float(damp), _thresh(dist_thresh), float(lambda_max), float(B),
@@ -567,15 +597,14 @@ def localize_batch(vertex, depth, K, prev_poses, maps, ds, mode=1, numiters=20, 
     ws = Workspace.get(dev)
     seqs = (_C.LocalizeSeq * Bn)()
     L = lib()
-    P3, P1 = H * W * 3 * 4, H * W * 4
-    v0, d0, k0, p0, t0 = vertex.data_ptr(), depth.data_ptr(), K.data_ptr(), prev_poses.data_ptr(), T.data_ptr()
+    k0, p0, t0 = K.data_ptr(), prev_poses.data_ptr(), T.data_ptr()
     for b in range(Bn):
         P, N, n_bound, n_dev = maps[b]
         require_device(P, N, n_dev)
         cap = P.shape[0]
         scratch = ws.bytes("localize%d" % b, L.gs_localize_scratch_bytes(H, W, int(ds), cap))
         q = seqs[b]
-        q.vertex, q.depth, q.K16, q.prev_pose16 = v0 + b * P3, d0 + b * P1, k0 + b * 64, p0 + b * 64
+        q.vertex, q.depth, q.K16, q.prev_pose16 = v0 + b * vs, d0 + b * dstr, k0 + b * 64, p0 + b * 64
         q.map = _map_view((P, N, None, None), cap, n_bound, n_dev)
         q.out_pose16, q.scratch = t0 + b * 64, scratch.data_ptr()
     check(L.gs_localize_batch_f32(seqs, Bn, H, W, int(ds), prm, stream(dev)), "gs_localize_batch_f32")
@@ -588,19 +617,23 @@ def update_map_fusion_batch_(maps, vertex, normal, depth, rgb, alpha, poses, K, 
     (gs_update_map_fusion_batch_f32: 6 launches for the whole batch).  maps: per sequence
     (points, normals, colors, ccounts, n_bound, n_dev).  vertex / normal / rgb (B, H, W, 3), depth / alpha (B, H, W),
     poses / K (B, 4, 4).  Returns (counts int64 (B,) on the device, gvertex, gnormal, best_pix (B, H*W))."""
-    vertex, normal, depth, rgb, alpha = _c(vertex), _c(normal), _c(depth), _c(rgb), _c(alpha)
     poses, K = _c(poses), _c(K)
-    dev = require_device(vertex, normal, depth, rgb, alpha, poses, K)
+    dev = require_device(poses, K)
     Bn, H, W = depth.shape
-    gv, gn = out if out is not None else (torch.empty_like(vertex), torch.empty_like(normal))
-    require_device(gv, gn)
+    views = [_batch_view(t, nd) for t, nd in ((vertex, 3), (normal, 3), (depth, 2), (rgb, 3), (alpha, 2))]
+    if any(v[0].device != dev for v in views):
+        raise _C.HipExtensionError("gradslam_amd kernels run on the GPU only; all tensors on one device")
+    gv, gn = out if out is not None else (torch.empty((Bn, H, W, 3), dtype=f32, device=dev),
+                                          torch.empty((Bn, H, W, 3), dtype=f32, device=dev))
+    gviews = [_batch_view(t, 3) for t in (gv, gn)]
+    assert gviews[0][0] is gv and gviews[1][0] is gn, "output global maps must have contiguous (H, W, 3) slices"
     best = torch.empty((Bn, H * W), dtype=torch.int32, device=dev)
     cnt = torch.empty(Bn, dtype=torch.int64, device=dev)
     ws = Workspace.get(dev)
     seqs = (_C.UpdateSeq * Bn)()
     L = lib()
-    P3, P1 = H * W * 3 * 4, H * W * 4
-    base = [t.data_ptr() for t in (vertex, normal, depth, rgb, alpha, poses, K, gv, gn, best, cnt)]
+    P1 = H * W * 4
+    base = [t.data_ptr() for t in (poses, K, best, cnt)]
     for b in range(Bn):
         P, N, Cc, F, n_bound, n_dev = maps[b]
         require_device(P, N, Cc, F, n_dev)
@@ -608,11 +641,10 @@ def update_map_fusion_batch_(maps, vertex, normal, depth, rgb, alpha, poses, K, 
         scratch = ws.bytes("map_update%d" % b, L.gs_update_map_scratch_bytes(cap, H, W))
         u = seqs[b]
         u.map = _map_view((P, N, Cc, F), cap, n_bound, n_dev)
-        u.vertex, u.normal, u.depth, u.rgb, u.alpha = (base[0] + b * P3, base[1] + b * P3, base[2] + b * P1,
-                                                       base[3] + b * P3, base[4] + b * P1)
-        u.pose16, u.K16 = base[5] + b * 64, base[6] + b * 64
-        u.gvertex, u.gnormal, u.best_pix = base[7] + b * P3, base[8] + b * P3, base[9] + b * P1
-        u.new_count_out, u.scratch = base[10] + b * 8, scratch.data_ptr()
+        u.vertex, u.normal, u.depth, u.rgb, u.alpha = (v[1] + b * v[2] for v in views)
+        u.pose16, u.K16 = base[0] + b * 64, base[1] + b * 64
+        u.gvertex, u.gnormal = gviews[0][1] + b * gviews[0][2], gviews[1][1] + b * gviews[1][2]
+        u.best_pix, u.new_count_out, u.scratch = base[2] + b * P1, base[3] + b * 8, scratch.data_ptr()
     check(L.gs_update_map_fusion_batch_f32(seqs, Bn, H, W, float(dist_th), float(dot_th), 1 if renorm_all else 0,
                                            stream(dev)), "gs_update_map_fusion_batch_f32")
     return cnt, gv, gn, best
@@ -745,12 +777,16 @@ class FrameMapsFunction(torch.autograd.Function):
         dev = require_device(depth_c, K_c)
         H, W = depth_c.shape
         v_bar, n_bar, a_bar = _c(v_bar), _c(n_bar), _c(a_bar)
-        d_bar = torch.empty((H, W), dtype=f32, device=dev)
+        d_bar = torch.empty((H, W), dtype=f32, device=dev) if ctx.needs_input_grad[0] else None
         scratch = torch.empty((H, W, 6), dtype=f32, device=dev) if n_bar is not None else None
+        K_bar, k_scratch = None, None
+        if ctx.needs_input_grad[1]:   # gradient w.r.t. the intrinsics (fx, fy, cx, cy entries)
+            K_bar = torch.empty((4, 4), dtype=f32, device=dev)
+            k_scratch = Workspace.get(dev).bytes("kbar", lib().gs_frame_maps_backward_kbar_scratch_bytes(H, W))
         check(lib().gs_frame_maps_backward_f32(ptr(depth_c), ptr(K_c), H, W, two_sigma_sq(ctx.sigma), ptr(v_bar),
-                                               ptr(n_bar), ptr(a_bar), ptr(d_bar), ptr(scratch), stream(dev)),
-              "gs_frame_maps_backward_f32")
-        return d_bar, None, None
+                                               ptr(n_bar), ptr(a_bar), ptr(d_bar), ptr(scratch), ptr(K_bar),
+                                               ptr(k_scratch), stream(dev)), "gs_frame_maps_backward_f32")
+        return d_bar, K_bar, None
 
 
 class GlobalMapsFunction(torch.autograd.Function):

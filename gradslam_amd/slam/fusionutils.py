@@ -514,10 +514,11 @@ def _update_map_one_call(pointclouds, rgbdimages, dist_th, dot_th, sigma):
     B, _, H, W = fr.shape
     alpha = fr._alpha_map(sigma)
     vm, nm = fr.vertex_map, fr.normal_map
-    rgb, depth = fr.rgb_image.contiguous().float(), fr.depth_image.contiguous().float()
+    rgb, depth = fr.rgb_image, fr.depth_image   # a frame slice of a (B, L, ...) stack is consumed in place (no copy)
     if len(pointclouds) == 0:
         pointclouds._init_empty_batch(B, 1)
-    gv, gn = torch.empty_like(vm), torch.empty_like(nm)
+    gv = torch.empty((B, 1, H, W, 3), dtype=torch.float32, device=fr.device)
+    gn = torch.empty_like(gv)
     maps = []
     for b in range(B):
         P, N, C, F = pointclouds._reserve(b, H * W, pointclouds.RESERVE_FRAMES)   # before _count_of: see _fuse

@@ -253,10 +253,30 @@ class Pointclouds(object):
         self._padded_cache[k] = (key, out)
         return out
 
-    points_list = property(lambda self: self._list("points"))
-    normals_list = property(lambda self: self._list("normals"))
-    colors_list = property(lambda self: self._list("colors"))
-    features_list = property(lambda self: self._list("features"))
+    # list representation: zero-copy views; the setters follow the reference (structures/pointclouds.py:824-878,
+    # :1431-1467: same container type, length and per-sequence shapes, values are cloned)
+    def _set_list(self, k, value, first_dim_only=False):
+        if not isinstance(value, list):
+            raise TypeError("value must be list of torch.Tensors. Got {}".format(type(value)))
+        if not self.has_points:
+            raise ValueError("cannot set list representation for an empty pointclouds object")
+        if len(self) != len(value):
+            raise ValueError("value must have same length as pointclouds.points_list. Got {} != {}.".format(
+                len(value), len(self)))
+        if any(v.ndim != 2 for v in value):
+            raise ValueError("ndim of all tensors in value list should be 2")
+        pts = self.points_list
+        if first_dim_only and any(pts[b].shape[:1] != value[b].shape[:1] for b in range(len(self))):
+            raise ValueError("shape of first 2 dims of tensors in value and pointclouds.points_list must match")
+        if (not first_dim_only) and any(pts[b].shape != value[b].shape for b in range(len(self))):
+            raise ValueError("shape of tensors in value and pointclouds.points_list must match")
+        self._buf[k] = [v.clone().to(self.device) for v in value]
+        self._padded_cache.pop(k, None)
+
+    points_list = property(lambda self: self._list("points"), lambda self, v: self._set_list("points", v))
+    normals_list = property(lambda self: self._list("normals"), lambda self, v: self._set_list("normals", v))
+    colors_list = property(lambda self: self._list("colors"), lambda self, v: self._set_list("colors", v))
+    features_list = property(lambda self: self._list("features"), lambda self, v: self._set_list("features", v, True))
 
     @property
     def points_padded(self):
@@ -538,6 +558,43 @@ class Pointclouds(object):
 
         self._apply("points", proj)
         return self
+
+    # arithmetic operators of the reference (structures/pointclouds.py:300-384): out-of-place offset / scale /
+    # rotation / rigid transform
+    def __add__(self, other):
+        try:
+            return self.clone().offset_(other)
+        except TypeError:
+            raise NotImplementedError("Pointclouds + {} currently not implemented.".format(type(other)))
+
+    def __sub__(self, other):
+        try:
+            return self.clone().offset_(other * -1)
+        except TypeError:
+            raise NotImplementedError("Pointclouds - {} currently not implemented.".format(type(other)))
+
+    def __mul__(self, other):
+        try:
+            return self.clone().scale_(other)
+        except TypeError:
+            raise NotImplementedError("Pointclouds * {} currently not implemented.".format(type(other)))
+
+    def __truediv__(self, other):
+        try:
+            return self.__mul__(1.0 / other)
+        except TypeError:
+            raise NotImplementedError("Pointclouds / {} currently not implemented.".format(type(other)))
+
+    def __matmul__(self, other):
+        if not torch.is_tensor(other):
+            raise NotImplementedError("Pointclouds @ {} currently not implemented.".format(type(other)))
+        if not ((other.ndim == 2 or other.ndim == 3) and (other.shape[-2:] == (3, 3) or other.shape[-2:] == (4, 4))):
+            msg = "Unsupported shape for Pointclouds @ operand: {}\n".format(other.shape)
+            msg += "Use tensor of shape (3, 3) or (B, 3, 3) for rotations, or (4, 4) or (B, 4, 4) for transformations"
+            raise ValueError(msg)
+        if other.shape[-2:] == (3, 3):
+            return self.clone().rotate_(other, pre_multiplication=False)
+        return self.clone().transform_(other, pre_multiplication=False)
 
     def offset(self, offset):
         return self.clone().offset_(offset)

@@ -73,6 +73,15 @@ class RGBDImages(object):
         self._depth_image, self._intrinsics = depth_image.to(self.device), intrinsics.to(self.device)
         self._poses = None if poses is None else poses.to(self.device)
         self._pixel_pos = None if pixel_pos is None else pixel_pos.to(self.device)
+        if self._pixel_pos is not None:
+            # the back-projection kernel generates (u, v, 1) itself: a caller-supplied grid must be that grid
+            hh, ww = (rgb_image.shape[3], rgb_image.shape[4]) if channels_first else (rgb_image.shape[2], rgb_image.shape[3])
+            v, u = torch.meshgrid(torch.arange(hh, dtype=torch.float32, device=self.device),
+                                  torch.arange(ww, dtype=torch.float32, device=self.device), indexing="ij")
+            std = torch.stack([u, v, torch.ones_like(u)], -1)
+            if not bool((self._pixel_pos.float() == std).all()):   # (B, L, H, W, 3) in either layout
+                raise NotImplementedError("gradslam_amd back-projects on the regular pixel grid (u, v, 1); a custom "
+                                          "pixel_pos is not supported")
 
         self._vertex_map = None
         self._global_vertex_map = None
@@ -132,7 +141,19 @@ class RGBDImages(object):
     depth_image = property(lambda self: self._depth_image)
     intrinsics = property(lambda self: self._intrinsics)
     poses = property(lambda self: self._poses)
-    pixel_pos = property(lambda self: self._pixel_pos)
+
+    @property
+    def pixel_pos(self):
+        """(B, L, H, W, 3) = [column u, row v, 1] per pixel once the vertex map has been computed, None before
+        (reference: structures/rgbdimages.py:308-317, :647-661).  The HIP kernel generates the grid in registers; this
+        tensor exists for API parity only."""
+        if self._pixel_pos is None and self._vertex_map is not None:
+            B, L, H, W = self.shape
+            v, u = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=self.device),
+                                  torch.arange(W, dtype=torch.float32, device=self.device), indexing="ij")
+            grid = torch.stack([u, v, torch.ones_like(u)], -1)
+            self._pixel_pos = grid.view(1, 1, H, W, 3).repeat(B, L, 1, 1, 1)
+        return self._pixel_pos
 
     @property
     def has_poses(self):
@@ -155,18 +176,18 @@ class RGBDImages(object):
         return t.permute(0, 1, 4, 2, 3).contiguous() if self.channels_first else t
 
     def _wants_grad(self):
-        return torch.is_grad_enabled() and self._depth_image.requires_grad
+        return torch.is_grad_enabled() and (self._depth_image.requires_grad or self._intrinsics.requires_grad)
 
     def _compute_local_maps(self, sigma=None):
         """vertex + normal (+ alpha when sigma is given) for every (b, l) frame: one kernel each.
         When depth requires grad the maps stay on the autograd tape (hand-written HIP backward)."""
         from .. import ops
         B, L, H, W = self.shape
-        depth = self._cl(self._depth_image)
         K = self._intrinsics.contiguous().float()
         if sigma is None:
             sigma = getattr(self, "_sigma_hint", None)
         if self._wants_grad():
+            depth = self._cl(self._depth_image)
             sg = 0.6 if sigma is None else float(sigma)
             rows = [[ops.FrameMapsFunction.apply(depth[b, s, ..., 0], K[b, 0], sg) for s in range(L)] for b in range(B)]
             vm = torch.stack([torch.stack([r[0] for r in row]) for row in rows])
@@ -178,9 +199,11 @@ class RGBDImages(object):
         vm = torch.empty((B, L, H, W, 3), dtype=torch.float32, device=self.device)
         nm = torch.empty_like(vm)
         am = torch.empty((B, L, H, W, 1), dtype=torch.float32, device=self.device) if sigma is not None else None
-        ops.frame_maps_batch(depth.view(B * L, H, W), K.view(B, 4, 4), L, sigma,
-                             out=(vm.view(B * L, H, W, 3), nm.view(B * L, H, W, 3),
-                                  None if am is None else am.view(B * L, H, W)))
+        # the depth stack is read in place (channels-last (B, L, H, W, 1): its last dimension is dropped by a view; a
+        # frame slice of a longer stack keeps its strides, nothing is copied)
+        depth = self._depth_image[:, :, 0] if self.channels_first else self._depth_image[..., 0]
+        ops.frame_maps_batch(depth, K.view(B, 4, 4), sigma,
+                             out=(vm, nm, None if am is None else am[..., 0]))
         self._vertex_map, self._normal_map = self._from_cl(vm), self._from_cl(nm)
         if am is not None:
             self._alpha_cache = (float(sigma), am)

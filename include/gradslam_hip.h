@@ -196,10 +196,15 @@ GS_API int gs_icp_f32(const float* src, int64_t n_src, const float* tgt, const f
  * Reverse mode of gs_frame_maps_f32 w.r.t. depth: depth_bar (H,W) from the adjoints of the local
  * vertex map, normal map and alpha (any may be NULL), as PyTorch autograd does through
  * structures/rgbdimages.py:643-743 and slam/fusionutils.py:69-72.  scratch_6hw: 6*H*W floats,
- * needed when normal_bar is given.  Gradients w.r.t. the intrinsics are not produced. */
+ * needed when normal_bar is given.  K_bar16 (may be NULL): the gradient w.r.t. the 4x4 intrinsics as autograd
+ * produces it through inverse_intrinsics (geometry/projutils.py:437-449): entries [0,0] (fx), [0,2] (cx), [1,1] (fy),
+ * [1,2] (cy), zero elsewhere; needs kbar_scratch of gs_frame_maps_backward_kbar_scratch_bytes(H, W) bytes (fixed-order
+ * float64 block sums).  depth_bar may be NULL when only K_bar16 is wanted. */
+GS_API int64_t gs_frame_maps_backward_kbar_scratch_bytes(int H, int W);
 GS_API int gs_frame_maps_backward_f32(const float* depth, const float* K16, int H, int W, float two_sigma_sq,
                                       const float* vertex_bar, const float* normal_bar, const float* alpha_bar,
-                                      float* depth_bar, float* scratch_6hw, void* stream);
+                                      float* depth_bar, float* scratch_6hw, float* K_bar16, void* kbar_scratch,
+                                      void* stream);
 /* Reverse mode of gs_global_maps_f32 w.r.t. the local maps (rgbdimages.py:681-762):
  * vertex_bar = R^T (gvertex_bar * valid), normal_bar = R^T gnormal_bar.  (No pose gradient.) */
 GS_API int gs_global_maps_backward_f32(const float* gvertex_bar, const float* gnormal_bar, const float* depth,
@@ -420,11 +425,14 @@ typedef struct gs_map_view {
   const int64_t* n_dev; /* device int64[1]: the actual count, or NULL when n_bound is exact */
 } gs_map_view;
 
-/* K1 for n_frames frames in one launch: depth (n_frames, H, W), frame f uses K16 + 16 * (f / frames_per_K)
- * (an RGBDImages of B sequences x L frames: frames_per_K = L); vertex / normal (n_frames, H, W, 3),
- * alpha (n_frames, H, W); normal / alpha may be NULL.  Same arithmetic as gs_frame_maps_f32. */
-GS_API int gs_frame_maps_batch_f32(const float* depth, const float* K16, int n_frames, int frames_per_K, int H, int W,
-                                   float two_sigma_sq, float* vertex, float* normal, float* alpha, void* stream);
+/* K1 for n_frames = B x frames_per_K frames in one launch (an RGBDImages of B sequences x L frames: frames_per_K =
+ * L): frame f = b * L + l reads the (H, W) depth image at depth + b * depth_stride_seq + l * depth_stride_frame
+ * (strides in floats: a contiguous stack has L*H*W and H*W; a one-frame slice frames[:, s] of a longer stack keeps
+ * the stack's strides, so no copy is needed) and the intrinsics K16 + 16 * b; outputs are dense: vertex / normal
+ * (n_frames, H, W, 3), alpha (n_frames, H, W); normal / alpha may be NULL.  Same arithmetic as gs_frame_maps_f32. */
+GS_API int gs_frame_maps_batch_f32(const float* depth, int64_t depth_stride_seq, int64_t depth_stride_frame,
+                                   const float* K16, int n_frames, int frames_per_K, int H, int W, float two_sigma_sq,
+                                   float* vertex, float* normal, float* alpha, void* stream);
 
 /* ICPSLAM._localize (slam/icpslam.py:238-247) for B sequences: ICP source = the live frame's [::ds, ::ds] lattice
  * under the previous pose (gs_lattice_source_f32), targets = the map rows that project onto that lattice in the

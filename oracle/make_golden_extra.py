@@ -98,6 +98,57 @@ def tum_items():
     print("icl_items.npz", {k: int(out[k]) for k in out if k.endswith("/len")})
 
 
+def scannet_items():
+    """scannet_items.npz: what the reference's Scannet loader (datasets/scannet.py) returns for
+    tests/tum_fixture.py:write_scannet (native-size frames), two constructor configurations."""
+    import tempfile
+    refimport.import_reference()
+    from gradslam.datasets.scannet import Scannet
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tum_fixture", os.path.join(REPO, "tests", "tum_fixture.py"))
+    fx = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fx)
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        base, meta = fx.write_scannet(root)
+        for case, kw in fx.SCANNET_CASES.items():
+            ds = Scannet(base, meta, **kw)
+            out[case + "/len"] = np.array(len(ds))
+            for i in range(len(ds)):
+                colors, depths, K, poses, transforms, names, labels = ds[i]
+                for k, v in (("colors", colors), ("depths", depths), ("intrinsics", K), ("poses", poses),
+                             ("transforms", transforms), ("labels", labels)):
+                    out["%s/%d/%s" % (case, i, k)] = v.numpy()
+                out["%s/%d/names" % (case, i)] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "scannet_items.npz"), **out)
+    print("scannet_items.npz", {k: int(out[k]) for k in out if k.endswith("/len")})
+
+
+def intrinsics_grad():
+    """intrinsics_grad.npz: the reference's autograd d/dK of <Wv, vertex_map> + <Wn, normal_map> + <Wa, alpha>
+    (structures/rgbdimages.py:662-675 through inverse_intrinsics, geometry/projutils.py:437-449) on a HOLE-FREE 96x128
+    frame: next to depth holes the normal normalisation makes the sums ill-conditioned (the reference's own float32
+    and float64 autograd then disagree by more than 100 %), so such a frame cannot pin anything."""
+    refimport.import_reference()
+    import torch
+    import gradslam
+    from gradslam.slam import fusionutils as fu
+    from gradslam_amd.datasets.synthetic import make_sequence
+    sq = make_sequence(2, 96, 128, seed=5, hole_frac=0.0)
+    g = np.load(os.path.join(OUT, "depth_grad.npz"))
+    T = torch.from_numpy
+    K = T(sq["intrinsics"][None]).clone().requires_grad_(True)
+    d1 = T(sq["depths"][None, 1:2]).clone().requires_grad_(True)
+    f1 = gradslam.RGBDImages(torch.zeros(1, 1, 96, 128, 3), d1, K, T(sq["poses"][None, :1]))
+    al = fu.get_alpha(f1.vertex_map, dim=4, keepdim=True, sigma=0.6)
+    ((f1.vertex_map[0, 0] * T(g["Wv"])).sum() + (f1.normal_map[0, 0] * T(g["Wn"])).sum()
+     + (al[0, 0, ..., 0] * T(g["Wa"])).sum()).backward()
+    np.savez_compressed(os.path.join(OUT, "intrinsics_grad.npz"), K_grad=K.grad[0, 0].numpy(),
+                        depth=sq["depths"][1, ..., 0], intrinsics=sq["intrinsics"][0], pose=sq["poses"][0],
+                        depth_grad=d1.grad[0, 0, ..., 0].numpy())
+    print("intrinsics_grad.npz", K.grad[0, 0].numpy())
+
+
 def icp0_grad():
     refimport.import_reference()
     import torch
@@ -176,6 +227,8 @@ def slam_grad0():
 if __name__ == "__main__":
     main()
     tum_items()
+    scannet_items()
+    intrinsics_grad()
     icp0_grad()
     fusion_grad()
     slam_grad0()

@@ -9,7 +9,10 @@ forward:  V[h,w] = ray[h,w] * depth * valid,  ray = (k00 w + k02, k11 h + k12, 1
 import numpy as np
 
 
-def frame_maps_backward(depth, K, sigma, v_bar, n_bar, a_bar):
+def frame_maps_backward(depth, K, sigma, v_bar, n_bar, a_bar, want_K=False):
+    """depth_bar (H, W); with want_K also K_bar (4, 4): the adjoint of the intrinsics through inverse_intrinsics
+    (k00 = 1 / (fx + eps), k02 = -cx / (fx + eps), same for y; geometry/projutils.py:437-449), pinned against
+    tests/golden/intrinsics_grad.npz."""
     depth = np.asarray(depth, np.float64)
     H, W = depth.shape
     fx, fy, cx, cy = (float(K[0, 0]) + 1e-6), (float(K[1, 1]) + 1e-6), float(K[0, 2]), float(K[1, 2])
@@ -44,4 +47,13 @@ def frame_maps_backward(depth, K, sigma, v_bar, n_bar, a_bar):
     np.add.at(Vb, (slice(None), w0), -dh_b)
     np.add.at(Vb, (h0 + 1,), dv_b)
     np.add.at(Vb, (h0,), -dv_b)
-    return (Vb * ray).sum(-1) * valid
+    depth_bar = (Vb * ray).sum(-1) * valid
+    if not want_K:
+        return depth_bar
+    dm = depth * valid
+    kb00, kb02 = (Vb[..., 0] * w * dm).sum(), (Vb[..., 0] * dm).sum()
+    kb11, kb12 = (Vb[..., 1] * h * dm).sum(), (Vb[..., 1] * dm).sum()
+    K_bar = np.zeros((4, 4))
+    K_bar[0, 0], K_bar[0, 2] = (-kb00 + kb02 * cx) / (fx * fx), -kb02 / fx
+    K_bar[1, 1], K_bar[1, 2] = (-kb11 + kb12 * cy) / (fy * fy), -kb12 / fy
+    return depth_bar, K_bar

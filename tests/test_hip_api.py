@@ -337,3 +337,30 @@ def test_icl_loader_on_device_matches_reference(tmp_path, golden):
             assert np.array_equal(K.cpu().numpy(), g["%s/%d/intrinsics" % (case, i)])
             assert np.abs(poses.cpu().numpy() - g["%s/%d/poses" % (case, i)]).max() <= 2e-6
             assert np.abs(transforms.cpu().numpy() - g["%s/%d/transforms" % (case, i)]).max() <= 2e-6
+
+
+def test_scannet_loader_on_device_matches_reference(tmp_path, golden):
+    """gradslam_amd.datasets.Scannet against the items the reference's own loader returned for the same files
+    (tests/golden/scannet_items.npz, oracle/make_golden_extra.py:scannet_items): colours, depths (scale 1000),
+    intrinsics, names and labels (both palettes) identical; poses / transforms within 2e-6."""
+    from gradslam_amd.datasets import Scannet
+    from tests import tum_fixture as fx
+    base, meta = fx.write_scannet(str(tmp_path))
+    g = golden("scannet_items")
+    for case, kw in fx.SCANNET_CASES.items():
+        ds = Scannet(base, meta, **kw)
+        assert len(ds) == int(g[case + "/len"])
+        gold = {str(g["%s/%d/names" % (case, j)]): j for j in range(len(ds))}
+        for k in range(len(ds)):
+            colors, depths, K, poses, transforms, names, labels = ds[k]
+            i = gold[names]
+            assert np.array_equal(colors.cpu().numpy(), g["%s/%d/colors" % (case, i)])
+            assert np.array_equal(depths.cpu().numpy(), g["%s/%d/depths" % (case, i)])
+            assert np.array_equal(K.cpu().numpy(), g["%s/%d/intrinsics" % (case, i)])
+            assert np.array_equal(labels.cpu().numpy(), g["%s/%d/labels" % (case, i)])
+            assert np.abs(poses.cpu().numpy() - g["%s/%d/poses" % (case, i)]).max() <= 2e-6
+            assert np.abs(transforms.cpu().numpy() - g["%s/%d/transforms" % (case, i)]).max() <= 2e-6
+    with pytest.raises(ValueError):
+        Scannet(base, meta, None, start=3, end=2)
+    with pytest.raises(TypeError):
+        Scannet(base, meta, 5)

@@ -54,12 +54,16 @@ def test_frame_maps_batch_equals_single_frames(ops):
     depth[rng.random(depth.shape) < 0.1] = 0
     K = np.stack([np.array([[100 + 7 * b, 0, 60, 0], [0, -(90 + 3 * b), 30, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
                   for b in range(B)])
-    v, n, a = ops.frame_maps_batch(dev(depth), dev(K), L, SIGMA)
+    stack = dev(depth).view(B, L, H, W)
+    v, n, a = ops.frame_maps_batch(stack, dev(K), SIGMA)
     for f in range(B * L):
         v1, n1, a1, _ = ops.frame_maps(dev(depth[f]), dev(K[f // L]), SIGMA)
-        assert torch.equal(v[f], v1) and torch.equal(n[f], n1) and torch.equal(a[f], a1)
-    v2, n2, a2 = ops.frame_maps_batch(dev(depth), dev(K), L, None)
+        assert torch.equal(v[f // L, f % L], v1) and torch.equal(n[f // L, f % L], n1) and torch.equal(a[f // L, f % L], a1)
+    v2, n2, a2 = ops.frame_maps_batch(stack, dev(K), None)
     assert a2 is None and torch.equal(v2, v) and torch.equal(n2, n)
+    # a one-frame slice of the stack is read in place (sequence stride = L frames)
+    v3, n3, a3 = ops.frame_maps_batch(stack[:, 1:2], dev(K), SIGMA)
+    assert torch.equal(v3[:, 0], v[:, 1]) and torch.equal(n3[:, 0], n[:, 1]) and torch.equal(a3[:, 0], a[:, 1])
 
 
 def _build_maps(ops, seeds, H, W, frames=2):
@@ -251,3 +255,20 @@ def test_two_ranks_rccl_gather():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["sequences_total"] == 4
+
+
+def test_pointfusion_1296x968_vs_oracle(gs):
+    """BASELINE configs[4] shape (ScanNet resolution): 3 frames of PointFusion(gradicp, numiters=6) against the oracle's
+    frame loop: 78k ICP queries against ~100k+ binned targets per solve, a map beyond 1.5M surfels: poses within 2e-6,
+    identical surfel counts, points within 1e-5."""
+    from oracle import slam as oslam
+    L, H, W = 3, 968, 1296
+    s = make_sequence(L, H, W, seed=3)
+    frames = frames_of(gs, [s])
+    pc, rp = gs.slam.PointFusion(odom="gradicp", numiters=6, device="cuda")(frames)
+    poses = s["poses"].copy()
+    poses[1:] = poses[:1]
+    m, op = oslam.run_sequence(s["colors"], s["depths"], s["intrinsics"][0], poses, numiters=6)
+    np.testing.assert_allclose(host(rp[0]), op, rtol=0, atol=2e-6)
+    assert pc.points_list[0].shape[0] == len(m) > 1_500_000
+    np.testing.assert_allclose(host(pc.points_list[0]), m.points, rtol=1e-5, atol=1e-5)

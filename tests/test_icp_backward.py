@@ -132,6 +132,29 @@ def test_depth_gradients_through_frame_maps(golden):
 
 
 @pytest.mark.gpu
+def test_intrinsics_gradients_through_frame_maps(golden):
+    """d/dK of <Wv, vertex_map> + <Wn, normal_map> + <Wa, alpha> vs the reference's autograd through
+    inverse_intrinsics (tests/golden/intrinsics_grad.npz, a hole-free frame: next to depth holes the reference's own
+    float32 and float64 gradients disagree): entries fx, fy, cx, cy; with and without a depth gradient."""
+    import gradslam_amd as gs
+    g, gk = golden("depth_grad"), golden("intrinsics_grad")
+    for depth_grad in (True, False):
+        K = dev(gk["intrinsics"][None, None]).requires_grad_(True)
+        d1 = dev(gk["depth"][None, None, ..., None]).requires_grad_(depth_grad)
+        f1 = gs.RGBDImages(torch.zeros((1, 1, 96, 128, 3), device="cuda"), d1, K, dev(gk["pose"][None, None]))
+        alpha = f1._alpha_map(0.6)
+        loss = ((f1.vertex_map[0, 0] * dev(g["Wv"])).sum() + (f1.normal_map[0, 0] * dev(g["Wn"])).sum()
+                + (alpha[0, 0, ..., 0] * dev(g["Wa"])).sum())
+        loss.backward()
+        got, ref = K.grad[0, 0].cpu().numpy(), gk["K_grad"]
+        assert np.isfinite(got).all() and np.array_equal(got == 0, ref == 0)
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), (got, ref)
+        if depth_grad:
+            err = np.abs(d1.grad[0, 0, ..., 0].cpu().numpy() - gk["depth_grad"])
+            assert err.max() <= 1e-3 * np.abs(gk["depth_grad"]).max()
+
+
+@pytest.mark.gpu
 def test_depth_to_pose_chain_matches_reference_autograd(golden):
     """depth -> vertex -> global vertex -> downsample_rgbdimages -> point_to_plane_gradICP -> <W,T>."""
     import gradslam_amd as gs

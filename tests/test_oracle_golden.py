@@ -233,3 +233,42 @@ def test_frame_maps_adjoint_matches_reference_autograd(golden):
     err = np.abs(got - ref)
     assert np.isfinite(got).all() and np.median(err) < 1e-4 * np.abs(ref).max()
     assert (err < 1e-2 * np.abs(ref).max()).mean() > 0.999
+
+
+def test_intrinsics_adjoint_matches_reference_autograd(golden):
+    """oracle/maps_backward.py K_bar against the reference's autograd d/dK (tests/golden/intrinsics_grad.npz)."""
+    from oracle import maps_backward as mb
+    g, gk = golden("depth_grad"), golden("intrinsics_grad")
+    d_bar, K_bar = mb.frame_maps_backward(gk["depth"], gk["intrinsics"], 0.6, g["Wv"], g["Wn"], g["Wa"], want_K=True)
+    ref = gk["K_grad"]
+    assert np.array_equal(K_bar == 0, ref == 0)
+    assert np.abs(K_bar - ref).max() <= 1e-4 * np.abs(ref).max(), (K_bar, ref)
+    assert np.abs(d_bar - gk["depth_grad"]).max() <= 1e-3 * np.abs(gk["depth_grad"]).max()
+
+
+def test_resize_known_answers_with_border_clamps():
+    """OpenCV is not installed here, so the resize arithmetic of the dataset ingest (oracle.ingest_* and, bit for bit
+    equal to it, gs_ingest_*: tests/test_hip_api.py) cannot be pinned against cv2 itself (PARITY UNPINNED for resized
+    frames).  These are hand-computed answers of cv2.resize's documented conventions: INTER_LINEAR samples
+    at (dst + 0.5) * scale - 0.5 and clamps at the borders; INTER_NEAREST takes floor(dst * scale)."""
+    from oracle import oracle as o
+    src = np.zeros((2, 2, 3), np.uint8)
+    src[..., 0] = [[0, 10], [20, 30]]
+    src[..., 1] = 255 - src[..., 0]
+    up = o.ingest_color(src, 4, 4)
+    want = np.array([[0, 2.5, 7.5, 10], [5, 7.5, 12.5, 15], [15, 17.5, 22.5, 25], [20, 22.5, 27.5, 30]], np.float32)
+    assert np.array_equal(up[..., 0], want) and np.array_equal(up[..., 1], 255 - want) and not up[..., 2].any()
+    # 4 -> 2: sample positions 0.5 and 2.5: the mean of the two neighbours
+    row = np.zeros((1, 4, 3), np.uint8)
+    row[0, :, 0] = [0, 10, 20, 40]
+    assert np.array_equal(o.ingest_color(row, 1, 2)[0, :, 0], np.array([5.0, 30.0], np.float32))
+    # 3 -> 2 (non-integer ratio 1.5): positions 0.25 and 1.75
+    r3 = np.zeros((1, 3, 3), np.uint8)
+    r3[0, :, 0] = [0, 100, 200]
+    assert np.allclose(o.ingest_color(r3, 1, 2)[0, :, 0], [25.0, 175.0], atol=1e-4)
+    assert np.array_equal(o.ingest_color(src, 2, 2, normalize=True)[..., 0], want[::3, ::3] / np.float32(255))
+    d = np.array([[1000, 2000, 3000], [4000, 5000, 6000]], np.uint16)
+    assert np.array_equal(o.ingest_depth(d, 2, 3, 1000.0), d.astype(np.float32) / 1000)
+    assert np.array_equal(o.ingest_depth(d, 4, 6, 1000.0)[::2, ::2], d.astype(np.float32) / 1000)   # floor(dst / 2)
+    assert np.array_equal(o.ingest_depth(d, 4, 6, 1000.0)[1::2, 1::2], d.astype(np.float32) / 1000)
+    assert np.array_equal(o.ingest_depth(d, 1, 2, 5000.0), np.array([[0.2, 0.4]], np.float32))      # floor(dst * 1.5)

@@ -84,3 +84,48 @@ ICL_CASES = {
     "strided": dict(seqlen=2, dilation=2, stride=1, start=1, end=7, height=H, width=W, normalize_color=True,
                     channels_first=True, trajectories=("living_room_traj2_frei_png",)),
 }
+
+
+# ------------------------------------------------------------------ ScanNet format
+def write_scannet(root, n_frames=6, seed=17):
+    """two scenes, one sequence each: `scans/<scene>/{color,depth,pose,label-filt,intrinsic}` + the per-sequence
+    metadata files in `seqmeta/` (the layout datasets/scannet.py:130-168 parses)."""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    base, meta = os.path.join(root, "scans"), os.path.join(root, "seqmeta")
+    os.makedirs(meta, exist_ok=True)
+    for si, scene in enumerate(("scene0000_00", "scene0001_00")):
+        d = os.path.join(base, scene)
+        for sub in ("color", "depth", "pose", "label-filt", "intrinsic"):
+            os.makedirs(os.path.join(d, sub), exist_ok=True)
+        K = np.array([[577.6 + si, 0, 318.9, 0], [0, 578.7, 242.7 - si, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+        np.savetxt(os.path.join(d, "intrinsic", "intrinsic_depth.txt"), K)
+        np.savetxt(os.path.join(d, "intrinsic", "intrinsic_color.txt"), K * 2)
+        lines = []
+        for k in range(n_frames):
+            Image.fromarray(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).save(os.path.join(d, "color/%d.png" % k))
+            dep = rng.integers(0, 9000, (H, W), dtype=np.uint16)
+            dep[rng.random((H, W)) < 0.07] = 0
+            Image.fromarray(dep).save(os.path.join(d, "depth/%d.png" % k))
+            Image.fromarray(rng.integers(0, 41, (H, W), dtype=np.uint8)).save(os.path.join(d, "label-filt/%d.png" % k))
+            a = 0.04 * k + 0.1 * si
+            T = np.eye(4)
+            T[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+            T[:3, 3] = [0.03 * k, 0.5 - 0.01 * k, 1.0 + 0.002 * k * k]
+            np.savetxt(os.path.join(d, "pose/%d.txt" % k), T)
+            rel = lambda sub, f: "%s/%s/%s" % (scene, sub, f)  # noqa: E731
+            lines.append(" ".join(["color", rel("color", "%d.png" % k), "depth", rel("depth", "%d.png" % k), "pose",
+                                   rel("pose", "%d.txt" % k), "label-filt", rel("label-filt", "%d.png" % k), "label",
+                                   "-", "instance-filt", "-", "instance", "-", "intrinsic_depth",
+                                   rel("intrinsic", "intrinsic_depth.txt"), "intrinsic_color",
+                                   rel("intrinsic", "intrinsic_color.txt")]))
+        with open(os.path.join(meta, "%s-seq_0.txt" % scene), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    return base, meta
+
+
+SCANNET_CASES = {
+    "default": dict(scenes=None, height=H, width=W),
+    "nyu40_cf": dict(scenes=("scene0001_00",), start=1, end=5, height=H, width=W, seg_classes="nyu40",
+                     channels_first=True, normalize_color=True),
+}

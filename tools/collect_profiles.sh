@@ -3,7 +3,7 @@
 # command, each in its own rocprofv3 run (PMC passes carry no trace options).  Outputs under gpurun_out/$1_*.
 # Usage: tools/collect_profiles.sh <tag>     then, locally:  python tools/summarize_profiles.py <tag>
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
 B="python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline-pass"

@@ -37,7 +37,7 @@ print("phases (us, mean / max over blocks): prologue %.2f / %.2f   first search 
                             rest[ok].mean(), rest[ok].max()))
 print("unresolved queries: total %d, per block max %d, blocks with any %d" % (nun.sum(), nun.max(), (nun > 0).sum()))
 print("queries left open by the 2x2x2 stage: total %d, per block max %d" % (csum.sum(), csum.max()))
-rot = int(os.environ.get("GRADSLAM_HIP_SEQ_ROT", 0))
+rot = 0
 for s in range(B):
     m = ((np.arange(len(rows)) + rot) % B) == s
     print("seq %d: %d blocks  end max %.2f  open after stage 0: %d  slowest stage 0 %.1f  slowest shells %.1f" % (
