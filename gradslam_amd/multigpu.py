@@ -5,7 +5,8 @@ odometry/icp.py:84), so the data path needs NO collective: rank r runs the seque
 `shard_sequences(B, world, r)` on its own MI355X.  The only exchange is the final gather of the
 recovered poses (64 B per frame) and, optionally, the maps (~40 B per surfel), done once with
 torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests):
-an all_gather of per-rank counts followed by one padded all_gather per attribute.
+one small object gather (per-sequence counts, attribute widths) followed by ONE padded all_gather of the packed
+surfels (poses: one padded all_gather).
 """
 import os
 from typing import List, Optional
@@ -70,22 +71,41 @@ def gather_poses(local_poses: torch.Tensor) -> torch.Tensor:
 
 def gather_maps(pointclouds: Pointclouds) -> Pointclouds:
     """Every rank's local maps -> one Pointclouds holding all sequences (rank order), on every rank.
-    Variable sizes are handled by flattening each attribute to (sum_b n_b, C) plus a count vector."""
+    Two collectives: the per-sequence counts and attribute widths of every rank (a small object gather), then ONE
+    padded all_gather of each rank's surfels packed row-wise as [points | normals | colors | features]."""
+    world = _world()
+    if world == 1:
+        return pointclouds
     dev = pointclouds.device
-    counts = torch.tensor(pointclouds._n, dtype=torch.int64, device=dev).reshape(-1)
-    all_counts = torch.cat(_gather_rows(counts), 0).tolist()
-    lists = {}
+    counts = list(pointclouds._n)
+    lists = {k: getattr(pointclouds, k + "_list") for k in ("points", "normals", "colors", "features")}
+    widths = {k: (0 if v is None or not len(v) else int(v[0].shape[-1])) for k, v in lists.items()}
+    meta = [None] * world
+    dist.all_gather_object(meta, (counts, widths))
+    # attribute set of the merged map: whatever any rank has (ranks without sequences contribute nothing)
+    w = {k: max(m[1][k] for m in meta) for k in widths}
+    width = sum(w.values())
+    rows = sum(counts)
+    packed = torch.zeros((rows, width), dtype=torch.float32, device=dev)
+    col = 0
     for k in ("points", "normals", "colors", "features"):
-        src = getattr(pointclouds, k + "_list")
-        has = torch.tensor([0 if src is None else src[0].shape[-1]], dtype=torch.int64, device=dev)
-        width = max(int(w.item()) for w in _gather_rows(has))
-        if width == 0:
-            lists[k] = None
-            continue
-        flat = (torch.cat(src, 0) if src is not None and len(src) else
-                torch.zeros((0, width), dtype=torch.float32, device=dev))
-        flat_all = torch.cat(_gather_rows(flat.contiguous()), 0)
-        lists[k] = list(torch.split(flat_all, all_counts, 0))
-    if not all_counts:
+        if w[k] and widths[k] and rows:
+            packed[:, col:col + w[k]] = torch.cat(lists[k], 0)
+        col += w[k]
+    cap = max(max(sum(m[0]) for m in meta), 1)
+    send = torch.zeros((cap, width), dtype=torch.float32, device=dev)
+    send[:rows] = packed
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)
+    out = {k: [] for k in w}
+    for r, (cnts, _) in enumerate(meta):
+        per_seq = torch.split(recv[r][: sum(cnts)], cnts, 0) if cnts else []
+        for t in per_seq:
+            col = 0
+            for k in ("points", "normals", "colors", "features"):
+                if w[k]:
+                    out[k].append(t[:, col:col + w[k]].contiguous())
+                col += w[k]
+    if not out["points"]:
         return Pointclouds(device=dev)
-    return Pointclouds(lists["points"], lists["normals"], lists["colors"], lists["features"])
+    return Pointclouds(out["points"], out["normals"] or None, out["colors"] or None, out["features"] or None)
