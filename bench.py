@@ -188,6 +188,8 @@ def main():
 
     rank, world, local = multigpu.init_from_env()
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
+    if os.environ.get("GRADSLAM_BENCH_SHARE_GPU") == "1":   # rehearsal of the N-rank path on fewer GPUs (gloo only)
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world != args.gpus and rank == 0:
@@ -249,6 +251,10 @@ def main():
     barrier()
     gather_ms = (time.perf_counter() - g0) * 1e3
     assert all_poses.shape[0] == args.batch and len(all_maps) == args.batch
+    # fingerprint of the gathered result: the same for every N (sequences do not interact; tests/test_hip_batch.py)
+    import hashlib
+    poses_sha = hashlib.sha256(all_poses.cpu().numpy().tobytes()).hexdigest()[:16]
+    n_map_all = [int(p.shape[0]) for p in all_maps.points_list]
 
     # ---------------- roofline pass: same frames from the same map state, HIP events inside the library
     roofline, roofline_hbm = None, None
@@ -316,7 +322,7 @@ def main():
                                    "sequences of the GPU), frames resident in HBM (BASELINE configs[%s])"
                                    % (args.odom, args.batch, Ww, Hh, world, B_local, "4" if args.workload == "c5" else "3"),
                        "sequences_total": args.batch, "sequences_per_gpu": B_local, "frames_timed_per_sequence": K,
-                       "map_surfels_end_rank0": n_map,
+                       "map_surfels_end_rank0": n_map, "map_surfels_all": n_map_all, "poses_sha": poses_sha,
                        "parity_mode": "renormalize_unmatched=True (reference-identical merge)",
                        "final_gather_ms": gather_ms, "api": "gradslam_amd.slam.PointFusion.step",
                        "host_enqueue_ms_per_step": t_enq / K * 1e3,

@@ -174,8 +174,8 @@ def stream(device):
 
 
 class Workspace:
-    """Per-device scratch buffers, grown on demand and reused every frame (the library never
-    allocates)."""
+    """Scratch buffers per (device, stream), grown on demand and reused every frame (the library never allocates).
+    Keyed by the stream the calls are enqueued on: two chains of calls on different streams never share scratch."""
     _instances = {}
 
     def __init__(self, device):
@@ -187,9 +187,10 @@ class Workspace:
         device = torch.device(device)
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        ws = cls._instances.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = cls._instances.get(key)
         if ws is None:
-            ws = cls._instances[device] = Workspace(device)
+            ws = cls._instances[key] = Workspace(device)
         return ws
 
     def bytes(self, name, nbytes):

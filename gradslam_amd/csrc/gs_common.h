@@ -7,6 +7,7 @@
 // (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -49,7 +50,7 @@ static inline size_t gs_align(size_t x, size_t a = 256) { return (x + a - 1) / a
 enum GsProfKind { GS_PROF_KNN = 0, GS_PROF_LINEARIZE = 1, GS_PROF_FRAME = 2, GS_PROF_PROJECT = 3,
                   GS_PROF_ASSOC = 4, GS_PROF_FUSE = 5, GS_PROF_COMPACT = 6, GS_PROF_SOLVE = 7, GS_PROF_ICP_FUSED = 8,
                   GS_PROF_KINDS = 9 };
-extern bool g_gs_prof_on;
+extern std::atomic<bool> g_gs_prof_on;  // set between gs_profile_begin / _end; records are guarded by a mutex
 int gs_prof_open(int kind, double work, hipStream_t st, int launches);
 void gs_prof_close(int slot, hipStream_t st);
 struct GsProf {

@@ -62,14 +62,21 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_cp_scatter_kernel(
     c += keep[i] ? 1 : 0;
   }
   int total;
-  int excl = gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &total);
-  int64_t pos = tile_offsets[blockIdx.x] + excl;
+  int w = gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &total);
+  // Survivors are first listed in LDS, then survivor r of the tile is emitted by thread r: consecutive lanes write
+  // consecutive output rows.  (Emitting from the thread that owns the input element scatters 4-byte stores of one
+  // wave over a 3 KB span; measured on MI355X that costs 6.6x the payload in HBM write traffic.)
+  __shared__ unsigned short loc_s[GS_CP_TILE];
 #pragma unroll
   for (int i = 0; i < GS_CP_ITEMS; ++i) {
-    if (keep[i]) {
-      if (cap < 0 || pos < cap) emit(base + i, pos);
-      ++pos;
-    }
+    if (keep[i]) loc_s[w++] = (unsigned short)(threadIdx.x * GS_CP_ITEMS + i);
+  }
+  __syncthreads();
+  const int64_t tile_base = (int64_t)blockIdx.x * GS_CP_TILE;
+  const int64_t off = tile_offsets[blockIdx.x];
+  for (int r = threadIdx.x; r < total; r += GS_CP_BLOCK) {
+    const int64_t pos = off + r;
+    if (cap < 0 || pos < cap) emit(tile_base + loc_s[r], pos);
   }
 }
 

@@ -18,9 +18,11 @@ void gs_set_error(const char* fmt, ...) {
 }
 
 // ---- optional kernel timing (see gs_common.h) ----
+#include <mutex>
 #include <vector>
-bool g_gs_prof_on = false;
+std::atomic<bool> g_gs_prof_on{false};
 namespace {
+std::mutex g_prof_mu;  // the record table is shared by every host thread that enqueues work
 struct ProfRec { hipEvent_t a, b; int kind; double work; bool closed; int launches; };
 std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
@@ -29,18 +31,21 @@ int64_t g_prof_n[GS_PROF_KINDS];
 }  // namespace
 
 int gs_prof_open(int kind, double work, hipStream_t st, int launches) {
-  if (g_prof_used >= g_prof.size()) return -1;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  if (!g_gs_prof_on.load() || g_prof_used >= g_prof.size()) return -1;
   ProfRec& r = g_prof[g_prof_used];
   r.kind = kind; r.work = work; r.closed = false; r.launches = launches;
   if (hipEventRecord(r.a, st) != hipSuccess) return -1;
   return (int)g_prof_used++;
 }
 void gs_prof_close(int slot, hipStream_t st) {
-  if (hipEventRecord(g_prof[slot].b, st) == hipSuccess) g_prof[slot].closed = true;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  if ((size_t)slot < g_prof_used && hipEventRecord(g_prof[slot].b, st) == hipSuccess) g_prof[slot].closed = true;
 }
 
 extern "C" int gs_profile_begin(int max_records) {
   GS_REQUIRE(max_records > 0 && max_records <= (1 << 20), "max_records out of range");
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   while (g_prof.size() < (size_t)max_records) {
     ProfRec r;
     GS_HIP(hipEventCreate(&r.a));
@@ -56,6 +61,7 @@ extern "C" int gs_profile_begin(int max_records) {
 extern "C" int gs_profile_end(void) {
   g_gs_prof_on = false;
   GS_HIP(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   for (size_t i = 0; i < g_prof_used; ++i) {
     const ProfRec& r = g_prof[i];
     if (!r.closed) continue;
@@ -67,6 +73,7 @@ extern "C" int gs_profile_end(void) {
 }
 extern "C" int gs_profile_read(int kind, double* ms_total, int64_t* launches, double* work_total) {
   GS_REQUIRE(kind >= 0 && kind < GS_PROF_KINDS && ms_total && launches && work_total, "bad arguments");
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   *ms_total = g_prof_ms[kind]; *launches = g_prof_n[kind]; *work_total = g_prof_work[kind];
   return GS_OK;
 }

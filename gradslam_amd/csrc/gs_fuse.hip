@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_append_kernel(const MuBatch
     all += v;
     if (t < (int64_t)blk) before += v;
   }
-  int tile_prefix, total_new, dummy;
+  int tile_prefix, total_new, tile_new;
   (void)gs_block_excl_scan<GS_CP_BLOCK>(before, smem, &tile_prefix);
   (void)gs_block_excl_scan<GS_CP_BLOCK>(all, smem, &total_new);
   const int64_t n_map = gs_count(q.n_map);
@@ -462,14 +462,20 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_append_kernel(const MuBatch
     keep[i] = p < mb.P && q.depth[p] > 0.0f && q.best_pix[p] < 0;
     c += keep[i] ? 1 : 0;
   }
-  int64_t pos = tile_prefix + gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &dummy);
-  const EmitAppend emit{q.points, q.normals, q.colors, q.ccounts, q.n_map, q.gvertex, q.gnormal, q.rgb, q.alpha};
+  int w = gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &tile_new);
+  // new pixels of the tile listed in LDS (pixel order), then row r of the tile's output range is written by thread r
+  // (see gs_cp_scatter_kernel: consecutive lanes -> consecutive rows)
+  __shared__ unsigned short loc_s[GS_CP_TILE];
 #pragma unroll
   for (int i = 0; i < GS_CP_ITEMS; ++i) {
-    if (keep[i]) {
-      if (n_map + pos < q.capacity) emit(base + i, pos);
-      ++pos;
-    }
+    if (keep[i]) loc_s[w++] = (unsigned short)(threadIdx.x * GS_CP_ITEMS + i);
+  }
+  __syncthreads();
+  const EmitAppend emit{q.points, q.normals, q.colors, q.ccounts, q.n_map, q.gvertex, q.gnormal, q.rgb, q.alpha};
+  const int64_t tile_base = (int64_t)blk * GS_CP_TILE;
+  for (int r = threadIdx.x; r < tile_new; r += GS_CP_BLOCK) {
+    const int64_t pos = (int64_t)tile_prefix + r;
+    if (n_map + pos < q.capacity) emit(tile_base + loc_s[r], pos);
   }
 }
 

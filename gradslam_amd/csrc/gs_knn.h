@@ -53,6 +53,7 @@ struct GridMem {
   int* cell_start;   // [MAXCELL + 1]
   int* tile_sums;    // [MAXCELL / 1024 + 2]
   float4* sorted;    // [n_tgt] (x, y, z, original index bits), grouped by cell
+  float4* tlist;     // [n_tgt] filtered builds: the rows that passed the filter, compacted by the bbox pass (any order)
   int* unres_list;   // [n_src]
 };
 
@@ -66,6 +67,7 @@ static inline GridMem grid_carve(void* scratch, int64_t n_src, int64_t n_tgt) {
   m.cell_start = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1));
   m.tile_sums = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL / GS_GRID_TILE + 2));
   m.sorted = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1));
+  m.tlist = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1));
   m.unres_list = reinterpret_cast<int*>(p);
   (void)n_src;
   return m;

@@ -129,7 +129,7 @@ int gs_knn_brute_launch(const float* src_in, const float* Tapply, float* src_out
 // ---------------------------------------------------------------- uniform grid ---------
 size_t gs_knn_grid_scratch_bytes(int64_t n_src, int64_t n_tgt) {
   return 512 + 2 * gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1)) + gs_align(4 * (size_t)(GS_GRID_MAXCELL / GS_GRID_TILE + 2)) +
-         gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1)) + gs_align(4 * (size_t)(n_src > 0 ? n_src : 1)) + 256;
+         2 * gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1)) + gs_align(4 * (size_t)(n_src > 0 ? n_src : 1)) + 256;
 }
 
 // Bounding box of the finite targets: block-local min / max, then 6 atomicMax on order-preserving
@@ -149,14 +149,15 @@ constexpr int GB_ITEMS = 8;
 // filter is evaluated on the value just computed.
 GS_DEV void grid_bbox_body(const float* __restrict__ tgt, const int64_t n_tgt, const GsTargetFilter flt,
                            const GsCamera* cam, int H, float u_hi, float v_hi, int32_t* __restrict__ pix_out,
-                           unsigned* __restrict__ bbox, int* __restrict__ unres_count, const unsigned blk) {
+                           unsigned* __restrict__ bbox, int* __restrict__ unres_count, float4* __restrict__ tlist,
+                           const unsigned blk) {
   if (blk == 0 && threadIdx.x == 0) { unres_count[0] = 0; unres_count[1] = 0; }
   if ((int64_t)blk * GB_BLOCK * GB_ITEMS >= n_tgt) return;
   __shared__ float red[6][GB_BLOCK / GS_WAVE];
-  __shared__ int hits_s;
-  if (threadIdx.x == 0) hits_s = 0;
-  __syncthreads();
+  __shared__ int scan_s[GB_BLOCK / GS_WAVE + 1];
+  __shared__ unsigned base_s;
   int hits = 0;
+  unsigned hitmask = 0;  // bit u: item u of this thread passed the filter
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
   for (int u = 0; u < GB_ITEMS; ++u) {
@@ -175,6 +176,7 @@ GS_DEV void grid_bbox_body(const float* __restrict__ tgt, const int64_t n_tgt, c
     }
     if (is_t) {
       ++hits;
+      hitmask |= 1u << u;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const float v = v3[k];
@@ -198,13 +200,27 @@ GS_DEV void grid_bbox_body(const float* __restrict__ tgt, const int64_t n_tgt, c
     if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = b; }
   }
   const bool filtered = flt.pix != nullptr || cam != nullptr;
-  if (filtered) {  // number of targets (the cell-size heuristic needs it): wave sums, one atomic per block
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) hits += __shfl_down(hits, d, GS_WAVE);
-    if (lane == 0 && hits) atomicAdd(&hits_s, hits);
-  }
   __syncthreads();
-  if (filtered && threadIdx.x == 3 && hits_s) atomicAdd(&bbox[6], (unsigned)hits_s);
+  if (filtered) {
+    // the rows that passed the filter (a few per cent of a map) are compacted into tlist: the count and scatter
+    // passes then walk that list instead of the map.  One atomic per block hands out the slots (bbox[6] is also the
+    // number of targets the cell-size heuristic needs); the order of the list does not matter (see the scatter).
+    int total;
+    int pos = gs_block_excl_scan<GB_BLOCK>(hits, scan_s, &total);
+    if (threadIdx.x == 0 && total) base_s = atomicAdd(&bbox[6], (unsigned)total);
+    __syncthreads();
+    if (hitmask) {
+      const unsigned base = base_s;
+#pragma unroll
+      for (int u = 0; u < GB_ITEMS; ++u) {
+        if (hitmask & (1u << u)) {
+          const int64_t i = ((int64_t)blk * GB_ITEMS + u) * GB_BLOCK + threadIdx.x;
+          tlist[base + (unsigned)pos] = make_float4(tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2], __int_as_float((int)i));
+          ++pos;
+        }
+      }
+    }
+  }
   if (threadIdx.x < 3) {
     const int k = threadIdx.x;
     float a = red[k][0], b = red[3 + k][0];
@@ -221,8 +237,9 @@ GS_DEV void grid_bbox_body(const float* __restrict__ tgt, const int64_t n_tgt, c
 __global__ void __launch_bounds__(GB_BLOCK) gs_grid_bbox_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
                                                                  const GsTargetFilter flt,
                                                                  unsigned* __restrict__ bbox,
-                                                                 int* __restrict__ unres_count) {
-  grid_bbox_body(tgt, gs_count(n_tgt_c), flt, nullptr, 0, 0.0f, 0.0f, nullptr, bbox, unres_count, blockIdx.x);
+                                                                 int* __restrict__ unres_count,
+                                                                 float4* __restrict__ tlist) {
+  grid_bbox_body(tgt, gs_count(n_tgt_c), flt, nullptr, 0, 0.0f, 0.0f, nullptr, bbox, unres_count, tlist, blockIdx.x);
 }
 
 // Cell size from the bounding box.  Heuristic: targets are a sampled surface (spacing ~ sqrt(area / n))
@@ -267,16 +284,31 @@ GS_DEV GsGrid grid_from_bbox(const unsigned* __restrict__ bbox, int64_t n_tgt, i
 // that follow), then counts its targets per cell.
 GS_DEV void grid_count_body(const float* __restrict__ tgt, const int64_t n_tgt, const GsTargetFilter flt,
                             const unsigned* __restrict__ bbox, GsGrid* __restrict__ gp, int* __restrict__ cell_count,
-                            int cells_cap, const unsigned blk) {
+                            int cells_cap, const float4* __restrict__ tlist, const unsigned blk, const unsigned nblk) {
   __shared__ GsGrid gsh;
+  if (flt.pix) {  // filtered build: walk the compacted list of the bbox pass (bbox[6] entries)
+    const int64_t n_list = (int64_t)bbox[6];
+    if ((int64_t)blk * 256 >= n_list && blk != 0) return;
+    if (threadIdx.x == 0) {
+      gsh = grid_from_bbox(bbox, n_list, cells_cap);
+      if (blk == 0) *gp = gsh;
+    }
+    __syncthreads();
+    const GsGrid g = gsh;
+    for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n_list; i += (int64_t)nblk * 256) {
+      const float4 t = tlist[i];
+      atomicAdd(&cell_count[grid_cell(g, t.x, t.y, t.z)], 1);
+    }
+    return;
+  }
   const int64_t i = (int64_t)blk * 256 + threadIdx.x;
   if ((int64_t)blk * 256 >= n_tgt && blk != 0) return;
   if (threadIdx.x == 0) {
-    gsh = grid_from_bbox(bbox, flt.pix ? (int64_t)bbox[6] : n_tgt, cells_cap);
+    gsh = grid_from_bbox(bbox, n_tgt, cells_cap);
     if (blk == 0) *gp = gsh;
   }
   __syncthreads();
-  if (i >= n_tgt || !gs_is_target(flt, i)) return;
+  if (i >= n_tgt) return;
   const GsGrid g = gsh;
   atomicAdd(&cell_count[grid_cell(g, tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2])], 1);
 }
@@ -284,8 +316,9 @@ __global__ void __launch_bounds__(256) gs_grid_count_kernel(const float* __restr
                                                             const GsTargetFilter flt,
                                                             const unsigned* __restrict__ bbox,
                                                             GsGrid* __restrict__ gp,
-                                                            int* __restrict__ cell_count, int cells_cap) {
-  grid_count_body(tgt, gs_count(n_tgt_c), flt, bbox, gp, cell_count, cells_cap, blockIdx.x);
+                                                            int* __restrict__ cell_count, int cells_cap,
+                                                            const float4* __restrict__ tlist) {
+  grid_count_body(tgt, gs_count(n_tgt_c), flt, bbox, gp, cell_count, cells_cap, tlist, blockIdx.x, gridDim.x);
 }
 
 // exclusive scan of cell_count[0 .. ncell] (ncell + 1 entries, the last one is the end sentinel)
@@ -341,9 +374,22 @@ __global__ void __launch_bounds__(256) gs_grid_scan_kernel(const int* __restrict
 
 GS_DEV void grid_scatter_body(const float* __restrict__ tgt, const int64_t n_tgt, const GsTargetFilter flt,
                               const GsGrid* __restrict__ gp, const int* __restrict__ cell_start,
-                              int* __restrict__ cell_count, float4* __restrict__ sorted, const unsigned blk) {
+                              int* __restrict__ cell_count, float4* __restrict__ sorted,
+                              const float4* __restrict__ tlist, const unsigned* __restrict__ bbox, const unsigned blk,
+                              const unsigned nblk) {
+  if (flt.pix) {
+    const int64_t n_list = (int64_t)bbox[6];
+    if ((int64_t)blk * 256 >= n_list) return;
+    const GsGrid g = *gp;
+    for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n_list; i += (int64_t)nblk * 256) {
+      const float4 t = tlist[i];
+      const int cid = grid_cell(g, t.x, t.y, t.z);
+      sorted[cell_start[cid] + atomicSub(&cell_count[cid], 1) - 1] = t;
+    }
+    return;
+  }
   const int64_t i = (int64_t)blk * 256 + threadIdx.x;
-  if (i >= n_tgt || !gs_is_target(flt, i)) return;
+  if (i >= n_tgt) return;
   const GsGrid g = *gp;
   const float x = tgt[3 * i], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
   const int cid = grid_cell(g, x, y, z);
@@ -357,8 +403,10 @@ __global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __res
                                                               const GsGrid* __restrict__ gp,
                                                               const int* __restrict__ cell_start,
                                                               int* __restrict__ cell_count,
-                                                              float4* __restrict__ sorted) {
-  grid_scatter_body(tgt, gs_count(n_tgt_c), flt, gp, cell_start, cell_count, sorted, blockIdx.x);
+                                                              float4* __restrict__ sorted,
+                                                              const float4* __restrict__ tlist,
+                                                              const unsigned* __restrict__ bbox) {
+  grid_scatter_body(tgt, gs_count(n_tgt_c), flt, gp, cell_start, cell_count, sorted, tlist, bbox, blockIdx.x, gridDim.x);
 }
 
 // ---- batched build: block b of a launch works for sequence b % B on its block b / B ----
@@ -370,15 +418,17 @@ __global__ void __launch_bounds__(GB_BLOCK) gs_gridb_bbox_kernel(const GsGridBat
     __shared__ GsCamera cam;
     if (threadIdx.x == 0) cam = gs_camera(q.pose16, q.K16);
     __syncthreads();
-    grid_bbox_body(q.tgt, gs_count(q.n_tgt), flt, &cam, gb.H, u_hi, v_hi, q.pix, q.m.bbox, q.m.unres_count, blk);
+    grid_bbox_body(q.tgt, gs_count(q.n_tgt), flt, &cam, gb.H, u_hi, v_hi, q.pix, q.m.bbox, q.m.unres_count, q.m.tlist,
+                   blk);
   } else {
-    grid_bbox_body(q.tgt, gs_count(q.n_tgt), flt, nullptr, 0, 0.0f, 0.0f, nullptr, q.m.bbox, q.m.unres_count, blk);
+    grid_bbox_body(q.tgt, gs_count(q.n_tgt), flt, nullptr, 0, 0.0f, 0.0f, nullptr, q.m.bbox, q.m.unres_count, q.m.tlist,
+                   blk);
   }
 }
 __global__ void __launch_bounds__(256) gs_gridb_count_kernel(const GsGridBatch gb) {
   const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
   grid_count_body(q.tgt, gs_count(q.n_tgt), GsTargetFilter{q.pix, gb.W, gb.ds}, q.m.bbox, q.m.g, q.m.cell_count,
-                  gb.cells_cap, blockIdx.x / gb.B);
+                  gb.cells_cap, q.m.tlist, blockIdx.x / gb.B, gridDim.x / gb.B);
 }
 __global__ void __launch_bounds__(256) gs_gridb_tile_sum_kernel(const GsGridBatch gb) {
   const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
@@ -391,7 +441,7 @@ __global__ void __launch_bounds__(256) gs_gridb_scan_kernel(const GsGridBatch gb
 __global__ void __launch_bounds__(256) gs_gridb_scatter_kernel(const GsGridBatch gb) {
   const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
   grid_scatter_body(q.tgt, gs_count(q.n_tgt), GsTargetFilter{q.pix, gb.W, gb.ds}, q.m.g, q.m.cell_start, q.m.cell_count,
-                    q.m.sorted, blockIdx.x / gb.B);
+                    q.m.sorted, q.m.tlist, q.m.bbox, blockIdx.x / gb.B, gridDim.x / gb.B);
 }
 
 // Cells the grid of a build may use (what is cleared and scanned per build): the target density the
@@ -420,11 +470,17 @@ int gs_knn_grid_build_batch(const GsGridBatch& gb, hipStream_t st) {
   const float u_hi = (float)((double)gb.W - 0.999), v_hi = (float)((double)gb.H - 0.999);
   hipLaunchKernelGGL(gs_gridb_bbox_kernel, dim3(B * (unsigned)gs_ceil_div(n_max, GB_BLOCK * GB_ITEMS)), dim3(GB_BLOCK), 0,
                      st, gb, u_hi, v_hi);
-  hipLaunchKernelGGL(gs_gridb_count_kernel, dim3(B * (unsigned)gs_ceil_div(n_max, 256)), dim3(256), 0, st, gb);
+  // filtered builds walk the compacted target list (a few entries per lattice slot) with a grid-stride loop
+  bool listed = true;
+  for (int b = 0; b < gb.B; ++b) listed = listed && gb.s[b].pix != nullptr;
+  const int64_t slots = (int64_t)gs_ceil_div(gb.H, gb.ds) * gs_ceil_div(gb.W, gb.ds);
+  unsigned nb_pts = (unsigned)gs_ceil_div(n_max, 256);
+  if (listed && gb.H > 0 && (unsigned)gs_ceil_div(3 * slots, 256) < nb_pts) nb_pts = (unsigned)gs_ceil_div(3 * slots, 256);
+  hipLaunchKernelGGL(gs_gridb_count_kernel, dim3(B * nb_pts), dim3(256), 0, st, gb);
   const unsigned ntile = (unsigned)gs_ceil_div(gb.cells_cap + 1, GS_GRID_TILE);
   hipLaunchKernelGGL(gs_gridb_tile_sum_kernel, dim3(B * ntile), dim3(256), 0, st, gb);
   hipLaunchKernelGGL(gs_gridb_scan_kernel, dim3(B * ntile), dim3(256), 0, st, gb);
-  hipLaunchKernelGGL(gs_gridb_scatter_kernel, dim3(B * (unsigned)gs_ceil_div(n_max, 256)), dim3(256), 0, st, gb);
+  hipLaunchKernelGGL(gs_gridb_scatter_kernel, dim3(B * nb_pts), dim3(256), 0, st, gb);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { gs_set_error("gs_knn_grid_build_batch: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
   return GS_OK;
@@ -442,15 +498,15 @@ int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* gr
   hipError_t e = hipMemsetAsync(m.g, 0, clear, st);
   if (e != hipSuccess) { gs_set_error("gs_knn_grid_build: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
   hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, GB_BLOCK * GB_ITEMS)),
-                     dim3(GB_BLOCK), 0, st, tgt, n_tgt_c, flt, m.bbox, m.unres_count);
+                     dim3(GB_BLOCK), 0, st, tgt, n_tgt_c, flt, m.bbox, m.unres_count, m.tlist);
   hipLaunchKernelGGL(gs_grid_count_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, 256)), dim3(256), 0, st,
-                     tgt, n_tgt_c, flt, m.bbox, m.g, m.cell_count, cells_cap);
+                     tgt, n_tgt_c, flt, m.bbox, m.g, m.cell_count, cells_cap, m.tlist);
   const unsigned ntile = (unsigned)gs_ceil_div(cells_cap + 1, GS_GRID_TILE);
   hipLaunchKernelGGL(gs_grid_tile_sum_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums);
   hipLaunchKernelGGL(gs_grid_scan_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums,
                      m.cell_start);
   hipLaunchKernelGGL(gs_grid_scatter_kernel, dim3((unsigned)gs_ceil_div(n_tgt, 256)), dim3(256), 0, st, tgt,
-                     n_tgt_c, flt, m.g, m.cell_start, m.cell_count, m.sorted);
+                     n_tgt_c, flt, m.g, m.cell_start, m.cell_count, m.sorted, m.tlist, m.bbox);
   return GS_OK;
 }
 

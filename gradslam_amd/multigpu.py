@@ -26,8 +26,8 @@ def init_from_env(backend: Optional[str] = None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # GRADSLAM_DIST_BACKEND=gloo: rehearsals of the N-rank path on a box with fewer GPUs
+            backend = os.environ.get("GRADSLAM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -47,6 +47,18 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _all_gather(out: List[torch.Tensor], t: torch.Tensor):
+    """dist.all_gather; gloo has no device-tensor all_gather, so under gloo (CPU tests, single-GPU rehearsals of the
+    N-rank path) device tensors are exchanged through the host."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        host = [torch.empty(o.shape, dtype=o.dtype) for o in out]
+        dist.all_gather(host, t.cpu())
+        for o, h in zip(out, host):
+            o.copy_(h)
+    else:
+        dist.all_gather(out, t)
+
+
 def _gather_rows(t: torch.Tensor) -> List[torch.Tensor]:
     """all_gather of a (n_r, ...) tensor whose first dimension differs per rank."""
     world = _world()
@@ -54,13 +66,13 @@ def _gather_rows(t: torch.Tensor) -> List[torch.Tensor]:
         return [t]
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
+    _all_gather(counts, n)
     counts = [int(c.item()) for c in counts]
     cap = max(max(counts), 1)
     padded = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     padded[: t.shape[0]] = t
     out = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(out, padded)
+    _all_gather(out, padded)
     return [o[:c] for o, c in zip(out, counts)]
 
 
@@ -96,7 +108,7 @@ def gather_maps(pointclouds: Pointclouds) -> Pointclouds:
     send = torch.zeros((cap, width), dtype=torch.float32, device=dev)
     send[:rows] = packed
     recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send)
+    _all_gather(recv, send)
     out = {k: [] for k in w}
     for r, (cnts, _) in enumerate(meta):
         per_seq = torch.split(recv[r][: sum(cnts)], cnts, 0) if cnts else []

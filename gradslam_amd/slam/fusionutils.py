@@ -527,7 +527,6 @@ def _update_map_one_call(pointclouds, rgbdimages, dist_th, dot_th, sigma):
     cnt, _, _, _ = ops.update_map_fusion_batch_(maps, vm[:, 0], nm[:, 0], depth[:, 0, ..., 0], rgb[:, 0],
                                                 alpha[:, 0, ..., 0], poses, K, dist_th, dot_th, RENORMALIZE_UNMATCHED,
                                                 out=(gv[:, 0], gn[:, 0]))
-    for b in range(B):
-        pointclouds._set_count_dev(b, cnt[b:b + 1], H * W)
+    pointclouds._set_counts_dev(cnt, H * W)
     fr._global_vertex_map, fr._global_normal_map = gv, gn
     return pointclouds

@@ -25,25 +25,24 @@ def _canon_device(device):
     return torch.Tensor().to(device).device
 
 
-class _DeviceCount(object):
-    """Surfel count of one sequence that lives ON THE DEVICE (written by the fuse/append kernels).
+class _CountGroup(object):
+    """Surfel counts of the sequences of a batch that live ON THE DEVICE (written by the fuse/append kernels).
 
-    The host only keeps an upper bound (launch geometry, capacity).  Every update queues an
-    asynchronous copy of the count into pinned memory; `poll()` tightens the bound from the copies
-    that have already landed and never waits, so the frame loop has no host<->device sync.
-    `resolve()` is the one blocking read-back, used when the exact count is finally needed."""
+    The host only keeps upper bounds (launch geometry, capacity).  Every EVERY-th update queues ONE asynchronous
+    copy of all the counts into pinned memory; `poll()` tightens the bounds from the copies that have already landed
+    and never waits, so the frame loop has no host<->device sync."""
     RING = 8
-    EVERY = 2       # one asynchronous read-back per EVERY updates (each one is a copy + an event on the stream)
+    EVERY = 2       # one asynchronous read-back per EVERY updates (a copy + an event on the stream)
     MAX_AHEAD = 2   # read-backs in flight before the host waits for the oldest: the host never runs more than
-                    # ~EVERY * (MAX_AHEAD + 1) frames ahead of the device, which keeps the bound (launch sizes,
-                    # capacity) within a few frames of the true count while the device always has work queued
+                    # ~EVERY * (MAX_AHEAD + 1) frames ahead of the device, which keeps the bounds (launch sizes,
+                    # capacity) within a few frames of the true counts while the device always has work queued
 
-    def __init__(self, dev, bound):
-        self.dev, self.bound = dev, int(bound)
+    def __init__(self, dev, bounds):
+        self.dev, self.bounds = dev, [int(x) for x in bounds]   # dev: (B,) int64 on the device
         self._updates = 0
-        self._pin = torch.empty(self.RING, dtype=torch.int64).pin_memory()
+        self._pin = torch.empty((self.RING, len(self.bounds)), dtype=torch.int64).pin_memory()
         self._events = [torch.cuda.Event() for _ in range(self.RING)]
-        self._pending = []   # [slot, rows that may have been added since that copy]
+        self._pending = []   # [slot, rows that may have been added to every sequence since that copy]
         self._slot = 0
         self._queue_copy()
 
@@ -52,15 +51,16 @@ class _DeviceCount(object):
             return
         s = self._slot
         self._slot = (s + 1) % self.RING
-        self._pin[s:s + 1].copy_(self.dev, non_blocking=True)
+        self._pin[s].copy_(self.dev, non_blocking=True)
         self._events[s].record()
         self._pending.append([s, 0])
 
     def advance(self, dev, max_growth):
+        g = int(max_growth)
         self.dev = dev
-        self.bound += int(max_growth)
+        self.bounds = [x + g for x in self.bounds]
         for p in self._pending:
-            p[1] += int(max_growth)
+            p[1] += g
         self._updates += 1
         if self._updates % self.EVERY == 0:
             self._queue_copy()
@@ -71,7 +71,28 @@ class _DeviceCount(object):
     def poll(self):
         while self._pending and self._events[self._pending[0][0]].query():
             s, grown = self._pending.pop(0)
-            self.bound = min(self.bound, int(self._pin[s]) + grown)
+            self.bounds = [min(x, v + grown) for x, v in zip(self.bounds, self._pin[s].tolist())]
+
+    def resolve(self):
+        return [int(v) for v in self.dev.cpu().tolist()]
+
+
+class _DeviceCount(object):
+    """The count of ONE sequence inside a _CountGroup (the group does the read-backs for all its sequences)."""
+
+    def __init__(self, group, index):
+        self.group, self.index = group, index
+
+    @property
+    def bound(self):
+        return self.group.bounds[self.index]
+
+    @property
+    def dev(self):
+        return self.group.dev[self.index:self.index + 1]
+
+    def poll(self):
+        self.group.poll()
 
     def resolve(self):
         return int(self.dev.item())
@@ -164,8 +185,11 @@ class Pointclouds(object):
     def _n(self):
         """Points per sequence.  Reading it resolves device-side counts (one read-back each)."""
         if self._dcount:
+            exact = {}   # one read-back per group
             for b, dc in self._dcount.items():
-                self._n_host[b] = dc.resolve()
+                if id(dc.group) not in exact:
+                    exact[id(dc.group)] = dc.group.resolve()
+                self._n_host[b] = exact[id(dc.group)][dc.index]
             self._dcount = {}
             self._invalidate()
         return self._n_host
@@ -395,12 +419,30 @@ class Pointclouds(object):
         """The kernels wrote the new count of sequence b to `dev_count`; at most `max_growth` rows
         were added.  Nothing is read back (see _DeviceCount)."""
         dc = self._dcount.get(b)
-        if dc is None:
-            self._dcount[b] = _DeviceCount(dev_count, self._n_host[b] + int(max_growth))
+        if dc is None or len(dc.group.bounds) != 1:
+            bound = (self._n_host[b] if dc is None else dc.bound) + int(max_growth)
+            self._dcount[b] = _DeviceCount(_CountGroup(dev_count.reshape(1), [bound]), 0)
         else:
-            dc.advance(dev_count, max_growth)
+            dc.group.advance(dev_count.reshape(1), max_growth)
         self._padded_cache.clear()
         self.equisized = True if len(self._n_host) == 1 else None
+
+    def _set_counts_dev(self, dev_counts, max_growth):
+        """Same for every sequence of the batch at once: dev_counts is the (B,) int64 tensor the batched kernels
+        wrote; ONE asynchronous read-back serves all sequences."""
+        B = len(self._n_host)
+        dcs = [self._dcount.get(b) for b in range(B)]
+        grp = dcs[0].group if dcs[0] is not None else None
+        if grp is not None and len(grp.bounds) == B and all(d is not None and d.group is grp and d.index == b
+                                                            for b, d in enumerate(dcs)):
+            grp.advance(dev_counts, max_growth)
+        else:
+            bounds = [(self._n_host[b] if d is None else d.bound) + int(max_growth) for b, d in enumerate(dcs)]
+            grp = _CountGroup(dev_counts, bounds)
+            for b in range(B):
+                self._dcount[b] = _DeviceCount(grp, b)
+        self._padded_cache.clear()
+        self.equisized = True if B == 1 else None
 
     # ------------------------------------------------------------------ copies / moves
     def clone(self):

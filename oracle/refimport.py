@@ -1,7 +1,7 @@
 """Imports the REAL reference (gradslam v0.1.0) from /root/reference with the shim modules in
 oracle/shims standing in for its uninstalled third-party imports.  Build-container only:
 /root/reference does not exist on the GPU box, so nothing under tests -m gpu, smoke() or
-bench.py may call this.  Used by oracle/make_golden.py and oracle/pin_arithmetic.py."""
+bench.py may call this.  Used by the oracle/make_golden*.py generators."""
 import os
 import sys
 import warnings

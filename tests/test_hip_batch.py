@@ -257,6 +257,32 @@ def test_two_ranks_rccl_gather():
     assert line["n_gpus"] == 2 and line["config"]["sequences_total"] == 4
 
 
+def test_two_ranks_sharing_one_gpu_rehearsal():
+    """The same N > 1 path when only one GPU is there: two self-spawned ranks share cuda:0 and rendezvous over gloo
+    (RCCL refuses two ranks on one device).  Exercises the spawn, the sharding, the barriers and max-over-ranks
+    timing, and both gathers with device tensors; the per-sequence results are checked against a single-rank run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "2", "--batch", "4", "--height", "120", "--width", "160", "--no-cpu-baseline",
+              "--no-roofline-pass"]
+    env = dict(os.environ, GRADSLAM_DIST_BACKEND="gloo", GRADSLAM_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    lines = []
+    for n in ("2", "1"):
+        r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", n] + common, capture_output=True,
+                           text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    two, one = lines
+    assert two["n_gpus"] == 2 and two["config"]["sequences_total"] == 4 and two["config"]["sequences_per_gpu"] == 2
+    assert one["n_gpus"] == 1 and one["config"]["sequences_per_gpu"] == 4
+    assert two["config"]["poses_sha"] == one["config"]["poses_sha"]          # gathered poses: identical bits
+    assert two["config"]["map_surfels_all"] == one["config"]["map_surfels_all"]
+
+
 def test_pointfusion_1296x968_vs_oracle(gs):
     """BASELINE configs[4] shape (ScanNet resolution): 3 frames of PointFusion(gradicp, numiters=6) against the oracle's
     frame loop: 78k ICP queries against ~100k+ binned targets per solve, a map beyond 1.5M surfels: poses within 2e-6,
