@@ -126,6 +126,7 @@ struct IcpHalfSeq {
   const GsGrid* gp;
   const int* cell_start;
   const float4* sorted;
+  const float4* sorted_n;   // normals binned with the targets (NULL: gather from tn)
   const double* partials_in;
   double* partials_out;
   const IcpSmall* st_in;
@@ -162,6 +163,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
   const float* __restrict__ tn = q.tn;
   const int* __restrict__ cell_start = q.cell_start;
   const float4* __restrict__ sorted = q.sorted;
+  const float4* __restrict__ sorted_n = q.sorted_n;
   const double* __restrict__ partials_in = q.partials_in;
   double* __restrict__ partials_out = q.partials_out;
   int64_t* __restrict__ out_idx = q.out_idx;
@@ -171,6 +173,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
   __shared__ double S[32];
   __shared__ double sub[FS_BLOCK / 32][32];
   __shared__ unsigned long long keys_s[NQ];
+  __shared__ int bslot_s[NQ];     // slot of the winning candidate in the binned arrays
   __shared__ float qs[NQ][3];
   __shared__ float qa_s[NQ][8];   // a0..a5, residual of every query of the block (zero when filtered out)
   __shared__ double sub_s[NU][FS_RG][LIN_NV];
@@ -255,7 +258,9 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
       float qx, qy, qz;
       gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
       bool done;
-      const unsigned long long key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, &done);
+      int win;
+      const unsigned long long key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win);
+      if (win >= 0 || (lane == 0 && key == ~0ull)) bslot_s[slot] = win;  // one writer: the winning lane
       if (lane == 0) {
         if (FULL) {  // the transformed cloud of this iteration
           src_out[3 * s] = qx;
@@ -274,8 +279,10 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
     for (int i = threadIdx.x / FS_HG; i < nh; i += FS_BLOCK / FS_HG) {
       const int hs = hard_q[i];
       bool done;
+      int win;
       const unsigned long long key = grid_search_rings<FS_HG>(g, cell_start, sorted, qs[hs][0], qs[hs][1], qs[hs][2],
-                                                              threadIdx.x & (FS_HG - 1), keys_s[hs], &done);
+                                                              threadIdx.x & (FS_HG - 1), keys_s[hs], &done, &win);
+      if (win >= 0) bslot_s[hs] = win;  // a candidate of the cubes beat the 2x2x2 stage
       if ((threadIdx.x & (FS_HG - 1)) == 0) {
         keys_s[hs] = key;
         if (!done) unres_q[atomicAdd(&unres_n, 1)] = hs;
@@ -291,8 +298,10 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
     if (tl && threadIdx.x == 0) { tl[7] += (unsigned long long)nun; if (u0 == u_first) tl[6] = wall_clock64(); }
     for (int u = 0; u < nun; ++u) {
       const int us = unres_q[u];
+      int win;
       const unsigned long long key = block_brute_min_sorted<FS_BLOCK>(qs[us][0], qs[us][1], qs[us][2], sorted,
-                                                                      cell_start[g.ncell], red);
+                                                                      cell_start[g.ncell], red, &win);
+      if (win >= 0) bslot_s[us] = win;
       if (threadIdx.x == 0) keys_s[us] = key;
     }
     if (nun) {
@@ -313,7 +322,11 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
         if (j >= n_tgt) j = 0;  // only when every distance was NaN
         const float d2 = __uint_as_float((uint32_t)(bb >> 32));
         const bool keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
-        gn_row(qs[slot][0], qs[slot][1], qs[slot][2], tgt, tn, j, a, res);
+        const int bsl = bslot_s[slot];
+        if (sorted_n && bsl >= 0 && bb != ~0ull)   // matched point and normal from the binned copies (same bits)
+          gn_row_pn(qs[slot][0], qs[slot][1], qs[slot][2], sorted[bsl], sorted_n[bsl], a, res);
+        else
+          gn_row(qs[slot][0], qs[slot][1], qs[slot][2], tgt, tn, j, a, res);
         if (FULL && out_idx) out_idx[s] = j;
         if (tape_idx) tape_idx[s] = keep ? (int32_t)j : -1;
         if (!keep) {
@@ -719,7 +732,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
 
   if (use_grid) {
     // the target set is fixed for all 2*numiters searches of this solve: bin it once
-    int rc = gs_knn_grid_build(tgt, n_tgt_c, n_src, sc.grid, st, flt);
+    int rc = gs_knn_grid_build(tgt, n_tgt_c, n_src, sc.grid, st, flt, tgt_normals);
     if (rc != GS_OK) return rc;
     GridMem gm = grid_carve(sc.grid, n_src, n_tgt);
     const int nfs = (int)icp_rows(n_src);
@@ -745,7 +758,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
     hb.B = 1;
     for (int it = 0; it < prm->numiters; ++it) {
       float* cur = cloud(it);
-      hb.s[0] = IcpHalfSeq{cur_in, cur, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted,
+      hb.s[0] = IcpHalfSeq{cur_in, cur, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, gm.sorted_n,
                            sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1], &sc.state->s[(h + 1) & 1],
                            sc.state->trace, out_idx, tidx(it, 0), nullptr};
       icp_half_launch<true>(plan, hb, n_src_c, prm, it, 0, st);
@@ -755,7 +768,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
         hipLaunchKernelGGL(gs_icp_reduce_rows_kernel, dim3(1), dim3(FS_BLOCK), 0, st, sc.partials[(h + 1) & 1], n_src_c,
                            sc.rowred);
       }
-      hb.s[0] = IcpHalfSeq{cur, nullptr, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted,
+      hb.s[0] = IcpHalfSeq{cur, nullptr, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, gm.sorted_n,
                            reduce_rows ? sc.rowred : sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
                            &sc.state->s[(h + 1) & 1], sc.state->trace, nullptr, tidx(it, 1), tp.sys};
       icp_half_launch<false>(plan, hb, n_src_c, prm, it, reduce_rows ? 1 : 0, st);
@@ -978,7 +991,8 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
     gm[b] = grid_carve(sc[b].grid, n_lat, q.map.n_bound);
     lb.s[b] = LocSeq{q.vertex, q.depth, q.prev_pose16, lattice, sc[b].state, q.out_pose16,
                      reinterpret_cast<char*>(gm[b].g), n_valid};
-    gb.s[b] = GsGridSeq{q.map.points, GsCount{q.map.n_bound, q.map.n_dev}, pix, q.prev_pose16, q.K16, gm[b]};
+    gb.s[b] = GsGridSeq{q.map.points, GsCount{q.map.n_bound, q.map.n_dev}, pix, q.prev_pose16, q.K16, q.map.normals,
+                        gm[b]};
     if (g_gs_prof_on) GS_HIP(hipMemsetAsync(n_valid, 0, 8, st));
   }
   lb.count_valid = g_gs_prof_on ? 1 : 0;
@@ -1020,7 +1034,7 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
       const float* cur_in = it == 0 ? lb.s[b].lattice : (((it - 1) & 1) ? sc[b].srcB : sc[b].srcA);
       float* cur = (it & 1) ? sc[b].srcB : sc[b].srcA;
       hb.s[b] = IcpHalfSeq{cur_in, cur, q.map.points, q.map.normals, GsCount{q.map.n_bound, q.map.n_dev}, gm[b].g,
-                           gm[b].cell_start, gm[b].sorted, sc[b].partials[(h + 1) & 1], sc[b].partials[h & 1],
+                           gm[b].cell_start, gm[b].sorted, gm[b].sorted_n, sc[b].partials[(h + 1) & 1], sc[b].partials[h & 1],
                            &sc[b].state->s[h & 1], &sc[b].state->s[(h + 1) & 1], sc[b].state->trace, nullptr, nullptr,
                            nullptr};
     }

@@ -20,6 +20,18 @@ GS_DEV void gn_row(float sx, float sy, float sz, const float* __restrict__ tgt,
   b = t + nz * (dz - sz);
 }
 
+// the same row from a target point / normal already in registers (the binned copies): same operations, same order
+GS_DEV void gn_row_pn(float sx, float sy, float sz, const float4 d, const float4 n, float* a, float& b) {
+  const float dx = d.x, dy = d.y, dz = d.z;
+  const float nx = n.x, ny = n.y, nz = n.z;
+  a[0] = nx; a[1] = ny; a[2] = nz;
+  a[3] = nz * sy - ny * sz;
+  a[4] = nx * sz - nz * sx;
+  a[5] = ny * sx - nx * sy;
+  const float t = nx * (dx - sx) + ny * (dy - sy);
+  b = t + nz * (dz - sz);
+}
+
 // ---------------------------------------------------------------- small dense algebra ---
 // Solve (AtA + damp I) x = Atb (odometry/icputils.py:85-90; the reference inverts in float32 with
 // LAPACK and multiplies).  The system is symmetric positive definite, so it is solved directly by

@@ -53,6 +53,7 @@ struct GridMem {
   int* cell_start;   // [MAXCELL + 1]
   int* tile_sums;    // [MAXCELL / 1024 + 2]
   float4* sorted;    // [n_tgt] (x, y, z, original index bits), grouped by cell
+  float4* sorted_n;  // [n_tgt] normal of the target in the same slot of `sorted` (builds that are given normals)
   float4* tlist;     // [n_tgt] filtered builds: the rows that passed the filter, compacted by the bbox pass (any order)
   int* unres_list;   // [n_src]
 };
@@ -67,6 +68,7 @@ static inline GridMem grid_carve(void* scratch, int64_t n_src, int64_t n_tgt) {
   m.cell_start = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1));
   m.tile_sums = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL / GS_GRID_TILE + 2));
   m.sorted = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1));
+  m.sorted_n = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1));
   m.tlist = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1));
   m.unres_list = reinterpret_cast<int*>(p);
   (void)n_src;
@@ -83,6 +85,7 @@ struct GsGridSeq {
   int32_t* pix;          // target filter (with W, ds of the batch); when pose16 != NULL it is WRITTEN first:
   const float* pose16;   //   pix[n] = projection of row n under (pose16, K16) (gs_project_map_f32)
   const float* K16;
+  const float* nrm;      // normals of the target rows (NULL: none): binned next to the points (m.sorted_n)
   GridMem m;             // grid_carve(scratch, n_src, n_tgt.host)
 };
 struct GsGridBatch {
@@ -99,7 +102,7 @@ size_t gs_knn_grid_clear_bytes(const GridMem& m, int cells_cap);
 int gs_knn_grid_build_batch(const GsGridBatch& gb, hipStream_t st);
 
 int gs_knn_grid_build(const float* tgt, GsCount n_tgt, int64_t n_src, void* grid_scratch, hipStream_t st,
-                      GsTargetFilter filter = GsTargetFilter{nullptr, 1, 1});
+                      GsTargetFilter filter = GsTargetFilter{nullptr, 1, 1}, const float* nrm = nullptr);
 int gs_knn_grid_query(const float* src_in, const float* Tapply, float* src_out, int64_t n_src,
                       const float* tgt, int64_t n_tgt, unsigned long long* best, void* grid_scratch,
                       hipStream_t st);
@@ -174,11 +177,12 @@ GS_DEV GsQueryCell grid_query_cell(const GsGrid& g, float qx, float qy, float qz
 template <int G>
 GS_DEV unsigned long long grid_search_stage0(const GsGrid& g, const int* __restrict__ cell_start,
                                              const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
-                                             bool* resolved) {
+                                             bool* resolved, int* win) {
   const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
   const float px = qc.px, py = qc.py, pz = qc.pz;
   const int cx = qc.cx, cy = qc.cy, cz = qc.cz;
   unsigned long long key = ~0ull;
+  int bs = -1;  // slot (in `sorted`) of this lane's best candidate
   // The 2x2x2 block of cells whose centre is nearest to the (projected) query.  Every target
   // outside that box is at least as far as the nearest box face that has cells behind it (>= half a cell
   // by construction); ICP queries sit within a fraction of a cell of their neighbour, so most searches
@@ -225,10 +229,18 @@ GS_DEV unsigned long long grid_search_stage0(const GsGrid& g, const int* __restr
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const unsigned long long k2 = in[u] ? grid_key(qx, qy, qz, p[u]) : ~0ull;
-      key = k2 < key ? k2 : key;
+      if (k2 < key) {
+        const int tt = t0 + u * G;  // in[u] holds here
+        key = k2;
+        bs = tt < e1 ? sb0 + tt : (tt < e2 ? sb1 + (tt - e1) : (tt < e3 ? sb2 + (tt - e2) : sb3 + (tt - e3)));
+      }
     }
   }
-  key = grid_group_min<G>(key);
+  {
+    const unsigned long long own = key;
+    key = grid_group_min<G>(key);
+    *win = own == key ? bs : -1;  // keys are unique (they carry the target index): at most one lane of the group wins
+  }
   // 0.1 % of a cell is orders of magnitude above the float rounding of the cell assignment
   const float rb = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
   const float bd = __uint_as_float((uint32_t)(key >> 32));  // NaN while nothing was found
@@ -242,9 +254,10 @@ GS_DEV unsigned long long grid_search_stage0(const GsGrid& g, const int* __restr
 template <int G>
 GS_DEV unsigned long long grid_search_rings(const GsGrid& g, const int* __restrict__ cell_start,
                                             const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
-                                            unsigned long long key, bool* resolved) {
+                                            unsigned long long key, bool* resolved, int* win) {
   const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
   bool done = false;
+  int bs = -1;  // slot of a candidate of THIS call that beats the incoming key (-1: the incoming key stands)
   for (int k = 1; k <= GS_GRID_RINGS && !done; ++k) {
     const int side = 2 * k + 1, nrow = side * side;
     const int xa = qc.cx - k < 0 ? 0 : qc.cx - k, xb = qc.cx + k >= g.nx ? g.nx - 1 : qc.cx + k;
@@ -255,10 +268,14 @@ GS_DEV unsigned long long grid_search_rings(const GsGrid& g, const int* __restri
       const int je = cell_start[row + xb + 1];
       for (int j = cell_start[row + xa]; j < je; ++j) {
         const unsigned long long k2 = grid_key(qx, qy, qz, sorted[j]);
-        key = k2 < key ? k2 : key;
+        if (k2 < key) { key = k2; bs = j; }
       }
     }
-    key = grid_group_min<G>(key);
+    {
+      const unsigned long long own = key;
+      key = grid_group_min<G>(key);
+      if (own != key) bs = -1;
+    }
     // every unvisited target is farther than k cells from the projected query; 0.1 % of a cell is
     // orders of magnitude above the float rounding of the cell assignment
     const float rb = (float)k * g.c * 0.999f;
@@ -266,6 +283,7 @@ GS_DEV unsigned long long grid_search_rings(const GsGrid& g, const int* __restri
     done = bd <= rb * rb;
   }
   *resolved = done;
+  *win = bs;
   return key;
 }
 
@@ -273,8 +291,9 @@ template <int G = GQ_G>
 GS_DEV unsigned long long grid_search_group(const GsGrid& g, const int* __restrict__ cell_start,
                                         const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
                                         bool* resolved) {
-  unsigned long long key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, resolved);
-  if (!*resolved) key = grid_search_rings<G>(g, cell_start, sorted, qx, qy, qz, lane, key, resolved);
+  int win;
+  unsigned long long key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, resolved, &win);
+  if (!*resolved) key = grid_search_rings<G>(g, cell_start, sorted, qx, qy, qz, lane, key, resolved, &win);
   return key;
 }
 
@@ -283,12 +302,14 @@ GS_DEV unsigned long long grid_search_group(const GsGrid& g, const int* __restri
 // copy only the targets.  Same distance arithmetic and key order, hence the same result.
 template <int BLOCK>
 GS_DEV unsigned long long block_brute_min_sorted(float qx, float qy, float qz, const float4* __restrict__ sorted,
-                                                 int n, unsigned long long* red) {
+                                                 int n, unsigned long long* red, int* win) {
   unsigned long long key = ~0ull;
+  int bs = -1;
   for (int j = threadIdx.x; j < n; j += BLOCK) {
     const unsigned long long k2 = grid_key(qx, qy, qz, sorted[j]);
-    key = k2 < key ? k2 : key;
+    if (k2 < key) { key = k2; bs = j; }
   }
+  const unsigned long long own = key;
 #pragma unroll
   for (int d = GS_WAVE / 2; d > 0; d >>= 1) {
     const unsigned long long o = __shfl_xor(key, d, GS_WAVE);
@@ -300,6 +321,7 @@ GS_DEV unsigned long long block_brute_min_sorted(float qx, float qy, float qz, c
   key = red[0];
 #pragma unroll
   for (int w = 1; w < BLOCK / GS_WAVE; ++w) key = red[w] < key ? red[w] : key;
+  *win = own == key ? bs : -1;  // the one thread that holds the winning candidate
   return key;
 }
 

@@ -129,7 +129,7 @@ int gs_knn_brute_launch(const float* src_in, const float* Tapply, float* src_out
 // ---------------------------------------------------------------- uniform grid ---------
 size_t gs_knn_grid_scratch_bytes(int64_t n_src, int64_t n_tgt) {
   return 512 + 2 * gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1)) + gs_align(4 * (size_t)(GS_GRID_MAXCELL / GS_GRID_TILE + 2)) +
-         2 * gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1)) + gs_align(4 * (size_t)(n_src > 0 ? n_src : 1)) + 256;
+         3 * gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1)) + gs_align(4 * (size_t)(n_src > 0 ? n_src : 1)) + 256;
 }
 
 // Bounding box of the finite targets: block-local min / max, then 6 atomicMax on order-preserving
@@ -375,7 +375,8 @@ __global__ void __launch_bounds__(256) gs_grid_scan_kernel(const int* __restrict
 GS_DEV void grid_scatter_body(const float* __restrict__ tgt, const int64_t n_tgt, const GsTargetFilter flt,
                               const GsGrid* __restrict__ gp, const int* __restrict__ cell_start,
                               int* __restrict__ cell_count, float4* __restrict__ sorted,
-                              const float4* __restrict__ tlist, const unsigned* __restrict__ bbox, const unsigned blk,
+                              const float4* __restrict__ tlist, const unsigned* __restrict__ bbox,
+                              const float* __restrict__ nrm, float4* __restrict__ sorted_n, const unsigned blk,
                               const unsigned nblk) {
   if (flt.pix) {
     const int64_t n_list = (int64_t)bbox[6];
@@ -384,7 +385,12 @@ GS_DEV void grid_scatter_body(const float* __restrict__ tgt, const int64_t n_tgt
     for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n_list; i += (int64_t)nblk * 256) {
       const float4 t = tlist[i];
       const int cid = grid_cell(g, t.x, t.y, t.z);
-      sorted[cell_start[cid] + atomicSub(&cell_count[cid], 1) - 1] = t;
+      const int slot = cell_start[cid] + atomicSub(&cell_count[cid], 1) - 1;
+      sorted[slot] = t;
+      if (nrm) {  // the normal travels with the point: the ICP kernels never gather from the map arrays
+        const int64_t r = (int64_t)__float_as_int(t.w);
+        sorted_n[slot] = make_float4(nrm[3 * r], nrm[3 * r + 1], nrm[3 * r + 2], 0.0f);
+      }
     }
     return;
   }
@@ -397,6 +403,7 @@ GS_DEV void grid_scatter_body(const float* __restrict__ tgt, const int64_t n_tgt
   // queries order candidates by (distance, original index).  Leaves cell_count all zero again.
   const int slot = cell_start[cid] + atomicSub(&cell_count[cid], 1) - 1;
   sorted[slot] = make_float4(x, y, z, __int_as_float((int)i));
+  if (nrm) sorted_n[slot] = make_float4(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2], 0.0f);
 }
 __global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
                                                               const GsTargetFilter flt,
@@ -405,8 +412,11 @@ __global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __res
                                                               int* __restrict__ cell_count,
                                                               float4* __restrict__ sorted,
                                                               const float4* __restrict__ tlist,
-                                                              const unsigned* __restrict__ bbox) {
-  grid_scatter_body(tgt, gs_count(n_tgt_c), flt, gp, cell_start, cell_count, sorted, tlist, bbox, blockIdx.x, gridDim.x);
+                                                              const unsigned* __restrict__ bbox,
+                                                              const float* __restrict__ nrm,
+                                                              float4* __restrict__ sorted_n) {
+  grid_scatter_body(tgt, gs_count(n_tgt_c), flt, gp, cell_start, cell_count, sorted, tlist, bbox, nrm, sorted_n, blockIdx.x,
+                    gridDim.x);
 }
 
 // ---- batched build: block b of a launch works for sequence b % B on its block b / B ----
@@ -441,7 +451,7 @@ __global__ void __launch_bounds__(256) gs_gridb_scan_kernel(const GsGridBatch gb
 __global__ void __launch_bounds__(256) gs_gridb_scatter_kernel(const GsGridBatch gb) {
   const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
   grid_scatter_body(q.tgt, gs_count(q.n_tgt), GsTargetFilter{q.pix, gb.W, gb.ds}, q.m.g, q.m.cell_start, q.m.cell_count,
-                    q.m.sorted, q.m.tlist, q.m.bbox, blockIdx.x / gb.B, gridDim.x / gb.B);
+                    q.m.sorted, q.m.tlist, q.m.bbox, q.nrm, q.m.sorted_n, blockIdx.x / gb.B, gridDim.x / gb.B);
 }
 
 // Cells the grid of a build may use (what is cleared and scanned per build): the target density the
@@ -487,7 +497,7 @@ int gs_knn_grid_build_batch(const GsGridBatch& gb, hipStream_t st) {
 }
 
 int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* grid_scratch, hipStream_t st,
-                      GsTargetFilter flt) {
+                      GsTargetFilter flt, const float* nrm) {
   const int64_t n_tgt = n_tgt_c.host;  // upper bound: launch geometry and scratch layout
   GridMem m = grid_carve(grid_scratch, n_src, n_tgt);
   const int cells_cap = grid_cells_cap(n_src, n_tgt_c.dev ? 0 : n_tgt);
@@ -506,7 +516,7 @@ int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* gr
   hipLaunchKernelGGL(gs_grid_scan_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums,
                      m.cell_start);
   hipLaunchKernelGGL(gs_grid_scatter_kernel, dim3((unsigned)gs_ceil_div(n_tgt, 256)), dim3(256), 0, st, tgt,
-                     n_tgt_c, flt, m.g, m.cell_start, m.cell_count, m.sorted, m.tlist, m.bbox);
+                     n_tgt_c, flt, m.g, m.cell_start, m.cell_count, m.sorted, m.tlist, m.bbox, nrm, m.sorted_n);
   return GS_OK;
 }
 
