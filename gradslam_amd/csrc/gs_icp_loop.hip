@@ -138,8 +138,12 @@ struct IcpHalfSeq {
 };
 
 // index pairs (into [a0..a5, res]) of the 28 accumulated products: 21 upper-triangular a_i a_k, 6 a_i res, res res
-__constant__ unsigned char FS_PA[LIN_NV] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6};
-__constant__ unsigned char FS_PB[LIN_NV] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6};
+// (three bits per entry in two 64-bit literals for the 21 matrix products; entries 21..27 are (i - 21, 6).  A table in
+// constant memory would pin two 64-bit addresses in VGPRs across the whole kernel, which sits at the 80-VGPR limit.)
+constexpr unsigned long long FS_PA_BITS = 0x591b692449240000ull;  // 0 0 0 0 0 0 1 1 1 1 1 2 2 2 2 3 3 3 4 4 5
+constexpr unsigned long long FS_PB_BITS = 0x5b2c76356346c688ull;  // 0 1 2 3 4 5 1 2 3 4 5 2 3 4 5 3 4 5 4 5 5
+GS_DEV int fs_pa(int i) { return i < 21 ? (int)((FS_PA_BITS >> (3 * i)) & 7ull) : i - 21; }
+GS_DEV int fs_pb(int i) { return i < 21 ? (int)((FS_PB_BITS >> (3 * i)) & 7ull) : 6; }
 
 // One half-iteration for one sequence.  G lanes serve a query, so a block holds NQ = FS_BLOCK / G query slots =
 // NU row units of FS_QPB (96) queries.  Every unit produces ONE partial row, always with the same fixed-order sums,
@@ -363,7 +367,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
     // threads add the sub-sums, always in index order.
     for (int w = threadIdx.x; w < NU * FS_RG * LIN_NV; w += FS_BLOCK) {
       const int i = w % LIN_NV, part = (w / LIN_NV) % FS_RG, un = w / (LIN_NV * FS_RG);
-      const int ia = FS_PA[i], ib = FS_PB[i];
+      const int ia = fs_pa(i), ib = fs_pb(i);
       const float* r0 = qa_s[un * FS_QPB + FS_RPG * part];
       double t = (double)r0[ia] * (double)r0[ib];
 #pragma unroll

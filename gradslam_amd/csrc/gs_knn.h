@@ -168,7 +168,11 @@ GS_DEV GsQueryCell grid_query_cell(const GsGrid& g, float qx, float qy, float qz
   // cell of the query's projection onto the bounding box (the projection onto a convex set never
   // increases the distance to points inside it, so shell bounds around it stay valid)
   GsQueryCell c;
-  c.px = fminf(fmaxf(qx, g.ox), g.mx); c.py = fminf(fmaxf(qy, g.oy), g.my); c.pz = fminf(fmaxf(qz, g.oz), g.mz);
+  // (compare + select rather than fminf / fmaxf: those canonicalise the block-uniform box corners into six VGPRs
+  // that stay live through the whole search; queries are never NaN here, the callers skip such points)
+  c.px = qx < g.ox ? g.ox : (qx > g.mx ? g.mx : qx);
+  c.py = qy < g.oy ? g.oy : (qy > g.my ? g.my : qy);
+  c.pz = qz < g.oz ? g.oz : (qz > g.mz ? g.mz : qz);
   c.cx = grid_axis(c.px, g.ox, g.inv_c, g.nx); c.cy = grid_axis(c.py, g.oy, g.inv_c, g.ny);
   c.cz = grid_axis(c.pz, g.oz, g.inv_c, g.nz);
   return c;
