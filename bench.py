@@ -91,11 +91,18 @@ def make_sequences(seeds, L, Hh, Ww):
     import multiprocessing as mp
     chunk = L if L <= 64 else 8   # up to 64 frames: exactly make_sequence(L, seed) (what the goldens were recorded on)
     jobs = [(min(chunk, L - f0), Hh, Ww, s, f0) for s in seeds for f0 in range(0, L, chunk)]
-    if len(jobs) == 1:
-        parts = [_make(jobs[0])]
+    # under rocprofv3 (its tool library is preloaded into forked workers and its SIGTERM handler can dead-lock a
+    # terminating pool) the sequences are generated in this process
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or "ROCPROFILER_LIBRARY_CTOR" in os.environ
+    if len(jobs) == 1 or profiled:
+        parts = [_make(j) for j in jobs]
     else:
-        with mp.get_context("fork").Pool(min(len(jobs), os.cpu_count() or 1)) as pool:
+        pool = mp.get_context("fork").Pool(min(len(jobs), os.cpu_count() or 1))
+        try:
             parts = pool.map(_make, jobs)
+        finally:
+            pool.close()   # workers leave on their own: no SIGTERM (Pool.__exit__ terminates)
+            pool.join()
     out, per = [], (L + chunk - 1) // chunk
     for i in range(len(seeds)):
         ps = parts[i * per:(i + 1) * per]

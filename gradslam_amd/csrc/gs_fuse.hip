@@ -28,6 +28,48 @@ __global__ void __launch_bounds__(256) gs_fuse_scatter_kernel(const int32_t* __r
   }
 }
 
+// slam/fusionutils.py:678-699 for one map row n (p = its winning pixel or -1).
+// All loads first, then the arithmetic, then the stores: the three floats of an attribute then travel as ONE 12-byte
+// access (interleaved loads and stores compile to 21 + 10 single-dword accesses, and the scattered frame gathers of
+// the matched rows make the kernel address-rate bound).
+GS_DEV void fuse_merge_row(float* __restrict__ points, float* __restrict__ normals, float* __restrict__ colors,
+                           float* __restrict__ ccounts, const int64_t n, const int32_t p,
+                           const float* __restrict__ gvertex, const float* __restrict__ gnormal,
+                           const float* __restrict__ rgb, const float* __restrict__ alpha) {
+  const float a = p >= 0 ? alpha[p] : 0.0f;
+  const float cc = ccounts[n];
+  float P[3], N[3], C[3], fp[3] = {0.0f, 0.0f, 0.0f}, fn[3] = {0.0f, 0.0f, 0.0f}, fc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    P[k] = points[3 * n + k];
+    N[k] = normals[3 * n + k];
+    C[k] = colors[3 * n + k];
+  }
+  if (p >= 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      fp[k] = gvertex[3 * (int64_t)p + k];
+      fn[k] = gnormal[3 * (int64_t)p + k];
+      fc[k] = rgb[3 * (int64_t)p + k];
+    }
+  }
+  const float cc2 = cc + a;
+  const float inv = 1.0f / (cc2 == 0.0f ? 1.0f : cc2);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    P[k] = ((cc * P[k]) + (a * fp[k])) * inv;
+    N[k] = ((cc * N[k]) + (a * fn[k])) * inv;
+    C[k] = ((cc * C[k]) + (a * fc[k])) * inv;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) points[3 * n + k] = P[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) normals[3 * n + k] = N[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) colors[3 * n + k] = C[k];
+  ccounts[n] = cc2;
+}
+
 // slam/fusionutils.py:678-699 applied to rows [0, n_map).
 __global__ void __launch_bounds__(256) gs_fuse_merge_kernel(
     float* __restrict__ points, float* __restrict__ normals, float* __restrict__ colors,
@@ -43,20 +85,7 @@ __global__ void __launch_bounds__(256) gs_fuse_merge_kernel(
   if (*any_flag == 0 && renorm_all != 2) return;
   const int32_t p = pix_of[n];
   if (p < 0 && !renorm_all) return;
-  const float a = p >= 0 ? alpha[p] : 0.0f;
-  const float cc = ccounts[n];
-  const float cc2 = cc + a;
-  const float inv = 1.0f / (cc2 == 0.0f ? 1.0f : cc2);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float fp = p >= 0 ? gvertex[3 * (int64_t)p + k] : 0.0f;
-    const float fn = p >= 0 ? gnormal[3 * (int64_t)p + k] : 0.0f;
-    const float fc = p >= 0 ? rgb[3 * (int64_t)p + k] : 0.0f;
-    points[3 * n + k] = ((cc * points[3 * n + k]) + (a * fp)) * inv;
-    normals[3 * n + k] = ((cc * normals[3 * n + k]) + (a * fn)) * inv;
-    colors[3 * n + k] = ((cc * colors[3 * n + k]) + (a * fc)) * inv;
-  }
-  ccounts[n] = cc2;
+  fuse_merge_row(points, normals, colors, ccounts, n, p, gvertex, gnormal, rgb, alpha);
 }
 
 struct PredNewPixel {
@@ -78,13 +107,29 @@ struct EmitAppend {
   const float* alpha;
   __device__ void operator()(int64_t p, int64_t pos) const {
     const int64_t r = gs_count(n_map) + pos;
+    float v[3], nn[3] = {0.0f, 0.0f, 0.0f}, c[3] = {0.0f, 0.0f, 0.0f};  // loads, then stores: 12-byte accesses
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      points[3 * r + k] = gvertex[3 * p + k];
-      if (normals) normals[3 * r + k] = gnormal[3 * p + k];
-      if (colors) colors[3 * r + k] = rgb[3 * p + k];
+    for (int k = 0; k < 3; ++k) v[k] = gvertex[3 * p + k];
+    if (normals) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) nn[k] = gnormal[3 * p + k];
     }
-    if (ccounts) ccounts[r] = alpha[p];
+    if (colors) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) c[k] = rgb[3 * p + k];
+    }
+    const float a = ccounts ? alpha[p] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) points[3 * r + k] = v[k];
+    if (normals) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) normals[3 * r + k] = nn[k];
+    }
+    if (colors) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) colors[3 * r + k] = c[k];
+    }
+    if (ccounts) ccounts[r] = a;
   }
 };
 
@@ -392,7 +437,9 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_winner_count_kernel(const M
       const int32_t n = q.best_pix[p];
       if (n >= 0 && n < n_map) {
         q.pix_of[n] = (int32_t)p;
-        *q.any_flag = 1;  // benign race: every writer stores the same value
+        // benign race: every writer stores the same value; once it is set nobody stores again (the stores of all
+        // the winners of a frame would otherwise queue up on one cache line)
+        if (*reinterpret_cast<volatile int32_t*>(q.any_flag) == 0) *q.any_flag = 1;
       }
       if (q.depth[p] > 0.0f && n < 0) ++c;
     }
@@ -402,26 +449,6 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_winner_count_kernel(const M
   if (threadIdx.x == 0) q.tile_counts[blk] = total;
 }
 
-// slam/fusionutils.py:678-699 applied to rows [0, n_map) (the arithmetic of gs_fuse_merge_kernel)
-GS_DEV void fuse_merge_row(float* __restrict__ points, float* __restrict__ normals, float* __restrict__ colors,
-                           float* __restrict__ ccounts, const int64_t n, const int32_t p,
-                           const float* __restrict__ gvertex, const float* __restrict__ gnormal,
-                           const float* __restrict__ rgb, const float* __restrict__ alpha) {
-  const float a = p >= 0 ? alpha[p] : 0.0f;
-  const float cc = ccounts[n];
-  const float cc2 = cc + a;
-  const float inv = 1.0f / (cc2 == 0.0f ? 1.0f : cc2);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float fp = p >= 0 ? gvertex[3 * (int64_t)p + k] : 0.0f;
-    const float fn = p >= 0 ? gnormal[3 * (int64_t)p + k] : 0.0f;
-    const float fc = p >= 0 ? rgb[3 * (int64_t)p + k] : 0.0f;
-    points[3 * n + k] = ((cc * points[3 * n + k]) + (a * fp)) * inv;
-    normals[3 * n + k] = ((cc * normals[3 * n + k]) + (a * fn)) * inv;
-    colors[3 * n + k] = ((cc * colors[3 * n + k]) + (a * fc)) * inv;
-  }
-  ccounts[n] = cc2;
-}
 __global__ void __launch_bounds__(256) gs_mu_merge_kernel(const MuBatch mb) {
   const MuSeq& q = mb.s[blockIdx.x % mb.B];
   const int64_t n = (int64_t)(blockIdx.x / mb.B) * 256 + threadIdx.x;

@@ -229,8 +229,13 @@ GS_DEV void grid_bbox_body(const float* __restrict__ tgt, const int64_t n_tgt, c
       b = red[3 + k][w] > b ? red[3 + k][w] : b;
     }
     if (a <= b) {  // at least one finite coordinate on this axis in this block
-      atomicMax(&bbox[k], ~grid_code(a));
-      atomicMax(&bbox[3 + k], grid_code(b));
+      // The seven words of the box share one cache line and every block of the build wants to update them: the
+      // atomics of a large map (thousands of blocks) serialise there.  The maxima only grow, so a block whose
+      // value does not beat what is already there (a plain, possibly stale read: staleness only costs a redundant
+      // atomic) skips it -- after the first blocks almost all do.
+      const unsigned ca = ~grid_code(a), cb = grid_code(b);
+      if (ca > *reinterpret_cast<volatile unsigned*>(&bbox[k])) atomicMax(&bbox[k], ca);
+      if (cb > *reinterpret_cast<volatile unsigned*>(&bbox[3 + k])) atomicMax(&bbox[3 + k], cb);
     }
   }
 }
