@@ -995,8 +995,14 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
     gm[b] = grid_carve(sc[b].grid, n_lat, q.map.n_bound);
     lb.s[b] = LocSeq{q.vertex, q.depth, q.prev_pose16, lattice, sc[b].state, q.out_pose16,
                      reinterpret_cast<char*>(gm[b].g), n_valid};
-    gb.s[b] = GsGridSeq{q.map.points, GsCount{q.map.n_bound, q.map.n_dev}, pix, q.prev_pose16, q.K16, q.map.normals,
-                        gm[b]};
+    static int binned_normals = -1;  // GRADSLAM_HIP_ICP_BINNED_NORMALS=0: gather the matches' normals from the map (A/B)
+    if (binned_normals < 0) {
+      const char* e = getenv("GRADSLAM_HIP_ICP_BINNED_NORMALS");
+      binned_normals = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    if (!binned_normals) gm[b].sorted_n = nullptr;
+    gb.s[b] = GsGridSeq{q.map.points, GsCount{q.map.n_bound, q.map.n_dev}, pix, q.prev_pose16, q.K16,
+                        binned_normals ? q.map.normals : nullptr, gm[b]};
     if (g_gs_prof_on) GS_HIP(hipMemsetAsync(n_valid, 0, 8, st));
   }
   lb.count_valid = g_gs_prof_on ? 1 : 0;
