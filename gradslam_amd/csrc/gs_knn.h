@@ -186,7 +186,7 @@ GS_DEV unsigned long long grid_search_stage0(const GsGrid& g, const int* __restr
   const float px = qc.px, py = qc.py, pz = qc.pz;
   const int cx = qc.cx, cy = qc.cy, cz = qc.cz;
   unsigned long long key = ~0ull;
-  int bs = -1;  // slot (in `sorted`) of this lane's best candidate
+  int bt = -1;  // flat position (in the candidate list) of this lane's best candidate
   // The 2x2x2 block of cells whose centre is nearest to the (projected) query.  Every target
   // outside that box is at least as far as the nearest box face that has cells behind it (>= half a cell
   // by construction); ICP queries sit within a fraction of a cell of their neighbour, so most searches
@@ -233,17 +233,18 @@ GS_DEV unsigned long long grid_search_stage0(const GsGrid& g, const int* __restr
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const unsigned long long k2 = in[u] ? grid_key(qx, qy, qz, p[u]) : ~0ull;
-      if (k2 < key) {
-        const int tt = t0 + u * G;  // in[u] holds here
-        key = k2;
-        bs = tt < e1 ? sb0 + tt : (tt < e2 ? sb1 + (tt - e1) : (tt < e3 ? sb2 + (tt - e2) : sb3 + (tt - e3)));
-      }
+      const bool better = k2 < key;
+      key = better ? k2 : key;
+      bt = better ? t0 + u * G : bt;
     }
   }
   {
-    const unsigned long long own = key;
-    key = grid_group_min<G>(key);
-    *win = own == key ? bs : -1;  // keys are unique (they carry the target index): at most one lane of the group wins
+    // keys are unique (they carry the target index): at most one lane of the group holds the minimum; it reports
+    // the slot of that candidate in `sorted`
+    const unsigned long long kmin = grid_group_min<G>(key);
+    const int bs = bt < e1 ? sb0 + bt : (bt < e2 ? sb1 + (bt - e1) : (bt < e3 ? sb2 + (bt - e2) : sb3 + (bt - e3)));
+    *win = (key == kmin && bt >= 0) ? bs : -1;
+    key = kmin;
   }
   // 0.1 % of a cell is orders of magnitude above the float rounding of the cell assignment
   const float rb = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
