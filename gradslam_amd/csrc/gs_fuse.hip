@@ -437,9 +437,7 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_winner_count_kernel(const M
       const int32_t n = q.best_pix[p];
       if (n >= 0 && n < n_map) {
         q.pix_of[n] = (int32_t)p;
-        // benign race: every writer stores the same value; once it is set nobody stores again (the stores of all
-        // the winners of a frame would otherwise queue up on one cache line)
-        if (*reinterpret_cast<volatile int32_t*>(q.any_flag) == 0) *q.any_flag = 1;
+        *q.any_flag = 1;  // benign race: every writer stores the same value
       }
       if (q.depth[p] > 0.0f && n < 0) ++c;
     }

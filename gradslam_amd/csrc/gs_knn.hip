@@ -143,74 +143,51 @@ GS_DEV float grid_decode(unsigned c) {
   return __uint_as_float((c & 0x80000000u) ? (c & 0x7fffffffu) : ~c);
 }
 constexpr int GB_BLOCK = 256;
-constexpr int GB_ITEMS = 8;    // rows per thread with their loads in flight together
-constexpr int GB_CHUNKS = 4;   // such rounds per block: the block-level tail (reductions, atomics, list hand-over) is
-                               // paid once per GB_ROWS rows (measured: 31 us -> see DESIGN.md with one round per block)
-constexpr int GB_ROWS = GB_BLOCK * GB_ITEMS * GB_CHUNKS;
+constexpr int GB_ITEMS = 8;
 // Body shared by the single-sequence and the batched kernels (blk = block index within the sequence).
 // cam != NULL: pix[] is an OUTPUT (projection of every row under the camera, gs_project_map_f32) and the
 // filter is evaluated on the value just computed.
-// Filtered builds also compact the rows that pass the filter (a few per cent of a map) into tlist: the count and
-// scatter passes then walk that list instead of the map.  Hits are collected in LDS (any order: the order of the
-// list does not matter, see the scatter), ONE atomic per block hands out the slots (bbox[6] is also the number of
-// targets the cell-size heuristic needs).
 GS_DEV void grid_bbox_body(const float* __restrict__ tgt, const int64_t n_tgt, const GsTargetFilter flt,
                            const GsCamera* cam, int H, float u_hi, float v_hi, int32_t* __restrict__ pix_out,
                            unsigned* __restrict__ bbox, int* __restrict__ unres_count, float4* __restrict__ tlist,
                            const unsigned blk) {
   if (blk == 0 && threadIdx.x == 0) { unres_count[0] = 0; unres_count[1] = 0; }
-  const int64_t row0 = (int64_t)blk * GB_ROWS;
-  if (row0 >= n_tgt) return;
+  if ((int64_t)blk * GB_BLOCK * GB_ITEMS >= n_tgt) return;
   __shared__ float red[6][GB_BLOCK / GS_WAVE];
-  __shared__ unsigned short list_s[GB_ROWS];  // offsets (from row0) of the rows that passed the filter
-  __shared__ unsigned cnt_s, base_s;
-  const bool filtered = flt.pix != nullptr || cam != nullptr;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) cnt_s = 0;
-  __syncthreads();
+  __shared__ int scan_s[GB_BLOCK / GS_WAVE + 1];
+  __shared__ unsigned base_s;
+  int hits = 0;
+  unsigned hitmask = 0;  // bit u: item u of this thread passed the filter
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int c = 0; c < GB_CHUNKS; ++c) {
-    if (row0 + (int64_t)c * GB_BLOCK * GB_ITEMS >= n_tgt) break;  // block-uniform
 #pragma unroll
-    for (int u = 0; u < GB_ITEMS; ++u) {
-      const int off = (c * GB_ITEMS + u) * GB_BLOCK + (int)threadIdx.x;
-      const int64_t i = row0 + off;
-      const bool valid = i < n_tgt;
-      bool is_t = false;
-      float v3[3] = {0.0f, 0.0f, 0.0f};
-      if (valid) {
-        if (cam) {
-          v3[0] = tgt[3 * i]; v3[1] = tgt[3 * i + 1]; v3[2] = tgt[3 * i + 2];
-          const int32_t p = gs_project_point(*cam, v3[0], v3[1], v3[2], H, flt.W, u_hi, v_hi);
-          pix_out[i] = p;
-          is_t = p >= 0 && ((p / flt.W) % flt.ds == 0) && ((p % flt.W) % flt.ds == 0);
-        } else {
-          is_t = gs_is_target(flt, i);
-          if (is_t) { v3[0] = tgt[3 * i]; v3[1] = tgt[3 * i + 1]; v3[2] = tgt[3 * i + 2]; }
-        }
-      }
-      if (filtered) {  // wave-aggregated append to the block's list
-        const unsigned long long m = __ballot(is_t);
-        if (m) {
-          const int leader = __ffsll((long long)m) - 1;
-          unsigned wbase = 0;
-          if (lane == leader) wbase = atomicAdd(&cnt_s, (unsigned)__popcll(m));
-          wbase = __shfl(wbase, leader, GS_WAVE);
-          if (is_t) list_s[wbase + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)off;
-        }
-      }
-      if (is_t) {
+  for (int u = 0; u < GB_ITEMS; ++u) {
+    const int64_t i = ((int64_t)blk * GB_ITEMS + u) * GB_BLOCK + threadIdx.x;
+    if (i >= n_tgt) continue;
+    bool is_t;
+    float v3[3];
+    if (cam) {
+      v3[0] = tgt[3 * i]; v3[1] = tgt[3 * i + 1]; v3[2] = tgt[3 * i + 2];
+      const int32_t p = gs_project_point(*cam, v3[0], v3[1], v3[2], H, flt.W, u_hi, v_hi);
+      pix_out[i] = p;
+      is_t = p >= 0 && ((p / flt.W) % flt.ds == 0) && ((p % flt.W) % flt.ds == 0);
+    } else {
+      is_t = gs_is_target(flt, i);
+      if (is_t) { v3[0] = tgt[3 * i]; v3[1] = tgt[3 * i + 1]; v3[2] = tgt[3 * i + 2]; }
+    }
+    if (is_t) {
+      ++hits;
+      hitmask |= 1u << u;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float v = v3[k];
-          if (v > -3.0e38f && v < 3.0e38f) {  // finite
-            lo[k] = v < lo[k] ? v : lo[k];
-            hi[k] = v > hi[k] ? v : hi[k];
-          }
+      for (int k = 0; k < 3; ++k) {
+        const float v = v3[k];
+        if (v > -3.0e38f && v < 3.0e38f) {  // finite
+          lo[k] = v < lo[k] ? v : lo[k];
+          hi[k] = v > hi[k] ? v : hi[k];
         }
       }
     }
   }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float a = lo[k], b = hi[k];
@@ -222,15 +199,26 @@ GS_DEV void grid_bbox_body(const float* __restrict__ tgt, const int64_t n_tgt, c
     }
     if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = b; }
   }
+  const bool filtered = flt.pix != nullptr || cam != nullptr;
   __syncthreads();
   if (filtered) {
-    const unsigned total = cnt_s;
-    if (threadIdx.x == 0 && total) base_s = atomicAdd(&bbox[6], total);
+    // the rows that passed the filter (a few per cent of a map) are compacted into tlist: the count and scatter
+    // passes then walk that list instead of the map.  One atomic per block hands out the slots (bbox[6] is also the
+    // number of targets the cell-size heuristic needs); the order of the list does not matter (see the scatter).
+    int total;
+    int pos = gs_block_excl_scan<GB_BLOCK>(hits, scan_s, &total);
+    if (threadIdx.x == 0 && total) base_s = atomicAdd(&bbox[6], (unsigned)total);
     __syncthreads();
-    const unsigned base = base_s;
-    for (unsigned j = threadIdx.x; j < total; j += GB_BLOCK) {
-      const int64_t i = row0 + list_s[j];
-      tlist[base + j] = make_float4(tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2], __int_as_float((int)i));
+    if (hitmask) {
+      const unsigned base = base_s;
+#pragma unroll
+      for (int u = 0; u < GB_ITEMS; ++u) {
+        if (hitmask & (1u << u)) {
+          const int64_t i = ((int64_t)blk * GB_ITEMS + u) * GB_BLOCK + threadIdx.x;
+          tlist[base + (unsigned)pos] = make_float4(tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2], __int_as_float((int)i));
+          ++pos;
+        }
+      }
     }
   }
   if (threadIdx.x < 3) {
@@ -490,8 +478,8 @@ int gs_knn_grid_build_batch(const GsGridBatch& gb, hipStream_t st) {
   for (int b = 0; b < gb.B; ++b) n_max = gb.s[b].n_tgt.host > n_max ? gb.s[b].n_tgt.host : n_max;
   const unsigned B = (unsigned)gb.B;
   const float u_hi = (float)((double)gb.W - 0.999), v_hi = (float)((double)gb.H - 0.999);
-  hipLaunchKernelGGL(gs_gridb_bbox_kernel, dim3(B * (unsigned)gs_ceil_div(n_max, GB_ROWS)), dim3(GB_BLOCK), 0, st, gb, u_hi,
-                     v_hi);
+  hipLaunchKernelGGL(gs_gridb_bbox_kernel, dim3(B * (unsigned)gs_ceil_div(n_max, GB_BLOCK * GB_ITEMS)), dim3(GB_BLOCK), 0,
+                     st, gb, u_hi, v_hi);
   // filtered builds walk the compacted target list (a few entries per lattice slot) with a grid-stride loop
   bool listed = true;
   for (int b = 0; b < gb.B; ++b) listed = listed && gb.s[b].pix != nullptr;
@@ -519,7 +507,7 @@ int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* gr
   const size_t clear = gs_knn_grid_clear_bytes(m, cells_cap);
   hipError_t e = hipMemsetAsync(m.g, 0, clear, st);
   if (e != hipSuccess) { gs_set_error("gs_knn_grid_build: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
-  hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, GB_ROWS)),
+  hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, GB_BLOCK * GB_ITEMS)),
                      dim3(GB_BLOCK), 0, st, tgt, n_tgt_c, flt, m.bbox, m.unres_count, m.tlist);
   hipLaunchKernelGGL(gs_grid_count_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, 256)), dim3(256), 0, st,
                      tgt, n_tgt_c, flt, m.bbox, m.g, m.cell_count, cells_cap, m.tlist);
