@@ -236,9 +236,16 @@ def main():
     snapshot = (pc.clone(), prev) if not args.no_roofline_pass else None
 
     # ---------------- timed region: exactly K steps (one frame of every sequence each)
+    segments, seg_every = [], (25 if args.workload == "c5" else 0)
+
+    def mark(p):   # c5 only: one sync every 25 frames, to report ms per frame against the map size
+        if len(recovered) > Wm and (len(recovered) - Wm) % seg_every == 0:
+            torch.cuda.synchronize(device)
+            segments.append((len(recovered) - Wm, time.perf_counter(), max(p._count_of(b)[0] for b in range(B_local))))
+
     barrier()
     t0 = time.perf_counter()
-    pc, prev_end = run_steps(slam, pc, frames, prev, Wm, L, recovered)
+    pc, prev_end = run_steps(slam, pc, frames, prev, Wm, L, recovered, after_step=mark if seg_every else None)
     t_enq = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
@@ -318,10 +325,16 @@ def main():
         cpu, op = cpu_baseline(seqs[0], args.cpu_frames, args.odom)
         ate_oracle = ate_np(poses_local[0, :op.shape[0]].cpu().numpy(), op)
 
+    seg_out, pn, pt = None, 0, t0
+    if segments:   # ms per frame of consecutive stretches of the timed region (growing map)
+        seg_out = []
+        for n, t, m in segments:
+            seg_out.append({"frames": "%d-%d" % (pn, n), "ms_per_frame": (t - pt) / (n - pn) * 1e3, "map_bound_end": m})
+            pn, pt = n, t
     if rank == 0:
         value = args.batch * K / elapsed
         out = {
-            "metric": "frames/sec PointFusion 640x480 RGB-D", "value": value, "unit": "frames/s",
+            "metric": "frames/sec PointFusion %dx%d RGB-D" % (Ww, Hh), "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PointFusion(odom=%s, dsratio=4, numiters=20) forward, B=%d independent %dx%d "
@@ -336,6 +349,7 @@ def main():
                        "host_readbacks_per_frame": 0 if gs.ops.DEVICE_COUNTS else 3,
                        "ate_vs_ground_truth_m_rank0_max": ate_gt, "ate_vs_oracle_m": ate_oracle,
                        "ate_vs_reference_golden": ate_ref},
+            "segments": seg_out,
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -39,6 +39,11 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = _hipcc()
+    # objects compiled with other flags (a debugging build) are stale whatever their age
+    stamp = os.path.join(HERE, ".build_flags")
+    flags_now = " ".join(FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     jobs = []
     for s in SOURCES:
@@ -62,6 +67,8 @@ def build(force=False, verbose=False):
     objs = [os.path.join(HERE, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     return LIB
 
 
