@@ -93,6 +93,8 @@ GS_DEV double icp_sum_col27(const double* __restrict__ partials, int nrows, doub
 constexpr int FS_BLOCK = 768;            // 12 waves; 2 blocks per CU keep all 200 blocks of a 640x480 solve resident
                                          // (measured alternatives at 8 lanes per query: 512 threads 11.8 us,
                                          // 1024 threads 11.2 us, 768 threads 10.7 us per kernel)
+constexpr int FS_HARD_RINGS = 5;         // cube radius (cells) the 16-lane groups go to before the brute-force fallback
+constexpr int FS_BQ = 4;                 // queries per pass of the block-wide brute-force fallback
 constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 96 queries per block, their rows are built by the first two waves
 constexpr int FS_RPG = (FS_QPB / 4) * LIN_NV <= FS_BLOCK ? 4 : 8;  // rows per group in the block reduction
 constexpr int FS_RG = FS_QPB / FS_RPG;                            // row groups
@@ -285,7 +287,8 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
       bool done;
       int win;
       const unsigned long long key = grid_search_rings<FS_HG>(g, cell_start, sorted, qs[hs][0], qs[hs][1], qs[hs][2],
-                                                              threadIdx.x & (FS_HG - 1), keys_s[hs], &done, &win);
+                                                              threadIdx.x & (FS_HG - 1), keys_s[hs], &done, &win,
+                                                              FS_HARD_RINGS);
       if (win >= 0) bslot_s[hs] = win;  // a candidate of the cubes beat the 2x2x2 stage
       if ((threadIdx.x & (FS_HG - 1)) == 0) {
         keys_s[hs] = key;
@@ -300,14 +303,9 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
     if (tl && threadIdx.x == 0 && u0 == u_first) { tl[5] = wall_clock64(); tl[2] += (unsigned long long)nh; }
     const int nun = unres_n;  // block-uniform
     if (tl && threadIdx.x == 0) { tl[7] += (unsigned long long)nun; if (u0 == u_first) tl[6] = wall_clock64(); }
-    for (int u = 0; u < nun; ++u) {
-      const int us = unres_q[u];
-      int win;
-      const unsigned long long key = block_brute_min_sorted<FS_BLOCK>(qs[us][0], qs[us][1], qs[us][2], sorted,
-                                                                      cell_start[g.ncell], red, &win);
-      if (win >= 0) bslot_s[us] = win;
-      if (threadIdx.x == 0) keys_s[us] = key;
-    }
+    for (int u = 0; u < nun; u += FS_BQ)  // FS_BQ queries per pass over the binned targets
+      block_brute_min_sorted_multi<FS_BLOCK, FS_BQ>(qs, unres_q + u, nun - u < FS_BQ ? nun - u : FS_BQ, sorted,
+                                                    cell_start[g.ncell], keys_s, bslot_s);
     if (nun) {
       __syncthreads();
       if (threadIdx.x == 0) unres_n = 0;

@@ -259,11 +259,12 @@ GS_DEV unsigned long long grid_search_stage0(const GsGrid& g, const int* __restr
 template <int G>
 GS_DEV unsigned long long grid_search_rings(const GsGrid& g, const int* __restrict__ cell_start,
                                             const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
-                                            unsigned long long key, bool* resolved, int* win) {
+                                            unsigned long long key, bool* resolved, int* win,
+                                            const int kmax = GS_GRID_RINGS) {
   const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
   bool done = false;
   int bs = -1;  // slot of a candidate of THIS call that beats the incoming key (-1: the incoming key stands)
-  for (int k = 1; k <= GS_GRID_RINGS && !done; ++k) {
+  for (int k = 1; k <= kmax && !done; ++k) {
     const int side = 2 * k + 1, nrow = side * side;
     const int xa = qc.cx - k < 0 ? 0 : qc.cx - k, xb = qc.cx + k >= g.nx ? g.nx - 1 : qc.cx + k;
     for (int r = lane; r < nrow; r += G) {
@@ -328,6 +329,58 @@ GS_DEV unsigned long long block_brute_min_sorted(float qx, float qy, float qz, c
   for (int w = 1; w < BLOCK / GS_WAVE; ++w) key = red[w] < key ? red[w] : key;
   *win = own == key ? bs : -1;  // the one thread that holds the winning candidate
   return key;
+}
+
+// The same for up to BQ queries in ONE pass over the binned targets (every thread of the block calls it with the same
+// arguments).  Far queries come in clusters (a frame border that looks at surface the map has not seen lands in one or
+// two blocks), and a pass per query made such launches 5x longer; a pass serves BQ of them for the price of one.
+// ids[0 .. nq): slots of the queries in qs / key_out / bslot_out (LDS arrays of the caller).
+template <int BLOCK, int BQ>
+GS_DEV void block_brute_min_sorted_multi(const float (*qs)[3], const int* ids, int nq,
+                                         const float4* __restrict__ sorted, int n, unsigned long long* key_out,
+                                         int* bslot_out) {
+  __shared__ unsigned long long red_m[BLOCK / GS_WAVE][BQ];
+  float q[BQ][3];
+  unsigned long long key[BQ];
+  int bs[BQ];
+#pragma unroll
+  for (int i = 0; i < BQ; ++i) {
+    const int id = ids[i < nq ? i : 0];
+    q[i][0] = qs[id][0]; q[i][1] = qs[id][1]; q[i][2] = qs[id][2];
+    key[i] = ~0ull;
+    bs[i] = -1;
+  }
+  for (int j = threadIdx.x; j < n; j += BLOCK) {
+    const float4 p = sorted[j];
+#pragma unroll
+    for (int i = 0; i < BQ; ++i) {
+      const unsigned long long k2 = grid_key(q[i][0], q[i][1], q[i][2], p);
+      if (k2 < key[i]) { key[i] = k2; bs[i] = j; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BQ; ++i) {
+    unsigned long long k = key[i];
+#pragma unroll
+    for (int d = GS_WAVE / 2; d > 0; d >>= 1) {
+      const unsigned long long o = __shfl_xor(k, d, GS_WAVE);
+      k = o < k ? o : k;
+    }
+    if ((threadIdx.x & (GS_WAVE - 1)) == 0) red_m[threadIdx.x / GS_WAVE][i] = k;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < BQ; ++i) {
+    if (i < nq) {
+      unsigned long long k = red_m[0][i];
+#pragma unroll
+      for (int w = 1; w < BLOCK / GS_WAVE; ++w) k = red_m[w][i] < k ? red_m[w][i] : k;
+      const int id = ids[i];
+      if (key[i] == k && bs[i] >= 0) bslot_out[id] = bs[i];  // the one thread that holds the winning candidate
+      if (threadIdx.x == 0) key_out[id] = k;
+    }
+  }
+  __syncthreads();
 }
 
 // Whole-block brute-force minimum for ONE query (all threads of a BLOCK-thread block call it with

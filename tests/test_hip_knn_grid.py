@@ -134,18 +134,28 @@ for f in range(2):
     gv, gn = ops.global_maps(v, n, d, torch.from_numpy(s["poses"][0]).cuda())
     pts.append(ops.downsample_frame(gv, gn, None, d, 2)[:2])
 (tgt, tn), (src, _) = pts
+import os
+if os.environ.get("GS_TEST_FAR_CLUSTERS") == "1":
+    # clusters of consecutive source points far from every target (a frame border that looks at unseen surface):
+    # they stay open after the 2x2x2 stage and the cube scans and land, several per block, in the block-wide
+    # brute-force pass (counts that are not multiples of the pass width included)
+    src = src.clone()
+    for start, count, off in ((1000, 13, 0.9), (1100, 4, 1.7), (5000, 1, 1.3), (9000, 38, 2.5), (9060, 7, -1.1)):
+        src[start:start + count] += torch.tensor([off, 0.3 * off, -off], device=src.device)
 T, idx, tr = ops.icp(src, tgt, tn, mode=1, numiters=20, return_trace=True)
 np.savez(sys.argv[1], T=T.cpu().numpy(), idx=idx.cpu().numpy(), tr=tr.cpu().numpy(), n=np.array([src.shape[0], tgt.shape[0]]))
 """
 
 
-def test_icp_identical_with_grid_and_brute_engines(tmp_path):
+@pytest.mark.parametrize("far_clusters", ["0", "1"])
+def test_icp_identical_with_grid_and_brute_engines(tmp_path, far_clusters):
     """Whole 20-iteration gradICP solve (19k x 19k points) run in two fresh processes, one per
-    engine: transforms, neighbour indices and the per-iteration trace must be bit-identical."""
+    engine: transforms, neighbour indices and the per-iteration trace must be bit-identical.  Second case: with
+    clusters of far source points, which exercises the cube scans and the multi-query brute-force pass."""
     outs = []
     for mode in ("grid", "brute"):
         out = str(tmp_path / (mode + ".npz"))
-        env = dict(os.environ, GRADSLAM_HIP_KNN=mode)
+        env = dict(os.environ, GRADSLAM_HIP_KNN=mode, GS_TEST_FAR_CLUSTERS=far_clusters)
         subprocess.run([sys.executable, "-c", _AB_SCRIPT % REPO, out], check=True, env=env, timeout=600)
         outs.append(np.load(out))
     a, b = outs
