@@ -303,35 +303,11 @@ GS_DEV unsigned long long grid_search_group(const GsGrid& g, const int* __restri
   return key;
 }
 
-// The same over the BINNED targets (sorted[0 .. n) = every target that passed the filter, as (x, y, z, index
-// bits)): what the fused ICP kernels use -- with a target filter the raw array holds the whole map, the binned
-// copy only the targets.  Same distance arithmetic and key order, hence the same result.
-template <int BLOCK>
-GS_DEV unsigned long long block_brute_min_sorted(float qx, float qy, float qz, const float4* __restrict__ sorted,
-                                                 int n, unsigned long long* red, int* win) {
-  unsigned long long key = ~0ull;
-  int bs = -1;
-  for (int j = threadIdx.x; j < n; j += BLOCK) {
-    const unsigned long long k2 = grid_key(qx, qy, qz, sorted[j]);
-    if (k2 < key) { key = k2; bs = j; }
-  }
-  const unsigned long long own = key;
-#pragma unroll
-  for (int d = GS_WAVE / 2; d > 0; d >>= 1) {
-    const unsigned long long o = __shfl_xor(key, d, GS_WAVE);
-    key = o < key ? o : key;
-  }
-  __syncthreads();
-  if ((threadIdx.x & (GS_WAVE - 1)) == 0) red[threadIdx.x / GS_WAVE] = key;
-  __syncthreads();
-  key = red[0];
-#pragma unroll
-  for (int w = 1; w < BLOCK / GS_WAVE; ++w) key = red[w] < key ? red[w] : key;
-  *win = own == key ? bs : -1;  // the one thread that holds the winning candidate
-  return key;
-}
-
-// The same for up to BQ queries in ONE pass over the binned targets (every thread of the block calls it with the same
+// Block-wide brute force over the BINNED targets (sorted[0 .. n) = every target that passed the filter, as (x, y, z,
+// index bits)): what the fused ICP kernels fall back to for queries the cube scans leave open -- with a target filter
+// the raw array holds the whole map, the binned copy only the targets.  Same distance arithmetic and key order as the
+// grid search and the brute-force engine, hence the same result.
+// Up to BQ queries are served in ONE pass over the binned targets (every thread of the block calls it with the same
 // arguments).  Far queries come in clusters (a frame border that looks at surface the map has not seen lands in one or
 // two blocks), and a pass per query made such launches 5x longer; a pass serves BQ of them for the price of one.
 // ids[0 .. nq): slots of the queries in qs / key_out / bslot_out (LDS arrays of the caller).
@@ -383,27 +359,3 @@ GS_DEV void block_brute_min_sorted_multi(const float (*qs)[3], const int* ids, i
   __syncthreads();
 }
 
-// Whole-block brute-force minimum for ONE query (all threads of a BLOCK-thread block call it with
-// the same query; used for the rare queries the grid cannot resolve).  red: BLOCK/64 u64 of LDS.
-template <int BLOCK>
-GS_DEV unsigned long long block_brute_min(float qx, float qy, float qz, const float* __restrict__ tgt,
-                                          int64_t n_tgt, unsigned long long* red) {
-  unsigned long long key = ~0ull;
-  for (int64_t j = threadIdx.x; j < n_tgt; j += BLOCK) {
-    const float4 p = make_float4(tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2], __int_as_float((int)j));
-    const unsigned long long k2 = grid_key(qx, qy, qz, p);
-    key = k2 < key ? k2 : key;
-  }
-#pragma unroll
-  for (int d = GS_WAVE / 2; d > 0; d >>= 1) {
-    const unsigned long long o = __shfl_xor(key, d, GS_WAVE);
-    key = o < key ? o : key;
-  }
-  __syncthreads();
-  if ((threadIdx.x & (GS_WAVE - 1)) == 0) red[threadIdx.x / GS_WAVE] = key;
-  __syncthreads();
-  key = red[0];
-#pragma unroll
-  for (int w = 1; w < BLOCK / GS_WAVE; ++w) key = red[w] < key ? red[w] : key;
-  return key;
-}
