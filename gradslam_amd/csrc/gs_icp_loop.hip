@@ -129,6 +129,8 @@ struct IcpHalfSeq {
   const int* cell_start;
   const float4* sorted;
   const float4* sorted_n;   // normals binned with the targets (NULL: gather from tn)
+  float* d2prev;            // [n_src] squared distance of every source point's neighbour in the previous half-iteration
+                            // (written by every launch, read by the next; NULL: no search bound)
   const double* partials_in;
   double* partials_out;
   const IcpSmall* st_in;
@@ -170,6 +172,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
   const int* __restrict__ cell_start = q.cell_start;
   const float4* __restrict__ sorted = q.sorted;
   const float4* __restrict__ sorted_n = q.sorted_n;
+  float* __restrict__ d2prev = q.d2prev;
   const double* __restrict__ partials_in = q.partials_in;
   double* __restrict__ partials_out = q.partials_out;
   int64_t* __restrict__ out_idx = q.out_idx;
@@ -197,12 +200,15 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
   // the global-memory latency hides behind the scalar stage
   const int lane = threadIdx.x & (G - 1), slot = threadIdx.x / G;
   float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
+  const bool bounded = d2prev != nullptr && !(FULL && it == 0);  // the first search of a solve has no predecessor
+  float dprev = __builtin_inff();
   {
     const int64_t s = (int64_t)u_first * FS_QPB + slot;
     if (slot / FS_QPB + u_first < u_last && s < n_src) {
       p0 = src_in[3 * s];
       p1 = src_in[3 * s + 1];
       p2 = src_in[3 * s + 2];
+      if (bounded) dprev = d2prev[s];
     }
   }
 
@@ -244,10 +250,12 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
     const bool live = (u0 + slot / FS_QPB < u_last) && s < n_src;  // this slot holds a source point
     if (u0 != u_first) {
       p0 = p1 = p2 = 0.0f;
+      dprev = __builtin_inff();
       if (live) {
         p0 = src_in[3 * s];
         p1 = src_in[3 * s + 1];
         p2 = src_in[3 * s + 2];
+        if (bounded) dprev = d2prev[s];
       }
     }
     // ---- search: one source point per G-lane group, pending transform applied to the loaded point.
@@ -263,9 +271,18 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
       const float* T = FULL ? sm.T_step : sm.Tr;
       float qx, qy, qz;
       gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
+      // search bound: the previous neighbour of this source point is still a target; the previous query was Tr * p in
+      // the look-ahead half (this half: T_step * p) resp. p itself in the first half (this half: Tr * p)
+      float rball;
+      {
+        float ox = p0, oy = p1, oz = p2;
+        if (FULL) gs_rigid_fma(sm.Tr, p0, p1, p2, ox, oy, oz);
+        const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
+        rball = sqrtf(dprev) + sqrtf(ex * ex + ey * ey + ez * ez);  // inf without a predecessor, NaN after a NaN match
+      }
       bool done;
       int win;
-      const unsigned long long key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win);
+      const unsigned long long key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win, rball);
       if (win >= 0 || (lane == 0 && key == ~0ull)) bslot_s[slot] = win;  // one writer: the winning lane
       if (lane == 0) {
         if (FULL) {  // the transformed cloud of this iteration
@@ -320,6 +337,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
         if (tape_idx) tape_idx[s] = -1;
       } else if (live) {
         const unsigned long long bb = keys_s[slot];
+        if (d2prev) d2prev[s] = __uint_as_float((uint32_t)(bb >> 32));  // NaN bits when nothing was found
         int64_t j = (int64_t)(bb & 0xffffffffull);
         if (j >= n_tgt) j = 0;  // only when every distance was NaN
         const float d2 = __uint_as_float((uint32_t)(bb >> 32));
@@ -761,7 +779,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
     for (int it = 0; it < prm->numiters; ++it) {
       float* cur = cloud(it);
       hb.s[0] = IcpHalfSeq{cur_in, cur, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, gm.sorted_n,
-                           sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1], &sc.state->s[(h + 1) & 1],
+                           reinterpret_cast<float*>(sc.best), sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1], &sc.state->s[(h + 1) & 1],
                            sc.state->trace, out_idx, tidx(it, 0), nullptr};
       icp_half_launch<true>(plan, hb, n_src_c, prm, it, 0, st);
       ++h;
@@ -771,7 +789,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
                            sc.rowred);
       }
       hb.s[0] = IcpHalfSeq{cur, nullptr, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, gm.sorted_n,
-                           reduce_rows ? sc.rowred : sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
+                           reinterpret_cast<float*>(sc.best), reduce_rows ? sc.rowred : sc.partials[(h + 1) & 1], sc.partials[h & 1], &sc.state->s[h & 1],
                            &sc.state->s[(h + 1) & 1], sc.state->trace, nullptr, tidx(it, 1), tp.sys};
       icp_half_launch<false>(plan, hb, n_src_c, prm, it, reduce_rows ? 1 : 0, st);
       ++h;
@@ -1042,7 +1060,8 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
       const float* cur_in = it == 0 ? lb.s[b].lattice : (((it - 1) & 1) ? sc[b].srcB : sc[b].srcA);
       float* cur = (it & 1) ? sc[b].srcB : sc[b].srcA;
       hb.s[b] = IcpHalfSeq{cur_in, cur, q.map.points, q.map.normals, GsCount{q.map.n_bound, q.map.n_dev}, gm[b].g,
-                           gm[b].cell_start, gm[b].sorted, gm[b].sorted_n, sc[b].partials[(h + 1) & 1], sc[b].partials[h & 1],
+                           gm[b].cell_start, gm[b].sorted, gm[b].sorted_n, reinterpret_cast<float*>(sc[b].best),
+                           sc[b].partials[(h + 1) & 1], sc[b].partials[h & 1],
                            &sc[b].state->s[h & 1], &sc[b].state->s[(h + 1) & 1], sc[b].state->trace, nullptr, nullptr,
                            nullptr};
     }

@@ -181,7 +181,7 @@ GS_DEV GsQueryCell grid_query_cell(const GsGrid& g, float qx, float qy, float qz
 template <int G>
 GS_DEV unsigned long long grid_search_stage0(const GsGrid& g, const int* __restrict__ cell_start,
                                              const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
-                                             bool* resolved, int* win) {
+                                             bool* resolved, int* win, const float rball = __builtin_inff()) {
   const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
   const float px = qc.px, py = qc.py, pz = qc.pz;
   const int cx = qc.cx, cy = qc.cy, cz = qc.cz;
@@ -200,14 +200,28 @@ GS_DEV unsigned long long grid_search_stage0(const GsGrid& g, const int* __restr
   const float ay = fminf(y0 >= 1 ? fy + (float)(cy - y0) : BIG, y0 + 2 < g.ny ? (float)(y0 + 2 - cy) - fy : BIG);
   const float az = fminf(z0 >= 1 ? fz + (float)(cz - z0) : BIG, z0 + 2 < g.nz ? (float)(z0 + 2 - cz) - fz : BIG);
   const float amin = fminf(ax, fminf(ay, az));
+  // rball: a radius within which the caller KNOWS a target lies (the previous neighbour of this source point, whose
+  // distance can only have grown by the displacement of the query since).  The nearest target is then inside that
+  // ball, and when the ball stays inside the box only the cells it touches can hold it: about half of the eight.
+  // Margins: 0.01 % on the radius, 0.002 cells on the cell assignment (float rounding is orders of magnitude below).
+  const float rc = rball * g.inv_c * 1.0001f + 0.002f;
+  const bool prune = rc < amin - 0.001f;  // false for rball = inf / NaN
+  bool ulx = true, uhx = true, uly = true, uhy = true, ulz = true, uhz = true;
+  if (prune) {
+    const float tx = fx + (float)(cx - x0), ty = fy + (float)(cy - y0), tz = fz + (float)(cz - z0);  // in [0.5, 1.5)
+    ulx = tx - rc < 1.0f; uhx = tx + rc >= 1.0f;
+    uly = ty - rc < 1.0f; uhy = ty + rc >= 1.0f;
+    ulz = tz - rc < 1.0f; uhz = tz + rc >= 1.0f;
+  }
   // The 4 row segments of the box (2 cells each) as ONE flat candidate list.  Every lane of the group fetches all
   // 8 segment bounds itself (the lanes' addresses coincide, so this costs one round trip and no cross-lane
   // traffic), then lane l takes the flat positions l, l + G, ...: position -> (segment, offset) is three
   // compares on registers.  No shuffles until the final min.
   int sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, e1 = 0, e2 = 0, e3 = 0, total = 0;
   {
-    const int xa = x0 < 0 ? 0 : x0, xb = x0 + 1 >= g.nx ? g.nx - 1 : x0 + 1;
-    const bool zl = z0 >= 0, zh = z0 + 1 < g.nz, yl = y0 >= 0, yh = y0 + 1 < g.ny;  // z0 + 1 >= 0, y0 + 1 >= 0 always
+    // (the cell of the query itself is never dropped: p sits in it, so at least one of each pair holds)
+    const int xa = (x0 >= 0 && ulx) ? x0 : x0 + 1, xb = (x0 + 1 < g.nx && uhx) ? x0 + 1 : x0;
+    const bool zl = z0 >= 0 && ulz, zh = z0 + 1 < g.nz && uhz, yl = y0 >= 0 && uly, yh = y0 + 1 < g.ny && uhy;
     const int r0 = (z0 * g.ny + y0) * g.nx, r1 = r0 + g.nx, r2 = r0 + g.ny * g.nx, r3 = r2 + g.nx;
     int se0 = 0, se1 = 0, se2 = 0, se3 = 0;
     if (zl && yl) { sb0 = cell_start[r0 + xa]; se0 = cell_start[r0 + xb + 1]; }
@@ -249,7 +263,8 @@ GS_DEV unsigned long long grid_search_stage0(const GsGrid& g, const int* __restr
   // 0.1 % of a cell is orders of magnitude above the float rounding of the cell assignment
   const float rb = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
   const float bd = __uint_as_float((uint32_t)(key >> 32));  // NaN while nothing was found
-  *resolved = rb > 0.0f && (rb >= 1.0e30f ? bd == bd : bd <= rb * rb);
+  // pruned scan: the ball lies inside the box and holds a target, every cell it touches was scanned
+  *resolved = prune ? (bd == bd) : (rb > 0.0f && (rb >= 1.0e30f ? bd == bd : bd <= rb * rb));
   return key;
 }
 
