@@ -4,7 +4,7 @@ build container) the reference.  Intrinsics follow the TUM convention the refere
 uses (datasets/tum.py:338-346: fx=fy=525, scaled with the image width)."""
 import numpy as np
 
-__all__ = ["make_sequence", "tum_intrinsics", "gt_pose"]
+__all__ = ["make_sequence", "tum_intrinsics", "gt_pose", "path_parameter"]
 
 
 def tum_intrinsics(H, W):
@@ -15,8 +15,20 @@ def tum_intrinsics(H, W):
     return K
 
 
+PATH_TURN = 150   # frames after which the camera path turns back (and forth: period 2 * PATH_TURN)
+
+
+def path_parameter(s):
+    """The camera sweeps out for PATH_TURN frames, then retraces its path, and so on: long sequences stay within
+    0.3 rad / 0.75 m of the start (the ray casting below assumes a camera that looks roughly along z) and revisit
+    mapped surface, so the map saturates instead of growing for ever.  Identity for the first PATH_TURN frames."""
+    p = s % (2 * PATH_TURN)
+    return p if p <= PATH_TURN else 2 * PATH_TURN - p
+
+
 def gt_pose(s, yaw_per_frame=0.002, tx_per_frame=0.005):
     """Camera-to-world pose of frame s: small yaw about y plus x translation."""
+    s = path_parameter(s)
     a = yaw_per_frame * s
     T = np.eye(4, dtype=np.float64)
     T[0, 0] = np.cos(a); T[0, 2] = np.sin(a)
