@@ -430,16 +430,25 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_winner_count_kernel(const M
   const int64_t n_map = gs_count(q.n_map);
   const int64_t base = (int64_t)blk * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
   int c = 0;
+  // all loads of the tile first (clamped index), then the work: inside the per-pixel control flow they are serialised
+  int32_t nn[GS_CP_ITEMS];
+  float dd[GS_CP_ITEMS];
+#pragma unroll
+  for (int i = 0; i < GS_CP_ITEMS; ++i) {
+    const int64_t pc = base + i < mb.P ? base + i : mb.P - 1;
+    nn[i] = q.best_pix[pc];
+    dd[i] = q.depth[pc];
+  }
 #pragma unroll
   for (int i = 0; i < GS_CP_ITEMS; ++i) {
     const int64_t p = base + i;
     if (p < mb.P) {
-      const int32_t n = q.best_pix[p];
+      const int32_t n = nn[i];
       if (n >= 0 && n < n_map) {
         q.pix_of[n] = (int32_t)p;
         *q.any_flag = 1;  // benign race: every writer stores the same value
       }
-      if (q.depth[p] > 0.0f && n < 0) ++c;
+      if (dd[i] > 0.0f && n < 0) ++c;
     }
   }
   int total;
@@ -481,11 +490,20 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_append_kernel(const MuBatch
   const int64_t base = (int64_t)blk * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
   bool keep[GS_CP_ITEMS];
   int c = 0;
+  {
+    int32_t nn[GS_CP_ITEMS];  // loads first (see gs_mu_winner_count_kernel)
+    float dd[GS_CP_ITEMS];
 #pragma unroll
-  for (int i = 0; i < GS_CP_ITEMS; ++i) {
-    const int64_t p = base + i;
-    keep[i] = p < mb.P && q.depth[p] > 0.0f && q.best_pix[p] < 0;
-    c += keep[i] ? 1 : 0;
+    for (int i = 0; i < GS_CP_ITEMS; ++i) {
+      const int64_t pc = base + i < mb.P ? base + i : mb.P - 1;
+      nn[i] = q.best_pix[pc];
+      dd[i] = q.depth[pc];
+    }
+#pragma unroll
+    for (int i = 0; i < GS_CP_ITEMS; ++i) {
+      keep[i] = base + i < mb.P && dd[i] > 0.0f && nn[i] < 0;
+      c += keep[i] ? 1 : 0;
+    }
   }
   int w = gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &tile_new);
   // new pixels of the tile listed in LDS (pixel order), then row r of the tile's output range is written by thread r

@@ -159,30 +159,68 @@ GS_DEV void grid_bbox_body(const float* __restrict__ tgt, const int64_t n_tgt, c
   int hits = 0;
   unsigned hitmask = 0;  // bit u: item u of this thread passed the filter
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  // Loads of all GB_ITEMS rows first (unconditional, on a clamped index), then the arithmetic: with the load inside
+  // the per-row control flow the compiler serialises them (load, wait, project, store, next load: 8 dependent round
+  // trips per thread; measured 31 us for a pass that moves 72 MB).
+  const int64_t i0 = (int64_t)blk * GB_ITEMS * GB_BLOCK + threadIdx.x;
+  if (cam) {
+    float v[GB_ITEMS][3];
 #pragma unroll
-  for (int u = 0; u < GB_ITEMS; ++u) {
-    const int64_t i = ((int64_t)blk * GB_ITEMS + u) * GB_BLOCK + threadIdx.x;
-    if (i >= n_tgt) continue;
-    bool is_t;
-    float v3[3];
-    if (cam) {
-      v3[0] = tgt[3 * i]; v3[1] = tgt[3 * i + 1]; v3[2] = tgt[3 * i + 2];
-      const int32_t p = gs_project_point(*cam, v3[0], v3[1], v3[2], H, flt.W, u_hi, v_hi);
-      pix_out[i] = p;
-      is_t = p >= 0 && ((p / flt.W) % flt.ds == 0) && ((p % flt.W) % flt.ds == 0);
-    } else {
-      is_t = gs_is_target(flt, i);
-      if (is_t) { v3[0] = tgt[3 * i]; v3[1] = tgt[3 * i + 1]; v3[2] = tgt[3 * i + 2]; }
+    for (int u = 0; u < GB_ITEMS; ++u) {
+      const int64_t i = i0 + (int64_t)u * GB_BLOCK, ic = i < n_tgt ? i : n_tgt - 1;
+      v[u][0] = tgt[3 * ic]; v[u][1] = tgt[3 * ic + 1]; v[u][2] = tgt[3 * ic + 2];
     }
-    if (is_t) {
-      ++hits;
-      hitmask |= 1u << u;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float v = v3[k];
-        if (v > -3.0e38f && v < 3.0e38f) {  // finite
-          lo[k] = v < lo[k] ? v : lo[k];
-          hi[k] = v > hi[k] ? v : hi[k];
+    for (int u = 0; u < GB_ITEMS; ++u) {
+      const int64_t i = i0 + (int64_t)u * GB_BLOCK;
+      if (i < n_tgt) {
+        const int32_t p = gs_project_point(*cam, v[u][0], v[u][1], v[u][2], H, flt.W, u_hi, v_hi);
+        pix_out[i] = p;
+        if (p >= 0 && ((p / flt.W) % flt.ds == 0) && ((p % flt.W) % flt.ds == 0)) {
+          ++hits;
+          hitmask |= 1u << u;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float w = v[u][k];
+            if (w > -3.0e38f && w < 3.0e38f) {  // finite
+              lo[k] = w < lo[k] ? w : lo[k];
+              hi[k] = w > hi[k] ? w : hi[k];
+            }
+          }
+        }
+      }
+    }
+  } else {
+    bool t[GB_ITEMS];
+    if (flt.pix) {
+      int32_t px[GB_ITEMS];
+#pragma unroll
+      for (int u = 0; u < GB_ITEMS; ++u) {
+        const int64_t i = i0 + (int64_t)u * GB_BLOCK;
+        px[u] = flt.pix[i < n_tgt ? i : n_tgt - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < GB_ITEMS; ++u) {
+        const int32_t p = px[u];
+        t[u] = (i0 + (int64_t)u * GB_BLOCK < n_tgt) && p >= 0 && ((p / flt.W) % flt.ds == 0) && ((p % flt.W) % flt.ds == 0);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < GB_ITEMS; ++u) t[u] = i0 + (int64_t)u * GB_BLOCK < n_tgt;
+    }
+#pragma unroll
+    for (int u = 0; u < GB_ITEMS; ++u) {
+      if (t[u]) {
+        const int64_t i = i0 + (int64_t)u * GB_BLOCK;
+        ++hits;
+        hitmask |= 1u << u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float w = tgt[3 * i + k];
+          if (w > -3.0e38f && w < 3.0e38f) {  // finite
+            lo[k] = w < lo[k] ? w : lo[k];
+            hi[k] = w > hi[k] ? w : hi[k];
+          }
         }
       }
     }
