@@ -161,7 +161,7 @@ GS_DEV void grid_bbox_body(const float* __restrict__ tgt, const int64_t n_tgt, c
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   // Loads of all GB_ITEMS rows first (unconditional, on a clamped index), then the arithmetic: with the load inside
   // the per-row control flow the compiler serialises them (load, wait, project, store, next load: 8 dependent round
-  // trips per thread; measured 31 us for a pass that moves 72 MB).
+  // trips per thread).
   const int64_t i0 = (int64_t)blk * GB_ITEMS * GB_BLOCK + threadIdx.x;
   if (cam) {
     float v[GB_ITEMS][3];
