@@ -26,9 +26,11 @@ GS_DEV GsCamera gs_camera(const float* __restrict__ pose16, const float* __restr
   return c;
 }
 
-// slam/fusionutils.py:250-274 for one point; returns h*W+w or -1.
-GS_DEV int32_t gs_project_point(const GsCamera& c, float p0, float p1, float p2, int H, int W,
-                                float u_hi, float v_hi) {
+// slam/fusionutils.py:250-274 for one point: pixel (h, w) it projects to; false when it falls outside the frame or
+// behind the camera.  32-bit integer arithmetic throughout: in_frame bounds u, v to (-1e-3, W - 0.999) x (-1e-3,
+// H - 0.999), so the rounded coordinates fit (the reference's int64 casts and clamps are value-identical).
+GS_DEV bool gs_project_point_hw(const GsCamera& c, float p0, float p1, float p2, int H, int W, float u_hi, float v_hi,
+                                int& h_out, int& w_out) {
   // Pointclouds.transform: rotate_ (einsum over N: FMA chain) then offset_
   const float q0 = gs_dot3_fma(p0, p1, p2, c.Ri[0], c.Ri[1], c.Ri[2]) + c.ti[0];
   const float q1 = gs_dot3_fma(p0, p1, p2, c.Ri[3], c.Ri[4], c.Ri[5]) + c.ti[1];
@@ -47,11 +49,26 @@ GS_DEV int32_t gs_project_point(const GsCamera& c, float p0, float p1, float p2,
   const float zz = (r[2] != 0.0f) ? r[2] : 1.0f;
   const float u = r[0] / zz, v = r[1] / zz;
   const bool in_frame = (u > -1e-3f) && (u < u_hi) && (v > -1e-3f) && (v < v_hi) && front;
-  if (!in_frame) return -1;
-  int64_t wi = (int64_t)__builtin_rintf(u), hi = (int64_t)__builtin_rintf(v);
+  if (!in_frame) return false;
+  int wi = (int)__builtin_rintf(u), hi = (int)__builtin_rintf(v);
   wi = wi < 0 ? 0 : (wi > W - 1 ? W - 1 : wi);
   hi = hi < 0 ? 0 : (hi > H - 1 ? H - 1 : hi);
-  return (int32_t)(hi * W + wi);
+  h_out = hi;
+  w_out = wi;
+  return true;
+}
+
+// the same as the flat pixel index h * W + w, or -1
+GS_DEV int32_t gs_project_point(const GsCamera& c, float p0, float p1, float p2, int H, int W,
+                                float u_hi, float v_hi) {
+  int h, w;
+  return gs_project_point_hw(c, p0, p1, p2, H, W, u_hi, v_hi, h, w) ? (int32_t)(h * W + w) : -1;
+}
+
+// (h, w) on the [::ds, ::ds] lattice; ds is block-uniform: a power of two (the usual 2 / 4 / 8) is a mask
+GS_DEV bool gs_on_lattice(int h, int w, int ds) {
+  if ((ds & (ds - 1)) == 0) return ((h | w) & (ds - 1)) == 0;
+  return ((unsigned)h % (unsigned)ds == 0u) && ((unsigned)w % (unsigned)ds == 0u);
 }
 
 // ---------------------------------------------------------------- K5b: similarity ------

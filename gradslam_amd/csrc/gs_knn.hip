@@ -174,9 +174,12 @@ GS_DEV void grid_bbox_body(const float* __restrict__ tgt, const int64_t n_tgt, c
     for (int u = 0; u < GB_ITEMS; ++u) {
       const int64_t i = i0 + (int64_t)u * GB_BLOCK;
       if (i < n_tgt) {
-        const int32_t p = gs_project_point(*cam, v[u][0], v[u][1], v[u][2], H, flt.W, u_hi, v_hi);
-        pix_out[i] = p;
-        if (p >= 0 && ((p / flt.W) % flt.ds == 0) && ((p % flt.W) % flt.ds == 0)) {
+        int ph = 0, pw = 0;
+        const bool in = gs_project_point_hw(*cam, v[u][0], v[u][1], v[u][2], H, flt.W, u_hi, v_hi, ph, pw);
+        pix_out[i] = in ? (int32_t)(ph * flt.W + pw) : -1;
+        // lattice test on (h, w) directly: dividing the flat index by run-time W and ds again was most of this pass's
+        // instructions, and the pass is VALU-bound (SQ counters: 77 VALU instructions per row at 4 cycles per wave64)
+        if (in && gs_on_lattice(ph, pw, flt.ds)) {
           ++hits;
           hitmask |= 1u << u;
 #pragma unroll
