@@ -519,9 +519,10 @@ static void icp_half_launch(const IcpHalfPlan& pl, IcpHalfBatch& hb, GsCount n_s
 }
 
 // Large solves (more rows than FS_REDUCE_ROWS): every block of the next kernel adding up all rows is
-// O(rows^2) L2 traffic (1634 rows of a 1296x968 frame: 366 KB per block, 600 MB per launch).  One
-// extra single-block launch adds them up once, in the same order, into a one-row buffer.
-constexpr int FS_REDUCE_ROWS = 640;
+// O(rows^2) L2 traffic.  One extra single-block launch adds them up once, in the same order, into a one-row
+// buffer.  The threshold sits above the 815 rows of a 1296x968 frame at dsratio 4: there the 20 extra launches per
+// solve cost more than the 182 KB of rows per block (measured 2 % of the frame).
+constexpr int FS_REDUCE_ROWS = 1024;
 __global__ void __launch_bounds__(FS_BLOCK) gs_icp_reduce_rows_kernel(const double* __restrict__ partials_in,
                                                                       GsCount n_src_c, double* __restrict__ row_out) {
   __shared__ double S[32];
