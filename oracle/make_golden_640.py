@@ -10,6 +10,8 @@ Build-container only (minutes of CPU).  Outputs (committed, travel to the GPU bo
   tests/golden/pf640.npz             poses (L,4,4), counts (L,), point / normal / colour / ccount sums per frame,
                                      a checksum of the input depths (the inputs are regenerated from the seed)
   tests/golden/cpu_ref_timing.json   seconds per frame of the unmodified reference on `cores` host cores
+    python -m oracle.make_golden_640 --slam icpslam --odom icp --frames 8 --tag icpslam640
+  tests/golden/icpslam640.npz        the same for ICPSLAM (hard-LM ICP odometry, aggregate mapping)
 """
 import argparse
 import json
@@ -34,9 +36,12 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tag", default="pf640")
+    ap.add_argument("--slam", default="pointfusion", choices=["pointfusion", "icpslam"])
+    ap.add_argument("--odom", default="gradicp", choices=["gradicp", "icp"])
     args = ap.parse_args()
     refimport.import_reference()
     import torch
+    from gradslam.slam.icpslam import ICPSLAM
     from gradslam.slam.pointfusion import PointFusion
     from gradslam.structures.pointclouds import Pointclouds
     from gradslam.structures.rgbdimages import RGBDImages
@@ -50,7 +55,7 @@ def main():
     poses = T(s["poses"][None]).clone()
     poses[:, 1:] = poses[:, :1]
     frames = RGBDImages(T(s["colors"][None]), T(s["depths"][None]), T(s["intrinsics"][None]), poses)
-    slam = PointFusion(odom="gradicp")
+    slam = (PointFusion if args.slam == "pointfusion" else ICPSLAM)(odom=args.odom)
     pc = Pointclouds()
     prev = None
     rec = np.zeros((L, 4, 4), np.float32)
@@ -68,17 +73,19 @@ def main():
             counts[f] = pc.points_list[0].shape[0]
             for k, lst in (("points", pc.points_list), ("normals", pc.normals_list), ("colors", pc.colors_list),
                            ("ccounts", pc.features_list)):
-                sums[k][f] = lst[0].double().sum(0).numpy()
+                if lst is not None:   # ICPSLAM's aggregate map carries no confidence counts
+                    sums[k][f] = lst[0].double().sum(0).numpy()
             print("frame %2d  %.2f s  %d surfels" % (f, secs[f], counts[f]), flush=True)
     np.savez_compressed(os.path.join(OUT, args.tag + ".npz"), poses=rec, counts=counts, gt_poses=s["poses"],
                         depth_sum=np.float64(s["depths"].astype(np.float64).sum()),
                         color_sum=np.float64(s["colors"].astype(np.float64).sum()),
                         seed=np.int64(args.seed), H=np.int64(H), W=np.int64(W),
                         last_points=pc.points_list[0][-4096:].numpy(), **{"sum_" + k: v for k, v in sums.items()})
-    timing = {"what": "unmodified gradslam v0.1.0 PointFusion(odom='gradicp').step on CPU (torch %s), synthetic %dx%d "
+    timing = {"what": "unmodified gradslam v0.1.0 %s(odom='%s').step on CPU (torch %s), synthetic %dx%d "
                       "sequence seed %d; chamferdist.knn_points replaced by an OpenMP brute-force stand-in "
-                      "(oracle/shims), everything else is the reference's own PyTorch code" % (torch.__version__, W, H,
-                                                                                             args.seed),
+                      "(oracle/shims), everything else is the reference's own PyTorch code"
+                      % ("PointFusion" if args.slam == "pointfusion" else "ICPSLAM", args.odom, torch.__version__, W, H,
+                         args.seed),
               "cores": cores, "frames": L, "seconds_per_frame": [float(x) for x in secs],
               "frames_per_s_steady": float((L - 2) / secs[2:].sum()) if L > 3 else None,
               "machine": "build container (not the GPU box's host)"}

@@ -206,6 +206,32 @@ def test_pointfusion_640x480_vs_reference_golden(gs, golden):
         np.testing.assert_allclose(sums[f], g["sum_points"][f], rtol=0, atol=1e-5 * counts[f] + 4.0 * diff[f] + 1e-3)
 
 
+def test_icpslam_640x480_vs_reference_golden(gs, golden):
+    """ICPSLAM(odom="icp": hard-LM ICP odometry, aggregate mapping) on the same sequence against the REAL reference's
+    run (tests/golden/icpslam640.npz): pose ATE <= 1e-4 m; aggregate mapping appends every valid pixel, so the map
+    sizes are identical by construction and the point sums differ only through the poses."""
+    g = golden("icpslam640")
+    L, H, W = int(g["poses"].shape[0]), int(g["H"]), int(g["W"])
+    s = make_sequence(L, H, W, seed=int(g["seed"]))
+    assert abs(float(s["depths"].astype(np.float64).sum()) - float(g["depth_sum"])) < 1e-6 * float(g["depth_sum"])
+    frames = frames_of(gs, [s])
+    slam = gs.slam.ICPSLAM(odom="icp", device="cuda")
+    pc, prev, rec = gs.Pointclouds(device="cuda"), None, []
+    for f in range(L):
+        live = frames[:, f]
+        pc, pose = slam.step(pc, live, prev, inplace=True)
+        prev = live
+        rec.append(host(pose[0, 0]))
+        n = pc.points_list[0].shape[0]
+        assert n == int(g["counts"][f]), (f, n, int(g["counts"][f]))
+        # a pose error e moves every point of the frame by <= e * (1 + |p|): 1e-4 per point is generous
+        np.testing.assert_allclose(host(pc.points_list[0].double().sum(0)), g["sum_points"][f], rtol=0, atol=1e-4 * n)
+    rec = np.stack(rec)
+    assert ate(rec, g["poses"]) <= 1e-4, ate(rec, g["poses"])
+    np.testing.assert_allclose(rec, g["poses"], rtol=0, atol=1e-4)
+    assert not pc.has_features
+
+
 def test_pointfusion_640x480_vs_oracle(gs):
     """the same config against the oracle's frame loop (float64 normal equations on both sides): poses within 2e-6,
     identical surfel counts, identical points where no ICP rounding enters (frame 0)."""

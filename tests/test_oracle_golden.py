@@ -172,6 +172,22 @@ def test_sequence_120(golden):
     assert len(m) == int(g["pf_gradicp_count"])
 
 
+def test_icpslam_640x480_first_frames(golden):
+    """The oracle's ICPSLAM(odom="icp") frame loop against the REAL reference at the benchmarked resolution
+    (tests/golden/icpslam640.npz, oracle/make_golden_640.py --slam icpslam): first 3 frames (the 8-frame run takes a
+    minute on 8 cores and agrees to ATE 2e-6; the HIP path is compared with all 8 in tests/test_hip_batch.py)."""
+    g = golden("icpslam640")
+    from gradslam_amd.datasets.synthetic import make_sequence
+    L = 3
+    s = make_sequence(int(g["poses"].shape[0]), int(g["H"]), int(g["W"]), seed=int(g["seed"]))
+    poses = s["poses"][:L].copy()
+    poses[1:] = poses[:1]
+    m, rp = oslam.run_sequence(s["colors"][:L], s["depths"][:L], s["intrinsics"][0], poses, slam="icpslam", odom="icp")
+    assert ate(rp, g["poses"][:L]) <= 1e-5
+    assert len(m) == int(g["counts"][L - 1])
+    np.testing.assert_allclose(m.points.astype(np.float64).sum(0), g["sum_points"][L - 1], rtol=0, atol=1e-5 * len(m))
+
+
 def test_relative_pose_matches_reference(golden):
     """gs_or_relative_pose against GroundTruthOdometryProvider / relative_transformation of the reference
     (torch.inverse in float32 there, double Gauss-Jordan here: equal to a few float32 ulps)."""
