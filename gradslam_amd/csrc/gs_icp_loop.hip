@@ -46,12 +46,12 @@ GS_DEV void tape_write_sys(float* __restrict__ sys, int it, const double* S, flo
 // chunk of CH rows number t/32 (then every STEP*CH rows further): its CH loads are 224 B apart, i.e.
 // one base address with immediate offsets, all in flight together; the chunk sums are then added in
 // chunk order.  Every block that runs this on the same rows gets bit-identical sums.
-template <int BLOCK>
+template <int BLOCK, int CH = 18>
 GS_DEV void icp_sum_rows(const double* __restrict__ partials, int nrows, double* S, double (*sub)[32]) {
   constexpr int STEP = BLOCK / 32;
-  constexpr int CH = 18;  // rows per thread per round of independent loads: a 640x480 solve (200 rows of 96
-                          // queries, 9 per thread at 768 threads) is ONE round of memory latency; more rows
-                          // in flight would push the kernel past 80 VGPRs (2 resident blocks per CU)
+  // CH = rows per thread per round of independent loads: a 640x480 solve of the row-unit engine (200 rows of 96
+  // queries, 9 per thread at 768 threads) is ONE round of memory latency with 18; more rows in flight would push
+  // the kernel past 80 VGPRs (2 resident blocks per CU).  The tile engine (50 rows) uses 4.
   const int i = threadIdx.x & 31, j = threadIdx.x >> 5;
   double s = 0.0;
   if (i < LIN_NV) {
@@ -871,6 +871,8 @@ extern "C" int gs_icp_map_dc_f32(const float* src, int64_t n_src_bound, const in
                  icp_scratch, nullptr, stream, n_src_dev, n_map_dev, GsTargetFilter{pix, W, ds});
 }
 
+#include "gs_icp_tile.h"
+
 // ---------------------------------------------------------------- batched localisation -----
 // ICPSLAM._localize (slam/icpslam.py:238-247) for B independent sequences in ONE chain of launches: every kernel
 // below runs for all sequences at once (block b -> sequence b % B), so the dependent-launch floor of the 2 x numiters
@@ -982,11 +984,151 @@ __global__ void __launch_bounds__(FS_BLOCK) gs_icp_finish_batch_kernel(const Icp
 
 static int64_t loc_lattice(int H, int W, int ds) { return (int64_t)((H + ds - 1) / ds) * ((W + ds - 1) / ds); }
 
+// what the tile engine adds behind the ICP scratch of a sequence: the slabs, two partial-row buffers (one row per tile)
+// and the reduced row of large solves
+struct ItMem {
+  char* slabs;
+  double* partials[2];
+  double* rowred;
+};
+static size_t it_row_bytes(int Hl, int Wl) { return gs_align(sizeof(double) * LIN_NV * (size_t)it_tiles(Hl, Wl)); }
+static size_t it_mem_bytes(int Hl, int Wl) { return it_slab_bytes(Hl, Wl) + 2 * it_row_bytes(Hl, Wl) + 256; }
+static ItMem it_carve(void* base, int Hl, int Wl) {
+  char* p = reinterpret_cast<char*>(base);
+  ItMem m;
+  m.slabs = p; p += it_slab_bytes(Hl, Wl);
+  for (int k = 0; k < 2; ++k) { m.partials[k] = reinterpret_cast<double*>(p); p += it_row_bytes(Hl, Wl); }
+  m.rowred = reinterpret_cast<double*>(p);
+  return m;
+}
+
 extern "C" int64_t gs_localize_scratch_bytes(int H, int W, int ds, int64_t n_map_bound) {
   if (H < 1 || W < 1 || ds < 1) return 0;
   const int64_t n_lat = loc_lattice(H, W, ds);
   return (int64_t)(gs_align(12 * (size_t)n_lat) + gs_align(4 * (size_t)(n_map_bound > 0 ? n_map_bound : 1)) + 256) +
-         gs_icp_scratch_bytes(n_lat, n_map_bound);
+         gs_icp_scratch_bytes(n_lat, n_map_bound) + (int64_t)it_mem_bytes((H + ds - 1) / ds, (W + ds - 1) / ds);
+}
+
+static GsCount n_src_rows(int nrows) { return GsCount{(int64_t)nrows * FS_QPB, nullptr}; }  // a count that yields nrows rows
+
+// GRADSLAM_HIP_ICP_ENGINE=rows: the row-unit kernels (gs_icp_half_batch_kernel) instead of the tile engine (A/B runs)
+static bool icp_tile_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GRADSLAM_HIP_ICP_ENGINE");
+    v = (e && strcmp(e, "rows") == 0) ? 0 : 1;
+  }
+  return v == 1;
+}
+
+// The 2 x numiters half-iterations + the final update of one chunk on the tile engine.  The grid of every sequence is
+// built; lattice / state / d2prev live where the row-unit engine keeps them.
+static int localize_tiles(const gs_localize_seq* seqs, int B, int Hl, int Wl, const gs_icp_params* prm, const LocBatch& lb,
+                          const IcpScratch* sc, const GridMem* gm, double prof_bytes, hipStream_t st) {
+  ItMem im[GS_MAX_BATCH];
+  ItBuildBatch bb;
+  ItBatch hb;
+  bb.B = hb.B = B;
+  bb.Wl = hb.Wl = Wl; bb.Hl = hb.Hl = Hl;
+  bb.tiles_x = hb.tiles_x = it_tiles_x(Wl);
+  const int ntiles = hb.ntiles = it_tiles(Hl, Wl);
+  const int64_t n_lat = (int64_t)Hl * Wl;
+  for (int b = 0; b < B; ++b) {
+    const gs_localize_seq& q = seqs[b];
+    im[b] = it_carve(reinterpret_cast<char*>(sc[b].state) + gs_icp_scratch_bytes(n_lat, q.map.n_bound), Hl, Wl);
+    bb.s[b] = ItBuildSeq{lb.s[b].lattice, gm[b].g, gm[b].cell_start, gm[b].sorted, gm[b].sorted_n, im[b].slabs};
+  }
+  {
+    GsProf prof(GS_PROF_COMPACT, 0.0, st);
+    hipLaunchKernelGGL(gs_it_slab_build_kernel, dim3((unsigned)(B * ntiles)), dim3(IT_NQ), 0, st, bb);
+  }
+  const bool reduce_rows = ntiles > FS_REDUCE_ROWS;
+  std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
+  const dim3 grid((unsigned)(B * ntiles)), block(IT_BLOCK);
+  int h = 0;
+  for (int it = 0; it < prm->numiters; ++it) {
+    for (int b = 0; b < B; ++b) {
+      const gs_localize_seq& q = seqs[b];
+      const float* cur_in = it == 0 ? lb.s[b].lattice : (((it - 1) & 1) ? sc[b].srcB : sc[b].srcA);
+      float* cur = (it & 1) ? sc[b].srcB : sc[b].srcA;
+      hb.s[b] = ItSeq{cur_in, cur, q.map.points, q.map.normals, GsCount{q.map.n_bound, q.map.n_dev}, gm[b].g,
+                      gm[b].cell_start, gm[b].sorted, gm[b].sorted_n, im[b].slabs, reinterpret_cast<float*>(sc[b].best),
+                      im[b].partials[(h + 1) & 1], im[b].partials[h & 1], &sc[b].state->s[h & 1],
+                      &sc[b].state->s[(h + 1) & 1], sc[b].state->trace};
+    }
+#ifdef GS_ICP_TIMELINE
+    // debugging builds (GRADSLAM_HIP_ICP_TIMELINE=<path>): record both launches of the last iteration
+    static const char* tl_path = getenv("GRADSLAM_HIP_ICP_TIMELINE");
+    static unsigned long long* tl_buf = nullptr;
+    const size_t tl_n = 8 * (size_t)B * ntiles;
+    const bool tl = tl_path && it == prm->numiters - 1;
+    hb.tl = nullptr;
+    if (tl) {
+      if (!tl_buf && hipMalloc(&tl_buf, 2 * 8 * 8 * 8 * 4096) != hipSuccess) tl_buf = nullptr;
+      if (tl_buf && 2 * tl_n <= 2 * 8 * 8 * 4096) {
+        hb.tl = tl_buf;
+        (void)hipMemsetAsync(tl_buf, 0, 2 * 8 * tl_n, st);
+      }
+    }
+#endif
+    hipLaunchKernelGGL((gs_icp_tile_half_kernel<true>), grid, block, 0, st, hb, prm->dist_thresh, *prm, it, 0);
+    ++h;
+    if (reduce_rows) {
+      ItRowsBatch rb;
+      rb.B = B; rb.nrows = ntiles;
+      for (int b = 0; b < B; ++b) { rb.in[b] = im[b].partials[(h + 1) & 1]; rb.out[b] = im[b].rowred; }
+      hipLaunchKernelGGL(gs_icp_tile_reduce_rows_kernel, dim3((unsigned)B), dim3(IT_BLOCK), 0, st, rb);
+    }
+    for (int b = 0; b < B; ++b) {
+      ItSeq& u = hb.s[b];
+      u.src_in = (it & 1) ? sc[b].srcB : sc[b].srcA;
+      u.src_out = nullptr;
+      u.partials_in = reduce_rows ? im[b].rowred : im[b].partials[(h + 1) & 1];
+      u.partials_out = im[b].partials[h & 1];
+      u.st_in = &sc[b].state->s[h & 1];
+      u.st_out = &sc[b].state->s[(h + 1) & 1];
+    }
+#ifdef GS_ICP_TIMELINE
+    if (hb.tl) hb.tl += tl_n;
+#endif
+    hipLaunchKernelGGL((gs_icp_tile_half_kernel<false>), grid, block, 0, st, hb, prm->dist_thresh, *prm, it,
+                       reduce_rows ? 1 : 0);
+    ++h;
+#ifdef GS_ICP_TIMELINE
+    if (hb.tl) {
+      std::unique_ptr<unsigned long long[]> hbuf(new unsigned long long[2 * tl_n]);
+      if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hbuf.get(), tl_buf, 2 * 8 * tl_n, hipMemcpyDeviceToHost) == hipSuccess) {
+        FILE* f = fopen(tl_path, "w");
+        if (f) {
+          fprintf(f, "# tile engine B=%d tiles=%d: half(0 full, 1 look-ahead) block start issued prologue search leftovers end n_open n_brute\n", B, ntiles);
+          for (size_t i = 0; i < 2 * tl_n / 8; ++i) {
+            fprintf(f, "%d %zu", (int)(i >= tl_n / 8), i % (tl_n / 8));
+            for (int k = 0; k < 8; ++k) fprintf(f, " %llu", hbuf[8 * i + k]);
+            fprintf(f, "\n");
+          }
+          fclose(f);
+        }
+      }
+      hb.tl = nullptr;
+    }
+#endif
+  }
+  prof_loop.reset();
+  {
+    GsProf prof(GS_PROF_SOLVE, 1.0, st);
+    IcpFinishBatch fb;
+    fb.B = B;
+    for (int b = 0; b < B; ++b) {
+      fb.partials_in[b] = im[b].partials[(h + 1) & 1];
+      fb.st[b] = sc[b].state;
+      fb.compose16[b] = seqs[b].prev_pose16;
+      fb.out_T16[b] = seqs[b].out_pose16;
+    }
+    hipLaunchKernelGGL(gs_icp_finish_batch_kernel, dim3((unsigned)B), dim3(FS_BLOCK), 0, st, fb, n_src_rows(ntiles), h & 1,
+                       *prm);
+  }
+  GS_LAUNCH_CHECK();
+  return GS_OK;
 }
 
 static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int ds, const gs_icp_params* prm,
@@ -1050,6 +1192,8 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
       prof_bytes += icp_alg_bytes(prm->numiters, n_lat, nv, hits);
     }
   }
+  if (icp_tile_enabled() && gm[0].sorted_n)  // (the binned normals are part of the slabs)
+    return localize_tiles(seqs, B, (H + ds - 1) / ds, Wl, prm, lb, sc, gm, prof_bytes, st);
   std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
   const IcpHalfPlan plan = icp_half_plan(n_lat, B);
   IcpHalfBatch hb;

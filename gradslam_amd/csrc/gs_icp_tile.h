@@ -1,0 +1,614 @@
+// gs_icp_tile.h — the lattice engine of the device-resident LM loop (included by gs_icp_loop.hip only).
+//
+// The ICP source of the SLAM loop (slam/icpslam.py:238-242, odometry/icputils.py:623-669) is the live frame's
+// [::ds, ::ds] pixel LATTICE, and the 2 x numiters exact 1-NN searches of a solve (odometry/icputils.py:200) all run
+// against the SAME binned target set with queries that move by a fraction of a grid cell.  So a workgroup owns a
+// 2-D tile of IT_TW x IT_TH lattice slots -- a compact patch of surface -- and everything its searches can touch is a
+// small box of grid cells that is known before the first search:
+//
+//   gs_it_slab_build_kernel (once per frame): per tile, the bounding box of its queries' cells at the initial pose,
+//     grown by IT_MARGIN cells, and a private copy ("slab") of that box of the global grid: the cell table rebased to
+//     16-bit offsets + the binned target points and normals of those cells, contiguous in memory.
+//   gs_icp_tile_half_kernel (2 x numiters per frame): the slab is copied into LDS by coalesced loads that are in
+//     flight while the prologue (row sums + scalar stage of the previous half-iteration) runs; the 2x2x2 stage of the
+//     search, the match and the Gauss-Newton row then read LDS only.  No dependent global gathers are left on the
+//     critical path of a launch (the row-unit kernel spent 6.8 of its 17.4 us there at 8 sequences per GPU).
+//
+// Exactness: the slab is a verbatim sub-box of the global grid, and the search applies the global engine's bound
+// (grid_search_stage0) to the same cells and candidates, so every query gets the brute-force neighbour.  A query
+// whose 2x2x2 block leaves the tile's box (it moved more than IT_MARGIN - 1 cells), or whose tile has no slab (box or
+// target count above the LDS budget), is served from the global arrays by the same code path as before.
+// Sums: one partial row per TILE (fixed order inside the tile: 24 groups of 16 queries, then the 24 sub-sums in
+// order); the next launch adds the tile rows in tile order.  The result does not depend on the batch size or on
+// which block runs which tile.
+#pragma once
+#include <stddef.h>
+
+constexpr int IT_TW = 16, IT_TH = 24;        // lattice tile of one workgroup
+constexpr int IT_NQ = IT_TW * IT_TH;         // 384 queries
+constexpr int IT_G = 2;                      // lanes per query
+constexpr int IT_BLOCK = IT_NQ * IT_G;       // 768 threads, 2 workgroups per CU
+constexpr int IT_PTS_CAP = 1024;             // binned targets a slab can hold
+constexpr int IT_CELLS_CAP = 4096;           // entries of a slab's cell table (cells + 1 end sentinel)
+constexpr int IT_MARGIN = 2;                 // cells added around the tile's query cells (1 for the 2x2x2 block + 1 of motion)
+constexpr int IT_RG = 24, IT_RPG = IT_NQ / IT_RG;  // row groups of the tile sum x queries per group
+constexpr int IT_HG = 16;                    // lanes per query of the leftover searches
+static_assert(IT_RG * LIN_NV <= IT_BLOCK && IT_NQ % IT_RG == 0, "tile sum shape");
+static_assert(IT_CELLS_CAP * 2 % 16 == 0 && IT_CELLS_CAP / 8 <= IT_BLOCK && 2 * IT_BLOCK >= IT_PTS_CAP, "slab copy shape");
+
+struct ItSlabHdr {   // 64 bytes in front of every slab
+  int mode;          // 0: no query in the tile, 1: slab valid, 2: no slab (searches use the global arrays)
+  int bx0, by0, bz0; // the box in global cell coordinates
+  int nbx, nby, nbz;
+  int ncell, npts;
+  int pad[7];
+};
+constexpr size_t IT_OFF_CELLS = 64;
+constexpr size_t IT_OFF_PTS = IT_OFF_CELLS + 2 * (size_t)IT_CELLS_CAP;
+constexpr size_t IT_OFF_NRM = IT_OFF_PTS + 16 * (size_t)IT_PTS_CAP;
+constexpr size_t IT_SLAB_BYTES = IT_OFF_NRM + 16 * (size_t)IT_PTS_CAP;
+static_assert(sizeof(ItSlabHdr) == 64 && IT_SLAB_BYTES % 64 == 0, "slab layout");
+
+static inline int it_tiles_x(int Wl) { return (Wl + IT_TW - 1) / IT_TW; }
+static inline int it_tiles(int Hl, int Wl) { return it_tiles_x(Wl) * ((Hl + IT_TH - 1) / IT_TH); }
+static inline size_t it_slab_bytes(int Hl, int Wl) { return gs_align(IT_SLAB_BYTES * (size_t)it_tiles(Hl, Wl)); }
+
+// ---------------------------------------------------------------- slab build ------------
+struct ItBuildSeq {
+  const float* lattice;      // [Hl * Wl][3] queries at the initial pose (NaN = empty slot)
+  const GsGrid* gp;
+  const int* cell_start;
+  const float4* sorted;
+  const float4* sorted_n;
+  char* slabs;
+};
+struct ItBuildBatch {
+  int B, Wl, Hl, tiles_x;
+  ItBuildSeq s[GS_MAX_BATCH];
+};
+
+__global__ void __launch_bounds__(IT_NQ) gs_it_slab_build_kernel(const ItBuildBatch bb) {
+  const ItBuildSeq& q = bb.s[blockIdx.x % bb.B];
+  const int tile = blockIdx.x / bb.B;
+  char* slab = q.slabs + IT_SLAB_BYTES * (size_t)tile;
+  ItSlabHdr* hdr = reinterpret_cast<ItSlabHdr*>(slab);
+  uint16_t* cells = reinterpret_cast<uint16_t*>(slab + IT_OFF_CELLS);
+  float4* pts = reinterpret_cast<float4*>(slab + IT_OFF_PTS);
+  float4* nrm = reinterpret_cast<float4*>(slab + IT_OFF_NRM);
+
+  __shared__ int red[6][IT_NQ / GS_WAVE];
+  __shared__ int rowbase[IT_CELLS_CAP + 1];   // first slab slot of every (z, y) row of the box
+  __shared__ int rowsrc[IT_CELLS_CAP];        // global slot of the first target of the row
+  __shared__ int scan_s[IT_NQ / GS_WAVE + 1];
+  __shared__ int box_s[8];
+
+  const GsGrid g = *q.gp;
+  const int lx = (tile % bb.tiles_x) * IT_TW + (int)threadIdx.x % IT_TW;
+  const int ly = (tile / bb.tiles_x) * IT_TH + (int)threadIdx.x / IT_TW;
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+  if (lx < bb.Wl && ly < bb.Hl) {
+    const int64_t s = (int64_t)ly * bb.Wl + lx;
+    const float p0 = q.lattice[3 * s], p1 = q.lattice[3 * s + 1], p2 = q.lattice[3 * s + 2];
+    if (p0 == p0) {
+      const GsQueryCell c = grid_query_cell(g, p0, p1, p2);
+      lo[0] = hi[0] = c.cx; lo[1] = hi[1] = c.cy; lo[2] = hi[2] = c.cz;
+    }
+  }
+  const int lane = threadIdx.x & (GS_WAVE - 1), wave = threadIdx.x / GS_WAVE;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int a = lo[k], b = hi[k];
+#pragma unroll
+    for (int d = GS_WAVE / 2; d > 0; d >>= 1) {
+      const int a2 = __shfl_down(a, d, GS_WAVE), b2 = __shfl_down(b, d, GS_WAVE);
+      a = a2 < a ? a2 : a;
+      b = b2 > b ? b2 : b;
+    }
+    if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int a[3], b[3];
+    for (int k = 0; k < 3; ++k) {
+      a[k] = red[k][0]; b[k] = red[3 + k][0];
+      for (int w = 1; w < IT_NQ / GS_WAVE; ++w) {
+        a[k] = red[k][w] < a[k] ? red[k][w] : a[k];
+        b[k] = red[3 + k][w] > b[k] ? red[3 + k][w] : b[k];
+      }
+    }
+    const int n[3] = {g.nx, g.ny, g.nz};
+    int mode = b[0] < 0 ? 0 : 1;
+    for (int k = 0; k < 3; ++k) {
+      a[k] = a[k] - IT_MARGIN < 0 ? 0 : a[k] - IT_MARGIN;
+      b[k] = b[k] + IT_MARGIN >= n[k] ? n[k] - 1 : b[k] + IT_MARGIN;
+      box_s[k] = a[k];
+      box_s[3 + k] = mode ? b[k] - a[k] + 1 : 0;
+    }
+    if (mode && (long long)box_s[3] * box_s[4] * box_s[5] + 1 > IT_CELLS_CAP) mode = 2;
+    box_s[6] = mode;
+  }
+  __syncthreads();
+  const int bx0 = box_s[0], by0 = box_s[1], bz0 = box_s[2], nbx = box_s[3], nby = box_s[4], nbz = box_s[5];
+  int mode = box_s[6];
+  if (mode != 1) {
+    if (threadIdx.x == 0) {
+      ItSlabHdr h = {mode, bx0, by0, bz0, nbx, nby, nbz, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
+      *hdr = h;
+    }
+    return;
+  }
+  // rows of the box: row r = (z - bz0) * nby + (y - by0) is the global slot range [cell_start[row + bx0],
+  // cell_start[row + bx0 + nbx)); thread t takes the contiguous rows [t * per, (t + 1) * per)
+  const int nrows = nby * nbz, ncell = nrows * nbx;
+  const int per = (nrows + IT_NQ - 1) / IT_NQ;
+  int mine = 0;
+  for (int k = 0; k < per; ++k) {
+    const int r = (int)threadIdx.x * per + k;
+    if (r < nrows) {
+      const int grow = ((bz0 + r / nby) * g.ny + (by0 + r % nby)) * g.nx + bx0;
+      const int b0 = q.cell_start[grow], e0 = q.cell_start[grow + nbx];
+      rowsrc[r] = b0;
+      rowbase[r] = e0 - b0;   // count for now
+      mine += e0 - b0;
+    }
+  }
+  int total;
+  int run = gs_block_excl_scan<IT_NQ>(mine, scan_s, &total);
+  for (int k = 0; k < per; ++k) {
+    const int r = (int)threadIdx.x * per + k;
+    if (r < nrows) {
+      const int c = rowbase[r];
+      rowbase[r] = run;
+      run += c;
+    }
+  }
+  if (threadIdx.x == 0) rowbase[nrows] = total;
+  __syncthreads();
+  if (total > IT_PTS_CAP) mode = 2;
+  if (threadIdx.x == 0) {
+    ItSlabHdr h = {mode, bx0, by0, bz0, nbx, nby, nbz, ncell, mode == 1 ? total : 0, {0, 0, 0, 0, 0, 0, 0}};
+    *hdr = h;
+  }
+  if (mode != 1) return;
+  // cell table: slab slot of the first target of every cell of the box (+ end sentinel)
+  for (int lc = threadIdx.x; lc <= ncell; lc += IT_NQ) {
+    int v = total;
+    if (lc < ncell) {
+      const int r = lc / nbx, x = lc % nbx;
+      const int grow = ((bz0 + r / nby) * g.ny + (by0 + r % nby)) * g.nx + bx0;
+      v = rowbase[r] + (q.cell_start[grow + x] - rowsrc[r]);
+    }
+    cells[lc] = (uint16_t)v;
+  }
+  // targets: slab slot i belongs to the row r with rowbase[r] <= i < rowbase[r + 1] (binary search over the rows)
+  for (int i = threadIdx.x; i < total; i += IT_NQ) {
+    int a = 0, b = nrows;  // invariant: rowbase[a] <= i < rowbase[b]
+    while (b - a > 1) {
+      const int m = (a + b) >> 1;
+      if (rowbase[m] <= i) a = m; else b = m;
+    }
+    const int src = rowsrc[a] + (i - rowbase[a]);
+    pts[i] = q.sorted[src];
+    nrm[i] = q.sorted_n[src];
+  }
+}
+
+// ---------------------------------------------------------------- half-iteration ---------
+struct ItSeq {
+  const float* src_in;       // lattice [Hl * Wl][3]
+  float* src_out;
+  const float* tgt;          // map rows (only for the degenerate "no target at all" row)
+  const float* tn;
+  GsCount n_tgt;
+  const GsGrid* gp;
+  const int* cell_start;
+  const float4* sorted;
+  const float4* sorted_n;
+  const char* slabs;
+  float* d2prev;
+  const double* partials_in;
+  double* partials_out;
+  const IcpSmall* st_in;
+  IcpSmall* st_out;
+  float* trace;
+};
+struct ItBatch {
+  int B, Wl, Hl, tiles_x, ntiles;
+  ItSeq s[GS_MAX_BATCH];
+#ifdef GS_ICP_TIMELINE
+  unsigned long long* tl;   // debugging builds: 8 words per block [start, loads issued, prologue done, search done,
+                            // leftovers done, end (100 MHz ticks), open after the 2x2x2 stage, left to brute force]
+#endif
+};
+#ifdef GS_ICP_TIMELINE
+#define IT_STAMP(k) do { if (hb.tl && threadIdx.x == 0) hb.tl[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
+#define IT_NOTE(k, v) do { if (hb.tl && threadIdx.x == 0) hb.tl[8 * (size_t)blockIdx.x + (k)] = (unsigned long long)(v); } while (0)
+#else
+#define IT_STAMP(k) do { } while (0)
+#define IT_NOTE(k, v) do { } while (0)
+#endif
+
+struct ItBox {
+  int x0, y0, z0, nx, ny, nz;
+};
+
+// grid_search_stage0 (gs_knn.h) on either the global grid (LOCAL = false; cells = cell_start, pts = sorted) or a
+// tile's slab in LDS (LOCAL = true; cells / pts = the LDS copies, box = the slab's box): same cells, same candidates,
+// same bound.  *served = false (LOCAL only): the 2x2x2 block of this query is not inside the box, nothing was searched.
+// *win: slot of the best candidate in `pts` (the one lane of the group that holds it; -1 in the others).
+template <int G, bool LOCAL, typename CT>
+GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT* __restrict__ cells,
+                                    const float4* __restrict__ pts, float qx, float qy, float qz, int lane,
+                                    const float rball, bool* resolved, bool* served, int* win) {
+  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
+  const float px = qc.px, py = qc.py, pz = qc.pz;
+  const int cx = qc.cx, cy = qc.cy, cz = qc.cz;
+  unsigned long long key = ~0ull;
+  int bt = -1;
+  const float fx = (px - g.ox) * g.inv_c - (float)cx, fy = (py - g.oy) * g.inv_c - (float)cy,
+              fz = (pz - g.oz) * g.inv_c - (float)cz;
+  const int x0 = (fx < 0.5f) ? cx - 1 : cx, y0 = (fy < 0.5f) ? cy - 1 : cy, z0 = (fz < 0.5f) ? cz - 1 : cz;
+  const float BIG = 3.0e38f;
+  const float ax = fminf(x0 >= 1 ? fx + (float)(cx - x0) : BIG, x0 + 2 < g.nx ? (float)(x0 + 2 - cx) - fx : BIG);
+  const float ay = fminf(y0 >= 1 ? fy + (float)(cy - y0) : BIG, y0 + 2 < g.ny ? (float)(y0 + 2 - cy) - fy : BIG);
+  const float az = fminf(z0 >= 1 ? fz + (float)(cz - z0) : BIG, z0 + 2 < g.nz ? (float)(z0 + 2 - cz) - fz : BIG);
+  const float amin = fminf(ax, fminf(ay, az));
+  const float rc = rball * g.inv_c * 1.0001f + 0.002f;
+  const bool prune = rc < amin - 0.001f;
+  bool ulx = true, uhx = true, uly = true, uhy = true, ulz = true, uhz = true;
+  if (prune) {
+    const float tx = fx + (float)(cx - x0), ty = fy + (float)(cy - y0), tz = fz + (float)(cz - z0);
+    ulx = tx - rc < 1.0f; uhx = tx + rc >= 1.0f;
+    uly = ty - rc < 1.0f; uhy = ty + rc >= 1.0f;
+    ulz = tz - rc < 1.0f; uhz = tz + rc >= 1.0f;
+  }
+  int sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, e1 = 0, e2 = 0, e3 = 0, total = 0;
+  {
+    const int xa = (x0 >= 0 && ulx) ? x0 : x0 + 1, xb = (x0 + 1 < g.nx && uhx) ? x0 + 1 : x0;
+    const bool zl = z0 >= 0 && ulz, zh = z0 + 1 < g.nz && uhz, yl = y0 >= 0 && uly, yh = y0 + 1 < g.ny && uhy;
+    int r0, sy, sz;
+    if (LOCAL) {
+      const int ya = yl ? y0 : y0 + 1, yb = yh ? y0 + 1 : y0, za = zl ? z0 : z0 + 1, zb = zh ? z0 + 1 : z0;
+      const bool inside = xa >= box.x0 && xb < box.x0 + box.nx && ya >= box.y0 && yb < box.y0 + box.ny &&
+                          za >= box.z0 && zb < box.z0 + box.nz;
+      if (!inside) {
+        *served = false;
+        *resolved = false;
+        *win = -1;
+        return ~0ull;
+      }
+      sy = box.nx; sz = box.ny * box.nx;
+      r0 = (z0 - box.z0) * sz + (y0 - box.y0) * sy - box.x0;
+    } else {
+      sy = g.nx; sz = g.ny * g.nx;
+      r0 = (z0 * g.ny + y0) * g.nx;
+    }
+    *served = true;
+    const int r1 = r0 + sy, r2 = r0 + sz, r3 = r2 + sy;
+    int se0 = 0, se1 = 0, se2 = 0, se3 = 0;
+    if (zl && yl) { sb0 = (int)cells[r0 + xa]; se0 = (int)cells[r0 + xb + 1]; }
+    if (zl && yh) { sb1 = (int)cells[r1 + xa]; se1 = (int)cells[r1 + xb + 1]; }
+    if (zh && yl) { sb2 = (int)cells[r2 + xa]; se2 = (int)cells[r2 + xb + 1]; }
+    if (zh && yh) { sb3 = (int)cells[r3 + xa]; se3 = (int)cells[r3 + xb + 1]; }
+    e1 = se0 - sb0;
+    e2 = e1 + (se1 - sb1);
+    e3 = e2 + (se2 - sb2);
+    total = e3 + (se3 - sb3);
+  }
+  for (int t0 = lane; t0 < total; t0 += 4 * G) {
+    float4 p[4];
+    bool in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * G;
+      in[u] = t < total;
+      const int tt = in[u] ? t : 0;
+      const int ix = tt < e1 ? sb0 + tt : (tt < e2 ? sb1 + (tt - e1) : (tt < e3 ? sb2 + (tt - e2) : sb3 + (tt - e3)));
+      p[u] = pts[ix];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned long long k2 = in[u] ? grid_key(qx, qy, qz, p[u]) : ~0ull;
+      const bool better = k2 < key;
+      key = better ? k2 : key;
+      bt = better ? t0 + u * G : bt;
+    }
+  }
+  {
+    const unsigned long long kmin = grid_group_min<G>(key);
+    const int bs = bt < e1 ? sb0 + bt : (bt < e2 ? sb1 + (bt - e1) : (bt < e3 ? sb2 + (bt - e2) : sb3 + (bt - e3)));
+    *win = (key == kmin && bt >= 0) ? bs : -1;
+    key = kmin;
+  }
+  const float rb = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
+  const float bd = __uint_as_float((uint32_t)(key >> 32));
+  *resolved = prune ? (bd == bd) : (rb > 0.0f && (rb >= 1.0e30f ? bd == bd : bd <= rb * rb));
+  return key;
+}
+
+// 16 bytes per lane from global memory straight into LDS: lane l of the wave lands at lds_wave_base + 16 l (the LDS
+// base must be wave-uniform; disabled lanes load nothing)
+GS_DEV void it_load_lds16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// slot codes in bslot_s: >= 0 slot in the LDS slab, <= -2 global slot -2 - code, -1 none
+GS_DEV int it_global_code(int slot) { return -2 - slot; }
+
+struct ItLds {
+  float4 pts[IT_PTS_CAP];          // slab: binned target points of the tile's box (x, y, z, map row bits)
+  float4 nrm[IT_PTS_CAP];          //       their normals
+  uint16_t cells[IT_CELLS_CAP];    //       cell table of the box
+  IcpSmall sm;                     // solver state
+  double S[32];
+  double sub[IT_BLOCK / 32][32];   // prologue: chunk sums of the partial rows; epilogue: the row groups' sub-sums
+  unsigned long long keys[IT_NQ];  // best (distance bits, map row) of every query
+  int bslot[IT_NQ];                // where its point / normal sit (slot codes above)
+  float qs[IT_NQ][3];              // transformed queries
+  float qa[IT_NQ][8];              // a0..a5, residual of every query (zero when filtered out)
+  int hard_q[IT_NQ], unres_q[IT_NQ];
+  int hard_n, unres_n;
+  unsigned long long red[IT_BLOCK / GS_WAVE];
+};
+static_assert(IT_RG * LIN_NV <= (IT_BLOCK / 32) * 32 && offsetof(ItLds, sm) % 16 == 0 && offsetof(ItLds, sm) + sizeof(IcpSmall) <= 65536, "LDS copy targets");
+
+template <bool FULL>
+__global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItBatch hb, const float dist_thresh,
+                                                                       const gs_icp_params prm, const int it,
+                                                                       const int rows_in_reduced) {
+  const unsigned B = (unsigned)hb.B, blk = blockIdx.x / B, nblk = gridDim.x / B;
+  const unsigned X = (GS_XCDS % B == 0) ? GS_XCDS / B : 1u;
+  const ItSeq& q = hb.s[blockIdx.x % B];
+  const int tile = (int)gs_xcd_block(blk, nblk, X);
+
+  // one LDS block with the targets of the global -> LDS copies first (their LDS address goes through M0: keep them in
+  // the low 64 KB whatever the hardware reads of it)
+  __shared__ ItLds L;
+  IcpSmall& sm = L.sm;
+  double* const S = L.S;
+  double (*const sub)[32] = L.sub;
+  uint16_t* const cells_s = L.cells;
+  float4* const pts_s = L.pts;
+  float4* const nrm_s = L.nrm;
+  unsigned long long* const keys_s = L.keys;
+  int* const bslot_s = L.bslot;
+  float (*const qs)[3] = L.qs;
+  float (*const qa_s)[8] = L.qa;
+  double (*const sub_s)[LIN_NV] = reinterpret_cast<double (*)[LIN_NV]>(L.sub);
+  int* const hard_q = L.hard_q;
+  int* const unres_q = L.unres_q;
+  int& hard_n = L.hard_n;
+  int& unres_n = L.unres_n;
+  unsigned long long* const red = L.red;
+
+  const float* __restrict__ src_in = q.src_in;
+  float* __restrict__ src_out = q.src_out;
+  const int* __restrict__ cell_start = q.cell_start;
+  const float4* __restrict__ sorted = q.sorted;
+  const float4* __restrict__ sorted_n = q.sorted_n;
+  float* __restrict__ d2prev = q.d2prev;
+  const double* __restrict__ partials_in = q.partials_in;
+  double* __restrict__ partials_out = q.partials_out;
+
+  IT_STAMP(0);
+  const int lane = threadIdx.x & (IT_G - 1), slot = threadIdx.x / IT_G;
+  const int lx = (tile % hb.tiles_x) * IT_TW + slot % IT_TW, ly = (tile / hb.tiles_x) * IT_TH + slot / IT_TW;
+  const bool live = lx < hb.Wl && ly < hb.Hl;
+  const int64_t s = (int64_t)ly * hb.Wl + lx;
+  const bool bounded = !(FULL && it == 0);  // the first search of a solve has no predecessor
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, dprev = __builtin_inff();
+  if (live) {
+    p0 = src_in[3 * s];
+    p1 = src_in[3 * s + 1];
+    p2 = src_in[3 * s + 2];
+    if (bounded) dprev = d2prev[s];
+  }
+  const GsGrid g = *q.gp;
+  const char* slab = q.slabs + IT_SLAB_BYTES * (size_t)tile;
+  const ItSlabHdr hdr = *reinterpret_cast<const ItSlabHdr*>(slab);
+  // state of the previous half-iteration: 240 bytes, 16 per lane of the second wave, straight into LDS (a register
+  // copy would make this wave wait for its loads before the slab and the partial rows are even requested)
+  static_assert(sizeof(IcpSmall) % 16 == 0, "state copy");
+  if (threadIdx.x >= GS_WAVE && threadIdx.x < GS_WAVE + (int)(sizeof(IcpSmall) / 16))
+    it_load_lds16(reinterpret_cast<const float4*>(q.st_in) + (threadIdx.x - GS_WAVE), &sm);
+
+  // the slab: global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + 16 B per lane, no staging
+  // registers), issued now; its latency hides behind the prologue and the next barrier drains it
+  const bool local = hdr.mode == 1;
+  {
+    const int npts = local ? hdr.npts : 0, ncw = local ? (hdr.ncell + 1 + 7) / 8 : 0;  // 16-byte words of the cell table
+    const float4* gp4 = reinterpret_cast<const float4*>(slab + IT_OFF_PTS);
+    const float4* gn4 = reinterpret_cast<const float4*>(slab + IT_OFF_NRM);
+    const uint4* gc4 = reinterpret_cast<const uint4*>(slab + IT_OFF_CELLS);
+    const int wv = threadIdx.x / GS_WAVE, ln = threadIdx.x & (GS_WAVE - 1);
+#pragma unroll
+    for (int c0 = 0; c0 < IT_PTS_CAP / GS_WAVE; c0 += IT_BLOCK / GS_WAVE) {
+      const int c = c0 + wv, i = c * GS_WAVE + ln;   // chunk c = slots [64 c, 64 c + 64)
+      if (c < IT_PTS_CAP / GS_WAVE && i < npts) {
+        it_load_lds16(gp4 + i, pts_s + c * GS_WAVE);
+        it_load_lds16(gn4 + i, nrm_s + c * GS_WAVE);
+      }
+    }
+    if (wv < IT_CELLS_CAP / 8 / GS_WAVE && (int)threadIdx.x < ncw)
+      it_load_lds16(gc4 + threadIdx.x, reinterpret_cast<uint4*>(cells_s) + wv * GS_WAVE);
+  }
+
+  IT_STAMP(1);
+  // ---- prologue: finish the previous half-iteration (identical in every block)
+  const int nrows_in = rows_in_reduced ? 1 : hb.ntiles;
+  if (FULL) {
+    double e1 = 0.0;
+    if (it > 0) e1 = icp_sum_col27<IT_BLOCK>(partials_in, nrows_in, reinterpret_cast<double*>(red));
+    else __syncthreads();
+    if (threadIdx.x == 0) {
+      if (it > 0)
+        icp_update_math((float)e1, sm, prm, (tile == 0 && it - 1 < GS_ICP_MAX_ITERS) ? q.trace + 12 * (it - 1) : nullptr);
+      unres_n = 0;
+      hard_n = 0;
+    }
+  } else {
+    icp_sum_rows<IT_BLOCK, 4>(partials_in, nrows_in, S, sub);
+    if (threadIdx.x < GS_WAVE) {
+      gs_solve_spd6_wave(S, sm.damp, sm.xi);   // 6x6 solve across the lanes of wave 0 (LDS accesses of a wave are ordered)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (threadIdx.x == 0) {
+        icp_solve_finish(S, sm);
+        unres_n = 0;
+        hard_n = 0;
+      }
+    }
+  }
+  __syncthreads();
+  if (tile == 0 && threadIdx.x < (int)(sizeof(IcpSmall) / 4))
+    reinterpret_cast<float*>(q.st_out)[threadIdx.x] = reinterpret_cast<const float*>(&sm)[threadIdx.x];
+
+  IT_STAMP(2);
+  // ---- search: one source point per IT_G-lane group, pending transform applied to the loaded point
+  const ItBox box = {hdr.bx0, hdr.by0, hdr.bz0, hdr.nbx, hdr.nby, hdr.nbz};
+  float qx = p0, qy = p0, qz = p0;
+  const bool skip = !live || p0 != p0;   // beyond the lattice, or an empty slot (NaN stays NaN, contributes no row)
+  if (!skip) {
+    const float* T = FULL ? sm.T_step : sm.Tr;
+    gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
+    float rball;
+    {
+      float ox = p0, oy = p1, oz = p2;
+      if (FULL) gs_rigid_fma(sm.Tr, p0, p1, p2, ox, oy, oz);
+      const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
+      rball = sqrtf(dprev) + sqrtf(ex * ex + ey * ey + ez * ez);
+    }
+    bool done, served;
+    int win;
+    unsigned long long key;
+    if (local) {
+      key = it_stage0<IT_G, true>(g, box, cells_s, pts_s, qx, qy, qz, lane, rball, &done, &served, &win);
+      if (win >= 0) bslot_s[slot] = win;
+    } else {
+      key = it_stage0<IT_G, false>(g, box, cell_start, sorted, qx, qy, qz, lane, rball, &done, &served, &win);
+      if (win >= 0) bslot_s[slot] = it_global_code(win);
+    }
+    if (lane == 0) {
+      if (key == ~0ull) bslot_s[slot] = -1;
+      keys_s[slot] = key;
+      // bit 31: not served by the slab (the leftover pass starts with the global 2x2x2 stage)
+      if (!done) hard_q[atomicAdd(&hard_n, 1)] = slot | (served ? 0 : (int)0x80000000);
+    }
+  }
+  if (lane == 0 && live) {
+    if (FULL) { src_out[3 * s] = qx; src_out[3 * s + 1] = qy; src_out[3 * s + 2] = qz; }
+    qs[slot][0] = qx; qs[slot][1] = qy; qs[slot][2] = qz;
+    if (skip) keys_s[slot] = ~0ull;
+  }
+  __syncthreads();
+  // ---- leftovers (neighbour farther than ~half a cell, or outside the slab): groups of IT_HG lanes on the global grid
+  const int nh = hard_n;  // block-uniform
+  IT_STAMP(3);
+  IT_NOTE(6, nh);
+  for (int i = threadIdx.x / IT_HG; i < nh; i += IT_BLOCK / IT_HG) {
+    const int e = hard_q[i], hs = e & 0x7fffffff, l16 = threadIdx.x & (IT_HG - 1);
+    const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
+    unsigned long long key = keys_s[hs];
+    bool done = false, served;
+    int win;
+    if (e < 0) {
+      key = it_stage0<IT_HG, false>(g, box, cell_start, sorted, hx, hy, hz, l16, __builtin_inff(), &done, &served, &win);
+      if (win >= 0) bslot_s[hs] = it_global_code(win);
+    }
+    if (!done) {
+      key = grid_search_rings<IT_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS);
+      if (win >= 0) bslot_s[hs] = it_global_code(win);
+    }
+    if (l16 == 0) {
+      keys_s[hs] = key;
+      if (!done) unres_q[atomicAdd(&unres_n, 1)] = hs;
+    }
+  }
+  if (nh) __syncthreads();
+  const int nun = unres_n;  // block-uniform
+  IT_NOTE(7, (unsigned long long)nun | ((unsigned long long)hdr.mode << 32) | ((unsigned long long)hdr.npts << 36) |
+                 ((unsigned long long)hdr.ncell << 48));
+  for (int u = 0; u < nun; u += FS_BQ)
+    block_brute_min_sorted_multi<IT_BLOCK, FS_BQ>(qs, unres_q + u, nun - u < FS_BQ ? nun - u : FS_BQ, sorted,
+                                                  cell_start[g.ncell], keys_s, bslot_s, true);
+
+  IT_STAMP(4);
+  // ---- Gauss-Newton row of every query: its group's first lane reads the match and leaves [a, res] in LDS
+  if (lane == 0) {
+    float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, res = 0.0f;
+    if (!skip) {
+      const unsigned long long bb = keys_s[slot];
+      d2prev[s] = __uint_as_float((uint32_t)(bb >> 32));  // NaN bits when nothing was found
+      const float d2 = __uint_as_float((uint32_t)(bb >> 32));
+      const bool keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
+      const int bsl = bslot_s[slot];
+      if (bb != ~0ull && bsl >= 0) {
+        gn_row_pn(qs[slot][0], qs[slot][1], qs[slot][2], pts_s[bsl], nrm_s[bsl], a, res);
+      } else if (bb != ~0ull && bsl <= -2) {
+        gn_row_pn(qs[slot][0], qs[slot][1], qs[slot][2], sorted[-2 - bsl], sorted_n[-2 - bsl], a, res);
+      } else {  // every distance was NaN / no target at all: row 0 of the target array, as the brute-force engine
+        gn_row(qs[slot][0], qs[slot][1], qs[slot][2], q.tgt, q.tn, 0, a, res);
+      }
+      if (!keep) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a[i] = 0.0f;
+        res = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) qa_s[slot][i] = a[i];
+    qa_s[slot][6] = res;
+  }
+  __syncthreads();
+  double* prow = partials_out + (int64_t)tile * LIN_NV;
+  if (!FULL) {  // residual only: wave sums of the IT_NQ squares, added in wave order
+    double* red2 = reinterpret_cast<double*>(red);
+    const int wave = threadIdx.x / GS_WAVE;
+    if (threadIdx.x < IT_NQ) {
+      const float res = qa_s[threadIdx.x][6];
+      const double sum = gs_wave_sum_f64((double)res * (double)res);
+      if ((threadIdx.x & (GS_WAVE - 1)) == 0) red2[wave] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = red2[0];
+#pragma unroll
+      for (int w = 1; w < IT_NQ / GS_WAVE; ++w) t += red2[w];
+      prow[27] = t;
+    }
+    IT_STAMP(5);
+    return;
+  }
+  // IT_RG groups of 28 threads add the products of IT_RPG queries each, then 28 threads add the sub-sums in order
+  if (threadIdx.x < IT_RG * LIN_NV) {
+    const int i = threadIdx.x % LIN_NV, part = threadIdx.x / LIN_NV;
+    const int ia = fs_pa(i), ib = fs_pb(i);
+    const float* r0 = qa_s[IT_RPG * part];
+    double t = (double)r0[ia] * (double)r0[ib];
+#pragma unroll
+    for (int u = 1; u < IT_RPG; ++u) t += (double)r0[8 * u + ia] * (double)r0[8 * u + ib];
+    sub_s[part][i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < LIN_NV) {
+    double t = sub_s[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < IT_RG; ++k) t += sub_s[k][threadIdx.x];
+    prow[threadIdx.x] = t;
+  }
+}
+
+// rows of a large solve added up once per half-iteration (more than FS_REDUCE_ROWS tiles)
+struct ItRowsBatch {
+  int B, nrows;
+  const double* in[GS_MAX_BATCH];
+  double* out[GS_MAX_BATCH];
+};
+__global__ void __launch_bounds__(IT_BLOCK) gs_icp_tile_reduce_rows_kernel(const ItRowsBatch rb) {
+  __shared__ double S[32];
+  __shared__ double sub[IT_BLOCK / 32][32];
+  icp_sum_rows<IT_BLOCK, 4>(rb.in[blockIdx.x], rb.nrows, S, sub);
+  if (threadIdx.x < LIN_NV) rb.out[blockIdx.x][threadIdx.x] = S[threadIdx.x];
+}

@@ -329,7 +329,7 @@ GS_DEV unsigned long long grid_search_group(const GsGrid& g, const int* __restri
 template <int BLOCK, int BQ>
 GS_DEV void block_brute_min_sorted_multi(const float (*qs)[3], const int* ids, int nq,
                                          const float4* __restrict__ sorted, int n, unsigned long long* key_out,
-                                         int* bslot_out) {
+                                         int* bslot_out, const bool code_global = false) {
   __shared__ unsigned long long red_m[BLOCK / GS_WAVE][BQ];
   float q[BQ][3];
   unsigned long long key[BQ];
@@ -367,7 +367,8 @@ GS_DEV void block_brute_min_sorted_multi(const float (*qs)[3], const int* ids, i
 #pragma unroll
       for (int w = 1; w < BLOCK / GS_WAVE; ++w) k = red_m[w][i] < k ? red_m[w][i] : k;
       const int id = ids[i];
-      if (key[i] == k && bs[i] >= 0) bslot_out[id] = bs[i];  // the one thread that holds the winning candidate
+      // the one thread that holds the winning candidate (code_global: the tile engine's code of a global slot)
+      if (key[i] == k && bs[i] >= 0) bslot_out[id] = code_global ? -2 - bs[i] : bs[i];
       if (threadIdx.x == 0) key_out[id] = k;
     }
   }
