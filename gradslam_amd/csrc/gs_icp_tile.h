@@ -28,13 +28,14 @@ constexpr int IT_TW = 16, IT_TH = 24;        // lattice tile of one workgroup
 constexpr int IT_NQ = IT_TW * IT_TH;         // 384 queries
 constexpr int IT_G = 2;                      // lanes per query
 constexpr int IT_BLOCK = IT_NQ * IT_G;       // 768 threads, 2 workgroups per CU
-constexpr int IT_PTS_CAP = 1024;             // binned targets a slab can hold
-constexpr int IT_CELLS_CAP = 4096;           // entries of a slab's cell table (cells + 1 end sentinel)
+constexpr int IT_PTS_CAP = 1408;             // binned targets a slab can hold (LDS: 32 bytes each)
+constexpr int IT_CELLS_CAP = 16384;          // entries of a slab's cell table (cells + 1 end sentinel; global memory only)
+constexpr int IT_ROWS_CAP = 2048;            // (z, y) rows of a slab's box
 constexpr int IT_MARGIN = 2;                 // cells added around the tile's query cells (1 for the 2x2x2 block + 1 of motion)
 constexpr int IT_RG = 24, IT_RPG = IT_NQ / IT_RG;  // row groups of the tile sum x queries per group
 constexpr int IT_HG = 16;                    // lanes per query of the leftover searches
 static_assert(IT_RG * LIN_NV <= IT_BLOCK && IT_NQ % IT_RG == 0, "tile sum shape");
-static_assert(IT_CELLS_CAP * 2 % 16 == 0 && IT_CELLS_CAP / 8 <= IT_BLOCK && 2 * IT_BLOCK >= IT_PTS_CAP, "slab copy shape");
+static_assert(IT_CELLS_CAP * 2 % 64 == 0 && IT_PTS_CAP % GS_WAVE == 0 && IT_PTS_CAP < 0xffff, "slab shape");
 
 struct ItSlabHdr {   // 64 bytes in front of every slab
   int mode;          // 0: no query in the tile, 1: slab valid, 2: no slab (searches use the global arrays)
@@ -77,8 +78,8 @@ __global__ void __launch_bounds__(IT_NQ) gs_it_slab_build_kernel(const ItBuildBa
   float4* nrm = reinterpret_cast<float4*>(slab + IT_OFF_NRM);
 
   __shared__ int red[6][IT_NQ / GS_WAVE];
-  __shared__ int rowbase[IT_CELLS_CAP + 1];   // first slab slot of every (z, y) row of the box
-  __shared__ int rowsrc[IT_CELLS_CAP];        // global slot of the first target of the row
+  __shared__ int rowbase[IT_ROWS_CAP + 1];   // first slab slot of every (z, y) row of the box
+  __shared__ int rowsrc[IT_ROWS_CAP];        // global slot of the first target of the row
   __shared__ int scan_s[IT_NQ / GS_WAVE + 1];
   __shared__ int box_s[8];
 
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(IT_NQ) gs_it_slab_build_kernel(const ItBuildBa
       box_s[k] = a[k];
       box_s[3 + k] = mode ? b[k] - a[k] + 1 : 0;
     }
-    if (mode && (long long)box_s[3] * box_s[4] * box_s[5] + 1 > IT_CELLS_CAP) mode = 2;
+    if (mode && ((long long)box_s[3] * box_s[4] * box_s[5] + 1 > IT_CELLS_CAP || box_s[4] * box_s[5] > IT_ROWS_CAP)) mode = 2;
     box_s[6] = mode;
   }
   __syncthreads();
@@ -205,7 +206,9 @@ struct ItSeq {
   const float4* sorted;
   const float4* sorted_n;
   const char* slabs;
-  float* d2prev;
+  float* d2prev;             // tiles without a slab: squared distance of every query's previous neighbour (search bound)
+  uint32_t* cand;            // [n_lat][6] candidate lists: 2 lanes x 6 slab slots (16 bit each, 0xffff = none)
+  float4* cq;                // [n_lat] (query position the list was built at, exactness radius R; R <= 0: no list)
   const double* partials_in;
   double* partials_out;
   const IcpSmall* st_in;
@@ -216,8 +219,8 @@ struct ItBatch {
   int B, Wl, Hl, tiles_x, ntiles;
   ItSeq s[GS_MAX_BATCH];
 #ifdef GS_ICP_TIMELINE
-  unsigned long long* tl;   // debugging builds: 8 words per block [start, loads issued, prologue done, search done,
-                            // leftovers done, end (100 MHz ticks), open after the 2x2x2 stage, left to brute force]
+  unsigned long long* tl;   // debugging builds: 8 words per block [start, loads issued, prologue done, list pass done,
+                            // scan pass done, leftovers done, end (100 MHz ticks), counts]
 #endif
 };
 #ifdef GS_ICP_TIMELINE
@@ -232,14 +235,27 @@ struct ItBox {
   int x0, y0, z0, nx, ny, nz;
 };
 
+// What a scan leaves behind for the searches that follow (EMIT): this lane's share of the query's CANDIDATE LIST -- the
+// slab slots of every target closer than R to the query position q0 of the scan -- and R itself (<= 0: no list).
+// Every target that is not on the list is at least R away from q0 (inside the 2x2x2 block by its computed distance,
+// outside by the block's face bound), so a later query position q with |q - q0| = delta has its exact nearest
+// neighbour on the list whenever the best list entry is closer than R - delta (it_list_search).
+struct ItList {
+  uint32_t w[3];   // six 16-bit slots, appended from the low end; 0xffff = empty
+  float R;
+};
+constexpr int IT_LIST_LANE = 6;
+constexpr float IT_RADD = 0.25f;   // R = (distance of the nearest neighbour) + IT_RADD cells, at most the block's bound
+
 // grid_search_stage0 (gs_knn.h) on either the global grid (LOCAL = false; cells = cell_start, pts = sorted) or a
-// tile's slab in LDS (LOCAL = true; cells / pts = the LDS copies, box = the slab's box): same cells, same candidates,
-// same bound.  *served = false (LOCAL only): the 2x2x2 block of this query is not inside the box, nothing was searched.
-// *win: slot of the best candidate in `pts` (the one lane of the group that holds it; -1 in the others).
-template <int G, bool LOCAL, typename CT>
+// tile's slab (LOCAL = true; cells = the slab's 16-bit cell table, pts = its points in LDS, box = the slab's box): same
+// cells, same candidates, same bound.  *served = false (LOCAL only): the 2x2x2 block of this query is not inside the
+// box, nothing was searched.  *win: slot of the best candidate in `pts` (the one lane of the group that holds it; -1
+// in the others).  EMIT (LOCAL, G = 2, called with rball = inf so that all 8 cells are scanned): also builds the list.
+template <int G, bool LOCAL, bool EMIT, typename CT>
 GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT* __restrict__ cells,
                                     const float4* __restrict__ pts, float qx, float qy, float qz, int lane,
-                                    const float rball, bool* resolved, bool* served, int* win) {
+                                    const float rball, bool* resolved, bool* served, int* win, ItList* lst = nullptr) {
   const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
   const float px = qc.px, py = qc.py, pz = qc.pz;
   const int cx = qc.cx, cy = qc.cy, cz = qc.cz;
@@ -262,6 +278,7 @@ GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT*
     uly = ty - rc < 1.0f; uhy = ty + rc >= 1.0f;
     ulz = tz - rc < 1.0f; uhz = tz + rc >= 1.0f;
   }
+  if (EMIT) { lst->w[0] = lst->w[1] = lst->w[2] = ~0u; lst->R = -1.0f; }
   int sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, e1 = 0, e2 = 0, e3 = 0, total = 0;
   {
     const int xa = (x0 >= 0 && ulx) ? x0 : x0 + 1, xb = (x0 + 1 < g.nx && uhx) ? x0 + 1 : x0;
@@ -295,11 +312,13 @@ GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT*
     e3 = e2 + (se2 - sb2);
     total = e3 + (se3 - sb3);
   }
-  for (int t0 = lane; t0 < total; t0 += 4 * G) {
-    float4 p[4];
-    bool in[4];
+  // candidates in flight per lane: 4 gathers from global memory (latency), 2 from LDS (registers)
+  constexpr int U = LOCAL ? 2 : 4;
+  for (int t0 = lane; t0 < total; t0 += U * G) {
+    float4 p[U];
+    bool in[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int t = t0 + u * G;
       in[u] = t < total;
       const int tt = in[u] ? t : 0;
@@ -307,7 +326,7 @@ GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT*
       p[u] = pts[ix];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const unsigned long long k2 = in[u] ? grid_key(qx, qy, qz, p[u]) : ~0ull;
       const bool better = k2 < key;
       key = better ? k2 : key;
@@ -323,7 +342,60 @@ GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT*
   const float rb = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
   const float bd = __uint_as_float((uint32_t)(key >> 32));
   *resolved = prune ? (bd == bd) : (rb > 0.0f && (rb >= 1.0e30f ? bd == bd : bd <= rb * rb));
+  if (EMIT) {
+    if (*resolved) {   // (the same for all lanes of the group)
+      float R = sqrtf(bd) + IT_RADD * g.c;
+      R = R < rb ? R : rb;
+      const float R2 = R * R;
+      uint32_t w0 = ~0u, w1 = ~0u, w2 = ~0u;
+      int cnt = 0;
+      for (int t = lane; t < total; t += G) {
+        const int ix = t < e1 ? sb0 + t : (t < e2 ? sb1 + (t - e1) : (t < e3 ? sb2 + (t - e2) : sb3 + (t - e3)));
+        const float4 c = pts[ix];
+        const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+        float d = dx * dx;
+        d = gs_fma(dy, dy, d);
+        d = gs_fma(dz, dz, d);
+        if (d < R2) {   // a NaN distance is never a neighbour
+          w2 = (w2 << 16) | (w1 >> 16);
+          w1 = (w1 << 16) | (w0 >> 16);
+          w0 = (w0 << 16) | (uint32_t)ix;
+          ++cnt;
+        }
+      }
+      const int over = cnt > IT_LIST_LANE ? 1 : 0;
+      const bool any_over = (over | __shfl_xor(over, 1, G)) != 0;
+      lst->w[0] = w0; lst->w[1] = w1; lst->w[2] = w2;
+      lst->R = any_over ? -1.0f : R;
+    }
+  }
   return key;
+}
+
+// The nearest neighbour of q among this lane's list entries (+ the other lane's: group minimum), and whether it is
+// PROVABLY the exact nearest neighbour: best distance + |q - q0| < R with a 1e-4 relative margin (float rounding of the
+// distances involved is ~1e-7 relative).
+GS_DEV unsigned long long it_list_search(const uint32_t* w, const float4 c0R, const float4* __restrict__ pts, float qx,
+                                         float qy, float qz, bool* proven, int* win) {
+  unsigned long long key = ~0ull;
+  int bs = -1;
+#pragma unroll
+  for (int u = 0; u < IT_LIST_LANE; ++u) {
+    const uint32_t sl = (w[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+    const bool in = sl != 0xffffu;
+    const float4 c = pts[in ? sl : 0u];
+    const unsigned long long k2 = in ? grid_key(qx, qy, qz, c) : ~0ull;
+    const bool better = k2 < key;
+    key = better ? k2 : key;
+    bs = better ? (int)sl : bs;
+  }
+  const unsigned long long kmin = grid_group_min<2>(key);
+  *win = (key == kmin && bs >= 0) ? bs : -1;
+  const float bd = __uint_as_float((uint32_t)(kmin >> 32));   // NaN: empty list
+  const float ex = qx - c0R.x, ey = qy - c0R.y, ez = qz - c0R.z;
+  const float delta = sqrtf(ex * ex + ey * ey + ez * ez);
+  *proven = sqrtf(bd) + delta < c0R.w * 0.9999f;   // false for NaN and for R <= 0
+  return kmin;
 }
 
 // 16 bytes per lane from global memory straight into LDS: lane l of the wave lands at lds_wave_base + 16 l (the LDS
@@ -339,7 +411,6 @@ GS_DEV int it_global_code(int slot) { return -2 - slot; }
 struct ItLds {
   float4 pts[IT_PTS_CAP];          // slab: binned target points of the tile's box (x, y, z, map row bits)
   float4 nrm[IT_PTS_CAP];          //       their normals
-  uint16_t cells[IT_CELLS_CAP];    //       cell table of the box
   IcpSmall sm;                     // solver state
   double S[32];
   double sub[IT_BLOCK / 32][32];   // prologue: chunk sums of the partial rows; epilogue: the row groups' sub-sums
@@ -347,11 +418,12 @@ struct ItLds {
   int bslot[IT_NQ];                // where its point / normal sit (slot codes above)
   float qs[IT_NQ][3];              // transformed queries
   float qa[IT_NQ][8];              // a0..a5, residual of every query (zero when filtered out)
-  int hard_q[IT_NQ], unres_q[IT_NQ];
-  int hard_n, unres_n;
+  int scan_q[IT_NQ], hard_q[IT_NQ];   // (the scan list's storage is reused for the queries left to brute force)
+  int scan_n, hard_n, unres_n;
   unsigned long long red[IT_BLOCK / GS_WAVE];
 };
-static_assert(IT_RG * LIN_NV <= (IT_BLOCK / 32) * 32 && offsetof(ItLds, sm) % 16 == 0 && offsetof(ItLds, sm) + sizeof(IcpSmall) <= 65536, "LDS copy targets");
+static_assert(IT_RG * LIN_NV <= (IT_BLOCK / 32) * 32 && offsetof(ItLds, sm) % 16 == 0 &&
+              offsetof(ItLds, sm) + sizeof(IcpSmall) <= 65536, "LDS copy targets");
 
 template <bool FULL>
 __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItBatch hb, const float dist_thresh,
@@ -368,7 +440,6 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   IcpSmall& sm = L.sm;
   double* const S = L.S;
   double (*const sub)[32] = L.sub;
-  uint16_t* const cells_s = L.cells;
   float4* const pts_s = L.pts;
   float4* const nrm_s = L.nrm;
   unsigned long long* const keys_s = L.keys;
@@ -376,10 +447,9 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   float (*const qs)[3] = L.qs;
   float (*const qa_s)[8] = L.qa;
   double (*const sub_s)[LIN_NV] = reinterpret_cast<double (*)[LIN_NV]>(L.sub);
+  int* const scan_q = L.scan_q;
   int* const hard_q = L.hard_q;
-  int* const unres_q = L.unres_q;
-  int& hard_n = L.hard_n;
-  int& unres_n = L.unres_n;
+  int* const unres_q = L.scan_q;
   unsigned long long* const red = L.red;
 
   const float* __restrict__ src_in = q.src_in;
@@ -393,34 +463,45 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
 
   IT_STAMP(0);
   const int lane = threadIdx.x & (IT_G - 1), slot = threadIdx.x / IT_G;
-  const int lx = (tile % hb.tiles_x) * IT_TW + slot % IT_TW, ly = (tile / hb.tiles_x) * IT_TH + slot / IT_TW;
+  const int tx0 = (tile % hb.tiles_x) * IT_TW, ty0 = (tile / hb.tiles_x) * IT_TH;
+  const int lx = tx0 + slot % IT_TW, ly = ty0 + slot / IT_TW;
   const bool live = lx < hb.Wl && ly < hb.Hl;
   const int64_t s = (int64_t)ly * hb.Wl + lx;
   const bool bounded = !(FULL && it == 0);  // the first search of a solve has no predecessor
-  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, dprev = __builtin_inff();
+  const GsGrid g = *q.gp;
+  const char* slab = q.slabs + IT_SLAB_BYTES * (size_t)tile;
+  const ItSlabHdr hdr = *reinterpret_cast<const ItSlabHdr*>(slab);
+  const bool local = hdr.mode == 1;
+  // Values that stay in registers across the prologue are kept few (the kernel sits at the 80-VGPR limit of two
+  // workgroups per CU): the list centre / radius (x, y, z, R) is split over the query's two lanes (ca, cb = x, y in
+  // lane 0 and z, R in lane 1, exchanged after the prologue); tiles without a slab keep the previous squared
+  // distance in ca instead.
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, ca = __builtin_inff(), cb = -1.0f;
+  uint32_t lw[3] = {~0u, ~0u, ~0u};
   if (live) {
     p0 = src_in[3 * s];
     p1 = src_in[3 * s + 1];
     p2 = src_in[3 * s + 2];
-    if (bounded) dprev = d2prev[s];
+    if (bounded && local) {
+      const uint32_t* cw = q.cand + 6 * s + 3 * lane;
+      lw[0] = cw[0]; lw[1] = cw[1]; lw[2] = cw[2];
+      const float* cf = reinterpret_cast<const float*>(q.cq + s) + 2 * lane;
+      ca = cf[0]; cb = cf[1];
+    }
+    if (bounded && !local) ca = d2prev[s];
   }
-  const GsGrid g = *q.gp;
-  const char* slab = q.slabs + IT_SLAB_BYTES * (size_t)tile;
-  const ItSlabHdr hdr = *reinterpret_cast<const ItSlabHdr*>(slab);
   // state of the previous half-iteration: 240 bytes, 16 per lane of the second wave, straight into LDS (a register
   // copy would make this wave wait for its loads before the slab and the partial rows are even requested)
   static_assert(sizeof(IcpSmall) % 16 == 0, "state copy");
   if (threadIdx.x >= GS_WAVE && threadIdx.x < GS_WAVE + (int)(sizeof(IcpSmall) / 16))
     it_load_lds16(reinterpret_cast<const float4*>(q.st_in) + (threadIdx.x - GS_WAVE), &sm);
 
-  // the slab: global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + 16 B per lane, no staging
-  // registers), issued now; its latency hides behind the prologue and the next barrier drains it
-  const bool local = hdr.mode == 1;
+  // the slab's points and normals: global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + 16 B per
+  // lane, no staging registers), issued now; the latency hides behind the prologue, the next barrier drains it
   {
-    const int npts = local ? hdr.npts : 0, ncw = local ? (hdr.ncell + 1 + 7) / 8 : 0;  // 16-byte words of the cell table
+    const int npts = local ? hdr.npts : 0;
     const float4* gp4 = reinterpret_cast<const float4*>(slab + IT_OFF_PTS);
     const float4* gn4 = reinterpret_cast<const float4*>(slab + IT_OFF_NRM);
-    const uint4* gc4 = reinterpret_cast<const uint4*>(slab + IT_OFF_CELLS);
     const int wv = threadIdx.x / GS_WAVE, ln = threadIdx.x & (GS_WAVE - 1);
 #pragma unroll
     for (int c0 = 0; c0 < IT_PTS_CAP / GS_WAVE; c0 += IT_BLOCK / GS_WAVE) {
@@ -430,8 +511,6 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
         it_load_lds16(gn4 + i, nrm_s + c * GS_WAVE);
       }
     }
-    if (wv < IT_CELLS_CAP / 8 / GS_WAVE && (int)threadIdx.x < ncw)
-      it_load_lds16(gc4 + threadIdx.x, reinterpret_cast<uint4*>(cells_s) + wv * GS_WAVE);
   }
 
   IT_STAMP(1);
@@ -444,8 +523,7 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
     if (threadIdx.x == 0) {
       if (it > 0)
         icp_update_math((float)e1, sm, prm, (tile == 0 && it - 1 < GS_ICP_MAX_ITERS) ? q.trace + 12 * (it - 1) : nullptr);
-      unres_n = 0;
-      hard_n = 0;
+      L.scan_n = 0; L.unres_n = 0; L.hard_n = 0;
     }
   } else {
     icp_sum_rows<IT_BLOCK, 4>(partials_in, nrows_in, S, sub);
@@ -456,8 +534,7 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (threadIdx.x == 0) {
         icp_solve_finish(S, sm);
-        unres_n = 0;
-        hard_n = 0;
+        L.scan_n = 0; L.unres_n = 0; L.hard_n = 0;
       }
     }
   }
@@ -466,35 +543,48 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
     reinterpret_cast<float*>(q.st_out)[threadIdx.x] = reinterpret_cast<const float*>(&sm)[threadIdx.x];
 
   IT_STAMP(2);
-  // ---- search: one source point per IT_G-lane group, pending transform applied to the loaded point
+  // ---- search, pass 1: one source point per IT_G-lane group, pending transform applied to the loaded point.
+  // Tiles with a slab try the candidate list first; what it cannot prove goes to the scan pass.
   const ItBox box = {hdr.bx0, hdr.by0, hdr.bz0, hdr.nbx, hdr.nby, hdr.nbz};
+  const uint16_t* __restrict__ slab_cells = reinterpret_cast<const uint16_t*>(slab + IT_OFF_CELLS);
   float qx = p0, qy = p0, qz = p0;
   const bool skip = !live || p0 != p0;   // beyond the lattice, or an empty slot (NaN stays NaN, contributes no row)
   if (!skip) {
     const float* T = FULL ? sm.T_step : sm.Tr;
     gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
-    float rball;
-    {
-      float ox = p0, oy = p1, oz = p2;
-      if (FULL) gs_rigid_fma(sm.Tr, p0, p1, p2, ox, oy, oz);
-      const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
-      rball = sqrtf(dprev) + sqrtf(ex * ex + ey * ey + ez * ez);
-    }
-    bool done, served;
-    int win;
-    unsigned long long key;
     if (local) {
-      key = it_stage0<IT_G, true>(g, box, cells_s, pts_s, qx, qy, qz, lane, rball, &done, &served, &win);
-      if (win >= 0) bslot_s[slot] = win;
+      bool proven = false;
+      int win = -1;
+      unsigned long long key = ~0ull;
+      const float oa = __shfl_xor(ca, 1, IT_G), ob = __shfl_xor(cb, 1, IT_G);
+      const float4 c0R = lane == 0 ? make_float4(ca, cb, oa, ob) : make_float4(oa, ob, ca, cb);
+      if (c0R.w > 0.0f) key = it_list_search(lw, c0R, pts_s, qx, qy, qz, &proven, &win);
+      if (proven) {
+        if (win >= 0) bslot_s[slot] = win;
+        if (lane == 0) keys_s[slot] = key;
+      } else if (lane == 0) {
+        scan_q[atomicAdd(&L.scan_n, 1)] = slot;
+      }
     } else {
-      key = it_stage0<IT_G, false>(g, box, cell_start, sorted, qx, qy, qz, lane, rball, &done, &served, &win);
+      // no slab: the global grid, scan bounded by what the previous search found (the previous neighbour is still a
+      // target; the previous query was Tr * p in the look-ahead half resp. p itself in the first half)
+      float rball;
+      {
+        float ox = p0, oy = p1, oz = p2;
+        if (FULL) gs_rigid_fma(sm.Tr, p0, p1, p2, ox, oy, oz);
+        const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
+        rball = sqrtf(ca) + sqrtf(ex * ex + ey * ey + ez * ez);
+      }
+      bool done, served;
+      int win;
+      const unsigned long long key = it_stage0<IT_G, false, false>(g, box, cell_start, sorted, qx, qy, qz, lane, rball,
+                                                                   &done, &served, &win);
       if (win >= 0) bslot_s[slot] = it_global_code(win);
-    }
-    if (lane == 0) {
-      if (key == ~0ull) bslot_s[slot] = -1;
-      keys_s[slot] = key;
-      // bit 31: not served by the slab (the leftover pass starts with the global 2x2x2 stage)
-      if (!done) hard_q[atomicAdd(&hard_n, 1)] = slot | (served ? 0 : (int)0x80000000);
+      if (lane == 0) {
+        if (key == ~0ull) bslot_s[slot] = -1;
+        keys_s[slot] = key;
+        if (!done) hard_q[atomicAdd(&L.hard_n, 1)] = slot;
+      }
     }
   }
   if (lane == 0 && live) {
@@ -503,10 +593,34 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
     if (skip) keys_s[slot] = ~0ull;
   }
   __syncthreads();
-  // ---- leftovers (neighbour farther than ~half a cell, or outside the slab): groups of IT_HG lanes on the global grid
-  const int nh = hard_n;  // block-uniform
   IT_STAMP(3);
-  IT_NOTE(6, nh);
+  // ---- pass 2 (tiles with a slab): the 2x2x2 scan for the queries without a proof, which also writes their new
+  // candidate lists (cells from the slab's table in global memory, candidates from LDS)
+  const int ns = L.scan_n;   // block-uniform
+  for (int i = threadIdx.x / IT_G; i < ns; i += IT_NQ) {
+    const int hs = scan_q[i];
+    const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
+    bool done, served;
+    int win;
+    ItList lst;
+    const unsigned long long key = it_stage0<IT_G, true, true>(g, box, slab_cells, pts_s, hx, hy, hz, lane,
+                                                               __builtin_inff(), &done, &served, &win, &lst);
+    if (win >= 0) bslot_s[hs] = win;
+    const int64_t sh = (int64_t)(ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
+    uint32_t* cw = q.cand + 6 * sh + 3 * lane;
+    cw[0] = lst.w[0]; cw[1] = lst.w[1]; cw[2] = lst.w[2];
+    if (lane == 0) {
+      q.cq[sh] = make_float4(hx, hy, hz, lst.R);
+      if (key == ~0ull) bslot_s[hs] = -1;
+      keys_s[hs] = key;
+      // bit 31: not served by the slab (the leftover pass starts with the global 2x2x2 stage)
+      if (!done) hard_q[atomicAdd(&L.hard_n, 1)] = hs | (served ? 0 : (int)0x80000000);
+    }
+  }
+  if (ns) __syncthreads();
+  IT_STAMP(4);
+  // ---- leftovers (neighbour farther than ~half a cell, or outside the slab): groups of IT_HG lanes on the global grid
+  const int nh = L.hard_n;  // block-uniform
   for (int i = threadIdx.x / IT_HG; i < nh; i += IT_BLOCK / IT_HG) {
     const int e = hard_q[i], hs = e & 0x7fffffff, l16 = threadIdx.x & (IT_HG - 1);
     const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
@@ -514,7 +628,8 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
     bool done = false, served;
     int win;
     if (e < 0) {
-      key = it_stage0<IT_HG, false>(g, box, cell_start, sorted, hx, hy, hz, l16, __builtin_inff(), &done, &served, &win);
+      key = it_stage0<IT_HG, false, false>(g, box, cell_start, sorted, hx, hy, hz, l16, __builtin_inff(), &done, &served,
+                                           &win);
       if (win >= 0) bslot_s[hs] = it_global_code(win);
     }
     if (!done) {
@@ -523,24 +638,24 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
     }
     if (l16 == 0) {
       keys_s[hs] = key;
-      if (!done) unres_q[atomicAdd(&unres_n, 1)] = hs;
+      if (!done) unres_q[atomicAdd(&L.unres_n, 1)] = hs;
     }
   }
   if (nh) __syncthreads();
-  const int nun = unres_n;  // block-uniform
-  IT_NOTE(7, (unsigned long long)nun | ((unsigned long long)hdr.mode << 32) | ((unsigned long long)hdr.npts << 36) |
-                 ((unsigned long long)hdr.ncell << 48));
+  const int nun = L.unres_n;  // block-uniform
+  IT_NOTE(7, (unsigned long long)nun | ((unsigned long long)hdr.mode << 10) | ((unsigned long long)ns << 12) |
+                 ((unsigned long long)nh << 22) | ((unsigned long long)hdr.npts << 32) | ((unsigned long long)hdr.ncell << 44));
   for (int u = 0; u < nun; u += FS_BQ)
     block_brute_min_sorted_multi<IT_BLOCK, FS_BQ>(qs, unres_q + u, nun - u < FS_BQ ? nun - u : FS_BQ, sorted,
                                                   cell_start[g.ncell], keys_s, bslot_s, true);
 
-  IT_STAMP(4);
+  IT_STAMP(5);
   // ---- Gauss-Newton row of every query: its group's first lane reads the match and leaves [a, res] in LDS
   if (lane == 0) {
     float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, res = 0.0f;
     if (!skip) {
       const unsigned long long bb = keys_s[slot];
-      d2prev[s] = __uint_as_float((uint32_t)(bb >> 32));  // NaN bits when nothing was found
+      if (!local) d2prev[s] = __uint_as_float((uint32_t)(bb >> 32));  // NaN bits when nothing was found
       const float d2 = __uint_as_float((uint32_t)(bb >> 32));
       const bool keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
       const int bsl = bslot_s[slot];
@@ -578,7 +693,7 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       for (int w = 1; w < IT_NQ / GS_WAVE; ++w) t += red2[w];
       prow[27] = t;
     }
-    IT_STAMP(5);
+    IT_STAMP(6);
     return;
   }
   // IT_RG groups of 28 threads add the products of IT_RPG queries each, then 28 threads add the sub-sums in order
@@ -598,6 +713,7 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
     for (int k = 1; k < IT_RG; ++k) t += sub_s[k][threadIdx.x];
     prow[threadIdx.x] = t;
   }
+  IT_STAMP(6);
 }
 
 // rows of a large solve added up once per half-iteration (more than FS_REDUCE_ROWS tiles)

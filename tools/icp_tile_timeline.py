@@ -1,6 +1,6 @@
 """Debugging aid: per-block timeline of the two half-iteration launches of the tile engine's last iteration.
 Needs a library built with GRADSLAM_HIP_BUILD_FLAGS=-DGS_ICP_TIMELINE.
-    GRADSLAM_HIP_ICP_TIMELINE=/tmp/tl.txt python tools/icp_tile_timeline.py [B] [H W]"""
+    GRADSLAM_HIP_ICP_TIMELINE=/tmp/tl.txt python tools/icp_tile_timeline.py [B] [H W] [frames]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ import gradslam_amd as gs
 from gradslam_amd.datasets.synthetic import make_sequence
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 H, W = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (480, 640)
-L = 4
+L = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 seqs = [make_sequence(L, H, W, seed=b) for b in range(B)]
 st = lambda k: torch.from_numpy(np.stack([s[k] for s in seqs])).cuda()
 poses = st("poses"); poses[:, 1:] = poses[:, :1]
@@ -22,21 +22,26 @@ torch.cuda.synchronize()
 path = os.environ["GRADSLAM_HIP_ICP_TIMELINE"]
 print(open(path).readline().strip())
 rows = np.loadtxt(path, dtype=np.uint64)
+names = ("issue", "prologue", "lists", "scans", "leftovers", "rows+sums")
+t_first = None
 for half, name in ((0, "full"), (1, "look-ahead")):
     r = rows[rows[:, 0] == half]
-    t = r[:, 2:8].astype(np.float64) / 100.0   # us
+    t = r[:, 2:9].astype(np.float64) / 100.0   # us
     t0 = t[:, 0].min()
+    t_first = t0 if t_first is None else t_first
     ph = np.diff(t, axis=1)
-    mode = ((r[:, 9] >> 32) & 0xf).astype(int)
-    npts = ((r[:, 9] >> 36) & 0xfff).astype(int)
-    ncell = (r[:, 9] >> 48).astype(int)
-    nbrute = (r[:, 9] & 0xffffffff).astype(int)
-    print("%-10s blocks %d  start %.2f..%.2f  end %.2f..%.2f us  life mean %.2f max %.2f" % (
-        name, len(r), (t[:, 0] - t0).min(), (t[:, 0] - t0).max(), (t[:, 5] - t0).min(), (t[:, 5] - t0).max(),
-        (t[:, 5] - t[:, 0]).mean(), (t[:, 5] - t[:, 0]).max()))
-    print("   phases mean / max (us): issue %.2f / %.2f  prologue %.2f / %.2f  search %.2f / %.2f  leftovers %.2f / %.2f  "
-          "rows+sums %.2f / %.2f" % tuple(x for k in range(5) for x in (ph[:, k].mean(), ph[:, k].max())))
-    print("   tiles by mode (0 empty, 1 slab, 2 global): %s   slab targets mean %.0f max %d   cells mean %.0f max %d   "
-          "open after 2x2x2: total %d max %d   brute: %d" % (np.bincount(mode, minlength=3).tolist(), npts[mode == 1].mean() if (mode == 1).any() else 0,
-                                                              npts.max(), ncell[mode == 1].mean() if (mode == 1).any() else 0, ncell.max(),
-                                                              int(r[:, 8].sum()), int(r[:, 8].max()), int(nbrute.sum())))
+    c = r[:, 9]
+    nun, mode, ns, nh = (c & 0x3ff).astype(int), ((c >> 10) & 3).astype(int), ((c >> 12) & 0x3ff).astype(int), ((c >> 22) & 0x3ff).astype(int)
+    npts, ncell = ((c >> 32) & 0xfff).astype(int), (c >> 44).astype(int)
+    print("%-10s blocks %d  launch starts at %.2f us  block start %.2f..%.2f  end %.2f..%.2f (pct 50/90/99: %s)  life mean %.2f max %.2f" % (
+        name, len(r), t0 - t_first, 0.0, (t[:, 0] - t0).max(), (t[:, 6] - t0).min(), (t[:, 6] - t0).max(),
+        np.round(np.percentile(t[:, 6] - t0, [50, 90, 99]), 2).tolist(), (t[:, 6] - t[:, 0]).mean(), (t[:, 6] - t[:, 0]).max()))
+    print("   phases mean / max (us): " + "  ".join("%s %.2f / %.2f" % (names[k], ph[:, k].mean(), ph[:, k].max()) for k in range(6)))
+    m1 = mode == 1
+    print("   tiles by mode (0 empty, 1 slab, 2 global): %s   slab targets mean %.0f max %d   cells mean %.0f max %d" % (
+        np.bincount(mode, minlength=3).tolist(), npts[m1].mean() if m1.any() else 0, npts.max(), ncell[m1].mean() if m1.any() else 0, ncell.max()))
+    print("   queries without a proof (scan pass): total %d  per tile mean %.1f max %d   open after the scan: total %d max %d   brute: %d" % (
+        ns.sum(), ns.mean(), ns.max(), nh.sum(), nh.max(), nun.sum()))
+    worst = np.argsort(-(t[:, 6] - t0))[:6]
+    print("   slowest blocks (block, end, mode, scans, open, phases): " + "; ".join(
+        "%d %.1f m%d s%d o%d [%s]" % (int(r[i, 1]), t[i, 6] - t0, mode[i], ns[i], nh[i], " ".join("%.1f" % x for x in ph[i])) for i in worst))
