@@ -988,21 +988,23 @@ static int64_t loc_lattice(int H, int W, int ds) { return (int64_t)((H + ds - 1)
 // and the reduced row of large solves
 struct ItMem {
   char* slabs;
-  uint32_t* cand;   // candidate lists, 24 bytes per lattice slot
+  uint32_t* cand;   // candidate lists, 16 bytes per lattice slot
   float4* cq;       // list centre + exactness radius, 16 bytes per lattice slot
+  float4* cn;       // normal of the previous match, 16 bytes per lattice slot
   double* partials[2];
   double* rowred;
 };
 static size_t it_row_bytes(int Hl, int Wl) { return gs_align(sizeof(double) * LIN_NV * (size_t)it_tiles(Hl, Wl)); }
 static size_t it_mem_bytes(int Hl, int Wl) {
-  return it_slab_bytes(Hl, Wl) + gs_align(24 * (size_t)Hl * Wl) + gs_align(16 * (size_t)Hl * Wl) + 2 * it_row_bytes(Hl, Wl) + 256;
+  return it_slab_bytes(Hl, Wl) + 3 * gs_align(16 * (size_t)Hl * Wl) + 2 * it_row_bytes(Hl, Wl) + 256;
 }
 static ItMem it_carve(void* base, int Hl, int Wl) {
   char* p = reinterpret_cast<char*>(base);
   ItMem m;
   m.slabs = p; p += it_slab_bytes(Hl, Wl);
-  m.cand = reinterpret_cast<uint32_t*>(p); p += gs_align(24 * (size_t)Hl * Wl);
+  m.cand = reinterpret_cast<uint32_t*>(p); p += gs_align(16 * (size_t)Hl * Wl);
   m.cq = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)Hl * Wl);
+  m.cn = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)Hl * Wl);
   for (int k = 0; k < 2; ++k) { m.partials[k] = reinterpret_cast<double*>(p); p += it_row_bytes(Hl, Wl); }
   m.rowred = reinterpret_cast<double*>(p);
   return m;
@@ -1059,7 +1061,7 @@ static int localize_tiles(const gs_localize_seq* seqs, int B, int Hl, int Wl, co
       float* cur = (it & 1) ? sc[b].srcB : sc[b].srcA;
       hb.s[b] = ItSeq{cur_in, cur, q.map.points, q.map.normals, GsCount{q.map.n_bound, q.map.n_dev}, gm[b].g,
                       gm[b].cell_start, gm[b].sorted, gm[b].sorted_n, im[b].slabs, reinterpret_cast<float*>(sc[b].best),
-                      im[b].cand, im[b].cq, im[b].partials[(h + 1) & 1], im[b].partials[h & 1], &sc[b].state->s[h & 1],
+                      im[b].cand, im[b].cq, im[b].cn, im[b].partials[(h + 1) & 1], im[b].partials[h & 1], &sc[b].state->s[h & 1],
                       &sc[b].state->s[(h + 1) & 1], sc[b].state->trace};
     }
 #ifdef GS_ICP_TIMELINE

@@ -28,12 +28,13 @@ constexpr int IT_TW = 16, IT_TH = 24;        // lattice tile of one workgroup
 constexpr int IT_NQ = IT_TW * IT_TH;         // 384 queries
 constexpr int IT_G = 2;                      // lanes per query
 constexpr int IT_BLOCK = IT_NQ * IT_G;       // 768 threads, 2 workgroups per CU
-constexpr int IT_PTS_CAP = 1408;             // binned targets a slab can hold (LDS: 32 bytes each)
+constexpr int IT_PTS_CAP = 2560;             // binned targets a slab can hold (LDS: 16 bytes each, the points; the normals stay in global memory)
 constexpr int IT_CELLS_CAP = 16384;          // entries of a slab's cell table (cells + 1 end sentinel; global memory only)
 constexpr int IT_ROWS_CAP = 2048;            // (z, y) rows of a slab's box
 constexpr int IT_MARGIN = 2;                 // cells added around the tile's query cells (1 for the 2x2x2 block + 1 of motion)
 constexpr int IT_RG = 24, IT_RPG = IT_NQ / IT_RG;  // row groups of the tile sum x queries per group
 constexpr int IT_HG = 16;                    // lanes per query of the leftover searches
+constexpr int IT_LOCAL_RINGS = 3;            // cube radius the leftover searches go to on the slab before the global grid
 static_assert(IT_RG * LIN_NV <= IT_BLOCK && IT_NQ % IT_RG == 0, "tile sum shape");
 static_assert(IT_CELLS_CAP * 2 % 64 == 0 && IT_PTS_CAP % GS_WAVE == 0 && IT_PTS_CAP < 0xffff, "slab shape");
 
@@ -207,8 +208,9 @@ struct ItSeq {
   const float4* sorted_n;
   const char* slabs;
   float* d2prev;             // tiles without a slab: squared distance of every query's previous neighbour (search bound)
-  uint32_t* cand;            // [n_lat][6] candidate lists: 2 lanes x 6 slab slots (16 bit each, 0xffff = none)
+  uint32_t* cand;            // [n_lat][4] candidate lists: 2 lanes x 4 slab slots (16 bit each, 0xffff = none)
   float4* cq;                // [n_lat] (query position the list was built at, exactness radius R; R <= 0: no list)
+  float4* cn;                // [n_lat] normal of the previous match (x, y, z, slab slot bits)
   const double* partials_in;
   double* partials_out;
   const IcpSmall* st_in;
@@ -241,11 +243,12 @@ struct ItBox {
 // outside by the block's face bound), so a later query position q with |q - q0| = delta has its exact nearest
 // neighbour on the list whenever the best list entry is closer than R - delta (it_list_search).
 struct ItList {
-  uint32_t w[3];   // six 16-bit slots, appended from the low end; 0xffff = empty
+  uint32_t w[2];   // four 16-bit slots, appended from the low end; 0xffff = empty
   float R;
 };
-constexpr int IT_LIST_LANE = 6;
-constexpr float IT_RADD = 0.25f;   // R = (distance of the nearest neighbour) + IT_RADD cells, at most the block's bound
+constexpr int IT_LIST_LANE = 4;
+constexpr float IT_RADD = 0.15f;   // R = (distance of the nearest neighbour) + IT_RADD cells, at most the block's bound;
+                                   // halved (up to 3 times) while a lane's share of the list does not fit
 
 // grid_search_stage0 (gs_knn.h) on either the global grid (LOCAL = false; cells = cell_start, pts = sorted) or a
 // tile's slab (LOCAL = true; cells = the slab's 16-bit cell table, pts = its points in LDS, box = the slab's box): same
@@ -278,7 +281,7 @@ GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT*
     uly = ty - rc < 1.0f; uhy = ty + rc >= 1.0f;
     ulz = tz - rc < 1.0f; uhz = tz + rc >= 1.0f;
   }
-  if (EMIT) { lst->w[0] = lst->w[1] = lst->w[2] = ~0u; lst->R = -1.0f; }
+  if (EMIT) { lst->w[0] = lst->w[1] = ~0u; lst->R = -1.0f; }
   int sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, e1 = 0, e2 = 0, e3 = 0, total = 0;
   {
     const int xa = (x0 >= 0 && ulx) ? x0 : x0 + 1, xb = (x0 + 1 < g.nx && uhx) ? x0 + 1 : x0;
@@ -344,29 +347,34 @@ GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT*
   *resolved = prune ? (bd == bd) : (rb > 0.0f && (rb >= 1.0e30f ? bd == bd : bd <= rb * rb));
   if (EMIT) {
     if (*resolved) {   // (the same for all lanes of the group)
-      float R = sqrtf(bd) + IT_RADD * g.c;
-      R = R < rb ? R : rb;
-      const float R2 = R * R;
-      uint32_t w0 = ~0u, w1 = ~0u, w2 = ~0u;
-      int cnt = 0;
-      for (int t = lane; t < total; t += G) {
-        const int ix = t < e1 ? sb0 + t : (t < e2 ? sb1 + (t - e1) : (t < e3 ? sb2 + (t - e2) : sb3 + (t - e3)));
-        const float4 c = pts[ix];
-        const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-        float d = dx * dx;
-        d = gs_fma(dy, dy, d);
-        d = gs_fma(dz, dz, d);
-        if (d < R2) {   // a NaN distance is never a neighbour
-          w2 = (w2 << 16) | (w1 >> 16);
-          w1 = (w1 << 16) | (w0 >> 16);
-          w0 = (w0 << 16) | (uint32_t)ix;
-          ++cnt;
+      const float d1 = sqrtf(bd);
+      float radd = IT_RADD * g.c;
+      for (int attempt = 0; attempt < 4; ++attempt, radd *= 0.5f) {
+        float R = d1 + radd;
+        R = R < rb ? R : rb;
+        const float R2 = R * R;
+        uint32_t w0 = ~0u, w1 = ~0u;
+        int cnt = 0;
+        for (int t = lane; t < total; t += G) {
+          const int ix = t < e1 ? sb0 + t : (t < e2 ? sb1 + (t - e1) : (t < e3 ? sb2 + (t - e2) : sb3 + (t - e3)));
+          const float4 c = pts[ix];
+          const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+          float d = dx * dx;
+          d = gs_fma(dy, dy, d);
+          d = gs_fma(dz, dz, d);
+          if (d < R2) {   // a NaN distance is never a neighbour
+            w1 = (w1 << 16) | (w0 >> 16);
+            w0 = (w0 << 16) | (uint32_t)ix;
+            ++cnt;
+          }
+        }
+        const int over = cnt > IT_LIST_LANE ? 1 : 0;
+        if ((over | __shfl_xor(over, 1, G)) == 0) {
+          lst->w[0] = w0; lst->w[1] = w1;
+          lst->R = R;
+          break;
         }
       }
-      const int over = cnt > IT_LIST_LANE ? 1 : 0;
-      const bool any_over = (over | __shfl_xor(over, 1, G)) != 0;
-      lst->w[0] = w0; lst->w[1] = w1; lst->w[2] = w2;
-      lst->R = any_over ? -1.0f : R;
     }
   }
   return key;
@@ -398,6 +406,110 @@ GS_DEV unsigned long long it_list_search(const uint32_t* w, const float4 c0R, co
   return kmin;
 }
 
+// Cubes of Chebyshev radius 1 .. kmax around the query's cell, on a tile's slab (grid_search_rings of gs_knn.h on the
+// slab's cell table and LDS points): serves the queries whose neighbour is farther than the 2x2x2 stage can prove,
+// as long as the cube stays inside the slab's box (*inbox = false otherwise: the caller goes to the global grid).
+// *kdone = radius of the last cube scanned completely.
+template <int G>
+GS_DEV unsigned long long it_rings_local(const GsGrid& g, const ItBox& box, const uint16_t* __restrict__ cells,
+                                         const float4* __restrict__ pts, float qx, float qy, float qz, int lane,
+                                         unsigned long long key, const int kmax, bool* resolved, bool* inbox, int* win,
+                                         int* kdone) {
+  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
+  bool done = false;
+  int bs = -1, k = 1;
+  *inbox = true;
+  *kdone = 0;
+  for (; k <= kmax && !done; ++k) {
+    const int xa = qc.cx - k < 0 ? 0 : qc.cx - k, xb = qc.cx + k >= g.nx ? g.nx - 1 : qc.cx + k;
+    const int ya = qc.cy - k < 0 ? 0 : qc.cy - k, yb = qc.cy + k >= g.ny ? g.ny - 1 : qc.cy + k;
+    const int za = qc.cz - k < 0 ? 0 : qc.cz - k, zb = qc.cz + k >= g.nz ? g.nz - 1 : qc.cz + k;
+    if (xa < box.x0 || xb >= box.x0 + box.nx || ya < box.y0 || yb >= box.y0 + box.ny || za < box.z0 || zb >= box.z0 + box.nz) {
+      *inbox = false;
+      break;
+    }
+    const int side = 2 * k + 1, nrow = side * side;
+    for (int r = lane; r < nrow; r += G) {
+      const int zz = qc.cz + r / side - k, yy = qc.cy + r % side - k;
+      if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
+      const int row = ((zz - box.z0) * box.ny + (yy - box.y0)) * box.nx - box.x0;
+      const int je = (int)cells[row + xb + 1];
+      for (int j = (int)cells[row + xa]; j < je; ++j) {
+        const unsigned long long k2 = grid_key(qx, qy, qz, pts[j]);
+        if (k2 < key) { key = k2; bs = j; }
+      }
+    }
+    {
+      const unsigned long long own = key;
+      key = grid_group_min<G>(key);
+      if (own != key) bs = -1;
+    }
+    const float rb = (float)k * g.c * 0.999f;
+    const float bd = __uint_as_float((uint32_t)(key >> 32));
+    done = bd <= rb * rb;
+    *kdone = k;
+  }
+  *resolved = done;
+  *win = bs;
+  return key;
+}
+
+// Candidate list of a query served by it_rings_local: every slab target closer than R = min(d1 + radd, 0.999 kE cells)
+// to the query, kE = the largest cube (<= kdone + 1) inside the box; up to 8 entries, collected by the G lanes into
+// `stage` (8 x 16 bit + a counter, LDS).  Returns R, or -1 when no radius down to d1 + radd / 8 gives a list that fits.
+template <int G>
+GS_DEV float it_emit_cube(const GsGrid& g, const ItBox& box, const uint16_t* __restrict__ cells,
+                          const float4* __restrict__ pts, float qx, float qy, float qz, int lane, const float d1,
+                          const int kdone, uint16_t* stage, int* stage_n) {
+  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
+  int kE = kdone + 1;
+  for (; kE > kdone; --kE) {   // kdone itself is inside the box (it was scanned)
+    const int xa = qc.cx - kE < 0 ? 0 : qc.cx - kE, xb = qc.cx + kE >= g.nx ? g.nx - 1 : qc.cx + kE;
+    const int ya = qc.cy - kE < 0 ? 0 : qc.cy - kE, yb = qc.cy + kE >= g.ny ? g.ny - 1 : qc.cy + kE;
+    const int za = qc.cz - kE < 0 ? 0 : qc.cz - kE, zb = qc.cz + kE >= g.nz ? g.nz - 1 : qc.cz + kE;
+    if (!(xa < box.x0 || xb >= box.x0 + box.nx || ya < box.y0 || yb >= box.y0 + box.ny || za < box.z0 || zb >= box.z0 + box.nz)) break;
+  }
+  const int xa = qc.cx - kE < 0 ? 0 : qc.cx - kE, xb = qc.cx + kE >= g.nx ? g.nx - 1 : qc.cx + kE;
+  const int side = 2 * kE + 1, nrow = side * side;
+  const float rcube = (float)kE * g.c * 0.999f;
+  float radd = IT_RADD * g.c, R = -1.0f;
+  for (int attempt = 0; attempt < 4; ++attempt, radd *= 0.5f) {
+    float Rt = d1 + radd;
+    Rt = Rt < rcube ? Rt : rcube;
+    const float R2 = Rt * Rt;
+    if (lane == 0) {
+      *stage_n = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) stage[u] = 0xffffu;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int r = lane; r < nrow; r += G) {
+      const int zz = qc.cz + r / side - kE, yy = qc.cy + r % side - kE;
+      if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
+      const int row = ((zz - box.z0) * box.ny + (yy - box.y0)) * box.nx - box.x0;
+      const int je = (int)cells[row + xb + 1];
+      for (int j = (int)cells[row + xa]; j < je; ++j) {
+        const float4 c = pts[j];
+        const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+        float d = dx * dx;
+        d = gs_fma(dy, dy, d);
+        d = gs_fma(dz, dz, d);
+        if (d < R2) {
+          const int pos = atomicAdd(stage_n, 1);
+          if (pos < 8) stage[pos] = (uint16_t)j;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n = *stage_n;   // the same for all lanes of the group (same wave: LDS accesses are ordered)
+    __builtin_amdgcn_wave_barrier();
+    if (n <= 8) { R = Rt; break; }
+  }
+  return R;
+}
+
 // 16 bytes per lane from global memory straight into LDS: lane l of the wave lands at lds_wave_base + 16 l (the LDS
 // base must be wave-uniform; disabled lanes load nothing)
 GS_DEV void it_load_lds16(const void* g, void* lds_wave_base) {
@@ -410,14 +522,14 @@ GS_DEV int it_global_code(int slot) { return -2 - slot; }
 
 struct ItLds {
   float4 pts[IT_PTS_CAP];          // slab: binned target points of the tile's box (x, y, z, map row bits)
-  float4 nrm[IT_PTS_CAP];          //       their normals
+  float4 nspec[IT_NQ];             // normal of every query's previous match (x, y, z, slab slot bits)
   IcpSmall sm;                     // solver state
   double S[32];
   double sub[IT_BLOCK / 32][32];   // prologue: chunk sums of the partial rows; epilogue: the row groups' sub-sums
   unsigned long long keys[IT_NQ];  // best (distance bits, map row) of every query
   int bslot[IT_NQ];                // where its point / normal sit (slot codes above)
   float qs[IT_NQ][3];              // transformed queries
-  float qa[IT_NQ][8];              // a0..a5, residual of every query (zero when filtered out)
+  alignas(16) float qa[IT_NQ][8];  // a0..a5, residual of every query (zero when filtered out)
   int scan_q[IT_NQ], hard_q[IT_NQ];   // (the scan list's storage is reused for the queries left to brute force)
   int scan_n, hard_n, unres_n;
   unsigned long long red[IT_BLOCK / GS_WAVE];
@@ -441,7 +553,7 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   double* const S = L.S;
   double (*const sub)[32] = L.sub;
   float4* const pts_s = L.pts;
-  float4* const nrm_s = L.nrm;
+  float4* const nspec_s = L.nspec;
   unsigned long long* const keys_s = L.keys;
   int* const bslot_s = L.bslot;
   float (*const qs)[3] = L.qs;
@@ -477,14 +589,14 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   // lane 0 and z, R in lane 1, exchanged after the prologue); tiles without a slab keep the previous squared
   // distance in ca instead.
   float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, ca = __builtin_inff(), cb = -1.0f;
-  uint32_t lw[3] = {~0u, ~0u, ~0u};
+  uint32_t lw[2] = {~0u, ~0u};
   if (live) {
     p0 = src_in[3 * s];
     p1 = src_in[3 * s + 1];
     p2 = src_in[3 * s + 2];
     if (bounded && local) {
-      const uint32_t* cw = q.cand + 6 * s + 3 * lane;
-      lw[0] = cw[0]; lw[1] = cw[1]; lw[2] = cw[2];
+      const uint32_t* cw = q.cand + 4 * s + 2 * lane;
+      lw[0] = cw[0]; lw[1] = cw[1];
       const float* cf = reinterpret_cast<const float*>(q.cq + s) + 2 * lane;
       ca = cf[0]; cb = cf[1];
     }
@@ -496,20 +608,22 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   if (threadIdx.x >= GS_WAVE && threadIdx.x < GS_WAVE + (int)(sizeof(IcpSmall) / 16))
     it_load_lds16(reinterpret_cast<const float4*>(q.st_in) + (threadIdx.x - GS_WAVE), &sm);
 
-  // the slab's points and normals: global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + 16 B per
-  // lane, no staging registers), issued now; the latency hides behind the prologue, the next barrier drains it
+  // the slab's points: global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + 16 B per lane, no
+  // staging registers), issued now; the latency hides behind the prologue, the next barrier drains it.  Likewise the
+  // normal of every query's previous match (thread t fetches query t's): the match rarely changes between searches,
+  // so the Gauss-Newton rows seldom have to wait for a gather from the slab's normals (which stay in global memory).
   {
     const int npts = local ? hdr.npts : 0;
     const float4* gp4 = reinterpret_cast<const float4*>(slab + IT_OFF_PTS);
-    const float4* gn4 = reinterpret_cast<const float4*>(slab + IT_OFF_NRM);
     const int wv = threadIdx.x / GS_WAVE, ln = threadIdx.x & (GS_WAVE - 1);
 #pragma unroll
     for (int c0 = 0; c0 < IT_PTS_CAP / GS_WAVE; c0 += IT_BLOCK / GS_WAVE) {
       const int c = c0 + wv, i = c * GS_WAVE + ln;   // chunk c = slots [64 c, 64 c + 64)
-      if (c < IT_PTS_CAP / GS_WAVE && i < npts) {
-        it_load_lds16(gp4 + i, pts_s + c * GS_WAVE);
-        it_load_lds16(gn4 + i, nrm_s + c * GS_WAVE);
-      }
+      if (c < IT_PTS_CAP / GS_WAVE && i < npts) it_load_lds16(gp4 + i, pts_s + c * GS_WAVE);
+    }
+    if (bounded && local && threadIdx.x < IT_NQ) {
+      const int tlx = tx0 + (int)threadIdx.x % IT_TW, tly = ty0 + (int)threadIdx.x / IT_TW;
+      if (tlx < hb.Wl && tly < hb.Hl) it_load_lds16(q.cn + ((int64_t)tly * hb.Wl + tlx), nspec_s + wv * GS_WAVE);
     }
   }
 
@@ -607,8 +721,8 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
                                                                __builtin_inff(), &done, &served, &win, &lst);
     if (win >= 0) bslot_s[hs] = win;
     const int64_t sh = (int64_t)(ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
-    uint32_t* cw = q.cand + 6 * sh + 3 * lane;
-    cw[0] = lst.w[0]; cw[1] = lst.w[1]; cw[2] = lst.w[2];
+    uint32_t* cw = q.cand + 4 * sh + 2 * lane;
+    cw[0] = lst.w[0]; cw[1] = lst.w[1];
     if (lane == 0) {
       q.cq[sh] = make_float4(hx, hy, hz, lst.R);
       if (key == ~0ull) bslot_s[hs] = -1;
@@ -631,6 +745,24 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       key = it_stage0<IT_HG, false, false>(g, box, cell_start, sorted, hx, hy, hz, l16, __builtin_inff(), &done, &served,
                                            &win);
       if (win >= 0) bslot_s[hs] = it_global_code(win);
+    } else if (local) {
+      // cubes on the slab; a query they serve gets a candidate list like any other, so that it costs a scan only once
+      bool inbox;
+      int kdone;
+      key = it_rings_local<IT_HG>(g, box, slab_cells, pts_s, hx, hy, hz, l16, key, IT_LOCAL_RINGS, &done, &inbox, &win,
+                                  &kdone);
+      if (win >= 0) bslot_s[hs] = win;
+      if (done) {
+        uint16_t* stage = reinterpret_cast<uint16_t*>(qa_s[hs]);   // (the rows are built after this pass)
+        int* stage_n = reinterpret_cast<int*>(&qa_s[hs][4]);
+        const float R = it_emit_cube<IT_HG>(g, box, slab_cells, pts_s, hx, hy, hz, l16,
+                                            sqrtf(__uint_as_float((uint32_t)(key >> 32))), kdone, stage, stage_n);
+        if (l16 == 0) {
+          const int64_t sh = (int64_t)(ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
+          *reinterpret_cast<uint4*>(q.cand + 4 * sh) = *reinterpret_cast<const uint4*>(stage);
+          q.cq[sh] = make_float4(hx, hy, hz, R);
+        }
+      }
     }
     if (!done) {
       key = grid_search_rings<IT_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS);
@@ -660,11 +792,19 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       const bool keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
       const int bsl = bslot_s[slot];
       if (bb != ~0ull && bsl >= 0) {
-        gn_row_pn(qs[slot][0], qs[slot][1], qs[slot][2], pts_s[bsl], nrm_s[bsl], a, res);
+        float4 nn = nspec_s[slot];
+        if (!bounded || __float_as_int(nn.w) != bsl) {   // the match changed (or the first search of the solve)
+          nn = reinterpret_cast<const float4*>(slab + IT_OFF_NRM)[bsl];
+          nn.w = __int_as_float(bsl);
+          q.cn[s] = nn;
+        }
+        gn_row_pn(qs[slot][0], qs[slot][1], qs[slot][2], pts_s[bsl], nn, a, res);
       } else if (bb != ~0ull && bsl <= -2) {
         gn_row_pn(qs[slot][0], qs[slot][1], qs[slot][2], sorted[-2 - bsl], sorted_n[-2 - bsl], a, res);
+        if (!bounded && local) q.cn[s] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));  // (nothing of an earlier frame)
       } else {  // every distance was NaN / no target at all: row 0 of the target array, as the brute-force engine
         gn_row(qs[slot][0], qs[slot][1], qs[slot][2], q.tgt, q.tn, 0, a, res);
+        if (!bounded && local) q.cn[s] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
       }
       if (!keep) {
 #pragma unroll
