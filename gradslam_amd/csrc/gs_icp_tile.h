@@ -33,6 +33,7 @@ constexpr int IT_CELLS_CAP = 16384;          // entries of a slab's cell table (
 constexpr int IT_ROWS_CAP = 2048;            // (z, y) rows of a slab's box
 constexpr int IT_MARGIN = 2;                 // cells added around the tile's query cells (1 for the 2x2x2 block + 1 of motion)
 constexpr int IT_RG = 24, IT_RPG = IT_NQ / IT_RG;  // row groups of the tile sum x queries per group
+constexpr int IT_PTS_EARLY = 1024;           // slab slots requested before the slab header has arrived
 constexpr int IT_HG = 16;                    // lanes per query of the leftover searches
 constexpr int IT_LOCAL_RINGS = 3;            // cube radius the leftover searches go to on the slab before the global grid
 static_assert(IT_RG * LIN_NV <= IT_BLOCK && IT_NQ % IT_RG == 0, "tile sum shape");
@@ -281,7 +282,7 @@ GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT*
     uly = ty - rc < 1.0f; uhy = ty + rc >= 1.0f;
     ulz = tz - rc < 1.0f; uhz = tz + rc >= 1.0f;
   }
-  if (EMIT) { lst->w[0] = lst->w[1] = ~0u; lst->R = -1.0f; }
+  if (EMIT) { lst->w[0] = lst->w[1] = ~0u; lst->R = 0.0f; }
   int sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, e1 = 0, e2 = 0, e3 = 0, total = 0;
   {
     const int xa = (x0 >= 0 && ulx) ? x0 : x0 + 1, xb = (x0 + 1 < g.nx && uhx) ? x0 + 1 : x0;
@@ -456,7 +457,7 @@ GS_DEV unsigned long long it_rings_local(const GsGrid& g, const ItBox& box, cons
 
 // Candidate list of a query served by it_rings_local: every slab target closer than R = min(d1 + radd, 0.999 kE cells)
 // to the query, kE = the largest cube (<= kdone + 1) inside the box; up to 8 entries, collected by the G lanes into
-// `stage` (8 x 16 bit + a counter, LDS).  Returns R, or -1 when no radius down to d1 + radd / 8 gives a list that fits.
+// `stage` (8 x 16 bit + a counter, LDS).  Returns R, or 0 when no radius down to d1 + radd / 8 gives a list that fits.
 template <int G>
 GS_DEV float it_emit_cube(const GsGrid& g, const ItBox& box, const uint16_t* __restrict__ cells,
                           const float4* __restrict__ pts, float qx, float qy, float qz, int lane, const float d1,
@@ -472,7 +473,7 @@ GS_DEV float it_emit_cube(const GsGrid& g, const ItBox& box, const uint16_t* __r
   const int xa = qc.cx - kE < 0 ? 0 : qc.cx - kE, xb = qc.cx + kE >= g.nx ? g.nx - 1 : qc.cx + kE;
   const int side = 2 * kE + 1, nrow = side * side;
   const float rcube = (float)kE * g.c * 0.999f;
-  float radd = IT_RADD * g.c, R = -1.0f;
+  float radd = IT_RADD * g.c, R = 0.0f;
   for (int attempt = 0; attempt < 4; ++attempt, radd *= 0.5f) {
     float Rt = d1 + radd;
     Rt = Rt < rcube ? Rt : rcube;
@@ -510,11 +511,135 @@ GS_DEV float it_emit_cube(const GsGrid& g, const ItBox& box, const uint16_t* __r
   return R;
 }
 
+// The same on the GLOBAL grid, for a query served by grid_search_rings (cube of radius kdone scanned): up to 4 global
+// slots (32 bit) collected into `stage`; R = min(d1 + radd, 0.999 kdone cells).  Returns R or 0 (no list).
+template <int G>
+GS_DEV float it_emit_cube_global(const GsGrid& g, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                 float qx, float qy, float qz, int lane, const float d1, const int kdone,
+                                 uint32_t* stage, int* stage_n) {
+  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
+  const int xa = qc.cx - kdone < 0 ? 0 : qc.cx - kdone, xb = qc.cx + kdone >= g.nx ? g.nx - 1 : qc.cx + kdone;
+  const int side = 2 * kdone + 1, nrow = side * side;
+  const float rcube = (float)kdone * g.c * 0.999f;
+  float radd = IT_RADD * g.c, R = 0.0f;
+  for (int attempt = 0; attempt < 4; ++attempt, radd *= 0.5f) {
+    float Rt = d1 + radd;
+    Rt = Rt < rcube ? Rt : rcube;
+    const float R2 = Rt * Rt;
+    if (lane == 0) {
+      *stage_n = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) stage[u] = ~0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int r = lane; r < nrow; r += G) {
+      const int zz = qc.cz + r / side - kdone, yy = qc.cy + r % side - kdone;
+      if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
+      const int row = (zz * g.ny + yy) * g.nx;
+      const int je = cell_start[row + xb + 1];
+      for (int j = cell_start[row + xa]; j < je; ++j) {
+        const float4 c = sorted[j];
+        const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+        float d = dx * dx;
+        d = gs_fma(dy, dy, d);
+        d = gs_fma(dz, dz, d);
+        if (d < R2) {
+          const int pos = atomicAdd(stage_n, 1);
+          if (pos < 4) stage[pos] = (uint32_t)j;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n = *stage_n;
+    __builtin_amdgcn_wave_barrier();
+    if (n <= 4) { R = Rt; break; }
+  }
+  return R;
+}
+
+// it_list_search for a list of global slots (2 per lane, 0xffffffff = none): candidates gathered from `sorted`.
+GS_DEV unsigned long long it_list_search_global(const uint32_t* w, const float4 c0R, const float4* __restrict__ sorted,
+                                                float qx, float qy, float qz, bool* proven, int* win) {
+  const bool in0 = w[0] != ~0u, in1 = w[1] != ~0u;
+  const float4 a = sorted[in0 ? w[0] : 0u], b = sorted[in1 ? w[1] : 0u];
+  const unsigned long long k0 = in0 ? grid_key(qx, qy, qz, a) : ~0ull, k1 = in1 ? grid_key(qx, qy, qz, b) : ~0ull;
+  const unsigned long long key = k1 < k0 ? k1 : k0;
+  const int bs = k1 < k0 ? (int)w[1] : (k0 != ~0ull ? (int)w[0] : -1);
+  const unsigned long long kmin = grid_group_min<2>(key);
+  *win = (key == kmin && bs >= 0) ? bs : -1;
+  const float bd = __uint_as_float((uint32_t)(kmin >> 32));
+  const float ex = qx - c0R.x, ey = qy - c0R.y, ez = qz - c0R.z;
+  const float delta = sqrtf(ex * ex + ey * ey + ez * ez);
+  *proven = sqrtf(bd) + delta < -c0R.w * 0.9999f;
+  return kmin;
+}
+
 // 16 bytes per lane from global memory straight into LDS: lane l of the wave lands at lds_wave_base + 16 l (the LDS
 // base must be wave-uniform; disabled lanes load nothing)
 GS_DEV void it_load_lds16(const void* g, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// icp_sum_rows<IT_BLOCK, IT_CH> / icp_sum_col27<IT_BLOCK> (gs_icp_loop.hip) in two steps, so that the loads of the first
+// round are requested at the very start of the kernel, before anything that waits for the slab header: same values
+// added in the same order.
+constexpr int IT_CH = 4;
+GS_DEV void it_rows_first(const double* __restrict__ partials, int nrows, double* a) {
+  // branch-free (clamped addresses, every lane loads): a load under a branch makes the compiler wait for it at the
+  // join, which would stall the requests that follow
+  const int i = (threadIdx.x & 31) < LIN_NV ? (threadIdx.x & 31) : LIN_NV - 1, j = threadIdx.x >> 5;
+#pragma unroll
+  for (int u = 0; u < IT_CH; ++u) {
+    const int b = j * IT_CH + u;
+    a[u] = partials[(int64_t)(b < nrows ? b : nrows - 1) * LIN_NV + i];
+  }
+}
+GS_DEV void it_rows_finish(const double* __restrict__ partials, int nrows, const double* a0, double* S, double (*sub)[32]) {
+  constexpr int STEP = IT_BLOCK / 32;
+  const int i = threadIdx.x & 31, j = threadIdx.x >> 5;
+  double s = 0.0;
+  if (i < LIN_NV) {
+    if (j * IT_CH < nrows) {
+#pragma unroll
+      for (int u = 0; u < IT_CH; ++u) s += (j * IT_CH + u < nrows) ? a0[u] : 0.0;
+    }
+    for (int b = j * IT_CH + IT_CH * STEP; b < nrows; b += IT_CH * STEP) {
+      const double* base = partials + (int64_t)b * LIN_NV + i;
+      const int left = nrows - b;
+      double a[IT_CH];
+#pragma unroll
+      for (int u = 0; u < IT_CH; ++u) a[u] = (u < left) ? base[u * LIN_NV] : 0.0;
+#pragma unroll
+      for (int u = 0; u < IT_CH; ++u) s += a[u];
+    }
+  }
+  sub[j][i] = s;
+  __syncthreads();
+  if (threadIdx.x < LIN_NV) {
+    double t = 0.0;
+    for (int k = 0; k < STEP; ++k) t += sub[k][threadIdx.x];
+    S[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+GS_DEV double it_col27_first(const double* __restrict__ partials, int nrows) {
+  const int b = (int)threadIdx.x < nrows ? (int)threadIdx.x : nrows - 1;   // (branch-free, see it_rows_first)
+  return partials[(int64_t)b * LIN_NV + 27];
+}
+GS_DEV double it_col27_finish(const double* __restrict__ partials, int nrows, const double first, double* red) {
+  double s = 0.0;
+  if ((int)threadIdx.x < nrows) s += first;
+  for (int b = threadIdx.x + IT_BLOCK; b < nrows; b += IT_BLOCK) s += partials[(int64_t)b * LIN_NV + 27];
+  s = gs_wave_sum_f64(s);
+  if ((threadIdx.x & (GS_WAVE - 1)) == 0) red[threadIdx.x / GS_WAVE] = s;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < IT_BLOCK / GS_WAVE; ++w) t += red[w];
+  __syncthreads();
+  return t;
 }
 
 // slot codes in bslot_s: >= 0 slot in the LDS slab, <= -2 global slot -2 - code, -1 none
@@ -578,61 +703,78 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   const int tx0 = (tile % hb.tiles_x) * IT_TW, ty0 = (tile / hb.tiles_x) * IT_TH;
   const int lx = tx0 + slot % IT_TW, ly = ty0 + slot / IT_TW;
   const bool live = lx < hb.Wl && ly < hb.Hl;
-  const int64_t s = (int64_t)ly * hb.Wl + lx;
+  const int s = ly * hb.Wl + lx;   // (32-bit on purpose: registers)
   const bool bounded = !(FULL && it == 0);  // the first search of a solve has no predecessor
-  const GsGrid g = *q.gp;
+  const int wv = threadIdx.x / GS_WAVE, ln = threadIdx.x & (GS_WAVE - 1);
   const char* slab = q.slabs + IT_SLAB_BYTES * (size_t)tile;
+  const float4* gp4 = reinterpret_cast<const float4*>(slab + IT_OFF_PTS);
+  const int nrows_in = rows_in_reduced ? 1 : hb.ntiles;
+  const GsGrid g = *q.gp;
   const ItSlabHdr hdr = *reinterpret_cast<const ItSlabHdr*>(slab);
   const bool local = hdr.mode == 1;
+
+  // ---- (1) everything that does not depend on the slab header is requested first.
   // Values that stay in registers across the prologue are kept few (the kernel sits at the 80-VGPR limit of two
   // workgroups per CU): the list centre / radius (x, y, z, R) is split over the query's two lanes (ca, cb = x, y in
-  // lane 0 and z, R in lane 1, exchanged after the prologue); tiles without a slab keep the previous squared
-  // distance in ca instead.
-  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, ca = __builtin_inff(), cb = -1.0f;
+  // lane 0 and z, R in lane 1, exchanged after the prologue).
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, ca = __builtin_inff(), cb = 0.0f;
   uint32_t lw[2] = {~0u, ~0u};
   if (live) {
     p0 = src_in[3 * s];
     p1 = src_in[3 * s + 1];
     p2 = src_in[3 * s + 2];
-    if (bounded && local) {
+    if (bounded) {
       const uint32_t* cw = q.cand + 4 * s + 2 * lane;
       lw[0] = cw[0]; lw[1] = cw[1];
       const float* cf = reinterpret_cast<const float*>(q.cq + s) + 2 * lane;
       ca = cf[0]; cb = cf[1];
     }
-    if (bounded && !local) ca = d2prev[s];
+  }
+  // partial rows of the previous half-iteration (first round of the sums below)
+  double rows0[IT_CH], col0 = 0.0;
+  if (FULL) {
+    if (it > 0) col0 = it_col27_first(partials_in, nrows_in);
+  } else {
+    it_rows_first(partials_in, nrows_in, rows0);
   }
   // state of the previous half-iteration: 240 bytes, 16 per lane of the second wave, straight into LDS (a register
   // copy would make this wave wait for its loads before the slab and the partial rows are even requested)
   static_assert(sizeof(IcpSmall) % 16 == 0, "state copy");
   if (threadIdx.x >= GS_WAVE && threadIdx.x < GS_WAVE + (int)(sizeof(IcpSmall) / 16))
     it_load_lds16(reinterpret_cast<const float4*>(q.st_in) + (threadIdx.x - GS_WAVE), &sm);
-
+  // the normal of every query's previous match (thread t fetches query t's): the match rarely changes between
+  // searches, so the Gauss-Newton rows seldom have to wait for a gather from the slab's normals (which stay in global
+  // memory)
+  if (bounded && threadIdx.x < IT_NQ) {
+    const int tlx = tx0 + (int)threadIdx.x % IT_TW, tly = ty0 + (int)threadIdx.x / IT_TW;
+    if (tlx < hb.Wl && tly < hb.Hl) it_load_lds16(q.cn + (tly * hb.Wl + tlx), nspec_s + wv * GS_WAVE);
+  }
   // the slab's points: global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + 16 B per lane, no
-  // staging registers), issued now; the latency hides behind the prologue, the next barrier drains it.  Likewise the
-  // normal of every query's previous match (thread t fetches query t's): the match rarely changes between searches,
-  // so the Gauss-Newton rows seldom have to wait for a gather from the slab's normals (which stay in global memory).
+  // staging registers); the latency hides behind the prologue, the next barrier drains it.  The first IT_PTS_EARLY
+  // slots are requested whatever the header says (the bytes exist; a slab is seldom smaller), the rest below.
+#pragma unroll
+  for (int c0 = 0; c0 < IT_PTS_EARLY / GS_WAVE; c0 += IT_BLOCK / GS_WAVE) {
+    const int c = c0 + wv;   // chunk c = slots [64 c, 64 c + 64)
+    if (c < IT_PTS_EARLY / GS_WAVE) it_load_lds16(gp4 + c * GS_WAVE + ln, pts_s + c * GS_WAVE);
+  }
+
+  // ---- (2) what depends on the header
   {
     const int npts = local ? hdr.npts : 0;
-    const float4* gp4 = reinterpret_cast<const float4*>(slab + IT_OFF_PTS);
-    const int wv = threadIdx.x / GS_WAVE, ln = threadIdx.x & (GS_WAVE - 1);
 #pragma unroll
-    for (int c0 = 0; c0 < IT_PTS_CAP / GS_WAVE; c0 += IT_BLOCK / GS_WAVE) {
-      const int c = c0 + wv, i = c * GS_WAVE + ln;   // chunk c = slots [64 c, 64 c + 64)
+    for (int c0 = IT_PTS_EARLY / GS_WAVE; c0 < IT_PTS_CAP / GS_WAVE; c0 += IT_BLOCK / GS_WAVE) {
+      const int c = c0 + wv, i = c * GS_WAVE + ln;
       if (c < IT_PTS_CAP / GS_WAVE && i < npts) it_load_lds16(gp4 + i, pts_s + c * GS_WAVE);
     }
-    if (bounded && local && threadIdx.x < IT_NQ) {
-      const int tlx = tx0 + (int)threadIdx.x % IT_TW, tly = ty0 + (int)threadIdx.x / IT_TW;
-      if (tlx < hb.Wl && tly < hb.Hl) it_load_lds16(q.cn + ((int64_t)tly * hb.Wl + tlx), nspec_s + wv * GS_WAVE);
-    }
   }
+  float dprev = __builtin_inff();   // tiles without a slab: one more dependent load, the price of the exception
+  if (!local && live && bounded) dprev = d2prev[s];
 
   IT_STAMP(1);
   // ---- prologue: finish the previous half-iteration (identical in every block)
-  const int nrows_in = rows_in_reduced ? 1 : hb.ntiles;
   if (FULL) {
     double e1 = 0.0;
-    if (it > 0) e1 = icp_sum_col27<IT_BLOCK>(partials_in, nrows_in, reinterpret_cast<double*>(red));
+    if (it > 0) e1 = it_col27_finish(partials_in, nrows_in, col0, reinterpret_cast<double*>(red));
     else __syncthreads();
     if (threadIdx.x == 0) {
       if (it > 0)
@@ -640,7 +782,7 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       L.scan_n = 0; L.unres_n = 0; L.hard_n = 0;
     }
   } else {
-    icp_sum_rows<IT_BLOCK, 4>(partials_in, nrows_in, S, sub);
+    it_rows_finish(partials_in, nrows_in, rows0, S, sub);
     if (threadIdx.x < GS_WAVE) {
       gs_solve_spd6_wave(S, sm.damp, sm.xi);   // 6x6 solve across the lanes of wave 0 (LDS accesses of a wave are ordered)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -670,11 +812,13 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       bool proven = false;
       int win = -1;
       unsigned long long key = ~0ull;
-      const float oa = __shfl_xor(ca, 1, IT_G), ob = __shfl_xor(cb, 1, IT_G);
+      const float oa = __shfl_xor(ca, 1, IT_G), ob = __shfl_xor(cb, 1, IT_G);   // (never loaded for tiles without a slab)
       const float4 c0R = lane == 0 ? make_float4(ca, cb, oa, ob) : make_float4(oa, ob, ca, cb);
+      // R > 0: list of slab slots; R < 0: list of global slots (a neighbour found by the cubes on the global grid)
       if (c0R.w > 0.0f) key = it_list_search(lw, c0R, pts_s, qx, qy, qz, &proven, &win);
+      else if (c0R.w < 0.0f) key = it_list_search_global(lw, c0R, sorted, qx, qy, qz, &proven, &win);
       if (proven) {
-        if (win >= 0) bslot_s[slot] = win;
+        if (win >= 0) bslot_s[slot] = c0R.w > 0.0f ? win : it_global_code(win);
         if (lane == 0) keys_s[slot] = key;
       } else if (lane == 0) {
         scan_q[atomicAdd(&L.scan_n, 1)] = slot;
@@ -687,7 +831,7 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
         float ox = p0, oy = p1, oz = p2;
         if (FULL) gs_rigid_fma(sm.Tr, p0, p1, p2, ox, oy, oz);
         const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
-        rball = sqrtf(ca) + sqrtf(ex * ex + ey * ey + ez * ez);
+        rball = sqrtf(dprev) + sqrtf(ex * ex + ey * ey + ez * ez);
       }
       bool done, served;
       int win;
@@ -702,7 +846,6 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
     }
   }
   if (lane == 0 && live) {
-    if (FULL) { src_out[3 * s] = qx; src_out[3 * s + 1] = qy; src_out[3 * s + 2] = qz; }
     qs[slot][0] = qx; qs[slot][1] = qy; qs[slot][2] = qz;
     if (skip) keys_s[slot] = ~0ull;
   }
@@ -720,7 +863,7 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
     const unsigned long long key = it_stage0<IT_G, true, true>(g, box, slab_cells, pts_s, hx, hy, hz, lane,
                                                                __builtin_inff(), &done, &served, &win, &lst);
     if (win >= 0) bslot_s[hs] = win;
-    const int64_t sh = (int64_t)(ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
+    const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
     uint32_t* cw = q.cand + 4 * sh + 2 * lane;
     cw[0] = lst.w[0]; cw[1] = lst.w[1];
     if (lane == 0) {
@@ -758,15 +901,27 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
         const float R = it_emit_cube<IT_HG>(g, box, slab_cells, pts_s, hx, hy, hz, l16,
                                             sqrtf(__uint_as_float((uint32_t)(key >> 32))), kdone, stage, stage_n);
         if (l16 == 0) {
-          const int64_t sh = (int64_t)(ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
+          const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
           *reinterpret_cast<uint4*>(q.cand + 4 * sh) = *reinterpret_cast<const uint4*>(stage);
           q.cq[sh] = make_float4(hx, hy, hz, R);
         }
       }
     }
     if (!done) {
-      key = grid_search_rings<IT_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS);
+      int kdone;
+      key = grid_search_rings<IT_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, &kdone);
       if (win >= 0) bslot_s[hs] = it_global_code(win);
+      if (done && local) {   // a list of global slots: the next searches of this query cost two gathers
+        uint32_t* stage = reinterpret_cast<uint32_t*>(qa_s[hs]);
+        int* stage_n = reinterpret_cast<int*>(&qa_s[hs][4]);
+        const float R = it_emit_cube_global<IT_HG>(g, cell_start, sorted, hx, hy, hz, l16,
+                                                   sqrtf(__uint_as_float((uint32_t)(key >> 32))), kdone, stage, stage_n);
+        if (l16 == 0) {
+          const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
+          *reinterpret_cast<uint4*>(q.cand + 4 * sh) = *reinterpret_cast<const uint4*>(stage);
+          q.cq[sh] = make_float4(hx, hy, hz, -R);
+        }
+      }
     }
     if (l16 == 0) {
       keys_s[hs] = key;
@@ -815,6 +970,9 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
 #pragma unroll
     for (int i = 0; i < 6; ++i) qa_s[slot][i] = a[i];
     qa_s[slot][6] = res;
+    // the transformed cloud of this iteration (stored here, behind the last wait for global memory: a store in
+    // flight at a barrier is waited for)
+    if (FULL && live) { src_out[3 * s] = qs[slot][0]; src_out[3 * s + 1] = qs[slot][1]; src_out[3 * s + 2] = qs[slot][2]; }
   }
   __syncthreads();
   double* prow = partials_out + (int64_t)tile * LIN_NV;

@@ -275,11 +275,12 @@ template <int G>
 GS_DEV unsigned long long grid_search_rings(const GsGrid& g, const int* __restrict__ cell_start,
                                             const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
                                             unsigned long long key, bool* resolved, int* win,
-                                            const int kmax = GS_GRID_RINGS) {
+                                            const int kmax = GS_GRID_RINGS, int* kdone = nullptr) {
   const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
   bool done = false;
   int bs = -1;  // slot of a candidate of THIS call that beats the incoming key (-1: the incoming key stands)
-  for (int k = 1; k <= kmax && !done; ++k) {
+  int k = 1;
+  for (; k <= kmax && !done; ++k) {
     const int side = 2 * k + 1, nrow = side * side;
     const int xa = qc.cx - k < 0 ? 0 : qc.cx - k, xb = qc.cx + k >= g.nx ? g.nx - 1 : qc.cx + k;
     for (int r = lane; r < nrow; r += G) {
@@ -305,6 +306,7 @@ GS_DEV unsigned long long grid_search_rings(const GsGrid& g, const int* __restri
   }
   *resolved = done;
   *win = bs;
+  if (kdone) *kdone = k - 1;   // radius of the last cube scanned
   return key;
 }
 
