@@ -1065,17 +1065,18 @@ static int localize_tiles(const gs_localize_seq* seqs, int B, int Hl, int Wl, co
                       &sc[b].state->s[(h + 1) & 1], sc[b].state->trace};
     }
 #ifdef GS_ICP_TIMELINE
-    // debugging builds (GRADSLAM_HIP_ICP_TIMELINE=<path>): record both launches of the last iteration
+    // debugging builds (GRADSLAM_HIP_ICP_TIMELINE=<path>): record every launch of the solve (the file holds the last
+    // solve of the process)
     static const char* tl_path = getenv("GRADSLAM_HIP_ICP_TIMELINE");
     static unsigned long long* tl_buf = nullptr;
-    const size_t tl_n = 8 * (size_t)B * ntiles;
-    const bool tl = tl_path && it == prm->numiters - 1;
+    const size_t tl_n = 8 * (size_t)B * ntiles;   // words per launch
+    const size_t tl_cap = (size_t)64 << 20;
     hb.tl = nullptr;
-    if (tl) {
-      if (!tl_buf && hipMalloc(&tl_buf, 2 * 8 * 8 * 8 * 4096) != hipSuccess) tl_buf = nullptr;
-      if (tl_buf && 2 * tl_n <= 2 * 8 * 8 * 4096) {
-        hb.tl = tl_buf;
-        (void)hipMemsetAsync(tl_buf, 0, 2 * 8 * tl_n, st);
+    if (tl_path) {
+      if (!tl_buf && hipMalloc(&tl_buf, tl_cap) != hipSuccess) tl_buf = nullptr;
+      if (tl_buf && 8 * tl_n * 2 * (size_t)prm->numiters <= tl_cap) {
+        if (it == 0) (void)hipMemsetAsync(tl_buf, 0, 8 * tl_n * 2 * (size_t)prm->numiters, st);
+        hb.tl = tl_buf + tl_n * (2 * (size_t)it);
       }
     }
 #endif
@@ -1103,22 +1104,23 @@ static int localize_tiles(const gs_localize_seq* seqs, int B, int Hl, int Wl, co
                        reduce_rows ? 1 : 0);
     ++h;
 #ifdef GS_ICP_TIMELINE
-    if (hb.tl) {
-      std::unique_ptr<unsigned long long[]> hbuf(new unsigned long long[2 * tl_n]);
-      if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hbuf.get(), tl_buf, 2 * 8 * tl_n, hipMemcpyDeviceToHost) == hipSuccess) {
+    if (hb.tl && it == prm->numiters - 1) {
+      const size_t nw = tl_n * 2 * (size_t)prm->numiters;
+      std::unique_ptr<unsigned long long[]> hbuf(new unsigned long long[nw]);
+      if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hbuf.get(), tl_buf, 8 * nw, hipMemcpyDeviceToHost) == hipSuccess) {
         FILE* f = fopen(tl_path, "w");
         if (f) {
-          fprintf(f, "# tile engine B=%d tiles=%d: half(0 full, 1 look-ahead) block start issued prologue lists scans leftovers end counts\n", B, ntiles);
-          for (size_t i = 0; i < 2 * tl_n / 8; ++i) {
-            fprintf(f, "%d %zu", (int)(i >= tl_n / 8), i % (tl_n / 8));
+          fprintf(f, "# tile engine B=%d tiles=%d: launch(2 it + half) block start issued prologue lists scans leftovers end counts\n", B, ntiles);
+          for (size_t i = 0; i < nw / 8; ++i) {
+            fprintf(f, "%zu %zu", i / (tl_n / 8), i % (tl_n / 8));
             for (int k = 0; k < 8; ++k) fprintf(f, " %llu", hbuf[8 * i + k]);
             fprintf(f, "\n");
           }
           fclose(f);
         }
       }
-      hb.tl = nullptr;
     }
+    hb.tl = nullptr;
 #endif
   }
   prof_loop.reset();

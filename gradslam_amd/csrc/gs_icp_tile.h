@@ -34,6 +34,7 @@ constexpr int IT_ROWS_CAP = 2048;            // (z, y) rows of a slab's box
 constexpr int IT_MARGIN = 2;                 // cells added around the tile's query cells (1 for the 2x2x2 block + 1 of motion)
 constexpr int IT_RG = 24, IT_RPG = IT_NQ / IT_RG;  // row groups of the tile sum x queries per group
 constexpr int IT_PTS_EARLY = 1024;           // slab slots requested before the slab header has arrived
+constexpr int IT_LDS_CELLS = IT_NQ * 8 * 2;   // cell-table entries that fit the LDS space of the Gauss-Newton rows (12 KB)
 constexpr int IT_HG = 16;                    // lanes per query of the leftover searches
 constexpr int IT_LOCAL_RINGS = 3;            // cube radius the leftover searches go to on the slab before the global grid
 static_assert(IT_RG * LIN_NV <= IT_BLOCK && IT_NQ % IT_RG == 0, "tile sum shape");
@@ -248,7 +249,7 @@ struct ItList {
   float R;
 };
 constexpr int IT_LIST_LANE = 4;
-constexpr float IT_RADD = 0.15f;   // R = (distance of the nearest neighbour) + IT_RADD cells, at most the block's bound;
+constexpr float IT_RADD = 0.3f;    // R = (distance of the nearest neighbour) + IT_RADD cells, at most the block's bound;
                                    // halved (up to 3 times) while a lane's share of the list does not fit
 
 // grid_search_stage0 (gs_knn.h) on either the global grid (LOCAL = false; cells = cell_start, pts = sorted) or a
@@ -306,11 +307,20 @@ GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT*
     }
     *served = true;
     const int r1 = r0 + sy, r2 = r0 + sz, r3 = r2 + sy;
+    // all eight bounds are loaded unconditionally (rows that are not used: the address of a row that is -- one of
+    // the four always is, the query's own cell is never dropped -- and the result ignored): loads under branches are
+    // waited for one branch at a time, four dependent round trips instead of one
+    const bool u0 = zl && yl, u1 = zl && yh, u2 = zh && yl, u3 = zh && yh;
+    const int rs = u0 ? r0 : (u1 ? r1 : (u2 ? r2 : r3));
+    const int a0 = (u0 ? r0 : rs) + xa, a1 = (u1 ? r1 : rs) + xa, a2 = (u2 ? r2 : rs) + xa, a3 = (u3 ? r3 : rs) + xa;
+    const int w = xb + 1 - xa;
+    const int lb0 = (int)cells[a0], lb1 = (int)cells[a1], lb2 = (int)cells[a2], lb3 = (int)cells[a3];
+    const int le0 = (int)cells[a0 + w], le1 = (int)cells[a1 + w], le2 = (int)cells[a2 + w], le3 = (int)cells[a3 + w];
     int se0 = 0, se1 = 0, se2 = 0, se3 = 0;
-    if (zl && yl) { sb0 = (int)cells[r0 + xa]; se0 = (int)cells[r0 + xb + 1]; }
-    if (zl && yh) { sb1 = (int)cells[r1 + xa]; se1 = (int)cells[r1 + xb + 1]; }
-    if (zh && yl) { sb2 = (int)cells[r2 + xa]; se2 = (int)cells[r2 + xb + 1]; }
-    if (zh && yh) { sb3 = (int)cells[r3 + xa]; se3 = (int)cells[r3 + xb + 1]; }
+    if (u0) { sb0 = lb0; se0 = le0; }
+    if (u1) { sb1 = lb1; se1 = le1; }
+    if (u2) { sb2 = lb2; se2 = le2; }
+    if (u3) { sb3 = lb3; se3 = le3; }
     e1 = se0 - sb0;
     e2 = e1 + (se1 - sb1);
     e3 = e2 + (se2 - sb2);
@@ -854,13 +864,24 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   // ---- pass 2 (tiles with a slab): the 2x2x2 scan for the queries without a proof, which also writes their new
   // candidate lists (cells from the slab's table in global memory, candidates from LDS)
   const int ns = L.scan_n;   // block-uniform
+  // The slab's cell table is only needed from here on, by the few launches that scan at all: it is copied into LDS
+  // (the space of the Gauss-Newton rows, written later) when it fits -- the cube searches below walk it row by row,
+  // and from global memory every step is a round trip (cold lines and pages: this table is not touched otherwise).
+  const uint16_t* ctab = slab_cells;
+  if (local && ns > 0 && hdr.ncell + 1 <= IT_LDS_CELLS) {
+    const int n16 = (hdr.ncell + 1 + 7) / 8;
+    uint4* dst = reinterpret_cast<uint4*>(&qa_s[0][0]);
+    for (int i = threadIdx.x; i < n16; i += IT_BLOCK) dst[i] = reinterpret_cast<const uint4*>(slab_cells)[i];
+    ctab = reinterpret_cast<const uint16_t*>(dst);
+    __syncthreads();
+  }
   for (int i = threadIdx.x / IT_G; i < ns; i += IT_NQ) {
     const int hs = scan_q[i];
     const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
     bool done, served;
     int win;
     ItList lst;
-    const unsigned long long key = it_stage0<IT_G, true, true>(g, box, slab_cells, pts_s, hx, hy, hz, lane,
+    const unsigned long long key = it_stage0<IT_G, true, true>(g, box, ctab, pts_s, hx, hy, hz, lane,
                                                                __builtin_inff(), &done, &served, &win, &lst);
     if (win >= 0) bslot_s[hs] = win;
     const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
@@ -892,13 +913,15 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       // cubes on the slab; a query they serve gets a candidate list like any other, so that it costs a scan only once
       bool inbox;
       int kdone;
-      key = it_rings_local<IT_HG>(g, box, slab_cells, pts_s, hx, hy, hz, l16, key, IT_LOCAL_RINGS, &done, &inbox, &win,
+      key = it_rings_local<IT_HG>(g, box, ctab, pts_s, hx, hy, hz, l16, key, IT_LOCAL_RINGS, &done, &inbox, &win,
                                   &kdone);
       if (win >= 0) bslot_s[hs] = win;
       if (done) {
-        uint16_t* stage = reinterpret_cast<uint16_t*>(qa_s[hs]);   // (the rows are built after this pass)
-        int* stage_n = reinterpret_cast<int*>(&qa_s[hs][4]);
-        const float R = it_emit_cube<IT_HG>(g, box, slab_cells, pts_s, hx, hy, hz, l16,
+        // staging: 32 bytes per group in the row-sum scratch (free between the prologue and the epilogue)
+        char* stg = reinterpret_cast<char*>(&sub[0][0]) + 32 * (threadIdx.x / IT_HG);
+        uint16_t* stage = reinterpret_cast<uint16_t*>(stg);
+        int* stage_n = reinterpret_cast<int*>(stg + 16);
+        const float R = it_emit_cube<IT_HG>(g, box, ctab, pts_s, hx, hy, hz, l16,
                                             sqrtf(__uint_as_float((uint32_t)(key >> 32))), kdone, stage, stage_n);
         if (l16 == 0) {
           const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
@@ -912,8 +935,9 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       key = grid_search_rings<IT_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, &kdone);
       if (win >= 0) bslot_s[hs] = it_global_code(win);
       if (done && local) {   // a list of global slots: the next searches of this query cost two gathers
-        uint32_t* stage = reinterpret_cast<uint32_t*>(qa_s[hs]);
-        int* stage_n = reinterpret_cast<int*>(&qa_s[hs][4]);
+        char* stg = reinterpret_cast<char*>(&sub[0][0]) + 32 * (threadIdx.x / IT_HG);
+        uint32_t* stage = reinterpret_cast<uint32_t*>(stg);
+        int* stage_n = reinterpret_cast<int*>(stg + 16);
         const float R = it_emit_cube_global<IT_HG>(g, cell_start, sorted, hx, hy, hz, l16,
                                                    sqrtf(__uint_as_float((uint32_t)(key >> 32))), kdone, stage, stage_n);
         if (l16 == 0) {

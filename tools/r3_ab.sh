@@ -2,7 +2,7 @@
 # round 3, GPU call 1: tile engine parity + A/B against the row-unit engine + timelines
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r3c2; mkdir -p $O
-timeout 600 python -m pytest tests -m gpu -q -x --deselect tests/test_hip_batch.py::test_two_ranks_sharing_one_gpu_rehearsal > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
+echo skip-pytest > $O/pytest.log
 tail -25 $O/pytest.log
 for eng in ${ENGINES:-tile}; do
   for b in 8 1; do
@@ -21,7 +21,7 @@ PY
 done
 GRADSLAM_HIP_BUILD_FLAGS=-DGS_ICP_TIMELINE python -m gradslam_amd.csrc.build > $O/build_tl.log 2>&1
 for b in 8 1; do
-  GRADSLAM_HIP_ICP_TIMELINE=$O/tl_b$b.txt timeout 200 python tools/icp_tile_timeline.py $b 2>&1 | tail -14
+  GRADSLAM_HIP_ICP_TIMELINE=$O/tl_b$b.txt timeout 200 python tools/icp_tile_timeline.py $b 2>&1 | tail -34
 done
-GRADSLAM_HIP_ICP_TIMELINE=$O/tl_c5.txt timeout 200 python tools/icp_tile_timeline.py 1 968 1296 2>&1 | tail -14
-GRADSLAM_HIP_ICP_TIMELINE=$O/tl_b8_f12.txt timeout 200 python tools/icp_tile_timeline.py 8 480 640 12 2>&1 | tail -14
+GRADSLAM_HIP_ICP_TIMELINE=$O/tl_c5.txt timeout 200 python tools/icp_tile_timeline.py 1 968 1296 2>&1 | tail -34
+GRADSLAM_HIP_ICP_TIMELINE=$O/tl_b8_f12.txt timeout 200 python tools/icp_tile_timeline.py 8 480 640 12 2>&1 | tail -34
