@@ -1039,6 +1039,8 @@ static int localize_tiles(const gs_localize_seq* seqs, int B, int Hl, int Wl, co
   bb.B = hb.B = B;
   bb.Wl = hb.Wl = Wl; bb.Hl = hb.Hl = Hl;
   bb.tiles_x = hb.tiles_x = it_tiles_x(Wl);
+  static const int force_scan = getenv("GRADSLAM_HIP_ICP_FORCE_SCAN") ? atoi(getenv("GRADSLAM_HIP_ICP_FORCE_SCAN")) : 0;
+  hb.force_scan = force_scan;
   const int ntiles = hb.ntiles = it_tiles(Hl, Wl);
   const int64_t n_lat = (int64_t)Hl * Wl;
   for (int b = 0; b < B; ++b) {

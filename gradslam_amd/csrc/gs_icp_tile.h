@@ -221,6 +221,7 @@ struct ItSeq {
 };
 struct ItBatch {
   int B, Wl, Hl, tiles_x, ntiles;
+  int force_scan;   // experiments (GRADSLAM_HIP_ICP_FORCE_SCAN): the first query of every tile always takes the scan pass
   ItSeq s[GS_MAX_BATCH];
 #ifdef GS_ICP_TIMELINE
   unsigned long long* tl;   // debugging builds: 8 words per block [start, loads issued, prologue done, list pass done,
@@ -249,8 +250,8 @@ struct ItList {
   float R;
 };
 constexpr int IT_LIST_LANE = 4;
-constexpr float IT_RADD = 0.3f;    // R = (distance of the nearest neighbour) + IT_RADD cells, at most the block's bound;
-                                   // halved (up to 3 times) while a lane's share of the list does not fit
+constexpr float IT_RADD = 0.3f;    // cube searches (far queries): R = nearest distance + IT_RADD cells, at most the cube's
+                                   // bound; halved (up to 3 times) while the list does not fit
 
 // grid_search_stage0 (gs_knn.h) on either the global grid (LOCAL = false; cells = cell_start, pts = sorted) or a
 // tile's slab (LOCAL = true; cells = the slab's 16-bit cell table, pts = its points in LDS, box = the slab's box): same
@@ -327,16 +328,21 @@ GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT*
     total = e3 + (se3 - sb3);
   }
   // candidates in flight per lane: 4 gathers from global memory (latency), 2 from LDS (registers)
-  constexpr int U = LOCAL ? 2 : 4;
+  constexpr int U = LOCAL ? (EMIT ? 1 : 2) : 4;
+  // EMIT: this lane's four nearest candidates (distance ascending, slab slots) and the smallest distance it dropped
+  float n0 = __builtin_inff(), n1 = n0, n2 = n0, n3 = n0, ndrop = n0;
+  uint32_t s0 = 0xffffu, s1 = 0xffffu, s2 = 0xffffu, s3 = 0xffffu;
   for (int t0 = lane; t0 < total; t0 += U * G) {
     float4 p[U];
     bool in[U];
+    int ixs[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * G;
       in[u] = t < total;
       const int tt = in[u] ? t : 0;
       const int ix = tt < e1 ? sb0 + tt : (tt < e2 ? sb1 + (tt - e1) : (tt < e3 ? sb2 + (tt - e2) : sb3 + (tt - e3)));
+      ixs[u] = ix;
       p[u] = pts[ix];
     }
 #pragma unroll
@@ -345,6 +351,17 @@ GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT*
       const bool better = k2 < key;
       key = better ? k2 : key;
       bt = better ? t0 + u * G : bt;
+      if (EMIT) {
+        // (a NaN distance -- key ~0 -- compares false everywhere: never listed, never the dropped minimum)
+        const float dn = k2 != ~0ull ? __uint_as_float((uint32_t)(k2 >> 32)) : __builtin_nanf("");
+        const uint32_t sn = (uint32_t)ixs[u];
+        const bool l0 = dn < n0, l1 = dn < n1, l2 = dn < n2, l3 = dn < n3;
+        ndrop = fminf(ndrop, l3 ? n3 : dn);
+        n3 = l2 ? n2 : (l3 ? dn : n3); s3 = l2 ? s2 : (l3 ? sn : s3);
+        n2 = l1 ? n1 : (l2 ? dn : n2); s2 = l1 ? s1 : (l2 ? sn : s2);
+        n1 = l0 ? n0 : (l1 ? dn : n1); s1 = l0 ? s0 : (l1 ? sn : s1);
+        n0 = l0 ? dn : n0;             s0 = l0 ? sn : s0;
+      }
     }
   }
   {
@@ -357,35 +374,14 @@ GS_DEV unsigned long long it_stage0(const GsGrid& g, const ItBox& box, const CT*
   const float bd = __uint_as_float((uint32_t)(key >> 32));
   *resolved = prune ? (bd == bd) : (rb > 0.0f && (rb >= 1.0e30f ? bd == bd : bd <= rb * rb));
   if (EMIT) {
+    // The list = the four nearest candidates of either lane.  Every other target is either outside the 2x2x2 block
+    // (at least rb away) or a candidate one of the lanes dropped (at least that lane's ndrop away): R = the minimum.
     if (*resolved) {   // (the same for all lanes of the group)
-      const float d1 = sqrtf(bd);
-      float radd = IT_RADD * g.c;
-      for (int attempt = 0; attempt < 4; ++attempt, radd *= 0.5f) {
-        float R = d1 + radd;
-        R = R < rb ? R : rb;
-        const float R2 = R * R;
-        uint32_t w0 = ~0u, w1 = ~0u;
-        int cnt = 0;
-        for (int t = lane; t < total; t += G) {
-          const int ix = t < e1 ? sb0 + t : (t < e2 ? sb1 + (t - e1) : (t < e3 ? sb2 + (t - e2) : sb3 + (t - e3)));
-          const float4 c = pts[ix];
-          const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-          float d = dx * dx;
-          d = gs_fma(dy, dy, d);
-          d = gs_fma(dz, dz, d);
-          if (d < R2) {   // a NaN distance is never a neighbour
-            w1 = (w1 << 16) | (w0 >> 16);
-            w0 = (w0 << 16) | (uint32_t)ix;
-            ++cnt;
-          }
-        }
-        const int over = cnt > IT_LIST_LANE ? 1 : 0;
-        if ((over | __shfl_xor(over, 1, G)) == 0) {
-          lst->w[0] = w0; lst->w[1] = w1;
-          lst->R = R;
-          break;
-        }
-      }
+      const float od = __shfl_xor(ndrop, 1, G);
+      const float R = fminf(sqrtf(fminf(ndrop, od)), rb);
+      lst->w[0] = s0 | (s1 << 16);
+      lst->w[1] = s2 | (s3 << 16);
+      lst->R = R;
     }
   }
   return key;
@@ -658,18 +654,19 @@ GS_DEV int it_global_code(int slot) { return -2 - slot; }
 struct ItLds {
   float4 pts[IT_PTS_CAP];          // slab: binned target points of the tile's box (x, y, z, map row bits)
   float4 nspec[IT_NQ];             // normal of every query's previous match (x, y, z, slab slot bits)
+  alignas(16) float qa[IT_NQ][8];  // a0..a5, residual of every query (zero when filtered out); before the rows are
+                                   // built: the slab's cell table
   IcpSmall sm;                     // solver state
   double S[32];
   double sub[IT_BLOCK / 32][32];   // prologue: chunk sums of the partial rows; epilogue: the row groups' sub-sums
   unsigned long long keys[IT_NQ];  // best (distance bits, map row) of every query
   int bslot[IT_NQ];                // where its point / normal sit (slot codes above)
   float qs[IT_NQ][3];              // transformed queries
-  alignas(16) float qa[IT_NQ][8];  // a0..a5, residual of every query (zero when filtered out)
   int scan_q[IT_NQ], hard_q[IT_NQ];   // (the scan list's storage is reused for the queries left to brute force)
   int scan_n, hard_n, unres_n;
   unsigned long long red[IT_BLOCK / GS_WAVE];
 };
-static_assert(IT_RG * LIN_NV <= (IT_BLOCK / 32) * 32 && offsetof(ItLds, sm) % 16 == 0 &&
+static_assert(IT_RG * LIN_NV <= (IT_BLOCK / 32) * 32 && offsetof(ItLds, sm) % 16 == 0 && offsetof(ItLds, qa) % 16 == 0 &&
               offsetof(ItLds, sm) + sizeof(IcpSmall) <= 65536, "LDS copy targets");
 
 template <bool FULL>
@@ -777,6 +774,15 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       if (c < IT_PTS_CAP / GS_WAVE && i < npts) it_load_lds16(gp4 + i, pts_s + c * GS_WAVE);
     }
   }
+  // the slab's cell table, needed by the launches that scan at all: into the LDS space of the Gauss-Newton rows
+  // (written after the searches) when it fits -- from global memory every look-up of a scan is a round trip to cold
+  // lines and pages (this table is touched by nothing else)
+  const uint16_t* ctab = reinterpret_cast<const uint16_t*>(slab + IT_OFF_CELLS);
+  if (local && hdr.ncell + 1 <= IT_LDS_CELLS) {
+    if ((int)threadIdx.x < (hdr.ncell + 1 + 7) / 8)
+      it_load_lds16(reinterpret_cast<const uint4*>(ctab) + threadIdx.x, reinterpret_cast<uint4*>(&qa_s[0][0]) + wv * GS_WAVE);
+    ctab = reinterpret_cast<const uint16_t*>(&qa_s[0][0]);
+  }
   float dprev = __builtin_inff();   // tiles without a slab: one more dependent load, the price of the exception
   if (!local && live && bounded) dprev = d2prev[s];
 
@@ -812,7 +818,6 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   // ---- search, pass 1: one source point per IT_G-lane group, pending transform applied to the loaded point.
   // Tiles with a slab try the candidate list first; what it cannot prove goes to the scan pass.
   const ItBox box = {hdr.bx0, hdr.by0, hdr.bz0, hdr.nbx, hdr.nby, hdr.nbz};
-  const uint16_t* __restrict__ slab_cells = reinterpret_cast<const uint16_t*>(slab + IT_OFF_CELLS);
   float qx = p0, qy = p0, qz = p0;
   const bool skip = !live || p0 != p0;   // beyond the lattice, or an empty slot (NaN stays NaN, contributes no row)
   if (!skip) {
@@ -827,6 +832,7 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       // R > 0: list of slab slots; R < 0: list of global slots (a neighbour found by the cubes on the global grid)
       if (c0R.w > 0.0f) key = it_list_search(lw, c0R, pts_s, qx, qy, qz, &proven, &win);
       else if (c0R.w < 0.0f) key = it_list_search_global(lw, c0R, sorted, qx, qy, qz, &proven, &win);
+      if (hb.force_scan && slot == 0) proven = false;
       if (proven) {
         if (win >= 0) bslot_s[slot] = c0R.w > 0.0f ? win : it_global_code(win);
         if (lane == 0) keys_s[slot] = key;
@@ -864,17 +870,6 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   // ---- pass 2 (tiles with a slab): the 2x2x2 scan for the queries without a proof, which also writes their new
   // candidate lists (cells from the slab's table in global memory, candidates from LDS)
   const int ns = L.scan_n;   // block-uniform
-  // The slab's cell table is only needed from here on, by the few launches that scan at all: it is copied into LDS
-  // (the space of the Gauss-Newton rows, written later) when it fits -- the cube searches below walk it row by row,
-  // and from global memory every step is a round trip (cold lines and pages: this table is not touched otherwise).
-  const uint16_t* ctab = slab_cells;
-  if (local && ns > 0 && hdr.ncell + 1 <= IT_LDS_CELLS) {
-    const int n16 = (hdr.ncell + 1 + 7) / 8;
-    uint4* dst = reinterpret_cast<uint4*>(&qa_s[0][0]);
-    for (int i = threadIdx.x; i < n16; i += IT_BLOCK) dst[i] = reinterpret_cast<const uint4*>(slab_cells)[i];
-    ctab = reinterpret_cast<const uint16_t*>(dst);
-    __syncthreads();
-  }
   for (int i = threadIdx.x / IT_G; i < ns; i += IT_NQ) {
     const int hs = scan_q[i];
     const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];

@@ -17,4 +17,5 @@ PY
 done
 GRADSLAM_HIP_BUILD_FLAGS=-DGS_ICP_TIMELINE python -m gradslam_amd.csrc.build > $O/build_tl.log 2>&1 || tail -20 $O/build_tl.log
 GRADSLAM_HIP_ICP_TIMELINE=$O/tl_b8_f12.txt TL_LAUNCHES=${TL_LAUNCHES:-0,1,2,3,4,39} timeout 200 python tools/icp_tile_timeline.py 8 480 640 12 2>&1 | grep -v amdgpu.ids | tail -40
+GRADSLAM_HIP_ICP_FORCE_SCAN=1 GRADSLAM_HIP_ICP_TIMELINE=$O/tl_b8_f12_force.txt TL_LAUNCHES=20,39 timeout 200 python tools/icp_tile_timeline.py 8 480 640 12 2>&1 | grep -v amdgpu.ids | tail -14
 GRADSLAM_HIP_ICP_TIMELINE=$O/tl_b1_f12.txt TL_LAUNCHES=${TL_LAUNCHES1:-0,1,39} timeout 200 python tools/icp_tile_timeline.py 1 480 640 12 2>&1 | grep -v amdgpu.ids | tail -20
