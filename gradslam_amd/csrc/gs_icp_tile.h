@@ -250,6 +250,8 @@ struct ItList {
   float R;
 };
 constexpr int IT_LIST_LANE = 4;
+constexpr float IT_MIN_ROOM = 0.3f;   // cells a query may move before its list loses the proof, below which the scan
+                                      // retries on the 3x3x3 cube
 constexpr float IT_RADD = 0.3f;    // cube searches (far queries): R = nearest distance + IT_RADD cells, at most the cube's
                                    // bound; halved (up to 3 times) while the list does not fit
 
@@ -411,6 +413,55 @@ GS_DEV unsigned long long it_list_search(const uint32_t* w, const float4 c0R, co
   const float delta = sqrtf(ex * ex + ey * ey + ez * ez);
   *proven = sqrtf(bd) + delta < c0R.w * 0.9999f;   // false for NaN and for R <= 0
   return kmin;
+}
+
+// Second chance for the list of a query whose 2x2x2 block leaves little room to move (R - d1 small because a block face
+// is near): the same four-nearest-per-lane list over the 3x3x3 cube around the query's cell, whose faces are at least
+// one cell away.  Needs the cube inside the slab's box (returns false otherwise, the 2x2x2 list stands).
+GS_DEV bool it_list_cube3(const GsGrid& g, const ItBox& box, const uint16_t* cells, const float4* __restrict__ pts,
+                          float qx, float qy, float qz, int lane, ItList* lst) {
+  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
+  const int xa = qc.cx - 1 < 0 ? 0 : qc.cx - 1, xb = qc.cx + 1 >= g.nx ? g.nx - 1 : qc.cx + 1;
+  const int ya = qc.cy - 1 < 0 ? 0 : qc.cy - 1, yb = qc.cy + 1 >= g.ny ? g.ny - 1 : qc.cy + 1;
+  const int za = qc.cz - 1 < 0 ? 0 : qc.cz - 1, zb = qc.cz + 1 >= g.nz ? g.nz - 1 : qc.cz + 1;
+  if (xa < box.x0 || xb >= box.x0 + box.nx || ya < box.y0 || yb >= box.y0 + box.ny || za < box.z0 || zb >= box.z0 + box.nz)
+    return false;
+  float n0 = __builtin_inff(), n1 = n0, n2 = n0, n3 = n0, ndrop = n0;
+  uint32_t s0 = 0xffffu, s1 = 0xffffu, s2 = 0xffffu, s3 = 0xffffu;
+  for (int r = lane; r < 9; r += 2) {
+    const int zz = qc.cz + r / 3 - 1, yy = qc.cy + r % 3 - 1;
+    if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
+    const int row = ((zz - box.z0) * box.ny + (yy - box.y0)) * box.nx - box.x0;
+    const int je = (int)cells[row + xb + 1];
+    for (int j = (int)cells[row + xa]; j < je; ++j) {
+      const float4 c = pts[j];
+      const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+      float dn = dx * dx;
+      dn = gs_fma(dy, dy, dn);
+      dn = gs_fma(dz, dz, dn);
+      const uint32_t sn = (uint32_t)j;
+      const bool l0 = dn < n0, l1 = dn < n1, l2 = dn < n2, l3 = dn < n3;
+      ndrop = fminf(ndrop, l3 ? n3 : dn);
+      n3 = l2 ? n2 : (l3 ? dn : n3); s3 = l2 ? s2 : (l3 ? sn : s3);
+      n2 = l1 ? n1 : (l2 ? dn : n2); s2 = l1 ? s1 : (l2 ? sn : s2);
+      n1 = l0 ? n0 : (l1 ? dn : n1); s1 = l0 ? s0 : (l1 ? sn : s1);
+      n0 = l0 ? dn : n0;             s0 = l0 ? sn : s0;
+    }
+  }
+  // distance (cells) from the projected query to the nearest cube face that has cells behind it
+  const float fx = (qc.px - g.ox) * g.inv_c - (float)qc.cx, fy = (qc.py - g.oy) * g.inv_c - (float)qc.cy,
+              fz = (qc.pz - g.oz) * g.inv_c - (float)qc.cz;
+  const float BIG = 3.0e38f;
+  const float ax = fminf(qc.cx - 1 >= 1 ? fx + 1.0f : BIG, qc.cx + 2 < g.nx ? 2.0f - fx : BIG);
+  const float ay = fminf(qc.cy - 1 >= 1 ? fy + 1.0f : BIG, qc.cy + 2 < g.ny ? 2.0f - fy : BIG);
+  const float az = fminf(qc.cz - 1 >= 1 ? fz + 1.0f : BIG, qc.cz + 2 < g.nz ? 2.0f - fz : BIG);
+  const float amin = fminf(ax, fminf(ay, az));
+  const float rb = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
+  const float od = __shfl_xor(ndrop, 1, 2);
+  lst->w[0] = s0 | (s1 << 16);
+  lst->w[1] = s2 | (s3 << 16);
+  lst->R = fminf(sqrtf(fminf(ndrop, od)), rb);
+  return true;
 }
 
 // Cubes of Chebyshev radius 1 .. kmax around the query's cell, on a tile's slab (grid_search_rings of gs_knn.h on the
@@ -879,6 +930,10 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
     const unsigned long long key = it_stage0<IT_G, true, true>(g, box, ctab, pts_s, hx, hy, hz, lane,
                                                                __builtin_inff(), &done, &served, &win, &lst);
     if (win >= 0) bslot_s[hs] = win;
+    if (done && lst.R - sqrtf(__uint_as_float((uint32_t)(key >> 32))) < IT_MIN_ROOM * g.c) {
+      ItList l3;
+      if (it_list_cube3(g, box, ctab, pts_s, hx, hy, hz, lane, &l3) && l3.R > lst.R) lst = l3;
+    }
     const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
     uint32_t* cw = q.cand + 4 * sh + 2 * lane;
     cw[0] = lst.w[0]; cw[1] = lst.w[1];
