@@ -250,8 +250,6 @@ struct ItList {
   float R;
 };
 constexpr int IT_LIST_LANE = 4;
-constexpr float IT_MIN_ROOM = 0.3f;   // cells a query may move before its list loses the proof, below which the scan
-                                      // retries on the 3x3x3 cube
 constexpr float IT_RADD = 0.3f;    // cube searches (far queries): R = nearest distance + IT_RADD cells, at most the cube's
                                    // bound; halved (up to 3 times) while the list does not fit
 
@@ -413,55 +411,6 @@ GS_DEV unsigned long long it_list_search(const uint32_t* w, const float4 c0R, co
   const float delta = sqrtf(ex * ex + ey * ey + ez * ez);
   *proven = sqrtf(bd) + delta < c0R.w * 0.9999f;   // false for NaN and for R <= 0
   return kmin;
-}
-
-// Second chance for the list of a query whose 2x2x2 block leaves little room to move (R - d1 small because a block face
-// is near): the same four-nearest-per-lane list over the 3x3x3 cube around the query's cell, whose faces are at least
-// one cell away.  Needs the cube inside the slab's box (returns false otherwise, the 2x2x2 list stands).
-GS_DEV bool it_list_cube3(const GsGrid& g, const ItBox& box, const uint16_t* cells, const float4* __restrict__ pts,
-                          float qx, float qy, float qz, int lane, ItList* lst) {
-  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
-  const int xa = qc.cx - 1 < 0 ? 0 : qc.cx - 1, xb = qc.cx + 1 >= g.nx ? g.nx - 1 : qc.cx + 1;
-  const int ya = qc.cy - 1 < 0 ? 0 : qc.cy - 1, yb = qc.cy + 1 >= g.ny ? g.ny - 1 : qc.cy + 1;
-  const int za = qc.cz - 1 < 0 ? 0 : qc.cz - 1, zb = qc.cz + 1 >= g.nz ? g.nz - 1 : qc.cz + 1;
-  if (xa < box.x0 || xb >= box.x0 + box.nx || ya < box.y0 || yb >= box.y0 + box.ny || za < box.z0 || zb >= box.z0 + box.nz)
-    return false;
-  float n0 = __builtin_inff(), n1 = n0, n2 = n0, n3 = n0, ndrop = n0;
-  uint32_t s0 = 0xffffu, s1 = 0xffffu, s2 = 0xffffu, s3 = 0xffffu;
-  for (int r = lane; r < 9; r += 2) {
-    const int zz = qc.cz + r / 3 - 1, yy = qc.cy + r % 3 - 1;
-    if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
-    const int row = ((zz - box.z0) * box.ny + (yy - box.y0)) * box.nx - box.x0;
-    const int je = (int)cells[row + xb + 1];
-    for (int j = (int)cells[row + xa]; j < je; ++j) {
-      const float4 c = pts[j];
-      const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-      float dn = dx * dx;
-      dn = gs_fma(dy, dy, dn);
-      dn = gs_fma(dz, dz, dn);
-      const uint32_t sn = (uint32_t)j;
-      const bool l0 = dn < n0, l1 = dn < n1, l2 = dn < n2, l3 = dn < n3;
-      ndrop = fminf(ndrop, l3 ? n3 : dn);
-      n3 = l2 ? n2 : (l3 ? dn : n3); s3 = l2 ? s2 : (l3 ? sn : s3);
-      n2 = l1 ? n1 : (l2 ? dn : n2); s2 = l1 ? s1 : (l2 ? sn : s2);
-      n1 = l0 ? n0 : (l1 ? dn : n1); s1 = l0 ? s0 : (l1 ? sn : s1);
-      n0 = l0 ? dn : n0;             s0 = l0 ? sn : s0;
-    }
-  }
-  // distance (cells) from the projected query to the nearest cube face that has cells behind it
-  const float fx = (qc.px - g.ox) * g.inv_c - (float)qc.cx, fy = (qc.py - g.oy) * g.inv_c - (float)qc.cy,
-              fz = (qc.pz - g.oz) * g.inv_c - (float)qc.cz;
-  const float BIG = 3.0e38f;
-  const float ax = fminf(qc.cx - 1 >= 1 ? fx + 1.0f : BIG, qc.cx + 2 < g.nx ? 2.0f - fx : BIG);
-  const float ay = fminf(qc.cy - 1 >= 1 ? fy + 1.0f : BIG, qc.cy + 2 < g.ny ? 2.0f - fy : BIG);
-  const float az = fminf(qc.cz - 1 >= 1 ? fz + 1.0f : BIG, qc.cz + 2 < g.nz ? 2.0f - fz : BIG);
-  const float amin = fminf(ax, fminf(ay, az));
-  const float rb = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
-  const float od = __shfl_xor(ndrop, 1, 2);
-  lst->w[0] = s0 | (s1 << 16);
-  lst->w[1] = s2 | (s3 << 16);
-  lst->R = fminf(sqrtf(fminf(ndrop, od)), rb);
-  return true;
 }
 
 // Cubes of Chebyshev radius 1 .. kmax around the query's cell, on a tile's slab (grid_search_rings of gs_knn.h on the
@@ -828,12 +777,9 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   // the slab's cell table, needed by the launches that scan at all: into the LDS space of the Gauss-Newton rows
   // (written after the searches) when it fits -- from global memory every look-up of a scan is a round trip to cold
   // lines and pages (this table is touched by nothing else)
-  const uint16_t* ctab = reinterpret_cast<const uint16_t*>(slab + IT_OFF_CELLS);
-  if (local && hdr.ncell + 1 <= IT_LDS_CELLS) {
-    if ((int)threadIdx.x < (hdr.ncell + 1 + 7) / 8)
-      it_load_lds16(reinterpret_cast<const uint4*>(ctab) + threadIdx.x, reinterpret_cast<uint4*>(&qa_s[0][0]) + wv * GS_WAVE);
-    ctab = reinterpret_cast<const uint16_t*>(&qa_s[0][0]);
-  }
+  if (local && hdr.ncell + 1 <= IT_LDS_CELLS && (int)threadIdx.x < (hdr.ncell + 1 + 7) / 8)
+    it_load_lds16(reinterpret_cast<const uint4*>(slab + IT_OFF_CELLS) + threadIdx.x,
+                  reinterpret_cast<uint4*>(&qa_s[0][0]) + wv * GS_WAVE);
   float dprev = __builtin_inff();   // tiles without a slab: one more dependent load, the price of the exception
   if (!local && live && bounded) dprev = d2prev[s];
 
@@ -888,7 +834,15 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
         if (win >= 0) bslot_s[slot] = c0R.w > 0.0f ? win : it_global_code(win);
         if (lane == 0) keys_s[slot] = key;
       } else if (lane == 0) {
-        scan_q[atomicAdd(&L.scan_n, 1)] = slot;
+        // the first search of a solve scans (pass 2: every query, all waves busy); a later query whose list lost its
+        // proof goes straight to the 16-lane cube search of the leftover pass, which also gives it a roomier list
+        if (!bounded) {
+          scan_q[atomicAdd(&L.scan_n, 1)] = slot;
+        } else {
+          keys_s[slot] = ~0ull;
+          bslot_s[slot] = -1;
+          hard_q[atomicAdd(&L.hard_n, 1)] = slot;
+        }
       }
     } else {
       // no slab: the global grid, scan bounded by what the previous search found (the previous neighbour is still a
@@ -918,91 +872,101 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   }
   __syncthreads();
   IT_STAMP(3);
-  // ---- pass 2 (tiles with a slab): the 2x2x2 scan for the queries without a proof, which also writes their new
-  // candidate lists (cells from the slab's table in global memory, candidates from LDS)
+  // ---- pass 2 (tiles with a slab, first search of a solve): the 2x2x2 scan, which also writes the candidate lists.
+  // The slab's cell table is read from its LDS copy when there is one (tab_lds), else from global memory; the two
+  // call sites keep the address space of the pointer known to the compiler.
+  const bool tab_lds = local && hdr.ncell + 1 <= IT_LDS_CELLS;
   const int ns = L.scan_n;   // block-uniform
-  for (int i = threadIdx.x / IT_G; i < ns; i += IT_NQ) {
-    const int hs = scan_q[i];
-    const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
-    bool done, served;
-    int win;
-    ItList lst;
-    const unsigned long long key = it_stage0<IT_G, true, true>(g, box, ctab, pts_s, hx, hy, hz, lane,
-                                                               __builtin_inff(), &done, &served, &win, &lst);
-    if (win >= 0) bslot_s[hs] = win;
-    if (done && lst.R - sqrtf(__uint_as_float((uint32_t)(key >> 32))) < IT_MIN_ROOM * g.c) {
-      ItList l3;
-      if (it_list_cube3(g, box, ctab, pts_s, hx, hy, hz, lane, &l3) && l3.R > lst.R) lst = l3;
-    }
-    const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
-    uint32_t* cw = q.cand + 4 * sh + 2 * lane;
-    cw[0] = lst.w[0]; cw[1] = lst.w[1];
-    if (lane == 0) {
-      q.cq[sh] = make_float4(hx, hy, hz, lst.R);
-      if (key == ~0ull) bslot_s[hs] = -1;
-      keys_s[hs] = key;
-      // bit 31: not served by the slab (the leftover pass starts with the global 2x2x2 stage)
-      if (!done) hard_q[atomicAdd(&L.hard_n, 1)] = hs | (served ? 0 : (int)0x80000000);
-    }
-  }
-  if (ns) __syncthreads();
-  IT_STAMP(4);
-  // ---- leftovers (neighbour farther than ~half a cell, or outside the slab): groups of IT_HG lanes on the global grid
-  const int nh = L.hard_n;  // block-uniform
-  for (int i = threadIdx.x / IT_HG; i < nh; i += IT_BLOCK / IT_HG) {
-    const int e = hard_q[i], hs = e & 0x7fffffff, l16 = threadIdx.x & (IT_HG - 1);
-    const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
-    unsigned long long key = keys_s[hs];
-    bool done = false, served;
-    int win;
-    if (e < 0) {
-      key = it_stage0<IT_HG, false, false>(g, box, cell_start, sorted, hx, hy, hz, l16, __builtin_inff(), &done, &served,
-                                           &win);
-      if (win >= 0) bslot_s[hs] = it_global_code(win);
-    } else if (local) {
-      // cubes on the slab; a query they serve gets a candidate list like any other, so that it costs a scan only once
-      bool inbox;
-      int kdone;
-      key = it_rings_local<IT_HG>(g, box, ctab, pts_s, hx, hy, hz, l16, key, IT_LOCAL_RINGS, &done, &inbox, &win,
-                                  &kdone);
+  auto scan_pass = [&](const uint16_t* tab) __attribute__((always_inline)) {
+    for (int i = threadIdx.x / IT_G; i < ns; i += IT_NQ) {
+      const int hs = scan_q[i];
+      const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
+      bool done, served;
+      int win;
+      ItList lst;
+      const unsigned long long key = it_stage0<IT_G, true, true>(g, box, tab, pts_s, hx, hy, hz, lane, __builtin_inff(),
+                                                                 &done, &served, &win, &lst);
       if (win >= 0) bslot_s[hs] = win;
-      if (done) {
-        // staging: 32 bytes per group in the row-sum scratch (free between the prologue and the epilogue)
-        char* stg = reinterpret_cast<char*>(&sub[0][0]) + 32 * (threadIdx.x / IT_HG);
-        uint16_t* stage = reinterpret_cast<uint16_t*>(stg);
-        int* stage_n = reinterpret_cast<int*>(stg + 16);
-        const float R = it_emit_cube<IT_HG>(g, box, ctab, pts_s, hx, hy, hz, l16,
-                                            sqrtf(__uint_as_float((uint32_t)(key >> 32))), kdone, stage, stage_n);
-        if (l16 == 0) {
-          const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
-          *reinterpret_cast<uint4*>(q.cand + 4 * sh) = *reinterpret_cast<const uint4*>(stage);
-          q.cq[sh] = make_float4(hx, hy, hz, R);
-        }
+      const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
+      uint32_t* cw = q.cand + 4 * sh + 2 * lane;
+      cw[0] = lst.w[0]; cw[1] = lst.w[1];
+      if (lane == 0) {
+        q.cq[sh] = make_float4(hx, hy, hz, lst.R);
+        if (key == ~0ull) bslot_s[hs] = -1;
+        keys_s[hs] = key;
+        // bit 31: not served by the slab (the leftover pass starts with the global 2x2x2 stage)
+        if (!done) hard_q[atomicAdd(&L.hard_n, 1)] = hs | (served ? 0 : (int)0x80000000);
       }
     }
-    if (!done) {
-      int kdone;
-      key = grid_search_rings<IT_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, &kdone);
-      if (win >= 0) bslot_s[hs] = it_global_code(win);
-      if (done && local) {   // a list of global slots: the next searches of this query cost two gathers
-        char* stg = reinterpret_cast<char*>(&sub[0][0]) + 32 * (threadIdx.x / IT_HG);
-        uint32_t* stage = reinterpret_cast<uint32_t*>(stg);
-        int* stage_n = reinterpret_cast<int*>(stg + 16);
-        const float R = it_emit_cube_global<IT_HG>(g, cell_start, sorted, hx, hy, hz, l16,
-                                                   sqrtf(__uint_as_float((uint32_t)(key >> 32))), kdone, stage, stage_n);
-        if (l16 == 0) {
-          const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
-          *reinterpret_cast<uint4*>(q.cand + 4 * sh) = *reinterpret_cast<const uint4*>(stage);
-          q.cq[sh] = make_float4(hx, hy, hz, -R);
-        }
-      }
-    }
-    if (l16 == 0) {
-      keys_s[hs] = key;
-      if (!done) unres_q[atomicAdd(&L.unres_n, 1)] = hs;
-    }
+  };
+  if (ns) {
+    if (tab_lds) scan_pass(reinterpret_cast<const uint16_t*>(&qa_s[0][0]));
+    else scan_pass(reinterpret_cast<const uint16_t*>(slab + IT_OFF_CELLS));
+    __syncthreads();
   }
-  if (nh) __syncthreads();
+  IT_STAMP(4);
+  // ---- leftovers (no proof from the list, neighbour farther than the 2x2x2 stage can prove, or outside the slab):
+  // groups of IT_HG lanes, cubes on the slab first, then on the global grid
+  const int nh = L.hard_n;  // block-uniform
+  auto hard_pass = [&](const uint16_t* tab) __attribute__((always_inline)) {
+    for (int i = threadIdx.x / IT_HG; i < nh; i += IT_BLOCK / IT_HG) {
+      const int e = hard_q[i], hs = e & 0x7fffffff, l16 = threadIdx.x & (IT_HG - 1);
+      const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
+      unsigned long long key = keys_s[hs];
+      bool done = false, served;
+      int win;
+      if (e < 0) {
+        key = it_stage0<IT_HG, false, false>(g, box, cell_start, sorted, hx, hy, hz, l16, __builtin_inff(), &done,
+                                             &served, &win);
+        if (win >= 0) bslot_s[hs] = it_global_code(win);
+      } else if (local) {
+        // cubes on the slab; a query they serve gets a candidate list, so that it costs a search only once
+        bool inbox;
+        int kdone;
+        key = it_rings_local<IT_HG>(g, box, tab, pts_s, hx, hy, hz, l16, key, IT_LOCAL_RINGS, &done, &inbox, &win, &kdone);
+        if (win >= 0) bslot_s[hs] = win;
+        if (done) {
+          // staging: 32 bytes per group in the row-sum scratch (free between the prologue and the epilogue)
+          char* stg = reinterpret_cast<char*>(&sub[0][0]) + 32 * (threadIdx.x / IT_HG);
+          uint16_t* stage = reinterpret_cast<uint16_t*>(stg);
+          int* stage_n = reinterpret_cast<int*>(stg + 16);
+          const float R = it_emit_cube<IT_HG>(g, box, tab, pts_s, hx, hy, hz, l16,
+                                              sqrtf(__uint_as_float((uint32_t)(key >> 32))), kdone, stage, stage_n);
+          if (l16 == 0) {
+            const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
+            *reinterpret_cast<uint4*>(q.cand + 4 * sh) = *reinterpret_cast<const uint4*>(stage);
+            q.cq[sh] = make_float4(hx, hy, hz, R);
+          }
+        }
+      }
+      if (!done) {
+        int kdone;
+        key = grid_search_rings<IT_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, &kdone);
+        if (win >= 0) bslot_s[hs] = it_global_code(win);
+        if (done && local) {   // a list of global slots: the next searches of this query cost two gathers
+          char* stg = reinterpret_cast<char*>(&sub[0][0]) + 32 * (threadIdx.x / IT_HG);
+          uint32_t* stage = reinterpret_cast<uint32_t*>(stg);
+          int* stage_n = reinterpret_cast<int*>(stg + 16);
+          const float R = it_emit_cube_global<IT_HG>(g, cell_start, sorted, hx, hy, hz, l16,
+                                                     sqrtf(__uint_as_float((uint32_t)(key >> 32))), kdone, stage, stage_n);
+          if (l16 == 0) {
+            const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
+            *reinterpret_cast<uint4*>(q.cand + 4 * sh) = *reinterpret_cast<const uint4*>(stage);
+            q.cq[sh] = make_float4(hx, hy, hz, -R);
+          }
+        }
+      }
+      if (l16 == 0) {
+        keys_s[hs] = key;
+        if (!done) unres_q[atomicAdd(&L.unres_n, 1)] = hs;
+      }
+    }
+  };
+  if (nh) {
+    if (tab_lds) hard_pass(reinterpret_cast<const uint16_t*>(&qa_s[0][0]));
+    else hard_pass(reinterpret_cast<const uint16_t*>(slab + IT_OFF_CELLS));
+    __syncthreads();
+  }
   const int nun = L.unres_n;  // block-uniform
   IT_NOTE(7, (unsigned long long)nun | ((unsigned long long)hdr.mode << 10) | ((unsigned long long)ns << 12) |
                  ((unsigned long long)nh << 22) | ((unsigned long long)hdr.npts << 32) | ((unsigned long long)hdr.ncell << 44));
