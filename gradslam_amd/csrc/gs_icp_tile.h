@@ -834,15 +834,7 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
         if (win >= 0) bslot_s[slot] = c0R.w > 0.0f ? win : it_global_code(win);
         if (lane == 0) keys_s[slot] = key;
       } else if (lane == 0) {
-        // the first search of a solve scans (pass 2: every query, all waves busy); a later query whose list lost its
-        // proof goes straight to the 16-lane cube search of the leftover pass, which also gives it a roomier list
-        if (!bounded) {
-          scan_q[atomicAdd(&L.scan_n, 1)] = slot;
-        } else {
-          keys_s[slot] = ~0ull;
-          bslot_s[slot] = -1;
-          hard_q[atomicAdd(&L.hard_n, 1)] = slot;
-        }
+        scan_q[atomicAdd(&L.scan_n, 1)] = slot;   // pass 2: the 2x2x2 scan, and a new list
       }
     } else {
       // no slab: the global grid, scan bounded by what the previous search found (the previous neighbour is still a
@@ -872,7 +864,7 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   }
   __syncthreads();
   IT_STAMP(3);
-  // ---- pass 2 (tiles with a slab, first search of a solve): the 2x2x2 scan, which also writes the candidate lists.
+  // ---- pass 2 (tiles with a slab): the 2x2x2 scan for the queries without a proof, which also writes their lists.
   // The slab's cell table is read from its LDS copy when there is one (tab_lds), else from global memory; the two
   // call sites keep the address space of the pointer known to the compiler.
   const bool tab_lds = local && hdr.ncell + 1 <= IT_LDS_CELLS;
