@@ -42,6 +42,15 @@ class UpdateSeq(C.Structure):
                 ("new_count_out", C.c_void_p), ("scratch", C.c_void_p)]
 
 
+class StepSeq(C.Structure):
+    """gs_step_seq: one sequence's part of gs_pointfusion_step_batch_f32."""
+    _fields_ = [("depth", C.c_void_p), ("rgb", C.c_void_p), ("K16", C.c_void_p), ("prev_pose16", C.c_void_p),
+                ("out_pose16", C.c_void_p), ("vertex", C.c_void_p), ("normal", C.c_void_p), ("alpha", C.c_void_p),
+                ("gvertex", C.c_void_p), ("gnormal", C.c_void_p), ("best_pix", C.c_void_p),
+                ("new_count_out", C.c_void_p), ("map", MapView), ("loc_scratch", C.c_void_p),
+                ("upd_scratch", C.c_void_p)]
+
+
 # name -> argtypes (return type is int unless listed in _RESTYPE)
 _PROTOS = {
     "gs_abi_version": [],
@@ -110,6 +119,7 @@ _PROTOS = {
     "gs_localize_scratch_bytes": [_i32, _i32, _i32, _i64],
     "gs_localize_batch_f32": [C.POINTER(LocalizeSeq), _i32, _i32, _i32, _i32, C.POINTER(IcpParams), _vp],
     "gs_update_map_fusion_batch_f32": [C.POINTER(UpdateSeq), _i32, _i32, _i32, _f, _f, _i32, _vp],
+    "gs_pointfusion_step_batch_f32": [C.POINTER(StepSeq), _i32, _i32, _i32, _i32, C.POINTER(IcpParams), _f, _f, _f, _i32, _vp],
 }
 _RESTYPE = {"gs_last_error": C.c_char_p, "gs_scratch_bytes": _i64, "gs_icp_scratch_bytes": _i64,
             "gs_knn1_grid_scratch_bytes": _i64, "gs_update_map_scratch_bytes": _i64, "gs_global_maps_pose_backward_scratch_bytes": _i64, "gs_icp_tape_bytes": _i64, "gs_icp_backward_scratch_bytes": _i64,

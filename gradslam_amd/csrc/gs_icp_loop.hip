@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <memory>
+#include <mutex>
 
 #include "gs_icp_math.h"
 #include "gs_knn.h"
@@ -1029,6 +1030,44 @@ static bool icp_tile_enabled() {
   return v == 1;
 }
 
+static int64_t loc_rows(const gs_map_view& m) { return m.capacity > m.n_bound ? m.capacity : m.n_bound; }
+
+// ---- replaying the half-iteration launches of a solve as a hipGraph.  Their kernel arguments depend on the scratch
+// layout, the map buffers and the solver parameters only (not on the frame), so the 2 x numiters launches of a chunk
+// are captured once and replayed every frame: one graph launch instead of 40 kernel launches on the host
+// (GRADSLAM_HIP_GRAPH=0: plain launches; profiling passes and debugging builds always use plain launches).
+struct ItGraphKey {
+  int dev, B, Hl, Wl;
+  gs_icp_params prm;
+  const void* ptr[GS_MAX_BATCH][3];   // scratch, map points, map normals
+  int64_t rows[GS_MAX_BATCH];
+};
+struct ItGraphEntry {
+  bool used;
+  ItGraphKey key;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  unsigned long long stamp;
+};
+constexpr int IT_GRAPH_SLOTS = 16;
+static ItGraphEntry g_it_graphs[IT_GRAPH_SLOTS];
+static unsigned long long g_it_graph_clock = 0;
+static std::mutex g_it_graph_mutex;
+static bool it_graphs_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GRADSLAM_HIP_GRAPH");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v == 1;
+}
+static hipStream_t it_capture_stream(int dev) {
+  static hipStream_t cs[64] = {};
+  if (dev < 0 || dev >= 64) return nullptr;
+  if (!cs[dev] && hipStreamCreateWithFlags(&cs[dev], hipStreamNonBlocking) != hipSuccess) cs[dev] = nullptr;
+  return cs[dev];
+}
+
 // The 2 x numiters half-iterations + the final update of one chunk on the tile engine.  The grid of every sequence is
 // built; lattice / state / d2prev live where the row-unit engine keeps them.
 static int localize_tiles(const gs_localize_seq* seqs, int B, int Hl, int Wl, const gs_icp_params* prm, const LocBatch& lb,
@@ -1045,7 +1084,7 @@ static int localize_tiles(const gs_localize_seq* seqs, int B, int Hl, int Wl, co
   const int64_t n_lat = (int64_t)Hl * Wl;
   for (int b = 0; b < B; ++b) {
     const gs_localize_seq& q = seqs[b];
-    im[b] = it_carve(reinterpret_cast<char*>(sc[b].state) + gs_icp_scratch_bytes(n_lat, q.map.n_bound), Hl, Wl);
+    im[b] = it_carve(reinterpret_cast<char*>(sc[b].state) + gs_icp_scratch_bytes(n_lat, loc_rows(q.map)), Hl, Wl);
     bb.s[b] = ItBuildSeq{lb.s[b].lattice, gm[b].g, gm[b].cell_start, gm[b].sorted, gm[b].sorted_n, im[b].slabs};
   }
   {
@@ -1053,15 +1092,16 @@ static int localize_tiles(const gs_localize_seq* seqs, int B, int Hl, int Wl, co
     hipLaunchKernelGGL(gs_it_slab_build_kernel, dim3((unsigned)(B * ntiles)), dim3(IT_NQ), 0, st, bb);
   }
   const bool reduce_rows = ntiles > FS_REDUCE_ROWS;
-  std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
   const dim3 grid((unsigned)(B * ntiles)), block(IT_BLOCK);
   int h = 0;
+  auto enqueue_halves = [&](hipStream_t st) {
+  h = 0;
   for (int it = 0; it < prm->numiters; ++it) {
     for (int b = 0; b < B; ++b) {
       const gs_localize_seq& q = seqs[b];
       const float* cur_in = it == 0 ? lb.s[b].lattice : (((it - 1) & 1) ? sc[b].srcB : sc[b].srcA);
       float* cur = (it & 1) ? sc[b].srcB : sc[b].srcA;
-      hb.s[b] = ItSeq{cur_in, cur, q.map.points, q.map.normals, GsCount{q.map.n_bound, q.map.n_dev}, gm[b].g,
+      hb.s[b] = ItSeq{cur_in, cur, q.map.points, q.map.normals, gm[b].g,
                       gm[b].cell_start, gm[b].sorted, gm[b].sorted_n, im[b].slabs, reinterpret_cast<float*>(sc[b].best),
                       im[b].cand, im[b].cq, im[b].cn, im[b].partials[(h + 1) & 1], im[b].partials[h & 1], &sc[b].state->s[h & 1],
                       &sc[b].state->s[(h + 1) & 1], sc[b].state->trace};
@@ -1125,7 +1165,59 @@ static int localize_tiles(const gs_localize_seq* seqs, int B, int Hl, int Wl, co
     hb.tl = nullptr;
 #endif
   }
-  prof_loop.reset();
+  };
+  bool plain = true;
+#ifndef GS_ICP_TIMELINE
+  if (it_graphs_enabled() && !g_gs_prof_on && !force_scan && prm->numiters > 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    ItGraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.dev = dev; key.B = B; key.Hl = Hl; key.Wl = Wl; key.prm = *prm;
+    for (int b = 0; b < B; ++b) {
+      key.ptr[b][0] = seqs[b].scratch; key.ptr[b][1] = seqs[b].map.points; key.ptr[b][2] = seqs[b].map.normals;
+      key.rows[b] = loc_rows(seqs[b].map);
+    }
+    std::lock_guard<std::mutex> lock(g_it_graph_mutex);
+    ItGraphEntry* hit = nullptr;
+    ItGraphEntry* victim = &g_it_graphs[0];
+    for (int i = 0; i < IT_GRAPH_SLOTS; ++i) {
+      ItGraphEntry& e = g_it_graphs[i];
+      if (e.used && memcmp(&e.key, &key, sizeof(key)) == 0) { hit = &e; break; }
+      if (!e.used || (victim->used && e.stamp < victim->stamp)) victim = &e;
+    }
+    if (!hit) {
+      hipStream_t cs = it_capture_stream(dev);
+      if (cs && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        enqueue_halves(cs);
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (hipStreamEndCapture(cs, &graph) == hipSuccess && graph &&
+            hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+          if (victim->used) { (void)hipGraphExecDestroy(victim->exec); (void)hipGraphDestroy(victim->graph); }
+          victim->used = true; victim->key = key; victim->graph = graph; victim->exec = exec;
+          hit = victim;
+        } else {
+          if (graph) (void)hipGraphDestroy(graph);
+          (void)hipGetLastError();
+        }
+      }
+    }
+    if (hit) {
+      hit->stamp = ++g_it_graph_clock;
+      if (hipGraphLaunch(hit->exec, st) == hipSuccess) {
+        plain = false;
+        h = 2 * prm->numiters;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+  }
+#endif
+  if (plain) {
+    std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
+    enqueue_halves(st);
+  }
   {
     GsProf prof(GS_PROF_SOLVE, 1.0, st);
     IcpFinishBatch fb;
@@ -1160,10 +1252,13 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
     const gs_localize_seq& q = seqs[b];
     char* p = reinterpret_cast<char*>(q.scratch);
     float* lattice = reinterpret_cast<float*>(p); p += gs_align(12 * (size_t)n_lat);
-    int32_t* pix = reinterpret_cast<int32_t*>(p); p += gs_align(4 * (size_t)q.map.n_bound);
+    // the layout follows the map's CAPACITY (what the scratch was sized for), not the count bound of this frame: every
+    // pointer below then stays the same from frame to frame (the half-iteration launches are replayed as a graph)
+    const int64_t rows = loc_rows(q.map);
+    int32_t* pix = reinterpret_cast<int32_t*>(p); p += gs_align(4 * (size_t)rows);
     int64_t* n_valid = reinterpret_cast<int64_t*>(p); p += 256;
     sc[b] = icp_carve(p, n_lat);
-    gm[b] = grid_carve(sc[b].grid, n_lat, q.map.n_bound);
+    gm[b] = grid_carve(sc[b].grid, n_lat, rows);
     lb.s[b] = LocSeq{q.vertex, q.depth, q.prev_pose16, lattice, sc[b].state, q.out_pose16,
                      reinterpret_cast<char*>(gm[b].g), n_valid};
     static int binned_normals = -1;  // GRADSLAM_HIP_ICP_BINNED_NORMALS=0: gather the matches' normals from the map (A/B)
@@ -1270,11 +1365,54 @@ extern "C" int gs_localize_batch_f32(const gs_localize_seq* seqs_host, int B, in
     GS_REQUIRE(q.vertex && q.depth && q.K16 && q.prev_pose16 && q.out_pose16 && q.scratch, "NULL pointer");
     GS_REQUIRE(q.map.points && q.map.normals && q.map.n_bound > 0 && q.map.n_bound < 0x7fffffffll,
                "every sequence needs a non-empty map (points + normals)");
+    GS_REQUIRE(q.map.capacity <= 0 || q.map.n_bound <= q.map.capacity, "map.n_bound exceeds map.capacity");
   }
   hipStream_t st = gs_stream(stream);
   for (int c0 = 0; c0 < B; c0 += GS_MAX_BATCH) {
     const int nb = B - c0 < GS_MAX_BATCH ? B - c0 : GS_MAX_BATCH;
     const int rc = localize_chunk(seqs_host + c0, nb, H, W, ds, prm, st);
+    if (rc != GS_OK) return rc;
+  }
+  return GS_OK;
+}
+
+extern "C" int gs_pointfusion_step_batch_f32(const gs_step_seq* seqs_host, int B, int H, int W, int ds,
+                                             const gs_icp_params* prm, float two_sigma_sq, float dist_th, float dot_th,
+                                             int renorm_all, void* stream) {
+  GS_REQUIRE(seqs_host && prm && B > 0 && H > 0 && W > 0 && ds > 0, "bad arguments");
+  const int64_t P = (int64_t)H * W;
+  const gs_step_seq& s0 = seqs_host[0];
+  const int64_t dstride = B > 1 ? seqs_host[1].depth - s0.depth : P;
+  for (int b = 0; b < B; ++b) {
+    const gs_step_seq& q = seqs_host[b];
+    GS_REQUIRE(q.depth && q.rgb && q.K16 && q.prev_pose16 && q.out_pose16 && q.vertex && q.normal && q.alpha && q.gvertex &&
+                   q.gnormal && q.best_pix && q.new_count_out && q.loc_scratch && q.upd_scratch, "NULL pointer");
+    GS_REQUIRE(q.out_pose16 != q.prev_pose16, "out_pose16 must not alias prev_pose16");
+    GS_REQUIRE(q.vertex == s0.vertex + 3 * P * b && q.normal == s0.normal + 3 * P * b && q.alpha == s0.alpha + P * b,
+               "vertex / normal / alpha of the batch must be dense");
+    GS_REQUIRE(q.depth == s0.depth + dstride * b && q.K16 == s0.K16 + 16 * (int64_t)b, "depth / K16 must be equally strided");
+  }
+  GS_REQUIRE(dstride >= P || B == 1, "overlapping depth images");
+  for (int c0 = 0; c0 < B; c0 += GS_MAX_BATCH) {   // the sequences are independent: chunk by chunk through the frame
+    const int nb = B - c0 < GS_MAX_BATCH ? B - c0 : GS_MAX_BATCH;
+    const gs_step_seq* sq = seqs_host + c0;
+    int rc = gs_frame_maps_batch_f32(sq[0].depth, dstride, P, sq[0].K16, nb, 1, H, W, two_sigma_sq, sq[0].vertex,
+                                     sq[0].normal, sq[0].alpha, stream);
+    if (rc != GS_OK) return rc;
+    gs_localize_seq ls[GS_MAX_BATCH];
+    gs_update_seq us[GS_MAX_BATCH];
+    for (int b = 0; b < nb; ++b) {
+      const gs_step_seq& q = sq[b];
+      ls[b].vertex = q.vertex; ls[b].depth = q.depth; ls[b].K16 = q.K16; ls[b].prev_pose16 = q.prev_pose16;
+      ls[b].map = q.map; ls[b].out_pose16 = q.out_pose16; ls[b].scratch = q.loc_scratch;
+      us[b].map = q.map; us[b].vertex = q.vertex; us[b].normal = q.normal; us[b].depth = q.depth; us[b].rgb = q.rgb;
+      us[b].alpha = q.alpha; us[b].pose16 = q.out_pose16; us[b].K16 = q.K16; us[b].gvertex = q.gvertex;
+      us[b].gnormal = q.gnormal; us[b].best_pix = q.best_pix; us[b].new_count_out = q.new_count_out;
+      us[b].scratch = q.upd_scratch;
+    }
+    rc = gs_localize_batch_f32(ls, nb, H, W, ds, prm, stream);
+    if (rc != GS_OK) return rc;
+    rc = gs_update_map_fusion_batch_f32(us, nb, H, W, dist_th, dot_th, renorm_all, stream);
     if (rc != GS_OK) return rc;
   }
   return GS_OK;

@@ -203,7 +203,6 @@ struct ItSeq {
   float* src_out;
   const float* tgt;          // map rows (only for the degenerate "no target at all" row)
   const float* tn;
-  GsCount n_tgt;
   const GsGrid* gp;
   const int* cell_start;
   const float4* sorted;

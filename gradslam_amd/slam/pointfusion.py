@@ -39,6 +39,18 @@ class PointFusion(ICPSLAM):
         self.dot_th = torch.cos(rad_th) if torch.is_tensor(rad_th) else math.cos(rad_th)
         self.sigma = sigma
 
+    def step(self, pointclouds: Pointclouds, live_frame: RGBDImages, prev_frame=None, inplace: bool = False):
+        # the plain SLAM loop (in place, nothing on the autograd tape, a map with surfels): one foreign call per frame
+        # (slam/_fastpath.py: same kernels in the same order as _localize + _map below); anything else, and every
+        # subclass that overrides _localize / _map, takes the generic path
+        if inplace and type(self) is PointFusion and isinstance(live_frame, RGBDImages) and \
+                isinstance(prev_frame, RGBDImages) and isinstance(pointclouds, Pointclouds):
+            from ._fastpath import try_step
+            res = try_step(self, pointclouds, live_frame, prev_frame)
+            if res is not None:
+                return res
+        return super().step(pointclouds, live_frame, prev_frame, inplace)
+
     def _localize(self, pointclouds: Pointclouds, live_frame: RGBDImages, prev_frame: RGBDImages):
         if isinstance(live_frame, RGBDImages):
             # the fusion step needs the sample confidences exp(-|v|^2 / 2 sigma^2): have the kernel that

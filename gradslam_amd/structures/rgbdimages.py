@@ -114,14 +114,31 @@ class RGBDImages(object):
                 raise IndexError("Incorrect indexing at dimension 0, make sure range is within 0 and {0}".format(self._B))
             if new_rgb.shape[1] == 0:
                 raise IndexError("Incorrect indexing at dimension 1, make sure range is within 0 and {0}".format(self._L))
-            other = RGBDImages(new_rgb, self._depth_image[slices[0], slices[1]], self._intrinsics[slices[0], :],
-                               channels_first=self.channels_first)
+            # a view of a validated object needs no second validation (frames[:, s] sits in every SLAM loop): copy
+            # the fields, slice the tensors, fix the shape-dependent ones
+            other = object.__new__(RGBDImages)
+            other.__dict__.update(self.__dict__)
+            other._rgb_image = new_rgb
+            other._depth_image = self._depth_image[slices[0], slices[1]]
+            other._intrinsics = self._intrinsics if slices[0] == slice(None, None) else self._intrinsics[slices[0], :]
             for k in self._INTERNAL_TENSORS:
-                if k in ["_rgb_image", "_depth_image", "_intrinsics"]:
+                if k in ("_rgb_image", "_depth_image", "_intrinsics"):
                     continue
                 v = getattr(self, k)
                 if torch.is_tensor(v):
                     setattr(other, k, v[slices[0], slices[1]])
+            ac = self._alpha_cache
+            other._alpha_cache = None if ac is None else (ac[0], ac[1][slices[0], slices[1]])
+            other._valid_depth_mask = None
+            full = tuple(new_rgb.shape)
+            c = other.cdim
+            other._rgb_image_shape = new_rgb.shape
+            other._depth_shape = other._depth_image_shape = full[:c] + (1,) + full[c + 1:]
+            other._intrinsics_shape = (full[0], 1, 4, 4)
+            other._poses_shape = full[:2] + (4, 4)
+            other._pixel_pos_shape = full[:c] + full[c + 1:] + (3,)
+            other._B, other._L = full[0], full[1]
+            other.shape = (other._B, other._L, other.h, other.w)
             return other
         raise IndexError(index)
 

@@ -474,6 +474,34 @@ typedef struct gs_update_seq {
 GS_API int gs_update_map_fusion_batch_f32(const gs_update_seq* seqs_host, int B, int H, int W, float dist_th,
                                           float dot_th, int renorm_all, void* stream);
 
+/* One frame of PointFusion.step (slam/icpslam.py:140-178 with the _map override of slam/pointfusion.py:107-112) for B
+ * sequences in ONE call: the live frames' local maps (gs_frame_maps_batch_f32), the poses (gs_localize_batch_f32) and the
+ * map update under those poses (gs_update_map_fusion_batch_f32) -- the same kernels in the same order, enqueued from
+ * C so that the host cost of a frame is one foreign call.  The 2 x numiters ICP half-iteration launches are replayed
+ * as a hipGraph while the scratch / map buffers of a sequence stay where they are.
+ * vertex / normal / alpha of all sequences must be dense ((B, H, W, 3) / (B, H, W): seqs[b].vertex = seqs[0].vertex +
+ * b * 3 * H * W, ...) and the depth images equally strided (seqs[b].depth = seqs[0].depth + b * stride). */
+typedef struct gs_step_seq {
+  const float* depth;        /* live frame (H, W) */
+  const float* rgb;          /* (H, W, 3) */
+  const float* K16;          /* intrinsics (of the previous = live frame) */
+  const float* prev_pose16;  /* pose of the previous frame */
+  float* out_pose16;         /* out: recovered pose of the live frame (must not alias prev_pose16) */
+  float* vertex;             /* out: LOCAL vertex / normal maps (H, W, 3), sample confidences (H, W) */
+  float* normal;
+  float* alpha;
+  float* gvertex;            /* out: global maps under the recovered pose */
+  float* gnormal;
+  int32_t* best_pix;         /* out: correspondence table (H*W) */
+  int64_t* new_count_out;    /* out: device int64[1], must not alias map.n_dev */
+  gs_map_view map;           /* all four attributes; n_bound > 0; capacity >= n_bound + H*W */
+  void* loc_scratch;         /* gs_localize_scratch_bytes(H, W, ds, map.capacity) */
+  void* upd_scratch;         /* gs_update_map_scratch_bytes(map.capacity, H, W) */
+} gs_step_seq;
+GS_API int gs_pointfusion_step_batch_f32(const gs_step_seq* seqs_host, int B, int H, int W, int ds,
+                                         const gs_icp_params* params_host, float two_sigma_sq, float dist_th,
+                                         float dot_th, int renorm_all, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
