@@ -412,6 +412,106 @@ GS_DEV unsigned long long it_list_search(const uint32_t* w, const float4 c0R, co
   return kmin;
 }
 
+// A whole wave serves ONE query whose list lost its proof: the 3x3x3 cube of cells around it as one flat candidate
+// list (lanes 0..8 fetch the nine row segments, a wave scan turns them into flat offsets, every lane then takes the
+// candidates lane, lane + 64, ...), nearest neighbour by a wave minimum, and the new candidate list by ballots: every
+// target closer than R = min(d1 + IT_RADD cells, 0.999 cells) -- all of them are inside the cube -- up to 8 entries.
+// The 2-lane scan costs such a query ~150 dependent LDS round trips; this is a handful.
+// Returns false when the cube is not inside the slab's box or holds more than 3 x 64 candidates (the caller hands the
+// query to the leftover pass).  *resolved = false: the neighbour is farther than the cube can prove.
+constexpr int IT_WC_ROUNDS = 3;
+GS_DEV bool it_wave_cube1(const GsGrid& g, const ItBox& box, const uint16_t* __restrict__ cells,
+                          const float4* __restrict__ pts, float qx, float qy, float qz, unsigned long long* key_out,
+                          bool* resolved, int* win, uint16_t* stage, float* R_out) {
+  const int l = threadIdx.x & (GS_WAVE - 1);
+  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
+  const int xa = qc.cx - 1 < 0 ? 0 : qc.cx - 1, xb = qc.cx + 1 >= g.nx ? g.nx - 1 : qc.cx + 1;
+  const int ya = qc.cy - 1 < 0 ? 0 : qc.cy - 1, yb = qc.cy + 1 >= g.ny ? g.ny - 1 : qc.cy + 1;
+  const int za = qc.cz - 1 < 0 ? 0 : qc.cz - 1, zb = qc.cz + 1 >= g.nz ? g.nz - 1 : qc.cz + 1;
+  if (xa < box.x0 || xb >= box.x0 + box.nx || ya < box.y0 || yb >= box.y0 + box.ny || za < box.z0 || zb >= box.z0 + box.nz)
+    return false;
+  int rb = 0, rn = 0;   // lane r < 9: first slab slot and length of row r of the cube
+  if (l < 9) {
+    const int zz = qc.cz + l / 3 - 1, yy = qc.cy + l % 3 - 1;
+    if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
+      const int row = ((zz - box.z0) * box.ny + (yy - box.y0)) * box.nx - box.x0;
+      rb = (int)cells[row + xa];
+      rn = (int)cells[row + xb + 1] - rb;
+    }
+  }
+  const int incl = gs_wave_incl_scan(rn);
+  const int total = __shfl(incl, 8, GS_WAVE);
+  if (total > IT_WC_ROUNDS * GS_WAVE) return false;
+  const int fs = incl - rn;   // flat offset of row l
+  float dd[IT_WC_ROUNDS];
+  int sl[IT_WC_ROUNDS];
+  unsigned long long key = ~0ull;
+  int bs = -1;
+#pragma unroll
+  for (int u = 0; u < IT_WC_ROUNDS; ++u) {
+    const int t = l + u * GS_WAVE;
+    dd[u] = __builtin_inff();
+    sl[u] = 0;
+    if (u * GS_WAVE < total) {   // (wave-uniform)
+      int slot = 0;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int f = __shfl(fs, r, GS_WAVE), b0 = __shfl(rb, r, GS_WAVE);
+        if (t >= f) slot = b0 + (t - f);   // the last row whose offset is <= t
+      }
+      if (t < total) {
+        const float4 c = pts[slot];
+        const unsigned long long k2 = grid_key(qx, qy, qz, c);
+        if (k2 != ~0ull) dd[u] = __uint_as_float((uint32_t)(k2 >> 32));
+        sl[u] = slot;
+        if (k2 < key) { key = k2; bs = slot; }
+      }
+    }
+  }
+  unsigned long long kmin = key;
+#pragma unroll
+  for (int d = GS_WAVE / 2; d > 0; d >>= 1) {
+    const unsigned long long o = __shfl_xor(kmin, d, GS_WAVE);
+    kmin = o < kmin ? o : kmin;
+  }
+  *win = (key == kmin && bs >= 0) ? bs : -1;
+  *key_out = kmin;
+  const float rcube = g.c * 0.999f;
+  const float bd = __uint_as_float((uint32_t)(kmin >> 32));   // NaN: nothing found
+  *resolved = bd <= rcube * rcube;
+  *R_out = 0.0f;
+  if (*resolved) {
+    const float d1 = sqrtf(bd);
+    float radd = IT_RADD * g.c;
+    for (int attempt = 0; attempt < 4; ++attempt, radd *= 0.5f) {
+      float R = d1 + radd;
+      R = R < rcube ? R : rcube;
+      const float R2 = R * R;
+      int n = 0, pos[IT_WC_ROUNDS];
+#pragma unroll
+      for (int u = 0; u < IT_WC_ROUNDS; ++u) {
+        const bool in = dd[u] < R2;
+        const unsigned long long m = __ballot(in);
+        pos[u] = in ? n + __popcll(m & ((1ull << l) - 1ull)) : -1;
+        n += __popcll(m);
+      }
+      if (n <= 8) {
+        if (l < 8) stage[l] = 0xffffu;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < IT_WC_ROUNDS; ++u)
+          if (pos[u] >= 0) stage[pos[u]] = (uint16_t)sl[u];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        *R_out = R;
+        break;
+      }
+    }
+  }
+  return true;
+}
+
 // Cubes of Chebyshev radius 1 .. kmax around the query's cell, on a tile's slab (grid_search_rings of gs_knn.h on the
 // slab's cell table and LDS points): serves the queries whose neighbour is farther than the 2x2x2 stage can prove,
 // as long as the cube stays inside the slab's box (*inbox = false otherwise: the caller goes to the global grid).
@@ -890,9 +990,36 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       }
     }
   };
+  // later searches: the few queries whose list lost its proof, a wave each (needs the cell table in LDS)
+  auto wave_pass = [&](const uint16_t* tab) __attribute__((always_inline)) {
+    const int wv2 = threadIdx.x / GS_WAVE;
+    for (int i = wv2; i < ns; i += IT_BLOCK / GS_WAVE) {
+      const int hs = scan_q[i];
+      const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
+      char* stg = reinterpret_cast<char*>(&sub[0][0]) + 32 * wv2;   // (row-sum scratch, free between prologue and epilogue)
+      unsigned long long key = ~0ull;
+      bool done = false;
+      int win = -1;
+      float R = 0.0f;
+      const bool served = it_wave_cube1(g, box, tab, pts_s, hx, hy, hz, &key, &done, &win, reinterpret_cast<uint16_t*>(stg), &R);
+      if (served && win >= 0) bslot_s[hs] = win;
+      if ((threadIdx.x & (GS_WAVE - 1)) == 0) {
+        const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
+        if (served && done) *reinterpret_cast<uint4*>(q.cand + 4 * sh) = *reinterpret_cast<const uint4*>(stg);
+        q.cq[sh] = make_float4(hx, hy, hz, served && done ? R : 0.0f);
+        if (!served || key == ~0ull) bslot_s[hs] = -1;
+        keys_s[hs] = served ? key : ~0ull;
+        if (!(served && done)) hard_q[atomicAdd(&L.hard_n, 1)] = hs;   // (the cubes of the leftover pass start over)
+      }
+    }
+  };
   if (ns) {
-    if (tab_lds) scan_pass(reinterpret_cast<const uint16_t*>(&qa_s[0][0]));
-    else scan_pass(reinterpret_cast<const uint16_t*>(slab + IT_OFF_CELLS));
+    if (!bounded || !tab_lds) {
+      if (tab_lds) scan_pass(reinterpret_cast<const uint16_t*>(&qa_s[0][0]));
+      else scan_pass(reinterpret_cast<const uint16_t*>(slab + IT_OFF_CELLS));
+    } else {
+      wave_pass(reinterpret_cast<const uint16_t*>(&qa_s[0][0]));
+    }
     __syncthreads();
   }
   IT_STAMP(4);
