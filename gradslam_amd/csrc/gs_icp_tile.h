@@ -412,104 +412,75 @@ GS_DEV unsigned long long it_list_search(const uint32_t* w, const float4 c0R, co
   return kmin;
 }
 
-// A whole wave serves ONE query whose list lost its proof: the 3x3x3 cube of cells around it as one flat candidate
-// list (lanes 0..8 fetch the nine row segments, a wave scan turns them into flat offsets, every lane then takes the
-// candidates lane, lane + 64, ...), nearest neighbour by a wave minimum, and the new candidate list by ballots: every
-// target closer than R = min(d1 + IT_RADD cells, 0.999 cells) -- all of them are inside the cube -- up to 8 entries.
-// The 2-lane scan costs such a query ~150 dependent LDS round trips; this is a handful.
-// Returns false when the cube is not inside the slab's box or holds more than 3 x 64 candidates (the caller hands the
-// query to the leftover pass).  *resolved = false: the neighbour is farther than the cube can prove.
-constexpr int IT_WC_ROUNDS = 3;
-GS_DEV bool it_wave_cube1(const GsGrid& g, const ItBox& box, const uint16_t* __restrict__ cells,
-                          const float4* __restrict__ pts, float qx, float qy, float qz, unsigned long long* key_out,
-                          bool* resolved, int* win, uint16_t* stage, float* R_out) {
-  const int l = threadIdx.x & (GS_WAVE - 1);
+// The scan of the first search of a solve (every query, all waves busy: throughput, not latency, is what counts):
+// exact nearest neighbour + candidate list from a block of cells chosen PER AXIS -- the two cells nearest to the query
+// where it sits within IT_SPAN_LO of a cell boundary, three cells (its own and both neighbours) where it sits near the
+// middle of its cell.  Every face of that block with cells behind it is then at least 0.65 cells away (the plain 2x2x2
+// block: 0.5), which is what leaves a list room to move: R - d1 >= ~0.4 cells for a typical neighbour distance, more
+// than a solve moves a query.  Lane l of the pair walks the rows l, l + 2, ... of the block.
+constexpr float IT_SPAN_LO = 0.35f;
+GS_DEV unsigned long long it_scan_adaptive(const GsGrid& g, const ItBox& box, const uint16_t* __restrict__ cells,
+                                           const float4* __restrict__ pts, float qx, float qy, float qz, int lane,
+                                           bool* resolved, bool* served, int* win, ItList* lst) {
   const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
-  const int xa = qc.cx - 1 < 0 ? 0 : qc.cx - 1, xb = qc.cx + 1 >= g.nx ? g.nx - 1 : qc.cx + 1;
-  const int ya = qc.cy - 1 < 0 ? 0 : qc.cy - 1, yb = qc.cy + 1 >= g.ny ? g.ny - 1 : qc.cy + 1;
-  const int za = qc.cz - 1 < 0 ? 0 : qc.cz - 1, zb = qc.cz + 1 >= g.nz ? g.nz - 1 : qc.cz + 1;
-  if (xa < box.x0 || xb >= box.x0 + box.nx || ya < box.y0 || yb >= box.y0 + box.ny || za < box.z0 || zb >= box.z0 + box.nz)
-    return false;
-  int rb = 0, rn = 0;   // lane r < 9: first slab slot and length of row r of the cube
-  if (l < 9) {
-    const int zz = qc.cz + l / 3 - 1, yy = qc.cy + l % 3 - 1;
-    if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
-      const int row = ((zz - box.z0) * box.ny + (yy - box.y0)) * box.nx - box.x0;
-      rb = (int)cells[row + xa];
-      rn = (int)cells[row + xb + 1] - rb;
-    }
+  const float fx = (qc.px - g.ox) * g.inv_c - (float)qc.cx, fy = (qc.py - g.oy) * g.inv_c - (float)qc.cy,
+              fz = (qc.pz - g.oz) * g.inv_c - (float)qc.cz;
+  const float BIG = 3.0e38f;
+  // per axis: first cell, last cell (clipped to the grid) and the distance (cells) to the nearest face with cells behind
+  int xa = fx > 1.0f - IT_SPAN_LO ? qc.cx : qc.cx - 1, xb = fx < IT_SPAN_LO ? qc.cx : qc.cx + 1;
+  int ya = fy > 1.0f - IT_SPAN_LO ? qc.cy : qc.cy - 1, yb = fy < IT_SPAN_LO ? qc.cy : qc.cy + 1;
+  int za = fz > 1.0f - IT_SPAN_LO ? qc.cz : qc.cz - 1, zb = fz < IT_SPAN_LO ? qc.cz : qc.cz + 1;
+  const float ax = fminf(xa >= 1 ? fx + (float)(qc.cx - xa) : BIG, xb + 1 < g.nx ? (float)(xb + 1 - qc.cx) - fx : BIG);
+  const float ay = fminf(ya >= 1 ? fy + (float)(qc.cy - ya) : BIG, yb + 1 < g.ny ? (float)(yb + 1 - qc.cy) - fy : BIG);
+  const float az = fminf(za >= 1 ? fz + (float)(qc.cz - za) : BIG, zb + 1 < g.nz ? (float)(zb + 1 - qc.cz) - fz : BIG);
+  const float amin = fminf(ax, fminf(ay, az));
+  xa = xa < 0 ? 0 : xa; xb = xb >= g.nx ? g.nx - 1 : xb;
+  ya = ya < 0 ? 0 : ya; yb = yb >= g.ny ? g.ny - 1 : yb;
+  za = za < 0 ? 0 : za; zb = zb >= g.nz ? g.nz - 1 : zb;
+  lst->w[0] = lst->w[1] = ~0u;
+  lst->R = 0.0f;
+  *win = -1;
+  if (xa < box.x0 || xb >= box.x0 + box.nx || ya < box.y0 || yb >= box.y0 + box.ny || za < box.z0 || zb >= box.z0 + box.nz) {
+    *served = false;
+    *resolved = false;
+    return ~0ull;
   }
-  const int incl = gs_wave_incl_scan(rn);
-  const int total = __shfl(incl, 8, GS_WAVE);
-  if (total > IT_WC_ROUNDS * GS_WAVE) return false;
-  const int fs = incl - rn;   // flat offset of row l
-  float dd[IT_WC_ROUNDS];
-  int sl[IT_WC_ROUNDS];
+  *served = true;
+  const int ny = yb - ya + 1, nrow = ny * (zb - za + 1);
   unsigned long long key = ~0ull;
   int bs = -1;
-#pragma unroll
-  for (int u = 0; u < IT_WC_ROUNDS; ++u) {
-    const int t = l + u * GS_WAVE;
-    dd[u] = __builtin_inff();
-    sl[u] = 0;
-    if (u * GS_WAVE < total) {   // (wave-uniform)
-      int slot = 0;
-#pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        const int f = __shfl(fs, r, GS_WAVE), b0 = __shfl(rb, r, GS_WAVE);
-        if (t >= f) slot = b0 + (t - f);   // the last row whose offset is <= t
-      }
-      if (t < total) {
-        const float4 c = pts[slot];
-        const unsigned long long k2 = grid_key(qx, qy, qz, c);
-        if (k2 != ~0ull) dd[u] = __uint_as_float((uint32_t)(k2 >> 32));
-        sl[u] = slot;
-        if (k2 < key) { key = k2; bs = slot; }
-      }
+  float n0 = __builtin_inff(), n1 = n0, n2 = n0, n3 = n0, ndrop = n0;
+  uint32_t s0 = 0xffffu, s1 = 0xffffu, s2 = 0xffffu, s3 = 0xffffu;
+  for (int r = lane; r < nrow; r += 2) {
+    const int zz = za + r / ny, yy = ya + r % ny;
+    const int row = ((zz - box.z0) * box.ny + (yy - box.y0)) * box.nx - box.x0;
+    const int je = (int)cells[row + xb + 1];
+    for (int j = (int)cells[row + xa]; j < je; ++j) {
+      const unsigned long long k2 = grid_key(qx, qy, qz, pts[j]);
+      if (k2 < key) { key = k2; bs = j; }
+      // (a NaN distance -- key ~0 -- compares false everywhere: never listed, never the dropped minimum)
+      const float dn = k2 != ~0ull ? __uint_as_float((uint32_t)(k2 >> 32)) : __builtin_nanf("");
+      const uint32_t sn = (uint32_t)j;
+      const bool l0 = dn < n0, l1 = dn < n1, l2 = dn < n2, l3 = dn < n3;
+      ndrop = fminf(ndrop, l3 ? n3 : dn);
+      n3 = l2 ? n2 : (l3 ? dn : n3); s3 = l2 ? s2 : (l3 ? sn : s3);
+      n2 = l1 ? n1 : (l2 ? dn : n2); s2 = l1 ? s1 : (l2 ? sn : s2);
+      n1 = l0 ? n0 : (l1 ? dn : n1); s1 = l0 ? s0 : (l1 ? sn : s1);
+      n0 = l0 ? dn : n0;             s0 = l0 ? sn : s0;
     }
   }
-  unsigned long long kmin = key;
-#pragma unroll
-  for (int d = GS_WAVE / 2; d > 0; d >>= 1) {
-    const unsigned long long o = __shfl_xor(kmin, d, GS_WAVE);
-    kmin = o < kmin ? o : kmin;
-  }
+  const unsigned long long kmin = grid_group_min<2>(key);
   *win = (key == kmin && bs >= 0) ? bs : -1;
-  *key_out = kmin;
-  const float rcube = g.c * 0.999f;
-  const float bd = __uint_as_float((uint32_t)(kmin >> 32));   // NaN: nothing found
-  *resolved = bd <= rcube * rcube;
-  *R_out = 0.0f;
+  const float rb = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
+  const float bd = __uint_as_float((uint32_t)(kmin >> 32));
+  *resolved = rb > 0.0f && (rb >= 1.0e30f ? bd == bd : bd <= rb * rb);
   if (*resolved) {
-    const float d1 = sqrtf(bd);
-    float radd = IT_RADD * g.c;
-    for (int attempt = 0; attempt < 4; ++attempt, radd *= 0.5f) {
-      float R = d1 + radd;
-      R = R < rcube ? R : rcube;
-      const float R2 = R * R;
-      int n = 0, pos[IT_WC_ROUNDS];
-#pragma unroll
-      for (int u = 0; u < IT_WC_ROUNDS; ++u) {
-        const bool in = dd[u] < R2;
-        const unsigned long long m = __ballot(in);
-        pos[u] = in ? n + __popcll(m & ((1ull << l) - 1ull)) : -1;
-        n += __popcll(m);
-      }
-      if (n <= 8) {
-        if (l < 8) stage[l] = 0xffffu;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int u = 0; u < IT_WC_ROUNDS; ++u)
-          if (pos[u] >= 0) stage[pos[u]] = (uint16_t)sl[u];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        *R_out = R;
-        break;
-      }
-    }
+    const float od = __shfl_xor(ndrop, 1, 2);
+    lst->w[0] = s0 | (s1 << 16);
+    lst->w[1] = s2 | (s3 << 16);
+    lst->R = fminf(sqrtf(fminf(ndrop, od)), rb);
   }
-  return true;
+  return kmin;
 }
 
 // Cubes of Chebyshev radius 1 .. kmax around the query's cell, on a tile's slab (grid_search_rings of gs_knn.h on the
@@ -975,8 +946,11 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       bool done, served;
       int win;
       ItList lst;
-      const unsigned long long key = it_stage0<IT_G, true, true>(g, box, tab, pts_s, hx, hy, hz, lane, __builtin_inff(),
-                                                                 &done, &served, &win, &lst);
+      // first search of a solve: the roomier per-axis block (every wave is busy, the extra cells cost throughput only);
+      // later (a list lost its proof, few queries per tile, latency counts): the plain 2x2x2 block
+      const unsigned long long key = !bounded
+          ? it_scan_adaptive(g, box, tab, pts_s, hx, hy, hz, lane, &done, &served, &win, &lst)
+          : it_stage0<IT_G, true, true>(g, box, tab, pts_s, hx, hy, hz, lane, __builtin_inff(), &done, &served, &win, &lst);
       if (win >= 0) bslot_s[hs] = win;
       const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
       uint32_t* cw = q.cand + 4 * sh + 2 * lane;
@@ -990,36 +964,9 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       }
     }
   };
-  // later searches: the few queries whose list lost its proof, a wave each (needs the cell table in LDS)
-  auto wave_pass = [&](const uint16_t* tab) __attribute__((always_inline)) {
-    const int wv2 = threadIdx.x / GS_WAVE;
-    for (int i = wv2; i < ns; i += IT_BLOCK / GS_WAVE) {
-      const int hs = scan_q[i];
-      const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
-      char* stg = reinterpret_cast<char*>(&sub[0][0]) + 32 * wv2;   // (row-sum scratch, free between prologue and epilogue)
-      unsigned long long key = ~0ull;
-      bool done = false;
-      int win = -1;
-      float R = 0.0f;
-      const bool served = it_wave_cube1(g, box, tab, pts_s, hx, hy, hz, &key, &done, &win, reinterpret_cast<uint16_t*>(stg), &R);
-      if (served && win >= 0) bslot_s[hs] = win;
-      if ((threadIdx.x & (GS_WAVE - 1)) == 0) {
-        const int sh = (ty0 + hs / IT_TW) * hb.Wl + (tx0 + hs % IT_TW);
-        if (served && done) *reinterpret_cast<uint4*>(q.cand + 4 * sh) = *reinterpret_cast<const uint4*>(stg);
-        q.cq[sh] = make_float4(hx, hy, hz, served && done ? R : 0.0f);
-        if (!served || key == ~0ull) bslot_s[hs] = -1;
-        keys_s[hs] = served ? key : ~0ull;
-        if (!(served && done)) hard_q[atomicAdd(&L.hard_n, 1)] = hs;   // (the cubes of the leftover pass start over)
-      }
-    }
-  };
   if (ns) {
-    if (!bounded || !tab_lds) {
-      if (tab_lds) scan_pass(reinterpret_cast<const uint16_t*>(&qa_s[0][0]));
-      else scan_pass(reinterpret_cast<const uint16_t*>(slab + IT_OFF_CELLS));
-    } else {
-      wave_pass(reinterpret_cast<const uint16_t*>(&qa_s[0][0]));
-    }
+    if (tab_lds) scan_pass(reinterpret_cast<const uint16_t*>(&qa_s[0][0]));
+    else scan_pass(reinterpret_cast<const uint16_t*>(slab + IT_OFF_CELLS));
     __syncthreads();
   }
   IT_STAMP(4);
