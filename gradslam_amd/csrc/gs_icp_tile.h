@@ -539,7 +539,7 @@ GS_DEV float it_emit_cube(const GsGrid& g, const ItBox& box, const uint16_t* __r
                           const float4* __restrict__ pts, float qx, float qy, float qz, int lane, const float d1,
                           const int kdone, uint16_t* stage, int* stage_n) {
   const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
-  int kE = kdone + 1;
+  int kE = kdone + (kdone < 2 ? 1 : 0);   // (beyond 5x5x5 the next cube costs more than the room it adds)
   for (; kE > kdone; --kE) {   // kdone itself is inside the box (it was scanned)
     const int xa = qc.cx - kE < 0 ? 0 : qc.cx - kE, xb = qc.cx + kE >= g.nx ? g.nx - 1 : qc.cx + kE;
     const int ya = qc.cy - kE < 0 ? 0 : qc.cy - kE, yb = qc.cy + kE >= g.ny ? g.ny - 1 : qc.cy + kE;
@@ -844,12 +844,7 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
       if (c < IT_PTS_CAP / GS_WAVE && i < npts) it_load_lds16(gp4 + i, pts_s + c * GS_WAVE);
     }
   }
-  // the slab's cell table, needed by the launches that scan at all: into the LDS space of the Gauss-Newton rows
-  // (written after the searches) when it fits -- from global memory every look-up of a scan is a round trip to cold
-  // lines and pages (this table is touched by nothing else)
-  if (local && hdr.ncell + 1 <= IT_LDS_CELLS && (int)threadIdx.x < (hdr.ncell + 1 + 7) / 8)
-    it_load_lds16(reinterpret_cast<const uint4*>(slab + IT_OFF_CELLS) + threadIdx.x,
-                  reinterpret_cast<uint4*>(&qa_s[0][0]) + wv * GS_WAVE);
+  // (the slab's cell table is fetched on demand, by the blocks that scan: see pass 2)
   float dprev = __builtin_inff();   // tiles without a slab: one more dependent load, the price of the exception
   if (!local && live && bounded) dprev = d2prev[s];
 
@@ -937,8 +932,19 @@ __global__ void __launch_bounds__(IT_BLOCK, 6) gs_icp_tile_half_kernel(const ItB
   // ---- pass 2 (tiles with a slab): the 2x2x2 scan for the queries without a proof, which also writes their lists.
   // The slab's cell table is read from its LDS copy when there is one (tab_lds), else from global memory; the two
   // call sites keep the address space of the pointer known to the compiler.
-  const bool tab_lds = local && hdr.ncell + 1 <= IT_LDS_CELLS;
+  // (look-ahead launches only: the first halves scan every query once per solve, with all waves busy, and hardly ever
+  // afterwards -- and their kernel has no scalar registers left for the copy)
+  const bool tab_lds = !FULL && local && hdr.ncell + 1 <= IT_LDS_CELLS;
   const int ns = L.scan_n;   // block-uniform
+  if (ns && tab_lds) {
+    // the cell table is needed from here on, by the few launches that scan at all: copied into the LDS space of the
+    // Gauss-Newton rows (written later); the scans and cube searches walk it row by row, from global memory every
+    // step would be a round trip to cold lines and pages (nothing else touches this table)
+    if ((int)threadIdx.x < (hdr.ncell + 1 + 7) / 8)   // (at most IT_LDS_CELLS / 8 = IT_BLOCK 16-byte words)
+      it_load_lds16(reinterpret_cast<const uint4*>(slab + IT_OFF_CELLS) + threadIdx.x,
+                    reinterpret_cast<uint4*>(&qa_s[0][0]) + wv * GS_WAVE);
+    __syncthreads();
+  }
   auto scan_pass = [&](const uint16_t* tab) __attribute__((always_inline)) {
     for (int i = threadIdx.x / IT_G; i < ns; i += IT_NQ) {
       const int hs = scan_q[i];
