@@ -1020,12 +1020,16 @@ extern "C" int64_t gs_localize_scratch_bytes(int H, int W, int ds, int64_t n_map
 
 static GsCount n_src_rows(int nrows) { return GsCount{(int64_t)nrows * FS_QPB, nullptr}; }  // a count that yields nrows rows
 
-// GRADSLAM_HIP_ICP_ENGINE=rows: the row-unit kernels (gs_icp_half_batch_kernel) instead of the tile engine (A/B runs)
+// GRADSLAM_HIP_ICP_ENGINE=tile: the tile engine (gs_icp_tile.h: LDS slabs + candidate lists) instead of the row-unit
+// kernels (gs_icp_half_batch_kernel).  Bit-identical results; measured in round 3: 11.6 / 13.5 us per
+// launch in the steady state of a solve against 17.3 us, but the launches that (re)build lists in the first iterations
+// cost what the steady state saves -- 6 640 against 6 740 frames/s end to end at 8 sequences per GPU -- so the row-unit
+// kernels stay the default.
 static bool icp_tile_enabled() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("GRADSLAM_HIP_ICP_ENGINE");
-    v = (e && strcmp(e, "rows") == 0) ? 0 : 1;
+    v = (e && strcmp(e, "tile") == 0) ? 1 : 0;
   }
   return v == 1;
 }
