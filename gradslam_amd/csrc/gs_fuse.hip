@@ -231,8 +231,10 @@ __global__ void __launch_bounds__(256) gs_fuse_bwd_rows_kernel(
     float* __restrict__ rgb_bar, float* __restrict__ alpha_bar) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= n_old) return;
+  // (renorm_all == 2: the forward pass rewrote every row even when this sequence had no match -- another sequence of the
+  // batch had one)
   const int32_t p = (*any_flag != 0) ? pix_of[n] : -1;
-  if (*any_flag == 0 || (p < 0 && !renorm_all)) {  // the row was not rewritten: identity
+  if ((*any_flag == 0 && renorm_all != 2) || (p < 0 && !renorm_all)) {  // the row was not rewritten: identity
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       oP_bar[3 * n + k] = P_bar[3 * n + k];
@@ -370,6 +372,12 @@ struct MuBatch {
   int B, H, W, renorm_all;
   int64_t P, ntiles;
   float u_hi, v_hi, dist_th, dot_th;
+  // "some sequence of the CALL has a match": batches beyond GS_MAX_BATCH sequences run in chunks, and the reference's
+  // test (fusionutils.py:659) looks at the table of the whole batch.  One word shared by all chunks of a call (in the
+  // first sequence's scratch), zeroed by the first chunk's pixel pass, set by every chunk's winner pass, read by the
+  // merge passes, which are enqueued after the winner passes of ALL chunks.
+  int32_t* call_flag;
+  int zero_call_flag;
   MuSeq s[GS_MAX_BATCH];
 };
 
@@ -377,6 +385,7 @@ __global__ void __launch_bounds__(256) gs_mu_pixel_init_kernel(const MuBatch mb)
   const MuSeq& q = mb.s[blockIdx.x % mb.B];
   const int64_t p = (int64_t)(blockIdx.x / mb.B) * 256 + threadIdx.x;
   if (p == 0) *q.any_flag = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && mb.zero_call_flag) *mb.call_flag = 0;
   if (p >= mb.P) return;
   float T[12];
 #pragma unroll
@@ -447,6 +456,7 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_winner_count_kernel(const M
       if (n >= 0 && n < n_map) {
         q.pix_of[n] = (int32_t)p;
         *q.any_flag = 1;  // benign race: every writer stores the same value
+        *mb.call_flag = 1;
       }
       if (dd[i] > 0.0f && n < 0) ++c;
     }
@@ -463,9 +473,7 @@ __global__ void __launch_bounds__(256) gs_mu_merge_kernel(const MuBatch mb) {
   // :659 -- the reference skips the whole merge only when the correspondence table of the WHOLE batch is empty
   // (pc2im_bnhw.shape[0] != 0 is a batch-level test): a sequence without matches is still renormalised when
   // another sequence of the same call has some
-  bool any = false;
-  for (int b = 0; b < mb.B; ++b) any = any || (*mb.s[b].any_flag != 0);
-  if (!any) return;
+  if (*mb.call_flag == 0) return;
   const int32_t p = q.pix_of[n];
   if (p < 0 && !mb.renorm_all) return;
   fuse_merge_row(q.points, q.normals, q.colors, q.ccounts, n, p, q.gvertex, q.gnormal, q.rgb, q.alpha);
@@ -529,10 +537,12 @@ extern "C" int64_t gs_update_map_scratch_bytes(int64_t n_map_bound, int H, int W
                    2 * gs_align(4 * (size_t)(n_map_bound > 0 ? n_map_bound : 1)) + 4096);
 }
 
+// phase 0: global maps, association, winner / tile counts; phase 1: merge + append (after phase 0 of every chunk)
 static int update_chunk(const gs_update_seq* seqs, int B, int H, int W, float dist_th, float dot_th, int renorm_all,
-                        hipStream_t st) {
+                        hipStream_t st, int phase, int32_t* call_flag, bool first_chunk) {
   MuBatch mb;
   mb.B = B; mb.H = H; mb.W = W; mb.renorm_all = renorm_all;
+  mb.call_flag = call_flag; mb.zero_call_flag = first_chunk ? 1 : 0;
   mb.P = (int64_t)H * W;
   mb.ntiles = gs_cp_tiles(mb.P);
   mb.u_hi = (float)((double)W - 0.999); mb.v_hi = (float)((double)H - 0.999);
@@ -562,19 +572,23 @@ static int update_chunk(const gs_update_seq* seqs, int B, int H, int W, float di
   }
   const unsigned uB = (unsigned)B;
   const unsigned pb = uB * (unsigned)gs_ceil_div(mb.P, 256), nb = uB * (unsigned)gs_ceil_div(n_max > 0 ? n_max : 1, 256);
-  {
-    GsProf prof(GS_PROF_FRAME, (double)B * (double)mb.P * 64.0, st);   // 28 B read + 24 B + 12 B written per pixel
-    hipLaunchKernelGGL(gs_mu_pixel_init_kernel, dim3(pb), dim3(256), 0, st, mb);
+  if (phase == 0) {
+    {
+      GsProf prof(GS_PROF_FRAME, (double)B * (double)mb.P * 64.0, st);   // 28 B read + 24 B + 12 B written per pixel
+      hipLaunchKernelGGL(gs_mu_pixel_init_kernel, dim3(pb), dim3(256), 0, st, mb);
+    }
+    if (n_max > 0) {
+      GsProf prof(GS_PROF_ASSOC, bytes_assoc, st, 2);
+      hipLaunchKernelGGL(gs_mu_project_key_kernel, dim3(nb), dim3(256), 0, st, mb);
+      hipLaunchKernelGGL(gs_mu_pick_kernel, dim3(nb), dim3(256), 0, st, mb);
+    }
+    GsProf prof(GS_PROF_FUSE, bytes_fuse / 3.0, st, 1);
+    hipLaunchKernelGGL(gs_mu_winner_count_kernel, dim3(uB * (unsigned)mb.ntiles), dim3(GS_CP_BLOCK), 0, st, mb);
+  } else {
+    GsProf prof(GS_PROF_FUSE, bytes_fuse * (2.0 / 3.0), st, n_max > 0 ? 2 : 1);
+    if (n_max > 0) hipLaunchKernelGGL(gs_mu_merge_kernel, dim3(nb), dim3(256), 0, st, mb);
+    hipLaunchKernelGGL(gs_mu_append_kernel, dim3(uB * (unsigned)mb.ntiles), dim3(GS_CP_BLOCK), 0, st, mb);
   }
-  if (n_max > 0) {
-    GsProf prof(GS_PROF_ASSOC, bytes_assoc, st, 2);
-    hipLaunchKernelGGL(gs_mu_project_key_kernel, dim3(nb), dim3(256), 0, st, mb);
-    hipLaunchKernelGGL(gs_mu_pick_kernel, dim3(nb), dim3(256), 0, st, mb);
-  }
-  GsProf prof(GS_PROF_FUSE, bytes_fuse, st, n_max > 0 ? 3 : 2);
-  hipLaunchKernelGGL(gs_mu_winner_count_kernel, dim3(uB * (unsigned)mb.ntiles), dim3(GS_CP_BLOCK), 0, st, mb);
-  if (n_max > 0) hipLaunchKernelGGL(gs_mu_merge_kernel, dim3(nb), dim3(256), 0, st, mb);
-  hipLaunchKernelGGL(gs_mu_append_kernel, dim3(uB * (unsigned)mb.ntiles), dim3(GS_CP_BLOCK), 0, st, mb);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }
@@ -593,10 +607,14 @@ extern "C" int gs_update_map_fusion_batch_f32(const gs_update_seq* seqs_host, in
     GS_REQUIRE(u.new_count_out != u.map.n_dev, "new_count_out must not alias the map's device count");
   }
   hipStream_t st = gs_stream(stream);
-  for (int c0 = 0; c0 < B; c0 += GS_MAX_BATCH) {
-    const int nb = B - c0 < GS_MAX_BATCH ? B - c0 : GS_MAX_BATCH;
-    const int rc = update_chunk(seqs_host + c0, nb, H, W, dist_th, dot_th, renorm_all, st);
-    if (rc != GS_OK) return rc;
+  // (second word of the first sequence's flag area: see MuBatch::call_flag)
+  int32_t* call_flag = reinterpret_cast<int32_t*>(seqs_host[0].scratch) + 32;
+  for (int phase = 0; phase < 2; ++phase) {
+    for (int c0 = 0; c0 < B; c0 += GS_MAX_BATCH) {
+      const int nb = B - c0 < GS_MAX_BATCH ? B - c0 : GS_MAX_BATCH;
+      const int rc = update_chunk(seqs_host + c0, nb, H, W, dist_th, dot_th, renorm_all, st, phase, call_flag, c0 == 0);
+      if (rc != GS_OK) return rc;
+    }
   }
   return GS_OK;
 }

@@ -179,7 +179,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
   int64_t* __restrict__ out_idx = q.out_idx;
   int32_t* __restrict__ tape_idx = q.tape_idx;
 
-  __shared__ IcpSmall sm;
+  __shared__ alignas(16) IcpSmall sm;
   __shared__ double S[32];
   __shared__ double sub[FS_BLOCK / 32][32];
   __shared__ unsigned long long keys_s[NQ];
@@ -216,8 +216,11 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
   // the state of the previous half and the grid header are fetched while the partial rows are summed
   // (their latency is off the critical path; the sums' __syncthreads publish sm)
   const GsGrid g = *q.gp;
-  if (threadIdx.x >= GS_WAVE && threadIdx.x < GS_WAVE + (int)(sizeof(IcpSmall) / 4))
-    reinterpret_cast<float*>(&sm)[threadIdx.x - GS_WAVE] = reinterpret_cast<const float*>(q.st_in)[threadIdx.x - GS_WAVE];
+  // (global -> LDS directly, 16 bytes per lane of the second wave: a copy through registers made that wave wait for
+  // its loads before it had even requested the partial rows, and the block waits for its slowest wave)
+  static_assert(sizeof(IcpSmall) % 16 == 0, "state copy");
+  if (threadIdx.x >= GS_WAVE && threadIdx.x < GS_WAVE + (int)(sizeof(IcpSmall) / 16))
+    it_load_lds16(reinterpret_cast<const float4*>(q.st_in) + (threadIdx.x - GS_WAVE), &sm);
 
   // ---- prologue: finish the previous half-iteration (identical in every block)
   if (FULL) {
@@ -1397,29 +1400,30 @@ extern "C" int gs_pointfusion_step_batch_f32(const gs_step_seq* seqs_host, int B
     GS_REQUIRE(q.depth == s0.depth + dstride * b && q.K16 == s0.K16 + 16 * (int64_t)b, "depth / K16 must be equally strided");
   }
   GS_REQUIRE(dstride >= P || B == 1, "overlapping depth images");
-  for (int c0 = 0; c0 < B; c0 += GS_MAX_BATCH) {   // the sequences are independent: chunk by chunk through the frame
+  // the sequences are independent: chunk by chunk through the frame maps and the localisation; the map update is ONE
+  // call for the whole batch (its merge looks at the correspondences of every sequence of the call)
+  std::unique_ptr<gs_update_seq[]> us(new gs_update_seq[B]);
+  for (int c0 = 0; c0 < B; c0 += GS_MAX_BATCH) {
     const int nb = B - c0 < GS_MAX_BATCH ? B - c0 : GS_MAX_BATCH;
     const gs_step_seq* sq = seqs_host + c0;
     int rc = gs_frame_maps_batch_f32(sq[0].depth, dstride, P, sq[0].K16, nb, 1, H, W, two_sigma_sq, sq[0].vertex,
                                      sq[0].normal, sq[0].alpha, stream);
     if (rc != GS_OK) return rc;
     gs_localize_seq ls[GS_MAX_BATCH];
-    gs_update_seq us[GS_MAX_BATCH];
     for (int b = 0; b < nb; ++b) {
       const gs_step_seq& q = sq[b];
       ls[b].vertex = q.vertex; ls[b].depth = q.depth; ls[b].K16 = q.K16; ls[b].prev_pose16 = q.prev_pose16;
       ls[b].map = q.map; ls[b].out_pose16 = q.out_pose16; ls[b].scratch = q.loc_scratch;
-      us[b].map = q.map; us[b].vertex = q.vertex; us[b].normal = q.normal; us[b].depth = q.depth; us[b].rgb = q.rgb;
-      us[b].alpha = q.alpha; us[b].pose16 = q.out_pose16; us[b].K16 = q.K16; us[b].gvertex = q.gvertex;
-      us[b].gnormal = q.gnormal; us[b].best_pix = q.best_pix; us[b].new_count_out = q.new_count_out;
-      us[b].scratch = q.upd_scratch;
+      gs_update_seq& u = us[c0 + b];
+      u.map = q.map; u.vertex = q.vertex; u.normal = q.normal; u.depth = q.depth; u.rgb = q.rgb;
+      u.alpha = q.alpha; u.pose16 = q.out_pose16; u.K16 = q.K16; u.gvertex = q.gvertex;
+      u.gnormal = q.gnormal; u.best_pix = q.best_pix; u.new_count_out = q.new_count_out;
+      u.scratch = q.upd_scratch;
     }
     rc = gs_localize_batch_f32(ls, nb, H, W, ds, prm, stream);
     if (rc != GS_OK) return rc;
-    rc = gs_update_map_fusion_batch_f32(us, nb, H, W, dist_th, dot_th, renorm_all, stream);
-    if (rc != GS_OK) return rc;
   }
-  return GS_OK;
+  return gs_update_map_fusion_batch_f32(us.get(), B, H, W, dist_th, dot_th, renorm_all, stream);
 }
 
 extern "C" int64_t gs_icp_tape_bytes(int64_t n_src, int numiters) { return (int64_t)gs_icp_tape_size(n_src, numiters); }

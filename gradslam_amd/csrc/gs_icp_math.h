@@ -6,6 +6,13 @@
 
 constexpr int LIN_NV = 28;  // 21 upper-triangular JtJ + 6 Jtr + 1 rtr
 
+// 16 bytes per lane from global memory straight into LDS: lane l of the wave lands at lds_wave_base + 16 l (the LDS
+// base must be wave-uniform; disabled lanes load nothing)
+GS_DEV void it_load_lds16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 // ---------------------------------------------------------------- K4: rows -------------
 // odometry/icputils.py:210-230 for one source point and its associated target.
 GS_DEV void gn_row(float sx, float sy, float sz, const float* __restrict__ tgt,

@@ -652,13 +652,6 @@ GS_DEV unsigned long long it_list_search_global(const uint32_t* w, const float4 
   return kmin;
 }
 
-// 16 bytes per lane from global memory straight into LDS: lane l of the wave lands at lds_wave_base + 16 l (the LDS
-// base must be wave-uniform; disabled lanes load nothing)
-GS_DEV void it_load_lds16(const void* g, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
 // icp_sum_rows<IT_BLOCK, IT_CH> / icp_sum_col27<IT_BLOCK> (gs_icp_loop.hip) in two steps, so that the loads of the first
 // round are requested at the very start of the kernel, before anything that waits for the slab header: same values
 // added in the same order.

@@ -30,7 +30,11 @@ def init_from_env(backend: Optional[str] = None):
             backend = os.environ.get("GRADSLAM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # device_id: the communicator is bound to this rank's GPU at once (eager init, no guessing from the first
+            # collective's tensors)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
@@ -81,13 +85,34 @@ def gather_poses(local_poses: torch.Tensor) -> torch.Tensor:
     return torch.cat(_gather_rows(local_poses.contiguous()), 0)
 
 
-def gather_maps(pointclouds: Pointclouds) -> Pointclouds:
-    """Every rank's local maps -> one Pointclouds holding all sequences (rank order), on every rank.
+def _gather_to(recv, send, dst):
+    """dist.gather to rank dst (gloo: device tensors through the host, see _all_gather)"""
+    me = dist.get_rank()
+    if send.is_cuda and dist.get_backend() == "gloo":
+        host = [torch.empty(send.shape, dtype=send.dtype) for _ in range(dist.get_world_size())] if me == dst else None
+        dist.gather(send.cpu(), host, dst=dst)
+        if me == dst:
+            for o, h in zip(recv, host):
+                o.copy_(h)
+    else:
+        dist.gather(send, recv if me == dst else None, dst=dst)
+
+
+ALL_GATHER_MAX_BYTES = 2 << 30   # per rank: beyond this an all-to-all map gather is refused (gather to one rank instead)
+
+
+def gather_maps(pointclouds: Pointclouds, dst: Optional[int] = None,
+                max_bytes: Optional[int] = None) -> Optional[Pointclouds]:
+    """Every rank's local maps -> one Pointclouds holding all sequences (rank order).
+
+    dst=None: on every rank (all_gather: every rank receives world x the largest rank's map, so this is for maps of
+    benchmark size; above `max_bytes` (default ALL_GATHER_MAX_BYTES) received bytes per rank it falls back to dst=0 with
+    a warning).  dst=r: on rank r only, the other ranks get None (gather: 1/world of the traffic and memory).
     Two collectives: the per-sequence counts and attribute widths of every rank (a small object gather), then ONE
-    padded all_gather of each rank's surfels packed row-wise as [points | normals | colors | features]."""
+    padded (all_)gather of each rank's surfels packed row-wise as [points | normals | colors | features]."""
     world = _world()
     if world == 1:
-        return pointclouds
+        return pointclouds.clone()   # (a new object, as with world > 1: callers may mutate the result)
     dev = pointclouds.device
     counts = list(pointclouds._n)
     lists = {k: getattr(pointclouds, k + "_list") for k in ("points", "normals", "colors", "features")}
@@ -98,17 +123,29 @@ def gather_maps(pointclouds: Pointclouds) -> Pointclouds:
     w = {k: max(m[1][k] for m in meta) for k in widths}
     width = sum(w.values())
     rows = sum(counts)
+    cap = max(max(sum(m[0]) for m in meta), 1)
+    if dst is None and world * cap * width * 4 > (ALL_GATHER_MAX_BYTES if max_bytes is None else max_bytes):
+        import warnings
+        warnings.warn("gather_maps: %.1f GB per rank for an all_gather of the maps; gathering to rank 0 only"
+                      % (world * cap * width * 4 / 1e9))
+        dst = 0
     packed = torch.zeros((rows, width), dtype=torch.float32, device=dev)
     col = 0
     for k in ("points", "normals", "colors", "features"):
         if w[k] and widths[k] and rows:
             packed[:, col:col + w[k]] = torch.cat(lists[k], 0)
         col += w[k]
-    cap = max(max(sum(m[0]) for m in meta), 1)
     send = torch.zeros((cap, width), dtype=torch.float32, device=dev)
     send[:rows] = packed
-    recv = [torch.empty_like(send) for _ in range(world)]
-    _all_gather(recv, send)
+    me = dist.get_rank()
+    if dst is None:
+        recv = [torch.empty_like(send) for _ in range(world)]
+        _all_gather(recv, send)
+    else:
+        recv = [torch.empty_like(send) for _ in range(world)] if me == dst else None
+        _gather_to(recv, send, dst)
+        if me != dst:
+            return None
     out = {k: [] for k in w}
     for r, (cnts, _) in enumerate(meta):
         per_seq = torch.split(recv[r][: sum(cnts)], cnts, 0) if cnts else []

@@ -601,6 +601,10 @@ def localize_batch(vertex, depth, K, prev_poses, maps, ds, mode=1, numiters=20, 
     for b in range(Bn):
         P, N, n_bound, n_dev = maps[b]
         require_device(P, N, n_dev)
+        if P.dtype != f32 or N.dtype != f32 or N.shape[0] < P.shape[0]:
+            # (raw pointers go to the library: a float64 / float16 map would be read as float32 garbage)
+            raise _C.HipExtensionError("localize_batch needs float32 map points / normals on buffers of equal capacity "
+                                       "(got %s / %s, %d / %d rows)" % (P.dtype, N.dtype, P.shape[0], N.shape[0]))
         cap = P.shape[0]
         scratch = ws.bytes("localize%d" % b, L.gs_localize_scratch_bytes(H, W, int(ds), cap))
         q = seqs[b]
@@ -735,7 +739,7 @@ class FuseAppendFunction(torch.autograd.Function):
             dst[:n0] = src
         n1 = fuse_append_(*bufs, n0, best_pix, gvertex, gnormal, rgb, alpha, depth, renorm_all)
         ctx.save_for_backward(points, normals, colors, ccounts, gvertex, gnormal, rgb, alpha, depth, best_pix)
-        ctx.renorm_all, ctx.n1 = bool(renorm_all), n1
+        ctx.renorm_all, ctx.n1 = int(renorm_all), n1
         return tuple(b[:n1] for b in bufs)
 
     @staticmethod
@@ -752,7 +756,7 @@ class FuseAppendFunction(torch.autograd.Function):
         ws = Workspace.get(dev)
         check(lib().gs_fuse_append_backward_f32(ptr(_c(points)), ptr(_c(normals)), ptr(_c(colors)), ptr(_c(ccounts)), n0,
                                                 ptr(best_pix), ptr(_c(gvertex)), ptr(_c(gnormal)), ptr(_c(rgb)),
-                                                ptr(_c(alpha)), ptr(_c(depth)), H, W, 1 if ctx.renorm_all else 0,
+                                                ptr(_c(alpha)), ptr(_c(depth)), H, W, int(ctx.renorm_all),
                                                 ptr(bars[0]), ptr(bars[1]), ptr(bars[2]), ptr(bars[3]), n1, ptr(old[0]),
                                                 ptr(old[1]), ptr(old[2]), ptr(old[3]), ptr(gv_b), ptr(gn_b), ptr(rgb_b),
                                                 ptr(a_b), ptr(ws.scratch(n0, H * W)), stream(dev)),

@@ -288,7 +288,7 @@ def _fuse(pointclouds, rgbdimages, best_pix, sigma, inplace):
     # fusionutils.py:659 skips the merge only when the table of the WHOLE batch is empty: with B > 1 a sequence
     # without matches is still renormalised when another one has some (mode 2 of gs_fuse_append_f32)
     renorm = RENORMALIZE_UNMATCHED
-    if renorm and B > 1 and any(bool((bp >= 0).any()) for bp in best_pix):
+    if renorm and B > 1 and bool(torch.stack([(bp >= 0).any() for bp in best_pix]).any()):   # (one read-back)
         renorm = 2
     for b in range(B):
         if inplace and ops.DEVICE_COUNTS:
@@ -461,6 +461,7 @@ def _fuse_differentiable(pointclouds, rgbdimages, dist_th, dot_th, sigma, inplac
     if len(pointclouds) == 0 and inplace:
         pointclouds._init_empty_batch(B, 1)
     new = {k: [] for k in ("points", "normals", "colors", "features")}
+    olds, bests = [], []
     for b in range(B):
         if len(pointclouds) == 0:
             old = [torch.empty((0, c), dtype=torch.float32, device=fr.device) for c in (3, 3, 3, 1)]
@@ -473,9 +474,16 @@ def _fuse_differentiable(pointclouds, rgbdimages, dist_th, dot_th, sigma, inplac
                 best = ops.associate(pix, old[0], old[1], old[3][:, :1], gv[b, 0], gn[b, 0], dist_th, dot_th)
             else:
                 best = torch.full((H * W,), -1, dtype=torch.int32, device=fr.device)
+        olds.append(old)
+        bests.append(best)
+    # the merge is skipped only when NO sequence of the batch has a match (fusionutils.py:659): mode 2, as in _fuse
+    renorm = RENORMALIZE_UNMATCHED
+    if renorm and B > 1 and bool(torch.stack([(bp >= 0).any() for bp in bests]).any()):
+        renorm = 2
+    for b in range(B):
+        old, best = olds[b], bests[b]
         fused = ops.FuseAppendFunction.apply(old[0], old[1], old[2], old[3], gv[b, 0], gn[b, 0], rgb[b, 0],
-                                             alpha[b, 0, ..., 0], depth[b, 0, ..., 0].detach(), best,
-                                             RENORMALIZE_UNMATCHED)
+                                             alpha[b, 0, ..., 0], depth[b, 0, ..., 0].detach(), best, renorm)
         for k, t in zip(new, fused):
             new[k].append(t)
     if not inplace and len(pointclouds) == 0:

@@ -294,7 +294,21 @@ class Pointclouds(object):
             raise ValueError("shape of first 2 dims of tensors in value and pointclouds.points_list must match")
         if (not first_dim_only) and any(pts[b].shape != value[b].shape for b in range(len(self))):
             raise ValueError("shape of tensors in value and pointclouds.points_list must match")
-        self._buf[k] = [v.clone().to(self.device) for v in value]
+        self._store_rows(k, [v.to(self.device) for v in value])
+
+    def _store_rows(self, k, rows):
+        """New values of attribute k (one (n_b, C) tensor per sequence) on buffers that keep the CAPACITY of the
+        sequence's points buffer: the in-place kernels size every attribute by that capacity (an exact-size clone here
+        would be overrun by the next fuse / append)."""
+        out = []
+        for b, v in enumerate(rows):
+            n = int(v.shape[0])
+            ref = self._buf["points"][b] if self._buf["points"] is not None else None
+            cap = max(n, int(ref.shape[0]) if ref is not None else n)
+            buf = torch.empty((cap, v.shape[-1]), dtype=v.dtype, device=self.device)
+            buf[:n] = v
+            out.append(buf)
+        self._buf[k] = out
         self._padded_cache.pop(k, None)
 
     points_list = property(lambda self: self._list("points"), lambda self, v: self._set_list("points", v))
@@ -340,8 +354,7 @@ class Pointclouds(object):
         if value.device != self.device:
             raise ValueError("value must have the same device as pointclouds object: {} != {}".format(
                 value.device, self.device))
-        self._buf[k] = [value[b, :n].clone() for b, n in enumerate(self._n)]
-        self._padded_cache.pop(k, None)
+        self._store_rows(k, [value[b, :n] for b, n in enumerate(self._n)])
 
     @points_padded.setter
     def points_padded(self, value):
@@ -383,7 +396,8 @@ class Pointclouds(object):
         append up to `extra` rows per frame for many frames, ask for several frames of room at once."""
         n_b = self._count_of(b)[0]
         need = n_b + int(extra)
-        cap = self._buf["points"][b].shape[0]
+        # (the smallest buffer counts: every attribute is written up to the same row)
+        cap = min(self._buf[k][b].shape[0] for k in _ATTRS if self._buf[k] is not None)
         if need > cap:
             # geometric growth, starting at RESERVE_FRAMES x the request: a surfel map of a few hundred MB is
             # nothing in 288 GB of HBM, and every reallocation (and every size class the bound-sized per-frame
@@ -393,6 +407,8 @@ class Pointclouds(object):
                 if self._buf[k] is None:
                     continue
                 old = self._buf[k][b]
+                if old.shape[0] >= new_cap:
+                    continue
                 new = torch.empty((new_cap, old.shape[-1]), dtype=old.dtype, device=self.device)
                 new[:n_b] = old[:n_b]
                 self._buf[k][b] = new

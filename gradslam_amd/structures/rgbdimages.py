@@ -56,7 +56,7 @@ class RGBDImages(object):
         self._depth_shape = self._depth_image_shape = full[:c] + (1,) + full[c + 1:]
         self._intrinsics_shape = (full[0], 1, 4, 4)
         self._poses_shape = full[:2] + (4, 4)
-        self._pixel_pos_shape = full[:c] + full[c + 1:] + (3,)
+        self._pixel_pos_shape = (full[:c] + (3,) + full[c + 1:]) if channels_first else (full[:c] + full[c + 1:] + (3,))
         if full[c] != 3:
             raise ValueError("Expected rgb_image to have 3 channels on dimension {0}. Got {1} instead".format(c, full[c]))
         for name, val, want in (("depth_image", depth_image, self._depth_shape),
@@ -74,12 +74,16 @@ class RGBDImages(object):
         self._poses = None if poses is None else poses.to(self.device)
         self._pixel_pos = None if pixel_pos is None else pixel_pos.to(self.device)
         if self._pixel_pos is not None:
-            # the back-projection kernel generates (u, v, 1) itself: a caller-supplied grid must be that grid
+            # the back-projection kernel generates (u, v, 1) itself: a caller-supplied grid must be that grid.  The
+            # shape was checked above; with channels_first the grid is (B, L, 3, H, W): compared channels-last
             hh, ww = (rgb_image.shape[3], rgb_image.shape[4]) if channels_first else (rgb_image.shape[2], rgb_image.shape[3])
             v, u = torch.meshgrid(torch.arange(hh, dtype=torch.float32, device=self.device),
                                   torch.arange(ww, dtype=torch.float32, device=self.device), indexing="ij")
             std = torch.stack([u, v, torch.ones_like(u)], -1)
-            if not bool((self._pixel_pos.float() == std).all()):   # (B, L, H, W, 3) in either layout
+            pp = self._pixel_pos.float()
+            if channels_first:
+                pp = pp.permute(0, 1, 3, 4, 2)
+            if not bool((pp == std).all()):
                 raise NotImplementedError("gradslam_amd back-projects on the regular pixel grid (u, v, 1); a custom "
                                           "pixel_pos is not supported")
 

@@ -443,3 +443,32 @@ def test_scannet_label_palettes():
         assert out[src] == want, src
     assert list(get_color_encoding("scannet20"))[13:16] == ["desk", "curtain", "refrigerator"]
     assert len(get_color_encoding("nyu40")) == 41 and len(get_color_encoding("scannet20")) == 21
+
+
+def test_setters_keep_the_capacity_of_the_store():
+    """the list / padded setters used to replace the capacity-backed buffers by exact-size clones; the
+    in-place kernels size every attribute by the points' capacity, so the next append would overrun them."""
+    pc = gs.Pointclouds(points=[torch.rand(5, 3)], normals=[torch.rand(5, 3)], colors=[torch.rand(5, 3)],
+                        features=[torch.rand(5, 1)])
+    pc._reserve(0, 1000)
+    new_n, new_f = torch.rand(5, 3), torch.rand(5, 1)
+    pc.normals_list = [new_n]
+    pc.features_list = [new_f]
+    pc.colors_padded = torch.rand(1, 5, 3)
+    caps = [pc._buf[k][0].shape[0] for k in ("points", "normals", "colors", "features")]
+    assert len(set(caps)) == 1 and caps[0] >= 1005
+    assert torch.equal(pc.normals_list[0], new_n) and torch.equal(pc.features_list[0], new_f)
+    assert all(t.shape[0] >= 1005 for t in pc._reserve(0, 1000))
+    # a short attribute buffer (set behind the store's back) is grown by _reserve too
+    pc._buf["colors"][0] = pc._buf["colors"][0][:5].clone()
+    assert all(t.shape[0] >= 1005 for t in pc._reserve(0, 1000))
+
+
+def test_pixel_pos_channels_first_standard_grid_is_accepted():
+    B, L, H, W = 1, 2, 3, 3
+    v, u = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([u, v, torch.ones_like(u)], 0).expand(B, L, 3, H, W).contiguous()
+    rgb, depth, K = torch.rand(B, L, 3, H, W), torch.rand(B, L, 1, H, W), torch.eye(4).view(1, 1, 4, 4)
+    gs.RGBDImages(rgb, depth, K, channels_first=True, pixel_pos=grid)
+    with pytest.raises(NotImplementedError):
+        gs.RGBDImages(rgb, depth, K, channels_first=True, pixel_pos=grid + 0.5)

@@ -46,6 +46,17 @@ def _worker(rank, world, port, B, out_dir):
         pc, poses = Pointclouds(), torch.zeros((0, 3, 4, 4))
     all_poses = multigpu.gather_poses(poses)
     all_maps = multigpu.gather_maps(pc)
+    # gather to one rank only: the others get None, rank 1 the same map as the all_gather
+    only1 = multigpu.gather_maps(pc, dst=1)
+    assert (only1 is None) == (rank != 1)
+    if rank == 1:
+        assert only1._n == all_maps._n and all(torch.equal(a, b) for a, b in zip(only1.points_list, all_maps.points_list))
+    # an all_gather beyond the size limit falls back to rank 0 (with a warning)
+    import warnings
+    with warnings.catch_warnings(record=True) as wrn:
+        warnings.simplefilter("always")
+        capped = multigpu.gather_maps(pc, max_bytes=1)
+    assert (capped is None) == (rank != 0) and any("rank 0 only" in str(x.message) for x in wrn)
     torch.save({"poses": all_poses, "points": all_maps.points_list, "features": all_maps.features_list,
                 "colors": all_maps.colors_list, "n": all_maps._n}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
@@ -82,4 +93,5 @@ def test_single_process_gather_is_identity():
     pts, nr, col, ft, poses = _fake_sequence_result(0)
     pc = Pointclouds(points=[pts], normals=[nr], colors=[col], features=[ft])
     out = multigpu.gather_maps(pc)
+    assert out is not pc   # a new object, as with world > 1
     assert torch.equal(out.points_list[0], pts) and torch.equal(multigpu.gather_poses(poses[None]), poses[None])
