@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--odom", default="gradicp", choices=["gradicp", "icp", "gt"])
     ap.add_argument("--workload", default="c4", choices=["c4", "c5"],
                     help="c4: B x 640x480 PointFusion (BASELINE configs[1]/[3]); c5: one 1296x968 sequence, growing map")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --batch sequences PER GPU (8 N in total by default)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs 2, 3 and 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2, help="full steps of the CPU oracle sample")
     ap.add_argument("--no-roofline-pass", action="store_true")
@@ -85,11 +87,12 @@ def _make(a):
     return make_sequence(*a[:3], seed=a[3], first=a[4])
 
 
-def make_sequences(seeds, L, Hh, Ww):
+def make_sequences(seeds, L, Hh, Ww, chunk=None):
     """the seeded synthetic sequences of this rank, generated in parallel on the host cores (a single long sequence
     in chunks of frames: every frame is a function of its index, only the hole / colour streams are per chunk)"""
     import multiprocessing as mp
-    chunk = L if L <= 64 else 8   # up to 64 frames: exactly make_sequence(L, seed) (what the goldens were recorded on)
+    if chunk is None:
+        chunk = L if L <= 64 else 8   # up to 64 frames: exactly make_sequence(L, seed) (what the goldens were recorded on)
     jobs = [(min(chunk, L - f0), Hh, Ww, s, f0) for s in seeds for f0 in range(0, L, chunk)]
     # under rocprofv3 (its tool library is preloaded into forked workers and its SIGTERM handler can dead-lock a
     # terminating pool) the sequences are generated in this process
@@ -119,16 +122,62 @@ def frames_on_device(gs, seqs, device):
     return gs.RGBDImages(st("colors"), st("depths"), st("intrinsics"), poses)
 
 
-def run_steps(slam, pc, frames, prev, first, last, poses_out=None, after_step=None):
+def run_steps(slam, pc, frames, prev, first, last, poses_out=None, after_step=None, events=None):
     for s in range(first, last):
         live = frames[:, s]
         pc, pose = slam.step(pc, live, prev, inplace=True)
         if poses_out is not None:
             poses_out.append(pose[:, 0])
         prev = live
+        if events is not None:   # one event per step on the launch stream: ms of every step without a host sync
+            import torch
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            events.append(ev)
         if after_step is not None:
             after_step(pc)
     return pc, prev
+
+
+def timed_steps(gs, slam, frames, Wm, K, device, barrier, seg_every=0):
+    """W warm-up steps (untimed; frame 0 only initialises the map), then exactly K timed steps bracketed by `barrier`.
+    Returns a dict: elapsed / host times, per-step GPU ms (events), poses, map."""
+    import torch
+    from gradslam_amd.structures.pointclouds import _CountGroup
+    pc = gs.Pointclouds(device=device)
+    recovered = []
+    pc, prev = run_steps(slam, pc, frames, None, 0, Wm, recovered)
+    torch.cuda.synchronize(device)
+    marks = []
+
+    def mark(p):   # one sync every seg_every frames, to report ms per frame against the map size
+        n = len(recovered) - Wm
+        if n > 0 and n % seg_every == 0:
+            torch.cuda.synchronize(device)
+            marks.append((n, time.perf_counter(), max(p._count_of(b)[0] for b in range(len(p._n_host)))))
+
+    ev0 = torch.cuda.Event(enable_timing=True)
+    events = []
+    barrier()
+    w0 = _CountGroup.wait_s
+    ev0.record()
+    t0 = time.perf_counter()
+    pc, prev = run_steps(slam, pc, frames, prev, Wm, Wm + K, recovered, after_step=mark if seg_every else None, events=events)
+    t_enq = time.perf_counter() - t0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    waits = _CountGroup.wait_s - w0
+    step_ms = [a.elapsed_time(b) for a, b in zip([ev0] + events[:-1], events)]
+    q = max(len(step_ms) // 4, 1)
+    seg_out, pn, pt = None, 0, t0
+    if marks:   # ms per frame of consecutive stretches of the timed region (growing map)
+        seg_out = []
+        for n, t, m in marks:
+            seg_out.append({"frames": "%d-%d" % (pn, n), "ms_per_frame": (t - pt) / (n - pn) * 1e3, "map_bound_end": m})
+            pn, pt = n, t
+    return {"elapsed": elapsed, "t_enq": t_enq, "waits": waits, "step_ms": step_ms,
+            "ms_first_quartile": sum(step_ms[:q]) / q, "ms_last_quartile": sum(step_ms[-q:]) / q,
+            "poses": torch.stack(recovered, 1), "pc": pc, "segments": seg_out}
 
 
 def pmc_traffic(kernel_prefix):
@@ -183,6 +232,106 @@ def cpu_baseline(seq, n_full_steps, odom):
     return out, op
 
 
+def secondary_measurements(gs, args, frames, device, barrier, Wm, K):
+    """Driver-observable numbers for the other BASELINE configs, in the same process after the headline (rank 0,
+    N = 1; bounded to a few tens of seconds):
+      b1_640x480      configs[1] = what ONE GPU runs when the 8 sequences are sharded over 8 GPUs (--gpus 8): sequence 0
+                      alone, K timed steps, with the ICP kernel's mean launch duration from a short profiled pass;
+      c3_gradicp      configs[2]: point_to_plane_gradICP on the 640x480 lattice (ds = 4), 20 iterations, forward and
+                      forward (taped) + backward through all iterations, ms per call;
+      c5_1296x968     configs[4] shape: one 1296x968 sequence, 60 timed frames, ms per frame against the map size."""
+    import torch
+    from gradslam_amd import _C, ops
+    lib = _C.lib()
+    out = {}
+    t_start = time.perf_counter()
+
+    # ---- configs[1]: one 640x480 sequence per GPU
+    slam = gs.slam.PointFusion(odom=args.odom, device=device)
+    one = frames[0:1]
+    r = timed_steps(gs, slam, one, Wm, K, device, barrier)
+    b1 = {"frames_per_s": K / r["elapsed"], "ms_per_step": r["elapsed"] / K * 1e3,
+          "ms_per_step_first_quartile": r["ms_first_quartile"], "ms_per_step_last_quartile": r["ms_last_quartile"],
+          "host_enqueue_ms_per_step": (r["t_enq"] - r["waits"]) / K * 1e3, "steps": K, "warmup": Wm,
+          "map_surfels_end": [int(p.shape[0]) for p in r["pc"].points_list],
+          "what": "sequence 0 of the headline workload alone on the GPU (the per-GPU shard of --gpus 8)"}
+    pc2, prev2 = run_steps(slam, gs.Pointclouds(device=device), one, None, 0, Wm)
+    torch.cuda.synchronize(device)
+    nprof = min(K, 6)
+    _C.check(lib.gs_profile_begin(64 * nprof + 1024), "gs_profile_begin")
+    run_steps(slam, pc2, one, prev2, Wm, Wm + nprof, after_step=lambda p: p._tighten_counts())
+    _C.check(lib.gs_profile_end(), "gs_profile_end")
+    ms, n, nbytes = read_profile(lib, 8)
+    if n > 0:
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        b1["roofline"] = {"kernel": "gs_icp_half_batch_kernel (one sequence per launch)", "bound": "hbm", "achieved": gbs,
+                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "launches": n,
+                          "avg_launch_us": ms * 1e3 / n, "alg_bytes_per_launch": nbytes / n, "profiled_steps": nprof}
+    out["b1_640x480"] = b1
+    del pc2, prev2, r
+
+    # ---- configs[2]: gradICP forward + backward through 20 iterations on the 640x480 lattice
+    try:
+        seq = make_sequences([0], 3, 480, 640)[0]
+        dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+        Kc, pose = dv(seq["intrinsics"][0]), dv(seq["poses"][0])
+        sets = []
+        for f in (0, 2):
+            d = dv(seq["depths"][f, ..., 0])
+            v, nm, _, _ = ops.frame_maps(d, Kc)
+            gv, gn = ops.global_maps(v, nm, d, pose)
+            sets.append(ops.downsample_frame(gv, gn, None, d, 4)[:2])
+        (tgt, tn), (src, _) = sets
+        src = src.clone().requires_grad_(True)
+
+        def fwd_bwd():
+            T, _ = ops.grad_icp(src, tgt, tn, None, 20, 1e-8, None, 2.0, 1.0, 1.0, 200.0)
+            T.sum().backward()
+
+        def fwd():
+            with torch.no_grad():
+                ops.icp(src.detach(), tgt, tn, numiters=20, return_idx=False)
+
+        def timeit(f, n=10):
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                f()
+            torch.cuda.synchronize(device)
+            return (time.perf_counter() - t0) / n * 1e3
+
+        out["c3_gradicp_640x480"] = {"forward_ms": timeit(fwd), "forward_taped_plus_backward_ms": timeit(fwd_bwd),
+                                     "src_points": int(src.shape[0]), "tgt_points": int(tgt.shape[0]), "iterations": 20,
+                                     "calls_timed": 10,
+                                     "what": "point_to_plane_gradICP between frames 0 and 2 of sequence 0 on the ds = 4 "
+                                             "lattice; backward = d(sum T)/d(src) through all 20 iterations"}
+    except Exception as e:   # noqa: BLE001  (a secondary number must not take the headline down)
+        out["c3_gradicp_640x480"] = {"error": repr(e)}
+
+    # ---- configs[4] shape: 1296x968, 60 timed frames, growing map
+    try:
+        Lc, Wc = 5 + 60, 5
+        seqs = make_sequences([0], Lc, 968, 1296, chunk=5)
+        fr5 = frames_on_device(gs, seqs, device)
+        slam5 = gs.slam.PointFusion(odom=args.odom, device=device)
+        r = timed_steps(gs, slam5, fr5, Wc, Lc - Wc, device, barrier, seg_every=15)
+        from tests.conftest import ate as ate_np
+        out["c5_1296x968"] = {"frames_per_s": (Lc - Wc) / r["elapsed"], "ms_per_frame": r["elapsed"] / (Lc - Wc) * 1e3,
+                              "ms_per_frame_first_quartile": r["ms_first_quartile"],
+                              "ms_per_frame_last_quartile": r["ms_last_quartile"], "frames_timed": Lc - Wc, "warmup": Wc,
+                              "segments": r["segments"], "map_surfels_end": int(r["pc"].points_list[0].shape[0]),
+                              "ate_vs_ground_truth_m": ate_np(r["poses"][0].cpu().numpy(), seqs[0]["poses"]),
+                              "what": "one 1296x968 sequence (BASELINE configs[4] shape, first 65 frames of the 500-frame "
+                                      "workload of --workload c5), dynamic map growth"}
+        del fr5, r
+    except Exception as e:   # noqa: BLE001
+        out["c5_1296x968"] = {"error": repr(e)}
+    out["seconds"] = time.perf_counter() - t_start
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -201,6 +350,8 @@ def main():
     device = torch.device("cuda", local)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    if args.weak:               # weak scaling: the per-GPU work is fixed (--batch sequences on every GPU)
+        args.batch = args.batch * world
     if args.workload == "c5":   # BASELINE configs[4]: one ScanNet-resolution sequence, dynamic map growth
         args.batch, args.height, args.width = world, 968, 1296
     Hh, Ww = args.height, args.width
@@ -228,46 +379,38 @@ def main():
     gc.collect()
     gc.freeze()
 
-    # ---------------- warm-up (untimed): map init + first ICP frames, allocator, kernels
-    pc = gs.Pointclouds(device=device)
-    recovered = []
-    pc, prev = run_steps(slam, pc, frames, None, 0, Wm, recovered)
-    torch.cuda.synchronize(device)
-
-    # ---------------- timed region: exactly K steps (one frame of every sequence each)
-    segments, seg_every = [], (25 if args.workload == "c5" else 0)
-
-    def mark(p):   # c5 only: one sync every 25 frames, to report ms per frame against the map size
-        if len(recovered) > Wm and (len(recovered) - Wm) % seg_every == 0:
-            torch.cuda.synchronize(device)
-            segments.append((len(recovered) - Wm, time.perf_counter(), max(p._count_of(b)[0] for b in range(B_local))))
-
-    barrier()
-    t0 = time.perf_counter()
-    pc, prev_end = run_steps(slam, pc, frames, prev, Wm, L, recovered, after_step=mark if seg_every else None)
-    t_enq = time.perf_counter() - t0
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # ---------------- warm-up (untimed: map init + first ICP frames, allocator, kernels), then exactly K timed steps
+    run = timed_steps(gs, slam, frames, Wm, K, device, barrier, seg_every=25 if args.workload == "c5" else 0)
+    pc, elapsed_local, t_enq = run["pc"], run["elapsed"], run["t_enq"]
+    elapsed = elapsed_local
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     n_map = [int(p.shape[0]) for p in pc.points_list]
-    poses_local = torch.stack(recovered, 1)  # (B_local, L, 4, 4) recovered trajectories of this rank's sequences
+    poses_local = run["poses"]  # (B_local, L, 4, 4) recovered trajectories of this rank's sequences
     ate_gt = max(ate_np(poses_local[b].cpu().numpy(), seqs[b]["poses"]) for b in range(B_local))
 
     # ---------------- the only exchange step: final pose (+ map) gather over RCCL
     barrier()
     g0 = time.perf_counter()
     all_poses = multigpu.gather_poses(poses_local)
-    all_maps = multigpu.gather_maps(pc) if world > 1 else pc
+    all_maps = multigpu.gather_maps(pc, dst=0) if world > 1 else pc   # (the maps go to rank 0 only)
     barrier()
     gather_ms = (time.perf_counter() - g0) * 1e3
-    assert all_poses.shape[0] == args.batch and len(all_maps) == args.batch
+    assert all_poses.shape[0] == args.batch and (rank != 0 or len(all_maps) == args.batch)
     # fingerprint of the gathered result: the same for every N (sequences do not interact; tests/test_hip_batch.py)
     import hashlib
-    poses_sha = hashlib.sha256(all_poses.cpu().numpy().tobytes()).hexdigest()[:16]
-    n_map_all = [int(p.shape[0]) for p in all_maps.points_list]
+    sha = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:16]  # noqa: E731
+    poses_sha = sha(all_poses)
+    n_map_all = [int(p.shape[0]) for p in all_maps.points_list] if rank == 0 else None
+    # what every rank saw: its own clock around the K steps, its sequences, the fingerprint of its poses
+    mine_info = {"rank": rank, "sequences": mine, "elapsed_s": elapsed_local, "ms_per_step": elapsed_local / K * 1e3,
+                 "host_enqueue_ms_per_step": (t_enq - run["waits"]) / K * 1e3, "poses_sha": sha(poses_local)}
+    ranks_info = [mine_info]
+    if world > 1:
+        ranks_info = [None] * world
+        torch.distributed.all_gather_object(ranks_info, mine_info)
 
     # ---------------- roofline pass: same frames from the same map state, HIP events inside the library
     roofline, roofline_hbm = None, None
@@ -327,18 +470,18 @@ def main():
         cpu, op = cpu_baseline(seqs[0], args.cpu_frames, args.odom)
         ate_oracle = ate_np(poses_local[0, :op.shape[0]].cpu().numpy(), op)
 
-    seg_out, pn, pt = None, 0, t0
-    if segments:   # ms per frame of consecutive stretches of the timed region (growing map)
-        seg_out = []
-        for n, t, m in segments:
-            seg_out.append({"frames": "%d-%d" % (pn, n), "ms_per_frame": (t - pt) / (n - pn) * 1e3, "map_bound_end": m})
-            pn, pt = n, t
+    seg_out = run["segments"]
+    second = None
+    if rank == 0 and world == 1 and not args.no_secondary and args.workload == "c4" and (Hh, Ww) == (480, 640):
+        second = secondary_measurements(gs, args, frames, device, barrier, Wm, K)
     if rank == 0:
         value = args.batch * K / elapsed
+        el = [r["elapsed_s"] for r in ranks_info]
         out = {
             "metric": "frames/sec PointFusion %dx%d RGB-D" % (Ww, Hh), "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
             "config": {"workload": "PointFusion(odom=%s, dsratio=4, numiters=20) forward, B=%d independent %dx%d "
                                    "sequences sharded over %d GPU(s) (%d per GPU, batched: every kernel serves all "
                                    "sequences of the GPU), frames resident in HBM (BASELINE configs[%s])"
@@ -347,11 +490,20 @@ def main():
                        "map_surfels_end_rank0": n_map, "map_surfels_all": n_map_all, "poses_sha": poses_sha,
                        "parity_mode": "renormalize_unmatched=True (reference-identical merge)",
                        "final_gather_ms": gather_ms, "api": "gradslam_amd.slam.PointFusion.step",
-                       "host_enqueue_ms_per_step": t_enq / K * 1e3,
+                       "host_enqueue_ms_per_step": (t_enq - run["waits"]) / K * 1e3,
+                       "host_wait_ms_per_step": run["waits"] / K * 1e3,
+                       "host_note": "host_enqueue = Python + launches of a step; host_wait = what the host spends blocked on "
+                                    "purpose (it is kept at most ~6 frames ahead of the device, structures/pointclouds.py)",
+                       "ms_per_step_first_quartile": run["ms_first_quartile"],
+                       "ms_per_step_last_quartile": run["ms_last_quartile"],
+                       "icp_engine": os.environ.get("GRADSLAM_HIP_ICP_ENGINE", "rows"),
                        "host_readbacks_per_frame": 0 if gs.ops.DEVICE_COUNTS else 3,
                        "ate_vs_ground_truth_m_rank0_max": ate_gt, "ate_vs_oracle_m": ate_oracle,
                        "ate_vs_reference_golden": ate_ref},
             "segments": seg_out,
+            "ranks": {"elapsed_s_min": min(el), "elapsed_s_max": max(el), "elapsed_s_mean": sum(el) / len(el),
+                      "per_rank": ranks_info},
+            "secondary": second,
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -12,6 +12,7 @@
 Only the container logic lives here (torch as memory plumbing); the arithmetic of the SLAM path
 is in libgradslam_hip.so.
 """
+import time
 from typing import List, Optional, Union
 
 import torch
@@ -32,6 +33,7 @@ class _CountGroup(object):
     copy of all the counts into pinned memory; `poll()` tightens the bounds from the copies that have already landed
     and never waits, so the frame loop has no host<->device sync."""
     RING = 8
+    wait_s = 0.0    # seconds the host has spent waiting in `advance` (class-wide; bench.py reports host time without it)
     EVERY = 2       # one asynchronous read-back per EVERY updates (a copy + an event on the stream)
     MAX_AHEAD = 2   # read-backs in flight before the host waits for the oldest: the host never runs more than
                     # ~EVERY * (MAX_AHEAD + 1) frames ahead of the device, which keeps the bounds (launch sizes,
@@ -65,7 +67,9 @@ class _CountGroup(object):
         if self._updates % self.EVERY == 0:
             self._queue_copy()
             if len(self._pending) > self.MAX_AHEAD:
+                t0 = time.perf_counter()
                 self._events[self._pending[0][0]].synchronize()   # frames old: the device is still busy behind it
+                _CountGroup.wait_s += time.perf_counter() - t0
         self.poll()
 
     def poll(self):
