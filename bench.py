@@ -248,7 +248,7 @@ def secondary_measurements(gs, args, frames, device, barrier, Wm, K):
 
     # ---- configs[1]: one 640x480 sequence per GPU
     slam = gs.slam.PointFusion(odom=args.odom, device=device)
-    one = frames[0:1]
+    one = frames[0:1, :]
     r = timed_steps(gs, slam, one, Wm, K, device, barrier)
     b1 = {"frames_per_s": K / r["elapsed"], "ms_per_step": r["elapsed"] / K * 1e3,
           "ms_per_step_first_quartile": r["ms_first_quartile"], "ms_per_step_last_quartile": r["ms_last_quartile"],
