@@ -427,13 +427,16 @@ __global__ void __launch_bounds__(256) gs_mu_project_key_kernel(const MuBatch mb
   const GsCamera c = gs_camera(q.pose16, q.K16);
   const int32_t p = gs_project_point(c, q.points[3 * n], q.points[3 * n + 1], q.points[3 * n + 2], mb.H, mb.W, mb.u_hi,
                                      mb.v_hi);
-  uint64_t k = ~0ull;
+  // pix[n] = the pixel this row competes for, or -1 (not in the frame, or not similar to the pixel): the pick pass
+  // then reads 4 bytes of most rows instead of 12, and the key is only stored for the rows that have one
+  int32_t pk = -1;
   if (p >= 0 && gs_is_similar(q.points, q.normals, q.gvertex, q.gnormal, n, p, mb.dist_th, mb.dot_th)) {
-    k = gs_assoc_key(q.points, q.ccounts, q.gvertex, n, p);
+    const uint64_t k = gs_assoc_key(q.points, q.ccounts, q.gvertex, n, p);
     atomicMin(reinterpret_cast<unsigned long long*>(&q.key_pix[p]), (unsigned long long)k);
+    q.key_pt[n] = k;
+    pk = p;
   }
-  q.pix[n] = p;
-  q.key_pt[n] = k;
+  q.pix[n] = pk;
   q.pix_of[n] = -1;
 }
 
@@ -441,10 +444,9 @@ __global__ void __launch_bounds__(256) gs_mu_pick_kernel(const MuBatch mb) {
   const MuSeq& q = mb.s[blockIdx.x % mb.B];
   const int64_t n = (int64_t)(blockIdx.x / mb.B) * 256 + threadIdx.x;
   if (n >= gs_count(q.n_map)) return;
-  const uint64_t k = q.key_pt[n];
-  if (k == ~0ull) return;
   const int32_t p = q.pix[n];
-  if (k == q.key_pix[p]) atomicMin(reinterpret_cast<unsigned*>(&q.best_pix[p]), (unsigned)n);
+  if (p < 0) return;
+  if (q.key_pt[n] == q.key_pix[p]) atomicMin(reinterpret_cast<unsigned*>(&q.best_pix[p]), (unsigned)n);
 }
 
 // per pixel tile of GS_CP_TILE pixels: inverse map of the winners + number of new pixels of the tile
