@@ -23,7 +23,7 @@ def pmc(kind):
 fetch, write = pmc("fetch"), pmc("write")
 short = lambda n: n.split("(")[0][:62]
 lines = ["# per kernel: calls and mean duration (rocprofv3 --kernel-trace --stats), HBM traffic per launch from separate",
-         "# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline-pass` (B = 8 sequences on one GPU);",
+         "# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline-pass --no-secondary` (B = 8 sequences on one GPU);",
          "# FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads; narrow gathers are then",
          "# over-estimated), WRITE_SIZE (KB) as reported.  GB/s = (2*fetch + write) / mean duration.",
          "%-64s %6s %9s %12s %12s %9s" % ("kernel", "calls", "avg_us", "fetchKB(x2)", "writeKB", "GB/s")]
