@@ -55,35 +55,19 @@ GS_DEV void fuse_merge_row(float* __restrict__ points, float* __restrict__ norma
   }
   const float cc2 = cc + a;
   const float inv = 1.0f / (cc2 == 0.0f ? 1.0f : cc2);
-  // An attribute is stored only when the pass changed one of its bits.  The reference rewrites every row every frame
-  // ((cc x) (1 / cc) for the unmatched ones, slam/fusionutils.py:678-699), which moves a value by at most an ulp and,
-  // being monotone in x, reaches a fixed point after a pass or two: from then on the rewrite is the identity, and
-  // most of a mature map is unmatched rows at their fixed point.  Skipping those stores changes no bit of the result
-  // and takes the write half out of this pass's traffic (the read half is needed to know).
-  bool dp = false, dn = false, dc = false;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float p1 = ((cc * P[k]) + (a * fp[k])) * inv;
-    const float n1 = ((cc * N[k]) + (a * fn[k])) * inv;
-    const float c1 = ((cc * C[k]) + (a * fc[k])) * inv;
-    dp = dp || __float_as_uint(p1) != __float_as_uint(P[k]);
-    dn = dn || __float_as_uint(n1) != __float_as_uint(N[k]);
-    dc = dc || __float_as_uint(c1) != __float_as_uint(C[k]);
-    P[k] = p1; N[k] = n1; C[k] = c1;
+    P[k] = ((cc * P[k]) + (a * fp[k])) * inv;
+    N[k] = ((cc * N[k]) + (a * fn[k])) * inv;
+    C[k] = ((cc * C[k]) + (a * fc[k])) * inv;
   }
-  if (dp) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) points[3 * n + k] = P[k];
-  }
-  if (dn) {
+  for (int k = 0; k < 3; ++k) points[3 * n + k] = P[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) normals[3 * n + k] = N[k];
-  }
-  if (dc) {
+  for (int k = 0; k < 3; ++k) normals[3 * n + k] = N[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) colors[3 * n + k] = C[k];
-  }
-  if (__float_as_uint(cc2) != __float_as_uint(cc)) ccounts[n] = cc2;
+  for (int k = 0; k < 3; ++k) colors[3 * n + k] = C[k];
+  ccounts[n] = cc2;
 }
 
 // slam/fusionutils.py:678-699 applied to rows [0, n_map).
