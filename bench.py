@@ -458,14 +458,19 @@ def main():
                         "hbm_frac_whole_step": (sum(read_profile(lib, k)[2] for k in (2, 4, 5, 6, 8)) / K) /
                                                (elapsed / K) / 1e9 / PEAK_HBM_GBS}
 
-    cpu, ate_oracle, ate_ref = None, None, None
-    if rank == 0:
-        gp = os.path.join(REPO, "tests", "golden", "pf640.npz")
-        if os.path.exists(gp) and mine[0] == 0 and (Hh, Ww) == (480, 640) and args.odom == "gradicp" and L <= 64:
-            g = np.load(gp)   # the REAL reference's poses on sequence 0 (oracle/make_golden_640.py)
-            nfr = min(L, g["poses"].shape[0])
-            ate_ref = {"value_m": ate_np(poses_local[0, :nfr].cpu().numpy(), g["poses"][:nfr]), "frames": nfr,
-                       "source": "tests/golden/pf640.npz (unmodified gradslam PointFusion on the same sequence)"}
+    cpu, ate_oracle, ate_ref, ate_refs = None, None, None, {}
+    if (Hh, Ww) == (480, 640) and args.odom == "gradicp" and L <= 64:
+        # the REAL reference's poses (oracle/make_golden_640.py) for every sequence of this rank that has a golden:
+        # seed 0 over 20 frames, seeds 1..3 over 5 frames
+        for b, sd in enumerate(mine):
+            gp = os.path.join(REPO, "tests", "golden", "pf640.npz" if sd == 0 else "pf640_s%d.npz" % sd)
+            if os.path.exists(gp):
+                g = np.load(gp)
+                nfr = min(L, g["poses"].shape[0])
+                ate_refs[str(sd)] = {"value_m": ate_np(poses_local[b, :nfr].cpu().numpy(), g["poses"][:nfr]), "frames": nfr,
+                                     "source": "tests/golden/" + os.path.basename(gp)}
+        if rank == 0 and "0" in ate_refs:
+            ate_ref = dict(ate_refs["0"], source="tests/golden/pf640.npz (unmodified gradslam PointFusion on the same sequence)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, op = cpu_baseline(seqs[0], args.cpu_frames, args.odom)
         ate_oracle = ate_np(poses_local[0, :op.shape[0]].cpu().numpy(), op)
@@ -499,7 +504,7 @@ def main():
                        "icp_engine": os.environ.get("GRADSLAM_HIP_ICP_ENGINE", "rows"),
                        "host_readbacks_per_frame": 0 if gs.ops.DEVICE_COUNTS else 3,
                        "ate_vs_ground_truth_m_rank0_max": ate_gt, "ate_vs_oracle_m": ate_oracle,
-                       "ate_vs_reference_golden": ate_ref},
+                       "ate_vs_reference_golden": ate_ref, "ate_vs_reference_goldens_by_seed_rank0": ate_refs},
             "segments": seg_out,
             "ranks": {"elapsed_s_min": min(el), "elapsed_s_max": max(el), "elapsed_s_mean": sum(el) / len(el),
                       "per_rank": ranks_info},

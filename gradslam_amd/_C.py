@@ -119,6 +119,9 @@ _PROTOS = {
     "gs_localize_scratch_bytes": [_i32, _i32, _i32, _i64],
     "gs_localize_batch_f32": [C.POINTER(LocalizeSeq), _i32, _i32, _i32, _i32, C.POINTER(IcpParams), _vp],
     "gs_update_map_fusion_batch_f32": [C.POINTER(UpdateSeq), _i32, _i32, _i32, _f, _f, _i32, _vp],
+    "gs_project_points_f32": [_vp, _i32, _i64, _vp, _i64, _vp, _vp],
+    "gs_unproject_points_f32": [_vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp],
+    "gs_lie_small_f32": [_i32, _vp, _vp, _vp],
     "gs_pointfusion_step_batch_f32": [C.POINTER(StepSeq), _i32, _i32, _i32, _i32, C.POINTER(IcpParams), _f, _f, _f, _i32, _vp],
 }
 _RESTYPE = {"gs_last_error": C.c_char_p, "gs_scratch_bytes": _i64, "gs_icp_scratch_bytes": _i64,

@@ -123,6 +123,95 @@ extern "C" int gs_transform_points_f32(const float* pts, int64_t n, const float*
   return GS_OK;
 }
 
+// ---------------------------------------------------------------- API-level projective helpers
+// project_points (geometry/projutils.py:92-238): pts = proj_mat [x y z w]^T (tiny matmul: plain mul / add, ascending
+// k), u = x' / z', v = y' / z' with z' replaced by 1 where it is 0.  Point i uses matrix i / pts_per_mat.
+__global__ void __launch_bounds__(256) gs_project_points_kernel(const float* __restrict__ cam, int cdim, int64_t n,
+                                                                const float* __restrict__ proj, int64_t pts_per_mat,
+                                                                float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* M = proj + 16 * (i / pts_per_mat);
+  float p[4] = {cam[cdim * i], cam[cdim * i + 1], cam[cdim * i + 2], cdim == 4 ? cam[4 * i + 3] : 1.0f};
+  float r[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float acc = M[4 * a] * p[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) acc = acc + M[4 * a + k] * p[k];
+    r[a] = acc;
+  }
+  const float z = r[2] != 0.0f ? r[2] : 1.0f;
+  out[2 * i] = r[0] / z;
+  out[2 * i + 1] = r[1] / z;
+}
+extern "C" int gs_project_points_f32(const float* cam_coords, int cdim, int64_t n, const float* proj16,
+                                     int64_t pts_per_mat, float* out_uv, void* stream) {
+  GS_REQUIRE(n >= 0 && (cdim == 3 || cdim == 4) && pts_per_mat > 0, "bad arguments");
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(cam_coords && proj16 && out_uv, "NULL pointer");
+  hipLaunchKernelGGL(gs_project_points_kernel, dim3((unsigned)gs_ceil_div(n, 256)), dim3(256), 0, gs_stream(stream),
+                     cam_coords, cdim, n, proj16, pts_per_mat, out_uv);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// unproject_points (geometry/projutils.py:241-402): (K^-1 [u v w]^T) * depth, w = 1 for (*, 2) inputs.
+__global__ void __launch_bounds__(256) gs_unproject_points_kernel(const float* __restrict__ pix, int pdim, int64_t n,
+                                                                  const float* __restrict__ kinv, int64_t pts_per_mat,
+                                                                  const float* __restrict__ depth,
+                                                                  float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* M = kinv + 9 * (i / pts_per_mat);
+  const float p[3] = {pix[pdim * i], pix[pdim * i + 1], pdim == 3 ? pix[3 * i + 2] : 1.0f};
+  const float d = depth[i];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float acc = M[3 * a] * p[0];
+    acc = acc + M[3 * a + 1] * p[1];
+    acc = acc + M[3 * a + 2] * p[2];
+    out[3 * i + a] = acc * d;
+  }
+}
+extern "C" int gs_unproject_points_f32(const float* pixel_coords, int pdim, int64_t n, const float* kinv9,
+                                       int64_t pts_per_mat, const float* depths, float* out_xyz, void* stream) {
+  GS_REQUIRE(n >= 0 && (pdim == 2 || pdim == 3) && pts_per_mat > 0, "bad arguments");
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(pixel_coords && kinv9 && depths && out_xyz, "NULL pointer");
+  hipLaunchKernelGGL(gs_unproject_points_kernel, dim3((unsigned)gs_ceil_div(n, 256)), dim3(256), 0, gs_stream(stream),
+                     pixel_coords, pdim, n, kinv9, pts_per_mat, depths, out_xyz);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// so3_hat / se3_hat / so3_exp (geometry/se3utils.py:11-74).  op 0: omega (3) -> 3x3 hat; op 1: xi (6) -> 4x4 hat;
+// op 2: omega (3) -> 3x3 rotation (the rotation block of gs_se3_exp_dev: double-precision Rodrigues, rounded once).
+__global__ void gs_lie_small_kernel(int op, const float* __restrict__ in, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  if (op == 2) {
+    const float xi[6] = {0.0f, 0.0f, 0.0f, in[0], in[1], in[2]};
+    float T[16];
+    gs_se3_exp_dev(xi, T);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) out[3 * i + j] = T[4 * i + j];
+    return;
+  }
+  const int n = op == 0 ? 3 : 4;
+  const float* w = op == 0 ? in : in + 3;
+  for (int i = 0; i < n * n; ++i) out[i] = 0.0f;
+  out[0 * n + 1] = -w[2]; out[1 * n + 0] = w[2];
+  out[0 * n + 2] = w[1];  out[2 * n + 0] = -w[1];
+  out[1 * n + 2] = -w[0]; out[2 * n + 1] = w[0];
+  if (op == 1) { out[3] = in[0]; out[7] = in[1]; out[11] = in[2]; }
+}
+extern "C" int gs_lie_small_f32(int op, const float* in, float* out, void* stream) {
+  GS_REQUIRE(op >= 0 && op <= 2 && in && out, "bad arguments");
+  hipLaunchKernelGGL(gs_lie_small_kernel, dim3(1), dim3(64), 0, gs_stream(stream), op, in, out);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 // ---------------------------------------------------------------- generic normal eq ----
 // solve_linear_system for A (n_rows, ncols <= 8): one block, float64 accumulation.
 __global__ void __launch_bounds__(256) gs_solve_normal_eq_kernel(const float* __restrict__ A,

@@ -281,6 +281,40 @@ def se3_exp(xi):
     return T
 
 
+def lie_small(op, vec, n_in, n_out):
+    """so3_hat (op 0) / se3_hat (1) / so3_exp (2) of a 3- / 6-vector (gs_lie_small_f32)."""
+    _warn_detached(("so3_hat", "se3_hat", "so3_exp")[op], vec)
+    v = _c(vec).reshape(n_in)
+    dev = require_device(v)
+    out = torch.empty((n_out, n_out), dtype=f32, device=dev)
+    check(lib().gs_lie_small_f32(int(op), ptr(v), ptr(out), stream(dev)), "gs_lie_small_f32")
+    return out
+
+
+def project_points(cam, proj, pts_per_mat):
+    """cam (n, 3|4), proj (m, 4, 4) with n = m * pts_per_mat -> (n, 2) (gs_project_points_f32)."""
+    _warn_detached("project_points", cam, proj)
+    cam, proj = _c(cam), _c(proj)
+    dev = require_device(cam, proj)
+    n = cam.shape[0]
+    out = torch.empty((n, 2), dtype=f32, device=dev)
+    check(lib().gs_project_points_f32(ptr(cam), int(cam.shape[1]), n, ptr(proj), int(pts_per_mat), ptr(out), stream(dev)),
+          "gs_project_points_f32")
+    return out
+
+
+def unproject_points(pix, kinv, depths, pts_per_mat):
+    """pix (n, 2|3), kinv (m, 3, 3), depths (n,) -> (n, 3) (gs_unproject_points_f32)."""
+    _warn_detached("unproject_points", pix, kinv, depths)
+    pix, kinv, depths = _c(pix), _c(kinv), _c(depths)
+    dev = require_device(pix, kinv, depths)
+    n = pix.shape[0]
+    out = torch.empty((n, 3), dtype=f32, device=dev)
+    check(lib().gs_unproject_points_f32(ptr(pix), int(pix.shape[1]), n, ptr(kinv), int(pts_per_mat), ptr(depths), ptr(out),
+                                        stream(dev)), "gs_unproject_points_f32")
+    return out
+
+
 def ingest_depth(raw_u16, H, W, scale_div):
     """(H0, W0) uint16 depth as decoded from the PNG -> (H, W) float32 metres."""
     raw = raw_u16.contiguous()

@@ -545,9 +545,23 @@ class Pointclouds(object):
     # Container algebra of the reference API (pointclouds.py:399-614).  The SLAM hot path does
     # NOT go through these (projection/association is fused in the HIP kernels).
     def _apply(self, k, fn):
-        if self._buf[k] is not None:
-            self._buf[k] = [fn(b, t[:n]) for b, (t, n) in enumerate(zip(self._buf[k], self._n))]
-            self._padded_cache.pop(k, None)
+        if self._buf[k] is not None:   # (results land on capacity-backed buffers again: _store_rows)
+            self._store_rows(k, [fn(b, t[:n]) for b, (t, n) in enumerate(zip(self._buf[k], self._n))])
+
+    @staticmethod
+    def _rigid_rows(t, M, tvec=None):
+        """t @ M (+ tvec) for the rows of one cloud.  On the GPU: gs_transform_points_f32 (the FMA chain of the
+        reference's batched matmul, then the translation); on the CPU (host-side logic, tests): the same as tensor ops."""
+        if t.is_cuda and t.dtype == torch.float32 and not t.requires_grad:
+            from .. import ops
+            T = torch.zeros((4, 4), dtype=torch.float32, device=t.device)
+            T[:3, :3] = M.transpose(0, 1)
+            if tvec is not None:
+                T[:3, 3] = tvec
+            T[3, 3] = 1.0
+            return ops.transform_points(t, T)
+        out = t @ M
+        return out if tvec is None else out + tvec
 
     def offset_(self, offset):
         if not (torch.is_tensor(offset) or isinstance(offset, (float, int))):
@@ -581,8 +595,8 @@ class Pointclouds(object):
         if pre_multiplication:
             rmat = rmat.transpose(-1, -2)
         pick = (lambda b: rmat[b]) if rmat.ndim == 3 else (lambda b: rmat)
-        self._apply("points", lambda b, t: t @ pick(b))
-        self._apply("normals", lambda b, t: t @ pick(b))
+        self._apply("points", lambda b, t: self._rigid_rows(t, pick(b)))
+        self._apply("normals", lambda b, t: self._rigid_rows(t, pick(b)))
         return self
 
     def transform_(self, transform: torch.Tensor, *, pre_multiplication=True):
@@ -614,6 +628,10 @@ class Pointclouds(object):
 
         def proj(b, t):
             K = pick(b)
+            if t.is_cuda and t.dtype == torch.float32 and not t.requires_grad:   # gs_project_points_f32
+                from .. import ops
+                uv = ops.project_points(t, K.reshape(1, 4, 4), max(int(t.shape[0]), 1))
+                return torch.cat([uv, torch.ones_like(uv[:, :1])], -1)
             h = torch.cat([t, torch.ones_like(t[:, :1])], -1) @ K.transpose(0, 1)
             z = torch.where(h[:, 2:3] != 0, h[:, 2:3], torch.ones_like(h[:, 2:3]))
             return torch.cat([h[:, :2] / z, torch.ones_like(z)], -1)

@@ -502,6 +502,17 @@ GS_API int gs_pointfusion_step_batch_f32(const gs_step_seq* seqs_host, int B, in
                                          const gs_icp_params* params_host, float two_sigma_sq, float dist_th,
                                          float dot_th, int renorm_all, void* stream);
 
+/* API-level projective / Lie helpers (the SLAM kernels fuse their own copies; these are the drop-in names).
+ * gs_project_points_f32: project_points (geometry/projutils.py:92-238) on n points of cdim (3 | 4) coordinates; point i
+ *   uses the 4x4 matrix proj16 + 16 * (i / pts_per_mat); out_uv (n, 2) = (x'/z', y'/z'), z' = 1 where it is 0.
+ * gs_unproject_points_f32: unproject_points (geometry/projutils.py:241-402): (K^-1 [u v w]) * depth, pdim (2 | 3).
+ * gs_lie_small_f32: op 0 so3_hat (3 -> 3x3), 1 se3_hat (6 -> 4x4), 2 so3_exp (3 -> 3x3) (geometry/se3utils.py:11-74). */
+GS_API int gs_project_points_f32(const float* cam_coords, int cdim, int64_t n, const float* proj16, int64_t pts_per_mat,
+                                 float* out_uv, void* stream);
+GS_API int gs_unproject_points_f32(const float* pixel_coords, int pdim, int64_t n, const float* kinv9,
+                                   int64_t pts_per_mat, const float* depths, float* out_xyz, void* stream);
+GS_API int gs_lie_small_f32(int op, const float* in, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -364,3 +364,41 @@ def test_scannet_loader_on_device_matches_reference(tmp_path, golden):
         Scannet(base, meta, None, start=3, end=2)
     with pytest.raises(TypeError):
         Scannet(base, meta, 5)
+
+
+def test_project_unproject_points_vs_reference_golden(golden):
+    """geometry.projutils.project_points / unproject_points (HIP kernels gs_project_points_f32 / gs_unproject_points_f32)
+    against the REAL reference on every broadcasting case of its docstrings (tests/golden/api_helpers.npz)."""
+    from gradslam_amd.geometry import projutils as P
+    g = golden("api_helpers")
+    d = lambda k: torch.from_numpy(g[k]).cuda()   # noqa: E731
+    for c in "abcd":
+        out = P.project_points(d("pp_%s_cam" % c), d("pp_%s_proj" % c))
+        assert out.shape == g["pp_%s_out" % c].shape
+        np.testing.assert_allclose(out.cpu().numpy(), g["pp_%s_out" % c], rtol=2e-6, atol=2e-6, err_msg=c)
+    for c in "abc":
+        out = P.unproject_points(d("up_%s_pix" % c), d("up_%s_kinv" % c), d("up_%s_depth" % c))
+        assert out.shape == g["up_%s_out" % c].shape
+        np.testing.assert_allclose(out.cpu().numpy(), g["up_%s_out" % c], rtol=2e-6, atol=2e-5, err_msg=c)
+    with pytest.raises(ValueError):
+        P.project_points(d("pp_c_cam"), d("pp_c_proj")[:1].repeat(3, 1, 1))
+    with pytest.raises(ValueError):
+        P.unproject_points(d("up_a_pix"), d("up_a_kinv"), d("up_a_depth")[:5])
+
+
+def test_so3_se3_helpers_vs_reference_golden(golden):
+    from gradslam_amd.geometry import se3utils as S
+    g = golden("api_helpers")
+    for i, om in enumerate(g["omega"]):
+        w = torch.from_numpy(om).cuda()
+        assert torch.equal(S.so3_hat(w).cpu(), torch.from_numpy(g["so3_hat"][i]))
+        np.testing.assert_allclose(S.so3_exp(w).cpu().numpy(), g["so3_exp"][i], rtol=0, atol=2e-6)
+    for i, xi in enumerate(g["xi"]):
+        assert torch.equal(S.se3_hat(torch.from_numpy(xi).cuda()).cpu(), torch.from_numpy(g["se3_hat"][i]))
+
+
+def test_pointclouds_algebra_vs_reference_golden_gpu(golden):
+    """offset_ / scale_ / rotate_ / transform_ / pinhole_projection_ and + - * / @ on the GPU (rigid ops and the
+    projection through gs_transform_points_f32 / gs_project_points_f32) against the REAL reference."""
+    from tests.test_host_api_cpu import check_pointclouds_algebra
+    check_pointclouds_algebra(golden, "cuda", 2e-6)

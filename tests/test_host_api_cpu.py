@@ -472,3 +472,37 @@ def test_pixel_pos_channels_first_standard_grid_is_accepted():
     gs.RGBDImages(rgb, depth, K, channels_first=True, pixel_pos=grid)
     with pytest.raises(NotImplementedError):
         gs.RGBDImages(rgb, depth, K, channels_first=True, pixel_pos=grid + 0.5)
+
+
+_PC_CASES = {
+    "offset_scalar": lambda pc, a: pc.offset_(0.25), "offset_vec": lambda pc, a: pc.offset_(a["off3"]),
+    "offset_batch": lambda pc, a: pc.offset_(a["offB"]), "scale_scalar": lambda pc, a: pc.scale_(1.5),
+    "scale_vec": lambda pc, a: pc.scale_(a["off3"]), "rotate_1_pre": lambda pc, a: pc.rotate_(a["R1"]),
+    "rotate_1_post": lambda pc, a: pc.rotate_(a["R1"], pre_multiplication=False),
+    "rotate_B_pre": lambda pc, a: pc.rotate_(a["RB"]), "transform_1_pre": lambda pc, a: pc.transform_(a["T1"]),
+    "transform_B_pre": lambda pc, a: pc.transform_(a["TB"]),
+    "transform_B_post": lambda pc, a: pc.transform_(a["TB"], pre_multiplication=False),
+    "pinhole": lambda pc, a: pc.pinhole_projection_(a["K"]), "op_add": lambda pc, a: pc + 0.25,
+    "op_sub": lambda pc, a: pc - a["off3"], "op_mul": lambda pc, a: pc * 1.5, "op_div": lambda pc, a: pc / 2.0,
+    "op_matmul_R": lambda pc, a: pc @ a["R1"], "op_matmul_T": lambda pc, a: pc @ a["TB"],
+}
+
+
+def check_pointclouds_algebra(golden, device, tol):
+    """Pointclouds.offset_ / scale_ / rotate_ / transform_ / pinhole_projection_ and + - * / @ against the REAL reference
+    (tests/golden/api_helpers.npz, oracle/make_golden_api.py); shared by the CPU and the GPU test."""
+    g = golden("api_helpers")
+    T = lambda k: torch.from_numpy(g[k]).to(device)   # noqa: E731
+    args = {k: T("arg_" + k) for k in ("R1", "RB", "T1", "TB", "K", "off3", "offB")}
+    for tag, fn in _PC_CASES.items():
+        pc = gs.Pointclouds(points=[T("pc_points0"), T("pc_points1")], normals=[T("pc_normals0"), T("pc_normals1")])
+        out = fn(pc, args)
+        for b in range(2):
+            np.testing.assert_allclose(out.points_list[b].cpu().numpy(), g["%s_p%d" % (tag, b)], rtol=tol, atol=tol,
+                                       err_msg=tag)
+            np.testing.assert_allclose(out.normals_list[b].cpu().numpy(), g["%s_n%d" % (tag, b)], rtol=tol, atol=tol,
+                                       err_msg=tag)
+
+
+def test_pointclouds_algebra_vs_reference_golden_cpu(golden):
+    check_pointclouds_algebra(golden, "cpu", 2e-6)
