@@ -413,13 +413,81 @@ static void solve_spd_f64(const float* AtA, const float* Atb, float damp, int n,
   for (int i = 0; i < n; ++i) x[i] = (float)a[i][n];
 }
 
+static void solve_spd_f32_experiment(const float* AtA, const float* Atb, float damp, int n, float* x);
+static int neq_f32_mode(void);
 static void solve_from_normal_eq(const float* AtA, const float* Atb, float damp, float* x6) {
+  if (neq_f32_mode()) { solve_spd_f32_experiment(AtA, Atb, damp, 6, x6); return; }
   solve_spd_f64(AtA, Atb, damp, 6, x6);
+}
+
+/* EXPERIMENT (tools/f32_normal_equations.py): GS_ORACLE_NEQ_F32=1 accumulates the normal equations in
+ * float32 the way a vectorised sgemm / dot does (16 running sums, element i into sum i % 16, added up at the end) and
+ * solves them in float32, to measure how much of the distance to the reference's poses is the float64 accumulation of
+ * the default path.  Not used by any test or by the product. */
+static int neq_f32_mode(void) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GS_ORACLE_NEQ_F32");
+    v = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return v;
+}
+static void normal_eq_f32_experiment(const float* A, const float* b, const uint8_t* keep, int64_t n, float* AtA,
+                                     float* Atb, float* err) {
+  float S[36][16], v[6][16], e[16];
+  memset(S, 0, sizeof(S)); memset(v, 0, sizeof(v)); memset(e, 0, sizeof(e));
+  int64_t k = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (keep && !keep[i]) continue;
+    const float* a = A + 6 * i;
+    const int l = (int)(k++ & 15);
+    for (int r = 0; r < 6; ++r) {
+      for (int c = r; c < 6; ++c) S[6 * r + c][l] = fmaf(a[r], a[c], S[6 * r + c][l]);
+      v[r][l] = fmaf(a[r], b[i], v[r][l]);
+    }
+    e[l] = fmaf(b[i], b[i], e[l]);
+  }
+  for (int r = 0; r < 6; ++r) {
+    for (int c = r; c < 6; ++c) {
+      float t = 0.0f;
+      for (int l = 0; l < 16; ++l) t += S[6 * r + c][l];
+      AtA[6 * r + c] = AtA[6 * c + r] = t;
+    }
+    float t = 0.0f;
+    for (int l = 0; l < 16; ++l) t += v[r][l];
+    Atb[r] = t;
+  }
+  if (err) {
+    float t = 0.0f;
+    for (int l = 0; l < 16; ++l) t += e[l];
+    *err = t;
+  }
+}
+static void solve_spd_f32_experiment(const float* AtA, const float* Atb, float damp, int n, float* x) {
+  float a[8][9];
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) a[i][j] = AtA[n * i + j] + ((i == j) ? damp : 0.0f);
+    a[i][n] = Atb[i];
+  }
+  for (int c = 0; c < n; ++c) {   /* partial pivoting, as LAPACK's LU */
+    int p = c;
+    for (int r = c + 1; r < n; ++r) if (fabsf(a[r][c]) > fabsf(a[p][c])) p = r;
+    if (p != c) for (int j = 0; j <= n; ++j) { float t = a[c][j]; a[c][j] = a[p][j]; a[p][j] = t; }
+    const float inv = 1.0f / a[c][c];
+    for (int j = c; j <= n; ++j) a[c][j] *= inv;
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const float f = a[r][c];
+      for (int j = c; j <= n; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int i = 0; i < n; ++i) x[i] = a[i][n];
 }
 
 /* A^T A, A^T b and b.b accumulated in double from float32 products, rounded once. */
 static void normal_eq_f64(const float* A, const float* b, const uint8_t* keep, int64_t n,
                           float* AtA, float* Atb, float* err) {
+  if (neq_f32_mode()) { normal_eq_f32_experiment(A, b, keep, n, AtA, Atb, err); return; }
   double S[36] = {0}, v[6] = {0}, e = 0;
   for (int64_t i = 0; i < n; ++i) {
     if (keep && !keep[i]) continue;
