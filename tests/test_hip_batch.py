@@ -333,6 +333,21 @@ def test_two_ranks_sharing_one_gpu_rehearsal():
     assert one["n_gpus"] == 1 and one["config"]["sequences_per_gpu"] == 4
     assert two["config"]["poses_sha"] == one["config"]["poses_sha"]          # gathered poses: identical bits
     assert two["config"]["map_surfels_all"] == one["config"]["map_surfels_all"]
+    # what every rank reports about itself: its sequences, its own clock, the fingerprint of its poses
+    pr = two["ranks"]["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and [r["sequences"] for r in pr] == [[0, 1], [2, 3]]
+    assert pr[0]["poses_sha"] != pr[1]["poses_sha"] and all(r["elapsed_s"] > 0 for r in pr)
+    assert two["ranks"]["elapsed_s_min"] <= two["ranks"]["elapsed_s_mean"] <= two["ranks"]["elapsed_s_max"]
+    assert abs(two["ranks"]["elapsed_s_max"] * 1e3 / two["steps"] - two["ms_per_step"]) < 0.5 * two["ms_per_step"]
+    assert two["scaling"] == "strong" and one["ranks"]["per_rank"][0]["sequences"] == [0, 1, 2, 3]
+    # weak scaling: --batch is per GPU (2 x 2 sequences = the same 4 sequences, the same result)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--weak"] +
+                       [("2" if a == "4" and common[i - 1] == "--batch" else a) for i, a in enumerate(common)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    weak = json.loads(r.stdout.strip().splitlines()[-1])
+    assert weak["scaling"] == "weak" and weak["config"]["sequences_total"] == 4
+    assert weak["config"]["poses_sha"] == one["config"]["poses_sha"]
 
 
 def test_pointfusion_1296x968_vs_oracle(gs):
