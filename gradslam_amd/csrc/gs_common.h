@@ -17,6 +17,19 @@
 
 // sequences per launch of the batched (multi-sequence) kernels; larger batches run in chunks of this size
 constexpr int GS_MAX_BATCH = 8;
+// Zero-fill riding along with another launch (extra blocks of 256 threads): `n` regions of `bytes` bytes each
+// (16-byte aligned, a multiple of 16).  Used by the one-call step: the frame-map launch also clears the grid scratch
+// of the localisation that follows, which then needs no clearing blocks of its own.
+struct GsClearJob {
+  int n;
+  size_t bytes;
+  char* ptr[GS_MAX_BATCH];
+};
+constexpr int GS_CLEAR_ITEMS = 8;  // 16-byte stores per thread of a clearing block (32 KB per block)
+// gs_frame_maps_batch_f32 + the clear job in the same launch (library-internal)
+int gs_frame_maps_batch_clear(const float* depth, int64_t depth_stride_seq, int64_t depth_stride_frame, const float* K16,
+                              int n_frames, int frames_per_K, int H, int W, float two_sigma_sq, float* vertex,
+                              float* normal, float* alpha, const GsClearJob* job, void* stream);
 
 // ---------------------------------------------------------------- error plumbing -------
 void gs_set_error(const char* fmt, ...);

@@ -201,11 +201,26 @@ __global__ void __launch_bounds__(256) gs_frame_maps_kernel(
     uint8_t* __restrict__ valid) {
   frame_maps_body(depth, K16, H, W, two_sigma_sq, vertex, normal, alpha, valid);
 }
-// blockIdx.z = frame of a contiguous (n_frames, H, W) stack
+// blockIdx.z = frame of a contiguous (n_frames, H, W) stack; slices z >= n_frames (if any) zero-fill the regions of
+// `job` (independent bytes: they ride along instead of costing a launch of their own)
 __global__ void __launch_bounds__(256) gs_frame_maps_batch_kernel(
     const float* __restrict__ depth, int64_t stride_seq, int64_t stride_frame, const float* __restrict__ K16,
     int frames_per_K, int H, int W, float two_sigma_sq, float* __restrict__ vertex, float* __restrict__ normal,
-    float* __restrict__ alpha) {
+    float* __restrict__ alpha, const int n_frames, const GsClearJob job) {
+  if ((int)blockIdx.z >= n_frames) {
+    const size_t blk = ((size_t)(blockIdx.z - n_frames) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const size_t n16 = job.bytes / 16, per = (n16 + 256 * GS_CLEAR_ITEMS - 1) / (256 * GS_CLEAR_ITEMS);
+    const size_t r = blk / per;
+    if (r >= (size_t)job.n) return;
+    float4* dst = reinterpret_cast<float4*>(job.ptr[r]);
+    const size_t base = (blk % per) * 256 * GS_CLEAR_ITEMS + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < GS_CLEAR_ITEMS; ++u) {
+      const size_t i = base + (size_t)u * 256;
+      if (i < n16) dst[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    return;
+  }
   const size_t f = blockIdx.z, P = (size_t)H * W;
   const size_t b = f / frames_per_K, l = f % frames_per_K;
   frame_maps_body(depth + b * stride_seq + l * stride_frame, K16 + 16 * b, H, W, two_sigma_sq, vertex + 3 * f * P,
@@ -226,20 +241,38 @@ extern "C" int gs_frame_maps_f32(const float* depth, const float* K16, int H, in
   return GS_OK;
 }
 
-extern "C" int gs_frame_maps_batch_f32(const float* depth, int64_t depth_stride_seq, int64_t depth_stride_frame,
-                                       const float* K16, int n_frames, int frames_per_K, int H, int W,
-                                       float two_sigma_sq, float* vertex, float* normal, float* alpha, void* stream) {
+int gs_frame_maps_batch_clear(const float* depth, int64_t depth_stride_seq, int64_t depth_stride_frame, const float* K16,
+                              int n_frames, int frames_per_K, int H, int W, float two_sigma_sq, float* vertex,
+                              float* normal, float* alpha, const GsClearJob* job, void* stream) {
   GS_REQUIRE(depth && K16 && vertex, "depth, K16 and vertex must not be NULL");
   GS_REQUIRE(H >= 2 && W >= 2, "image must be at least 2x2");
   GS_REQUIRE(n_frames > 0 && n_frames <= 65535 && frames_per_K > 0 && n_frames % frames_per_K == 0, "bad frame count");
   GS_REQUIRE(depth_stride_frame >= (int64_t)H * W && depth_stride_seq >= 0, "bad depth strides");
   dim3 grid((unsigned)gs_ceil_div(W, FM_TW), (unsigned)gs_ceil_div(H, FM_TH), (unsigned)n_frames);
+  GsClearJob none;
+  none.n = 0; none.bytes = 0;
+  if (job && job->n > 0 && job->bytes > 0) {
+    GS_REQUIRE(job->n <= GS_MAX_BATCH && job->bytes % 16 == 0, "bad clear job");
+    const int64_t per = gs_ceil_div((int64_t)(job->bytes / 16), 256 * GS_CLEAR_ITEMS);
+    const int64_t slices = gs_ceil_div(per * job->n, (int64_t)grid.x * grid.y);
+    GS_REQUIRE(n_frames + slices <= 65535, "clear job too large for the launch");
+    grid.z += (unsigned)slices;
+  } else {
+    job = &none;
+  }
   const double bytes = (double)n_frames * H * W * (4.0 + 12.0 + (normal ? 12 : 0) + (alpha ? 4 : 0));
   GsProf prof(GS_PROF_FRAME, bytes, gs_stream(stream));
   hipLaunchKernelGGL(gs_frame_maps_batch_kernel, grid, dim3(256), 0, gs_stream(stream), depth, depth_stride_seq,
-                     depth_stride_frame, K16, frames_per_K, H, W, two_sigma_sq, vertex, normal, alpha);
+                     depth_stride_frame, K16, frames_per_K, H, W, two_sigma_sq, vertex, normal, alpha, n_frames, *job);
   GS_LAUNCH_CHECK();
   return GS_OK;
+}
+
+extern "C" int gs_frame_maps_batch_f32(const float* depth, int64_t depth_stride_seq, int64_t depth_stride_frame,
+                                       const float* K16, int n_frames, int frames_per_K, int H, int W,
+                                       float two_sigma_sq, float* vertex, float* normal, float* alpha, void* stream) {
+  return gs_frame_maps_batch_clear(depth, depth_stride_seq, depth_stride_frame, K16, n_frames, frames_per_K, H, W,
+                                   two_sigma_sq, vertex, normal, alpha, nullptr, stream);
 }
 
 // local -> global: R v + t re-masked (rgbdimages.py:700-708), R n (rgbdimages.py:760-762)

@@ -348,7 +348,7 @@ extern "C" int gs_fuse_append_backward_f32(const float* points, const float* nor
 //   U2 per surfel: project, similarity test, per-pixel atomicMin of the (1/ccount, ray) key; pix_of = -1
 //   U3 per surfel: atomicMin of the surfel index among the rows that attain their pixel's key
 //   U4 per pixel : winner -> pix_of[winner] = pixel (+ "any match" flag); count of new pixels per tile
-//   U5 per surfel: confidence-weighted merge (parity mode rewrites every row)
+//   U5 per surfel: confidence-weighted merge (parity mode rewrites every row)       } one launch
 //   U6 per pixel : ordered append of the new pixels; every block derives its output offset from the tile
 //                  counts itself (no separate scan launch); block 0 also writes the new surfel count
 struct MuSeq {
@@ -468,9 +468,9 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_winner_count_kernel(const M
   if (threadIdx.x == 0) q.tile_counts[blk] = total;
 }
 
-__global__ void __launch_bounds__(256) gs_mu_merge_kernel(const MuBatch mb) {
-  const MuSeq& q = mb.s[blockIdx.x % mb.B];
-  const int64_t n = (int64_t)(blockIdx.x / mb.B) * 256 + threadIdx.x;
+GS_DEV void mu_merge_body(const MuBatch& mb, const unsigned bid) {
+  const MuSeq& q = mb.s[bid % mb.B];
+  const int64_t n = (int64_t)(bid / mb.B) * 256 + threadIdx.x;
   if (n >= gs_count(q.n_map)) return;
   // :659 -- the reference skips the whole merge only when the correspondence table of the WHOLE batch is empty
   // (pc2im_bnhw.shape[0] != 0 is a batch-level test): a sequence without matches is still renormalised when
@@ -482,10 +482,10 @@ __global__ void __launch_bounds__(256) gs_mu_merge_kernel(const MuBatch mb) {
 }
 
 // ordered append without a scan launch: block b adds up the counts of the tiles before it (fixed order)
-__global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_append_kernel(const MuBatch mb) {
+GS_DEV void mu_append_body(const MuBatch& mb, const unsigned bid) {
   __shared__ int smem[GS_CP_BLOCK / GS_WAVE + 1];
-  const MuSeq& q = mb.s[blockIdx.x % mb.B];
-  const unsigned blk = blockIdx.x / mb.B;
+  const MuSeq& q = mb.s[bid % mb.B];
+  const unsigned blk = bid / mb.B;
   int before = 0, all = 0;
   for (int64_t t = threadIdx.x; t < mb.ntiles; t += GS_CP_BLOCK) {
     const int v = q.tile_counts[t];
@@ -530,6 +530,15 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_append_kernel(const MuBatch
     const int64_t pos = (int64_t)tile_prefix + r;
     if (n_map + pos < q.capacity) emit(tile_base + loc_s[r], pos);
   }
+}
+
+// U5 + U6 in ONE launch: the merge touches rows [0, n_map), the append rows [n_map, ...) and neither reads what the
+// other writes (both read the frame, best_pix / pix_of and the tile counts of the winner pass).  The append blocks
+// (few, latency-bound: 23 us alone) come first and run under the merge blocks' streaming.
+static_assert(GS_CP_BLOCK == 256, "merge and append blocks share a launch");
+__global__ void __launch_bounds__(256) gs_mu_merge_append_kernel(const MuBatch mb, const unsigned nb_append) {
+  if (blockIdx.x < nb_append) mu_append_body(mb, blockIdx.x);
+  else mu_merge_body(mb, blockIdx.x - nb_append);
 }
 
 extern "C" int64_t gs_update_map_scratch_bytes(int64_t n_map_bound, int H, int W) {
@@ -587,9 +596,9 @@ static int update_chunk(const gs_update_seq* seqs, int B, int H, int W, float di
     GsProf prof(GS_PROF_FUSE, bytes_fuse / 3.0, st, 1);
     hipLaunchKernelGGL(gs_mu_winner_count_kernel, dim3(uB * (unsigned)mb.ntiles), dim3(GS_CP_BLOCK), 0, st, mb);
   } else {
-    GsProf prof(GS_PROF_FUSE, bytes_fuse * (2.0 / 3.0), st, n_max > 0 ? 2 : 1);
-    if (n_max > 0) hipLaunchKernelGGL(gs_mu_merge_kernel, dim3(nb), dim3(256), 0, st, mb);
-    hipLaunchKernelGGL(gs_mu_append_kernel, dim3(uB * (unsigned)mb.ntiles), dim3(GS_CP_BLOCK), 0, st, mb);
+    GsProf prof(GS_PROF_FUSE, bytes_fuse * (2.0 / 3.0), st, 1);
+    const unsigned nb_append = uB * (unsigned)mb.ntiles;
+    hipLaunchKernelGGL(gs_mu_merge_append_kernel, dim3(nb_append + (n_max > 0 ? nb : 0u)), dim3(256), 0, st, mb, nb_append);
   }
   GS_LAUNCH_CHECK();
   return GS_OK;

@@ -23,6 +23,7 @@
 
 #include "gs_icp_math.h"
 #include "gs_knn.h"
+#include "gs_knn_bbox.h"
 
 constexpr int GS_ICP_MAX_ITERS = 1024;  // rows of the per-iteration trace kept in the scratch
 struct GsIcpState {
@@ -99,6 +100,7 @@ constexpr int FS_BQ = 4;                 // queries per pass of the block-wide b
 constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 96 queries per block, their rows are built by the first two waves
 constexpr int FS_RPG = (FS_QPB / 4) * LIN_NV <= FS_BLOCK ? 4 : 8;  // rows per group in the block reduction
 constexpr int FS_RG = FS_QPB / FS_RPG;                            // row groups
+constexpr int FS_FAR_MIN_RING = 2;   // queries served by a cube of at least this radius get a candidate list (gs_knn.h)
 constexpr int FS_HG = 16;  // lanes per query of the shell search for queries the 2x2x2 stage leaves open
 static_assert(FS_QPB <= 2 * GS_WAVE && FS_QPB % FS_RPG == 0 && FS_RG * LIN_NV <= FS_BLOCK, "block shape");
 
@@ -140,6 +142,14 @@ struct IcpHalfSeq {
   int64_t* out_idx;
   int32_t* tape_idx;
   float* tape_sys;
+  // candidate lists of far queries (gs_knn.h; NULL: none kept): far_cq[s] = (position the list of source point s was
+  // built at, exactness radius), far_c[GS_FAR_SLOTS * s ..] = its slots of `sorted`, written by gs_icp_far_build_kernel
+  // after the first search of a solve.  "s has a list" travels in the sign bit of d2prev[s], which every search loads
+  // anyway (and which the first search of a solve rewrites: nothing of an earlier frame is ever read).
+  float4* far_cq;
+  uint32_t* far_c;
+  int* far_idx;   // source points the first search of the solve found far from every target, far_n[0] of them
+  int* far_n;
 };
 
 // index pairs (into [a0..a5, res]) of the 28 accumulated products: 21 upper-triangular a_i a_k, 6 a_i res, res res
@@ -155,7 +165,7 @@ GS_DEV int fs_pb(int i) { return i < 21 ? (int)((FS_PB_BITS >> (3 * i)) & 7ull) 
 // so the normal equations do not depend on G, on the number of blocks or on which block works on which unit: a
 // block owns the contiguous units [lb * upb, (lb + 1) * upb) and walks them NU at a time (grids smaller than the
 // unit count are how a GPU shared by 8 sequences keeps every block resident and pays the prologue once per block).
-template <bool FULL, int G>
+template <bool FULL, int G, bool FAR>
 GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const float dist_thresh, const gs_icp_params& prm,
                           const int it, const int rows_in_reduced, const unsigned lb, const int upb,
                           unsigned long long* __restrict__ tl_arg = nullptr) {
@@ -187,9 +197,15 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
   __shared__ float qs[NQ][3];
   __shared__ float qa_s[NQ][8];   // a0..a5, residual of every query of the block (zero when filtered out)
   __shared__ double sub_s[NU][FS_RG][LIN_NV];
-  __shared__ int unres_q[NQ], hard_q[NQ];
+  __shared__ int unres_q[NQ], hard_q[NQ];   // (hard_q: bit 31 = the query has a candidate list)
   __shared__ int unres_n, hard_n;
   __shared__ unsigned long long red[FS_BLOCK / GS_WAVE];
+  __shared__ uint8_t far_s[NQ];   // the query's candidate list proved this search (it keeps its flag)
+  float4* __restrict__ far_cq = q.far_cq;
+  uint32_t* __restrict__ far_c = q.far_c;
+  // (FAR is a template parameter: the kernels sit at their register limit, and the code of the lists costs the
+  // variant without them 0.5 us per launch when it is merely present)
+  const bool far_on = FAR && far_cq != nullptr && d2prev != nullptr;
 
   const int64_t n_src = gs_count(n_src_c), n_tgt = gs_count(q.n_tgt);
   const int nunits = (int)((n_src + FS_QPB - 1) / FS_QPB);
@@ -270,8 +286,11 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
         if (FULL) { src_out[3 * s] = p0; src_out[3 * s + 1] = p0; src_out[3 * s + 2] = p0; }
         qs[slot][0] = p0; qs[slot][1] = p0; qs[slot][2] = p0;
         keys_s[slot] = ~0ull;
+        if (FAR) far_s[slot] = 0;
       }
     } else if (live) {
+      const bool has_far = far_on && bounded && (__float_as_uint(dprev) >> 31) != 0u;
+      if (far_on) dprev = __builtin_fabsf(dprev);
       const float* T = FULL ? sm.T_step : sm.Tr;
       float qx, qy, qz;
       gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
@@ -296,7 +315,8 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
         }
         qs[slot][0] = qx; qs[slot][1] = qy; qs[slot][2] = qz;
         keys_s[slot] = key;
-        if (!done) hard_q[atomicAdd(&hard_n, 1)] = slot;
+        if (FAR) far_s[slot] = 0;
+        if (!done) hard_q[atomicAdd(&hard_n, 1)] = slot | (has_far ? (int)0x80000000 : 0);
       }
     }
     __syncthreads();
@@ -304,15 +324,30 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
     // by groups of FS_HG lanes, so that they do not hold up the waves of the common case
     const int nh = hard_n;  // block-uniform
     for (int i = threadIdx.x / FS_HG; i < nh; i += FS_BLOCK / FS_HG) {
-      const int hs = hard_q[i];
-      bool done;
-      int win;
-      const unsigned long long key = grid_search_rings<FS_HG>(g, cell_start, sorted, qs[hs][0], qs[hs][1], qs[hs][2],
-                                                              threadIdx.x & (FS_HG - 1), keys_s[hs], &done, &win,
-                                                              FS_HARD_RINGS);
-      if (win >= 0) bslot_s[hs] = win;  // a candidate of the cubes beat the 2x2x2 stage
-      if ((threadIdx.x & (FS_HG - 1)) == 0) {
+      const int e = hard_q[i], hs = e & 0x7fffffff, l16 = threadIdx.x & (FS_HG - 1);
+      const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
+      const int64_t sq = (int64_t)u0 * FS_QPB + hs;   // the query's source point
+      bool done = false, listed = false;
+      int win = -1;
+      unsigned long long key = keys_s[hs];
+      if (FAR && e < 0) {   // (only with far_on) the list of an earlier search of this solve: exact while the query stays close
+        const float4 c0R = far_cq[sq];
+        const unsigned long long kl = far_list_search<FS_HG>(c0R, far_c + GS_FAR_SLOTS * sq, sorted, hx, hy, hz, l16, &done, &win);
+        if (done) { key = kl; listed = true; }
+        else win = -1;
+      }
+      if (!done) {
+        int kdone;
+        key = grid_search_rings<FS_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, &kdone);
+        // first search of a solve: queries that needed a cube of radius >= FS_FAR_MIN_RING (or the brute-force pass) are
+        // handed to gs_icp_far_build_kernel, which gives them candidate lists before the next launch
+        if (FULL && it == 0 && far_on && l16 == 0 && (!done || kdone >= FS_FAR_MIN_RING))
+          q.far_idx[atomicAdd(q.far_n, 1)] = (int)sq;
+      }
+      if (win >= 0) bslot_s[hs] = win;  // a candidate of the list / the cubes beat the 2x2x2 stage
+      if (l16 == 0) {
         keys_s[hs] = key;
+        if (FAR && listed) far_s[hs] = 1;
         if (!done) unres_q[atomicAdd(&unres_n, 1)] = hs;
       }
     }
@@ -341,7 +376,12 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
         if (tape_idx) tape_idx[s] = -1;
       } else if (live) {
         const unsigned long long bb = keys_s[slot];
-        if (d2prev) d2prev[s] = __uint_as_float((uint32_t)(bb >> 32));  // NaN bits when nothing was found
+        // NaN bits when nothing was found; with candidate lists the sign bit says "source point s has one"
+        if (d2prev) {
+          uint32_t db = (uint32_t)(bb >> 32);
+          if (far_on) db = (db & 0x7fffffffu) | (far_s[slot] ? 0x80000000u : 0u);
+          d2prev[s] = __uint_as_float(db);
+        }
         int64_t j = (int64_t)(bb & 0xffffffffull);
         if (j >= n_tgt) j = 0;  // only when every distance was NaN
         const float d2 = __uint_as_float((uint32_t)(bb >> 32));
@@ -417,7 +457,7 @@ struct IcpHalfBatch {
   unsigned long long* timeline;  // debugging aid (GRADSLAM_HIP_ICP_TIMELINE): per block [start, end, hw id, xcc id]
   IcpHalfSeq s[GS_MAX_BATCH];
 };
-template <bool FULL, int G>
+template <bool FULL, int G, bool FAR>
 __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_batch_kernel(const IcpHalfBatch hb, GsCount n_src_c,
                                                                         float dist_thresh, gs_icp_params prm, int it,
                                                                         int rows_in_reduced) {
@@ -427,7 +467,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_batch_kernel(const Ic
   unsigned long long t0 = 0;
   if (hb.timeline && threadIdx.x == 0) t0 = wall_clock64();
 #endif
-  icp_half_body<FULL, G>(hb.s[blockIdx.x % B], n_src_c, dist_thresh, prm, it, rows_in_reduced,
+  icp_half_body<FULL, G, FAR>(hb.s[blockIdx.x % B], n_src_c, dist_thresh, prm, it, rows_in_reduced,
                          gs_xcd_block(blk, nblk, X), hb.upb, hb.timeline ? hb.timeline + 72 * (size_t)blockIdx.x : nullptr);
 #ifdef GS_ICP_TIMELINE
   if (hb.timeline && threadIdx.x == 0) {
@@ -495,15 +535,14 @@ static void icp_half_launch(const IcpHalfPlan& pl, IcpHalfBatch& hb, GsCount n_s
     }
   }
   const dim3 grid((unsigned)(hb.B * pl.nb)), block(FS_BLOCK);
-  if (pl.G == 8)
-    hipLaunchKernelGGL((gs_icp_half_batch_kernel<FULL, 8>), grid, block, 0, st, hb, n_src_c, prm->dist_thresh, *prm, it,
-                       rows_in_reduced);
-  else if (pl.G == 4)
-    hipLaunchKernelGGL((gs_icp_half_batch_kernel<FULL, 4>), grid, block, 0, st, hb, n_src_c, prm->dist_thresh, *prm, it,
-                       rows_in_reduced);
-  else
-    hipLaunchKernelGGL((gs_icp_half_batch_kernel<FULL, 2>), grid, block, 0, st, hb, n_src_c, prm->dist_thresh, *prm, it,
-                       rows_in_reduced);
+  const bool far = hb.s[0].far_cq != nullptr;   // candidate lists of far queries: the same for all sequences of a batch
+#define GS_HALF_LAUNCH(G_, FAR_)                                                                                        \
+  hipLaunchKernelGGL((gs_icp_half_batch_kernel<FULL, G_, FAR_>), grid, block, 0, st, hb, n_src_c, prm->dist_thresh, *prm, \
+                     it, rows_in_reduced)
+  if (pl.G == 8) { if (far) GS_HALF_LAUNCH(8, true); else GS_HALF_LAUNCH(8, false); }
+  else if (pl.G == 4) { if (far) GS_HALF_LAUNCH(4, true); else GS_HALF_LAUNCH(4, false); }
+  else { if (far) GS_HALF_LAUNCH(2, true); else GS_HALF_LAUNCH(2, false); }
+#undef GS_HALF_LAUNCH
   if (hb.timeline) {  // debugging aid: synchronous dump of this launch's block records
     std::unique_ptr<unsigned long long[]> h(new unsigned long long[tl_n]);
     if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.get(), tl_buf, 8 * tl_n, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -892,6 +931,7 @@ struct LocSeq {
   float* out_pose16;
   char* clear_ptr;       // grid scratch bytes that must be zero before the build
   int64_t* n_valid;      // number of lattice slots with depth (profiling / roofline accounting)
+  int* far_n;            // counter of the far-query list of the solve (NULL: no candidate lists), zeroed here
 };
 struct LocBatch {
   int B, W, ds, Wl;
@@ -905,9 +945,9 @@ struct LocBatch {
 constexpr int LP_CLEAR_ITEMS = 8;  // 16-byte stores per thread of a clearing block (32 KB per block)
 
 // lattice source (gs_lattice_source_kernel) + solver state (gs_icp_init_kernel) + zeroing of the grid scratch
-__global__ void __launch_bounds__(256) gs_loc_prep_kernel(const LocBatch lb, unsigned nb_lat) {
-  const LocSeq& q = lb.s[blockIdx.x % lb.B];
-  const unsigned blk = blockIdx.x / lb.B;
+GS_DEV void loc_prep_block(const LocBatch& lb, const unsigned bid, const unsigned nb_lat) {
+  const LocSeq& q = lb.s[bid % lb.B];
+  const unsigned blk = bid / lb.B;
   if (blk < nb_lat) {
     const int64_t e = (int64_t)blk * 256 + threadIdx.x;
     int valid = 0;
@@ -937,6 +977,7 @@ __global__ void __launch_bounds__(256) gs_loc_prep_kernel(const LocBatch lb, uns
       sm.pad[0] = sm.pad[1] = 0.0f;
       q.state->s[0] = sm;
       q.state->s[1] = sm;
+      if (q.far_n) *q.far_n = 0;
       if (lb.numiters == 0) icp_write_result(sm, q.pose16, q.out_pose16);
     }
     return;
@@ -949,6 +990,19 @@ __global__ void __launch_bounds__(256) gs_loc_prep_kernel(const LocBatch lb, uns
     const size_t i = base + (size_t)u * 256;
     if (i < n16) dst[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
+}
+__global__ void __launch_bounds__(256) gs_loc_prep_kernel(const LocBatch lb, unsigned nb_lat) {
+  loc_prep_block(lb, blockIdx.x, nb_lat);
+}
+// The one-call step clears the grid scratch in its frame-map launch (gs_frame_maps_batch_clear): the lattice blocks
+// then have nothing to wait for and share a launch with the first pass of the grid build (projection of the map under
+// the previous pose + bounding box + target list), which does not read what they write.
+static_assert(GB_BLOCK == 256, "lattice and bbox blocks share a launch");
+__global__ void __launch_bounds__(256) gs_loc_prep_bbox_kernel(const LocBatch lb, const GsGridBatch gb, const unsigned nb_lat,
+                                                               const float u_hi, const float v_hi) {
+  const unsigned n_prep = (unsigned)lb.B * nb_lat;
+  if (blockIdx.x < n_prep) loc_prep_block(lb, blockIdx.x, nb_lat);
+  else gridb_bbox_block(gb, blockIdx.x - n_prep, u_hi, v_hi);
 }
 
 struct IcpRowsBatch {
@@ -1014,11 +1068,115 @@ static ItMem it_carve(void* base, int Hl, int Wl) {
   return m;
 }
 
+// candidate lists of far queries (gs_knn.h), behind the tile engine's part of a sequence's scratch
+struct FarMem {
+  uint32_t* c;    // [n_lat][GS_FAR_SLOTS] slots of `sorted`
+  float4* cq;     // [n_lat] (position the list was built at, exactness radius)
+  int* idx;       // [n_lat] source points handed to the list builder by the first search of the solve
+  int* n;         // [1] how many
+};
+static size_t far_mem_bytes(int64_t n_lat) {
+  return gs_align(4 * GS_FAR_SLOTS * (size_t)n_lat) + gs_align(16 * (size_t)n_lat) + gs_align(4 * (size_t)n_lat) + 256;
+}
+static FarMem far_carve(void* base, int64_t n_lat) {
+  char* p = reinterpret_cast<char*>(base);
+  FarMem m;
+  m.c = reinterpret_cast<uint32_t*>(p); p += gs_align(4 * GS_FAR_SLOTS * (size_t)n_lat);
+  m.cq = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)n_lat);
+  m.idx = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)n_lat);
+  m.n = reinterpret_cast<int*>(p);
+  return m;
+}
+
+// Lists for the source points the first search of a solve found far from every target (IcpHalfSeq::far_idx): one launch
+// between the first and the second half-iteration.  A group of FS_HG lanes per point runs the cube search again from
+// the point's position (the transformed cloud of iteration 0) and collects everything within R of it; points the cubes
+// do not reach are finished by the block (brute-force pass + collecting pass, FS_BQ points at a time).  The flag in the
+// sign bit of d2prev[s] tells the following searches that s has a list.
+struct FarBuildSeq {
+  const float* src;         // transformed cloud of iteration 0
+  const GsGrid* gp;
+  const int* cell_start;
+  const float4* sorted;
+  float* d2prev;
+  FarMem m;
+};
+struct FarBuildBatch {
+  int B;
+  FarBuildSeq s[GS_MAX_BATCH];
+};
+constexpr int64_t FAR_MIN_LATTICE = 40000;   // source lattices from this size on keep candidate lists by default
+constexpr int FAR_BLOCK = 256;
+constexpr int FAR_BLOCKS_PER_SEQ = 32;
+__global__ void __launch_bounds__(FAR_BLOCK) gs_icp_far_build_kernel(const FarBuildBatch fb) {
+  const FarBuildSeq& q = fb.s[blockIdx.x % fb.B];
+  const int blk = (int)(blockIdx.x / fb.B);
+  const int n = *q.m.n;
+  if (blk >= n) return;   // (entry i is served by block i % FAR_BLOCKS_PER_SEQ)
+  constexpr int NG = FAR_BLOCK / FS_HG;
+  __shared__ float qs[NG][3];
+  __shared__ unsigned long long keys_s[NG];
+  __shared__ int bslot_s[NG];
+  __shared__ uint8_t flag_s[NG];
+  __shared__ int unres_q[NG], sq_s[NG];
+  __shared__ int unres_n;
+  __shared__ uint32_t stage_s[NG][GS_FAR_SLOTS + 4];
+  const GsGrid g = *q.gp;
+  const int grp = threadIdx.x / FS_HG, l16 = threadIdx.x & (FS_HG - 1);
+  // entries of this block: blk, blk + NBLK, ...; NG of them per round
+  for (int base = blk; base < n; base += FAR_BLOCKS_PER_SEQ * NG) {   // block-uniform
+    if (threadIdx.x == 0) unres_n = 0;
+    __syncthreads();
+    const int e = base + grp * FAR_BLOCKS_PER_SEQ;
+    int sq = -1;
+    if (e < n) {
+      sq = q.m.idx[e];
+      const float hx = q.src[3 * (int64_t)sq], hy = q.src[3 * (int64_t)sq + 1], hz = q.src[3 * (int64_t)sq + 2];
+      bool done;
+      int win, kdone;
+      const unsigned long long key = grid_search_rings<FS_HG>(g, q.cell_start, q.sorted, hx, hy, hz, l16, ~0ull, &done, &win,
+                                                              FS_HARD_RINGS, &kdone);
+      if (done) {
+        const float R = far_emit_cube<FS_HG>(g, q.cell_start, q.sorted, hx, hy, hz, l16,
+                                             sqrtf(__uint_as_float((uint32_t)(key >> 32))), kdone, stage_s[grp],
+                                             reinterpret_cast<int*>(&stage_s[grp][GS_FAR_SLOTS]));
+        q.m.c[GS_FAR_SLOTS * (int64_t)sq + l16] = stage_s[grp][l16];
+        if (l16 == 0) {
+          q.m.cq[sq] = make_float4(hx, hy, hz, R);
+          if (R > 0.0f) q.d2prev[sq] = __uint_as_float(__float_as_uint(q.d2prev[sq]) | 0x80000000u);
+        }
+      } else if (l16 == 0) {
+        qs[grp][0] = hx; qs[grp][1] = hy; qs[grp][2] = hz;
+        sq_s[grp] = sq;
+        unres_q[atomicAdd(&unres_n, 1)] = grp;
+      }
+    }
+    __syncthreads();
+    const int nun = unres_n;   // block-uniform
+    for (int u = 0; u < nun; u += FS_BQ) {
+      const int nq = nun - u < FS_BQ ? nun - u : FS_BQ;
+      if (threadIdx.x < nq) keys_s[unres_q[u + threadIdx.x]] = ~0ull;
+      __syncthreads();
+      block_brute_min_sorted_multi<FAR_BLOCK, FS_BQ>(qs, unres_q + u, nq, q.sorted, q.cell_start[g.ncell], keys_s, bslot_s);
+      block_brute_collect_multi<FAR_BLOCK, FS_BQ>(qs, unres_q + u, nq, q.sorted, q.cell_start[g.ncell], keys_s,
+                                                  GS_FAR_RADD * g.c, sq_s, q.m.cq, q.m.c, flag_s);
+      __syncthreads();
+      if (threadIdx.x < nq) {
+        const int gq = unres_q[u + threadIdx.x];
+        const int s2 = sq_s[gq];
+        if (flag_s[gq]) q.d2prev[s2] = __uint_as_float(__float_as_uint(q.d2prev[s2]) | 0x80000000u);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int64_t gs_localize_scratch_bytes(int H, int W, int ds, int64_t n_map_bound) {
   if (H < 1 || W < 1 || ds < 1) return 0;
   const int64_t n_lat = loc_lattice(H, W, ds);
   return (int64_t)(gs_align(12 * (size_t)n_lat) + gs_align(4 * (size_t)(n_map_bound > 0 ? n_map_bound : 1)) + 256) +
-         gs_icp_scratch_bytes(n_lat, n_map_bound) + (int64_t)it_mem_bytes((H + ds - 1) / ds, (W + ds - 1) / ds);
+         gs_icp_scratch_bytes(n_lat, n_map_bound) + (int64_t)it_mem_bytes((H + ds - 1) / ds, (W + ds - 1) / ds) +
+         (int64_t)far_mem_bytes(n_lat);
 }
 
 static GsCount n_src_rows(int nrows) { return GsCount{(int64_t)nrows * FS_QPB, nullptr}; }  // a count that yields nrows rows
@@ -1242,8 +1400,32 @@ static int localize_tiles(const gs_localize_seq* seqs, int B, int Hl, int Wl, co
   return GS_OK;
 }
 
+// scratch of one sequence: lattice | pix | n_valid | ICP scratch (which holds the grid)
+struct LocCarve {
+  float* lattice;
+  int32_t* pix;
+  int64_t* n_valid;
+  IcpScratch sc;
+  GridMem gm;
+};
+static LocCarve loc_carve(const gs_localize_seq& q, int64_t n_lat) {
+  LocCarve c;
+  char* p = reinterpret_cast<char*>(q.scratch);
+  c.lattice = reinterpret_cast<float*>(p); p += gs_align(12 * (size_t)n_lat);
+  // the layout follows the map's CAPACITY (what the scratch was sized for), not the count bound of this frame: every
+  // pointer below then stays the same from frame to frame (the half-iteration launches are replayed as a graph)
+  const int64_t rows = loc_rows(q.map);
+  c.pix = reinterpret_cast<int32_t*>(p); p += gs_align(4 * (size_t)rows);
+  c.n_valid = reinterpret_cast<int64_t*>(p); p += 256;
+  c.sc = icp_carve(p, n_lat);
+  c.gm = grid_carve(c.sc.grid, n_lat, rows);
+  return c;
+}
+
+// grid_cleared: the caller has zeroed the first gs_knn_grid_clear_bytes() bytes of every sequence's grid scratch
+// (loc_carve().gm.g) on the stream already
 static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int ds, const gs_icp_params* prm,
-                          hipStream_t st) {
+                          hipStream_t st, bool grid_cleared) {
   const int64_t n_lat = loc_lattice(H, W, ds);
   const int Wl = (W + ds - 1) / ds;
   LocBatch lb;
@@ -1257,17 +1439,14 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   gb.cells_cap = gs_knn_grid_cells_cap(n_lat);
   for (int b = 0; b < B; ++b) {
     const gs_localize_seq& q = seqs[b];
-    char* p = reinterpret_cast<char*>(q.scratch);
-    float* lattice = reinterpret_cast<float*>(p); p += gs_align(12 * (size_t)n_lat);
-    // the layout follows the map's CAPACITY (what the scratch was sized for), not the count bound of this frame: every
-    // pointer below then stays the same from frame to frame (the half-iteration launches are replayed as a graph)
-    const int64_t rows = loc_rows(q.map);
-    int32_t* pix = reinterpret_cast<int32_t*>(p); p += gs_align(4 * (size_t)rows);
-    int64_t* n_valid = reinterpret_cast<int64_t*>(p); p += 256;
-    sc[b] = icp_carve(p, n_lat);
-    gm[b] = grid_carve(sc[b].grid, n_lat, rows);
+    const LocCarve cv = loc_carve(q, n_lat);
+    float* lattice = cv.lattice;
+    int32_t* pix = cv.pix;
+    int64_t* n_valid = cv.n_valid;
+    sc[b] = cv.sc;
+    gm[b] = cv.gm;
     lb.s[b] = LocSeq{q.vertex, q.depth, q.prev_pose16, lattice, sc[b].state, q.out_pose16,
-                     reinterpret_cast<char*>(gm[b].g), n_valid};
+                     reinterpret_cast<char*>(gm[b].g), n_valid, nullptr};
     static int binned_normals = -1;  // GRADSLAM_HIP_ICP_BINNED_NORMALS=0: gather the matches' normals from the map (A/B)
     if (binned_normals < 0) {
       const char* e = getenv("GRADSLAM_HIP_ICP_BINNED_NORMALS");
@@ -1278,6 +1457,25 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
                         binned_normals ? q.map.normals : nullptr, gm[b]};
     if (g_gs_prof_on) GS_HIP(hipMemsetAsync(n_valid, 0, 8, st));
   }
+  // candidate lists of far queries (gs_knn.h; the results do not depend on them), row-unit kernels only, behind the tile
+  // engine's part of the scratch.
+  // Policy (measured): at 1296x968 (78k source points, clusters of far ones at the frame borders)
+  // +4 % frames/s over 200 frames; at 640x480 the handful of far points does not pay for the list checks (-2 %).
+  // GRADSLAM_HIP_ICP_FAR=1 / 0 forces the lists on / off.
+  static int far_lists = -1;
+  if (far_lists < 0) {
+    const char* e = getenv("GRADSLAM_HIP_ICP_FAR");
+    far_lists = e ? (atoi(e) != 0 ? 1 : 0) : 2;
+  }
+  const bool far_on = (far_lists == 1 || (far_lists == 2 && n_lat >= FAR_MIN_LATTICE)) && prm->numiters > 0 &&
+                      !(icp_tile_enabled() && gm[0].sorted_n);
+  FarMem fm[GS_MAX_BATCH];
+  for (int b = 0; b < B; ++b) {
+    fm[b] = far_carve(reinterpret_cast<char*>(sc[b].state) + gs_icp_scratch_bytes(n_lat, loc_rows(seqs[b].map)) +
+                          it_mem_bytes((H + ds - 1) / ds, Wl), n_lat);
+    if (!far_on) fm[b] = FarMem{nullptr, nullptr, nullptr, nullptr};
+    lb.s[b].far_n = fm[b].n;
+  }
   lb.count_valid = g_gs_prof_on ? 1 : 0;
   lb.clear_bytes = gs_knn_grid_clear_bytes(gm[0], gb.cells_cap);  // same layout offsets for every sequence
   const unsigned nb_lat = (unsigned)gs_ceil_div(n_lat, 256);
@@ -1285,9 +1483,17 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   {
     double bytes = 0.0;  // lattice 28 B per slot; projection 16 B + two filter passes 4 B per map row; cell table
     for (int b = 0; b < B; ++b) bytes += 28.0 * n_lat + 24.0 * seqs[b].map.n_bound + 16.0 * gb.cells_cap;
-    GsProf prof(GS_PROF_COMPACT, bytes, st, 6);
-    hipLaunchKernelGGL(gs_loc_prep_kernel, dim3((unsigned)B * (nb_lat + nb_clear)), dim3(256), 0, st, lb, nb_lat);
-    int rc = gs_knn_grid_build_batch(gb, st);
+    GsProf prof(GS_PROF_COMPACT, bytes, st, grid_cleared ? 4 : 5);
+    int rc;
+    if (grid_cleared) {
+      const float u_hi = (float)((double)W - 0.999), v_hi = (float)((double)H - 0.999);   // (as gs_knn_grid_build_batch)
+      hipLaunchKernelGGL(gs_loc_prep_bbox_kernel, dim3((unsigned)B * nb_lat + gs_knn_gridb_bbox_blocks(gb)), dim3(256), 0, st,
+                         lb, gb, nb_lat, u_hi, v_hi);
+      rc = gs_knn_grid_build_batch(gb, st, true);
+    } else {
+      hipLaunchKernelGGL(gs_loc_prep_kernel, dim3((unsigned)B * (nb_lat + nb_clear)), dim3(256), 0, st, lb, nb_lat);
+      rc = gs_knn_grid_build_batch(gb, st);
+    }
     if (rc != GS_OK) return rc;
   }
   if (prm->numiters == 0) { GS_LAUNCH_CHECK(); return GS_OK; }
@@ -1322,9 +1528,16 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
                            gm[b].cell_start, gm[b].sorted, gm[b].sorted_n, reinterpret_cast<float*>(sc[b].best),
                            sc[b].partials[(h + 1) & 1], sc[b].partials[h & 1],
                            &sc[b].state->s[h & 1], &sc[b].state->s[(h + 1) & 1], sc[b].state->trace, nullptr, nullptr,
-                           nullptr};
+                           nullptr, fm[b].cq, fm[b].c, fm[b].idx, fm[b].n};
     }
     icp_half_launch<true>(plan, hb, n_src_c, prm, it, 0, st);
+    if (it == 0 && far_on) {   // lists for the far source points the first search found (one launch per solve)
+      FarBuildBatch fbb;
+      fbb.B = B;
+      for (int b = 0; b < B; ++b)
+        fbb.s[b] = FarBuildSeq{sc[b].srcA, gm[b].g, gm[b].cell_start, gm[b].sorted, reinterpret_cast<float*>(sc[b].best), fm[b]};
+      hipLaunchKernelGGL(gs_icp_far_build_kernel, dim3((unsigned)B * FAR_BLOCKS_PER_SEQ), dim3(FAR_BLOCK), 0, st, fbb);
+    }
     ++h;
     if (reduce_rows) {
       IcpRowsBatch rb;
@@ -1361,8 +1574,8 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   return GS_OK;
 }
 
-extern "C" int gs_localize_batch_f32(const gs_localize_seq* seqs_host, int B, int H, int W, int ds,
-                                     const gs_icp_params* prm, void* stream) {
+static int localize_batch(const gs_localize_seq* seqs_host, int B, int H, int W, int ds, const gs_icp_params* prm,
+                          void* stream, bool grid_cleared) {
   GS_REQUIRE(seqs_host && prm && B > 0 && H > 0 && W > 0 && ds > 0, "bad arguments");
   GS_REQUIRE(prm->numiters >= 0 && prm->numiters <= GS_ICP_MAX_ITERS, "numiters must be in [0, 1024]");
   GS_REQUIRE(prm->mode == 0 || prm->mode == 1, "mode must be 0 (ICP) or 1 (gradICP)");
@@ -1377,9 +1590,45 @@ extern "C" int gs_localize_batch_f32(const gs_localize_seq* seqs_host, int B, in
   hipStream_t st = gs_stream(stream);
   for (int c0 = 0; c0 < B; c0 += GS_MAX_BATCH) {
     const int nb = B - c0 < GS_MAX_BATCH ? B - c0 : GS_MAX_BATCH;
-    const int rc = localize_chunk(seqs_host + c0, nb, H, W, ds, prm, st);
+    const int rc = localize_chunk(seqs_host + c0, nb, H, W, ds, prm, st, grid_cleared);
     if (rc != GS_OK) return rc;
   }
+  return GS_OK;
+}
+extern "C" int gs_localize_batch_f32(const gs_localize_seq* seqs_host, int B, int H, int W, int ds,
+                                     const gs_icp_params* prm, void* stream) {
+  return localize_batch(seqs_host, B, H, W, ds, prm, stream, false);
+}
+
+__global__ void __launch_bounds__(256) gs_far_stats_kernel(const int* __restrict__ far_idx, const int* __restrict__ far_n,
+                                                          const float* __restrict__ d2prev, int* __restrict__ out2) {
+  const int n = *far_n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) out2[0] = n;
+  int c = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    c += (__float_as_uint(d2prev[far_idx[i]]) >> 31) ? 1 : 0;
+  if (c) atomicAdd(&out2[1], c);
+}
+extern "C" int gs_localize_far_stats_i64(const void* scratch, int H, int W, int ds, int64_t map_rows, int64_t* out2_host,
+                                         void* stream) {
+  GS_REQUIRE(scratch && out2_host && H > 0 && W > 0 && ds > 0 && map_rows > 0, "bad arguments");
+  const int64_t n_lat = loc_lattice(H, W, ds);
+  gs_localize_seq q;
+  memset(&q, 0, sizeof(q));
+  q.scratch = const_cast<void*>(scratch);
+  q.map.capacity = map_rows; q.map.n_bound = map_rows;
+  const LocCarve cv = loc_carve(q, n_lat);
+  const FarMem fm = far_carve(reinterpret_cast<char*>(cv.sc.state) + gs_icp_scratch_bytes(n_lat, map_rows) +
+                                  it_mem_bytes((H + ds - 1) / ds, (W + ds - 1) / ds), n_lat);
+  hipStream_t st = gs_stream(stream);
+  // (the two result words live behind the counter, in the 256 bytes reserved for it)
+  int* out2 = fm.n + 8;
+  GS_HIP(hipMemsetAsync(out2, 0, 8, st));
+  hipLaunchKernelGGL(gs_far_stats_kernel, dim3(64), dim3(256), 0, st, fm.idx, fm.n, reinterpret_cast<const float*>(cv.sc.best), out2);
+  int h[2] = {0, 0};
+  GS_HIP(hipMemcpyAsync(h, out2, 8, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  out2_host[0] = h[0]; out2_host[1] = h[1];
   return GS_OK;
 }
 
@@ -1406,9 +1655,6 @@ extern "C" int gs_pointfusion_step_batch_f32(const gs_step_seq* seqs_host, int B
   for (int c0 = 0; c0 < B; c0 += GS_MAX_BATCH) {
     const int nb = B - c0 < GS_MAX_BATCH ? B - c0 : GS_MAX_BATCH;
     const gs_step_seq* sq = seqs_host + c0;
-    int rc = gs_frame_maps_batch_f32(sq[0].depth, dstride, P, sq[0].K16, nb, 1, H, W, two_sigma_sq, sq[0].vertex,
-                                     sq[0].normal, sq[0].alpha, stream);
-    if (rc != GS_OK) return rc;
     gs_localize_seq ls[GS_MAX_BATCH];
     for (int b = 0; b < nb; ++b) {
       const gs_step_seq& q = sq[b];
@@ -1420,7 +1666,21 @@ extern "C" int gs_pointfusion_step_batch_f32(const gs_step_seq* seqs_host, int B
       u.gnormal = q.gnormal; u.best_pix = q.best_pix; u.new_count_out = q.new_count_out;
       u.scratch = q.upd_scratch;
     }
-    rc = gs_localize_batch_f32(ls, nb, H, W, ds, prm, stream);
+    // the frame-map launch also zeroes the grid scratch of this chunk's localisation (which then starts with ONE launch
+    // for the source lattice and the map projection instead of a clearing launch followed by the projection)
+    const int64_t n_lat = loc_lattice(H, W, ds);
+    GsClearJob job;
+    job.n = nb;
+    for (int b = 0; b < nb; ++b) {
+      GS_REQUIRE(ls[b].map.points && ls[b].map.n_bound > 0, "every sequence needs a non-empty map");
+      const LocCarve cv = loc_carve(ls[b], n_lat);
+      job.ptr[b] = reinterpret_cast<char*>(cv.gm.g);
+      if (b == 0) job.bytes = gs_knn_grid_clear_bytes(cv.gm, gs_knn_grid_cells_cap(n_lat));
+    }
+    int rc = gs_frame_maps_batch_clear(sq[0].depth, dstride, P, sq[0].K16, nb, 1, H, W, two_sigma_sq, sq[0].vertex,
+                                       sq[0].normal, sq[0].alpha, &job, stream);
+    if (rc != GS_OK) return rc;
+    rc = localize_batch(ls, nb, H, W, ds, prm, stream, true);
     if (rc != GS_OK) return rc;
   }
   return gs_update_map_fusion_batch_f32(us.get(), B, H, W, dist_th, dot_th, renorm_all, stream);

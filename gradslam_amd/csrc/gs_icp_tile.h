@@ -249,7 +249,7 @@ struct ItList {
   float R;
 };
 constexpr int IT_LIST_LANE = 4;
-constexpr float IT_RADD = 0.3f;    // cube searches (far queries): R = nearest distance + IT_RADD cells, at most the cube's
+constexpr float IT_RADD = 0.6f;    // cube searches (far queries): R = nearest distance + IT_RADD cells, at most the cube's
                                    // bound; halved (up to 3 times) while the list does not fit
 
 // grid_search_stage0 (gs_knn.h) on either the global grid (LOCAL = false; cells = cell_start, pts = sorted) or a
@@ -418,7 +418,7 @@ GS_DEV unsigned long long it_list_search(const uint32_t* w, const float4 c0R, co
 // middle of its cell.  Every face of that block with cells behind it is then at least 0.65 cells away (the plain 2x2x2
 // block: 0.5), which is what leaves a list room to move: R - d1 >= ~0.4 cells for a typical neighbour distance, more
 // than a solve moves a query.  Lane l of the pair walks the rows l, l + 2, ... of the block.
-constexpr float IT_SPAN_LO = 0.35f;
+constexpr float IT_SPAN_LO = 0.25f;
 GS_DEV unsigned long long it_scan_adaptive(const GsGrid& g, const ItBox& box, const uint16_t* __restrict__ cells,
                                            const float4* __restrict__ pts, float qx, float qy, float qz, int lane,
                                            bool* resolved, bool* served, int* win, ItList* lst) {

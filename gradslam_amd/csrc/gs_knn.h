@@ -64,9 +64,11 @@ static inline GridMem grid_carve(void* scratch, int64_t n_src, int64_t n_tgt) {
   m.g = reinterpret_cast<GsGrid*>(p); p += 128;
   m.bbox = reinterpret_cast<unsigned*>(p); p += 128;
   m.unres_count = reinterpret_cast<int*>(p); p += 256;
+  // (the tile sums sit in front of the cell counts: both are accumulated by the count pass and must be zero before it,
+  // so they are part of the one cleared range, gs_knn_grid_clear_bytes)
+  m.tile_sums = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL / GS_GRID_TILE + 2));
   m.cell_count = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1));
   m.cell_start = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL + 1));
-  m.tile_sums = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)(GS_GRID_MAXCELL / GS_GRID_TILE + 2));
   m.sorted = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1));
   m.sorted_n = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1));
   m.tlist = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1));
@@ -97,9 +99,10 @@ struct GsGridBatch {
 int gs_knn_grid_cells_cap(int64_t n_src);
 // bytes from the start of the grid scratch that must be ZERO before a build (header, bbox, counters, cell counts)
 size_t gs_knn_grid_clear_bytes(const GridMem& m, int cells_cap);
-// projection (optional) + bbox, count, tile sums, scan, scatter: 5 launches for all B sequences; the caller has
+// projection (optional) + bbox, count (+ tile sums), scan, scatter: 4 launches for all B sequences; the caller has
 // cleared gs_knn_grid_clear_bytes() of every scratch
-int gs_knn_grid_build_batch(const GsGridBatch& gb, hipStream_t st);
+// bbox_done: the caller already ran the bbox pass (gridb_bbox_block of gs_knn_bbox.h) in a launch of its own
+int gs_knn_grid_build_batch(const GsGridBatch& gb, hipStream_t st, bool bbox_done = false);
 
 int gs_knn_grid_build(const float* tgt, GsCount n_tgt, int64_t n_src, void* grid_scratch, hipStream_t st,
                       GsTargetFilter filter = GsTargetFilter{nullptr, 1, 1}, const float* nrm = nullptr);
@@ -310,6 +313,82 @@ GS_DEV unsigned long long grid_search_rings(const GsGrid& g, const int* __restri
   return key;
 }
 
+// ---- candidate lists of far queries (the fused ICP kernels search the SAME target set 2 x numiters times from
+// slowly moving query positions).  A query whose neighbour the 2x2x2 stage cannot prove -- it sits several cells from
+// every target: a frame border that looks at surface the map has not seen -- pays a cube scan or a block-wide pass over
+// all binned targets per search.  Once resolved it gets a list: ALL targets within R of its position q0 (<= 8 slots of
+// `sorted`).  A later search from q is exact on the list alone when  sqrt(best list distance) + |q - q0| < R:  every
+// target at least as close to q as the list's best is within R of q0, hence on the list (ties included), and the key
+// order is that of every other engine.
+constexpr int GS_FAR_SLOTS = 16;
+constexpr float GS_FAR_RADD = 1.0f;    // R = distance of the neighbour + GS_FAR_RADD cells (reduced until the list fits)
+
+// the list of one query, checked by a group of G >= GS_FAR_SLOTS lanes: returns the minimum key, *proven = exactness
+template <int G>
+GS_DEV unsigned long long far_list_search(const float4 c0R, const uint32_t* __restrict__ slots,
+                                          const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
+                                          bool* proven, int* win) {
+  static_assert(G >= GS_FAR_SLOTS, "one lane per list entry");
+  const uint32_t sl = lane < GS_FAR_SLOTS ? slots[lane] : ~0u;
+  const float4 a = sorted[sl != ~0u ? sl : 0u];
+  const unsigned long long k = sl != ~0u ? grid_key(qx, qy, qz, a) : ~0ull;
+  const unsigned long long kmin = grid_group_min<G>(k);
+  *win = (k == kmin && sl != ~0u) ? (int)sl : -1;
+  const float bd = __uint_as_float((uint32_t)(kmin >> 32));
+  const float ex = qx - c0R.x, ey = qy - c0R.y, ez = qz - c0R.z;
+  const float delta = sqrtf(ex * ex + ey * ey + ez * ez);
+  *proven = sqrtf(bd) + delta < c0R.w * 0.9999f;   // false for NaN, for an empty list and for R <= 0
+  return kmin;
+}
+
+// list of a query that grid_search_rings served with the cube of radius kdone: every target within
+// R = min(d1 + radd, 0.999 kE cells) of the query, kE = kdone or kdone + 1 (the larger cube when the smaller one leaves
+// less than radd of room); collected by the G lanes into `stage` (GS_FAR_SLOTS x 32 bit + a counter, LDS of the group).
+// Returns R, or 0 when no radius down to d1 + radd / 8 gives a list that fits.
+template <int G>
+GS_DEV float far_emit_cube(const GsGrid& g, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
+                           float qx, float qy, float qz, int lane, const float d1, const int kdone, uint32_t* stage,
+                           int* stage_n) {
+  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
+  float radd = GS_FAR_RADD * g.c, R = 0.0f;
+  const int kE = (d1 + radd > (float)kdone * g.c * 0.999f) ? kdone + 1 : kdone;
+  const int xa = qc.cx - kE < 0 ? 0 : qc.cx - kE, xb = qc.cx + kE >= g.nx ? g.nx - 1 : qc.cx + kE;
+  const int side = 2 * kE + 1, nrow = side * side;
+  const float rcube = (float)kE * g.c * 0.999f;
+  for (int attempt = 0; attempt < 4; ++attempt, radd *= 0.5f) {
+    float Rt = d1 + radd;
+    Rt = Rt < rcube ? Rt : rcube;
+    const float R2 = Rt * Rt;
+    if (lane == 0) *stage_n = 0;
+    if (lane < GS_FAR_SLOTS) stage[lane] = ~0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int r = lane; r < nrow; r += G) {
+      const int zz = qc.cz + r / side - kE, yy = qc.cy + r % side - kE;
+      if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
+      const int row = (zz * g.ny + yy) * g.nx;
+      const int je = cell_start[row + xb + 1];
+      for (int j = cell_start[row + xa]; j < je; ++j) {
+        const float4 c = sorted[j];
+        const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+        float d = dx * dx;
+        d = gs_fma(dy, dy, d);
+        d = gs_fma(dz, dz, d);
+        if (d < R2) {
+          const int pos = atomicAdd(stage_n, 1);
+          if (pos < GS_FAR_SLOTS) stage[pos] = (uint32_t)j;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n = *stage_n;   // the same for all lanes of the group (same wave: LDS accesses are ordered)
+    __builtin_amdgcn_wave_barrier();
+    if (n <= GS_FAR_SLOTS) { R = Rt; break; }
+  }
+  return R;
+}
+
 template <int G = GQ_G>
 GS_DEV unsigned long long grid_search_group(const GsGrid& g, const int* __restrict__ cell_start,
                                         const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
@@ -375,5 +454,73 @@ GS_DEV void block_brute_min_sorted_multi(const float (*qs)[3], const int* ids, i
     }
   }
   __syncthreads();
+}
+
+// Lists for the queries block_brute_min_sorted_multi just served (same ids; key_out holds their results): one more
+// pass over the binned targets collects, per query, every target within R = d1 + radd; a list that does not fit is
+// retried once with radd / 4, then given up (R = 0: the query is searched again next time).  Writes far_cq[gidx] =
+// (query, R), the GS_FAR_SLOTS slots of far_c[gidx] (gidx[id] = index of query id in those arrays; LDS) and
+// flag_out[id] = the list is valid.
+template <int BLOCK, int BQ>
+GS_DEV void block_brute_collect_multi(const float (*qs)[3], const int* ids, int nq, const float4* __restrict__ sorted,
+                                      int n, const unsigned long long* key_in, const float radd0, const int* gidx,
+                                      float4* __restrict__ far_cq, uint32_t* __restrict__ far_c, uint8_t* flag_out) {
+  __shared__ uint32_t lst[BQ][GS_FAR_SLOTS];
+  __shared__ int cnt[BQ];
+  float q[BQ][3], d1[BQ], Rt[BQ];
+  bool open[BQ];
+#pragma unroll
+  for (int i = 0; i < BQ; ++i) {
+    const int id = ids[i < nq ? i : 0];
+    q[i][0] = qs[id][0]; q[i][1] = qs[id][1]; q[i][2] = qs[id][2];
+    d1[i] = sqrtf(__uint_as_float((uint32_t)(key_in[id] >> 32)));
+    open[i] = i < nq && d1[i] == d1[i];   // (NaN: nothing was found, no list)
+    Rt[i] = 0.0f;
+  }
+  float radd = radd0;
+  for (int attempt = 0; attempt < 2; ++attempt, radd *= 0.25f) {
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < BQ; ++i) any = any || open[i];
+    if (!any) break;   // block-uniform
+    if (threadIdx.x < BQ) cnt[threadIdx.x] = 0;
+    if (threadIdx.x < BQ * GS_FAR_SLOTS) lst[threadIdx.x / GS_FAR_SLOTS][threadIdx.x % GS_FAR_SLOTS] = ~0u;
+    __syncthreads();
+    float R2[BQ];
+#pragma unroll
+    for (int i = 0; i < BQ; ++i) { const float r = d1[i] + radd; R2[i] = open[i] ? r * r : -1.0f; }
+    for (int j = threadIdx.x; j < n; j += BLOCK) {
+      const float4 p = sorted[j];
+#pragma unroll
+      for (int i = 0; i < BQ; ++i) {
+        const float dx = q[i][0] - p.x, dy = q[i][1] - p.y, dz = q[i][2] - p.z;
+        float d = dx * dx;
+        d = gs_fma(dy, dy, d);
+        d = gs_fma(dz, dz, d);
+        if (d < R2[i]) {
+          const int pos = atomicAdd(&cnt[i], 1);
+          if (pos < GS_FAR_SLOTS) lst[i][pos] = (uint32_t)j;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BQ; ++i) {
+      if (open[i] && cnt[i] <= GS_FAR_SLOTS) {   // block-uniform
+        open[i] = false;
+        Rt[i] = d1[i] + radd;
+        if (threadIdx.x < GS_FAR_SLOTS) far_c[(int64_t)gidx[ids[i]] * GS_FAR_SLOTS + threadIdx.x] = lst[i][threadIdx.x];
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < BQ; ++i)
+      if (i < nq) {
+        far_cq[gidx[ids[i]]] = make_float4(q[i][0], q[i][1], q[i][2], Rt[i]);
+        flag_out[ids[i]] = Rt[i] > 0.0f ? 1 : 0;   // (LDS of the caller: the list is valid after this search)
+      }
+  }
 }
 

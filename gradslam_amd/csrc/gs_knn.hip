@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "gs_assoc_dev.h"
+#include "gs_knn_bbox.h"
 
 constexpr int KNN_BLOCK = 256;
 constexpr int KNN_TCHUNK = 512;
@@ -132,149 +133,6 @@ size_t gs_knn_grid_scratch_bytes(int64_t n_src, int64_t n_tgt) {
          3 * gs_align(16 * (size_t)(n_tgt > 0 ? n_tgt : 1)) + gs_align(4 * (size_t)(n_src > 0 ? n_src : 1)) + 256;
 }
 
-// Bounding box of the finite targets: block-local min / max, then 6 atomicMax on order-preserving
-// codes (min and max are order-independent, so the result is deterministic).  code(v) grows with v;
-// the lower corner is kept as max(~code): zero-initialised words mean "nothing seen yet".
-GS_DEV unsigned grid_code(float v) {
-  const unsigned b = __float_as_uint(v);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-GS_DEV float grid_decode(unsigned c) {
-  return __uint_as_float((c & 0x80000000u) ? (c & 0x7fffffffu) : ~c);
-}
-constexpr int GB_BLOCK = 256;
-constexpr int GB_ITEMS = 8;
-// Body shared by the single-sequence and the batched kernels (blk = block index within the sequence).
-// cam != NULL: pix[] is an OUTPUT (projection of every row under the camera, gs_project_map_f32) and the
-// filter is evaluated on the value just computed.
-GS_DEV void grid_bbox_body(const float* __restrict__ tgt, const int64_t n_tgt, const GsTargetFilter flt,
-                           const GsCamera* cam, int H, float u_hi, float v_hi, int32_t* __restrict__ pix_out,
-                           unsigned* __restrict__ bbox, int* __restrict__ unres_count, float4* __restrict__ tlist,
-                           const unsigned blk) {
-  if (blk == 0 && threadIdx.x == 0) { unres_count[0] = 0; unres_count[1] = 0; }
-  if ((int64_t)blk * GB_BLOCK * GB_ITEMS >= n_tgt) return;
-  __shared__ float red[6][GB_BLOCK / GS_WAVE];
-  __shared__ int scan_s[GB_BLOCK / GS_WAVE + 1];
-  __shared__ unsigned base_s;
-  int hits = 0;
-  unsigned hitmask = 0;  // bit u: item u of this thread passed the filter
-  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  // Loads of all GB_ITEMS rows first (unconditional, on a clamped index), then the arithmetic: with the load inside
-  // the per-row control flow the compiler serialises them (load, wait, project, store, next load: 8 dependent round
-  // trips per thread).
-  const int64_t i0 = (int64_t)blk * GB_ITEMS * GB_BLOCK + threadIdx.x;
-  if (cam) {
-    float v[GB_ITEMS][3];
-#pragma unroll
-    for (int u = 0; u < GB_ITEMS; ++u) {
-      const int64_t i = i0 + (int64_t)u * GB_BLOCK, ic = i < n_tgt ? i : n_tgt - 1;
-      v[u][0] = tgt[3 * ic]; v[u][1] = tgt[3 * ic + 1]; v[u][2] = tgt[3 * ic + 2];
-    }
-#pragma unroll
-    for (int u = 0; u < GB_ITEMS; ++u) {
-      const int64_t i = i0 + (int64_t)u * GB_BLOCK;
-      if (i < n_tgt) {
-        int ph = 0, pw = 0;
-        const bool in = gs_project_point_hw(*cam, v[u][0], v[u][1], v[u][2], H, flt.W, u_hi, v_hi, ph, pw);
-        pix_out[i] = in ? (int32_t)(ph * flt.W + pw) : -1;
-        // lattice test on (h, w) directly: dividing the flat index by run-time W and ds again was most of this pass's
-        // instructions, and the pass is VALU-bound (SQ counters: 77 VALU instructions per row at 4 cycles per wave64)
-        if (in && gs_on_lattice(ph, pw, flt.ds)) {
-          ++hits;
-          hitmask |= 1u << u;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float w = v[u][k];
-            if (w > -3.0e38f && w < 3.0e38f) {  // finite
-              lo[k] = w < lo[k] ? w : lo[k];
-              hi[k] = w > hi[k] ? w : hi[k];
-            }
-          }
-        }
-      }
-    }
-  } else {
-    bool t[GB_ITEMS];
-    if (flt.pix) {
-      int32_t px[GB_ITEMS];
-#pragma unroll
-      for (int u = 0; u < GB_ITEMS; ++u) {
-        const int64_t i = i0 + (int64_t)u * GB_BLOCK;
-        px[u] = flt.pix[i < n_tgt ? i : n_tgt - 1];
-      }
-#pragma unroll
-      for (int u = 0; u < GB_ITEMS; ++u) {
-        const int32_t p = px[u];
-        t[u] = (i0 + (int64_t)u * GB_BLOCK < n_tgt) && p >= 0 && ((p / flt.W) % flt.ds == 0) && ((p % flt.W) % flt.ds == 0);
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < GB_ITEMS; ++u) t[u] = i0 + (int64_t)u * GB_BLOCK < n_tgt;
-    }
-#pragma unroll
-    for (int u = 0; u < GB_ITEMS; ++u) {
-      if (t[u]) {
-        const int64_t i = i0 + (int64_t)u * GB_BLOCK;
-        ++hits;
-        hitmask |= 1u << u;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float w = tgt[3 * i + k];
-          if (w > -3.0e38f && w < 3.0e38f) {  // finite
-            lo[k] = w < lo[k] ? w : lo[k];
-            hi[k] = w > hi[k] ? w : hi[k];
-          }
-        }
-      }
-    }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float a = lo[k], b = hi[k];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      const float a2 = __shfl_down(a, d, GS_WAVE), b2 = __shfl_down(b, d, GS_WAVE);
-      a = a2 < a ? a2 : a;
-      b = b2 > b ? b2 : b;
-    }
-    if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = b; }
-  }
-  const bool filtered = flt.pix != nullptr || cam != nullptr;
-  __syncthreads();
-  if (filtered) {
-    // the rows that passed the filter (a few per cent of a map) are compacted into tlist: the count and scatter
-    // passes then walk that list instead of the map.  One atomic per block hands out the slots (bbox[6] is also the
-    // number of targets the cell-size heuristic needs); the order of the list does not matter (see the scatter).
-    int total;
-    int pos = gs_block_excl_scan<GB_BLOCK>(hits, scan_s, &total);
-    if (threadIdx.x == 0 && total) base_s = atomicAdd(&bbox[6], (unsigned)total);
-    __syncthreads();
-    if (hitmask) {
-      const unsigned base = base_s;
-#pragma unroll
-      for (int u = 0; u < GB_ITEMS; ++u) {
-        if (hitmask & (1u << u)) {
-          const int64_t i = ((int64_t)blk * GB_ITEMS + u) * GB_BLOCK + threadIdx.x;
-          tlist[base + (unsigned)pos] = make_float4(tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2], __int_as_float((int)i));
-          ++pos;
-        }
-      }
-    }
-  }
-  if (threadIdx.x < 3) {
-    const int k = threadIdx.x;
-    float a = red[k][0], b = red[3 + k][0];
-    for (int w = 1; w < GB_BLOCK / GS_WAVE; ++w) {
-      a = red[k][w] < a ? red[k][w] : a;
-      b = red[3 + k][w] > b ? red[3 + k][w] : b;
-    }
-    if (a <= b) {  // at least one finite coordinate on this axis in this block
-      atomicMax(&bbox[k], ~grid_code(a));
-      atomicMax(&bbox[3 + k], grid_code(b));
-    }
-  }
-}
 __global__ void __launch_bounds__(GB_BLOCK) gs_grid_bbox_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
                                                                  const GsTargetFilter flt,
                                                                  unsigned* __restrict__ bbox,
@@ -322,65 +180,57 @@ GS_DEV GsGrid grid_from_bbox(const unsigned* __restrict__ bbox, int64_t n_tgt, i
 }
 
 // Every block derives the grid header from the bounding box (block 0 publishes it for the kernels
-// that follow), then counts its targets per cell.
+// that follow), then counts its targets per cell -- and per tile of GS_GRID_TILE cells, which is what the scan pass
+// needs of the other tiles (no separate tile-sum launch): block-local histogram in LDS, one global atomic per tile the
+// block touched (integer sums: the order does not matter).
 GS_DEV void grid_count_body(const float* __restrict__ tgt, const int64_t n_tgt, const GsTargetFilter flt,
                             const unsigned* __restrict__ bbox, GsGrid* __restrict__ gp, int* __restrict__ cell_count,
-                            int cells_cap, const float4* __restrict__ tlist, const unsigned blk, const unsigned nblk) {
+                            int* __restrict__ tile_sums, int cells_cap, const float4* __restrict__ tlist,
+                            const unsigned blk, const unsigned nblk) {
   __shared__ GsGrid gsh;
-  if (flt.pix) {  // filtered build: walk the compacted list of the bbox pass (bbox[6] entries)
-    const int64_t n_list = (int64_t)bbox[6];
-    if ((int64_t)blk * 256 >= n_list && blk != 0) return;
-    if (threadIdx.x == 0) {
-      gsh = grid_from_bbox(bbox, n_list, cells_cap);
-      if (blk == 0) *gp = gsh;
-    }
-    __syncthreads();
-    const GsGrid g = gsh;
-    for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n_list; i += (int64_t)nblk * 256) {
-      const float4 t = tlist[i];
-      atomicAdd(&cell_count[grid_cell(g, t.x, t.y, t.z)], 1);
-    }
-    return;
-  }
-  const int64_t i = (int64_t)blk * 256 + threadIdx.x;
-  if ((int64_t)blk * 256 >= n_tgt && blk != 0) return;
+  __shared__ int th[GS_GRID_MAXCELL / GS_GRID_TILE + 1];
+  const int64_t n_items = flt.pix ? (int64_t)bbox[6] : n_tgt;   // filtered build: the compacted list of the bbox pass
+  if ((int64_t)blk * 256 >= n_items && blk != 0) return;
   if (threadIdx.x == 0) {
-    gsh = grid_from_bbox(bbox, n_tgt, cells_cap);
+    gsh = grid_from_bbox(bbox, n_items, cells_cap);
     if (blk == 0) *gp = gsh;
   }
   __syncthreads();
-  if (i >= n_tgt) return;
   const GsGrid g = gsh;
-  atomicAdd(&cell_count[grid_cell(g, tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2])], 1);
+  const int ntile = g.ncell / GS_GRID_TILE + 1;
+  for (int t = threadIdx.x; t < ntile; t += 256) th[t] = 0;
+  __syncthreads();
+  if (flt.pix) {
+    for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n_items; i += (int64_t)nblk * 256) {
+      const float4 t = tlist[i];
+      const int cid = grid_cell(g, t.x, t.y, t.z);
+      atomicAdd(&cell_count[cid], 1);
+      atomicAdd(&th[cid / GS_GRID_TILE], 1);
+    }
+  } else {
+    const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+    if (i < n_tgt) {
+      const int cid = grid_cell(g, tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2]);
+      atomicAdd(&cell_count[cid], 1);
+      atomicAdd(&th[cid / GS_GRID_TILE], 1);
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntile; t += 256) {
+    const int v = th[t];
+    if (v) atomicAdd(&tile_sums[t], v);
+  }
 }
 __global__ void __launch_bounds__(256) gs_grid_count_kernel(const float* __restrict__ tgt, GsCount n_tgt_c,
                                                             const GsTargetFilter flt,
                                                             const unsigned* __restrict__ bbox,
                                                             GsGrid* __restrict__ gp,
-                                                            int* __restrict__ cell_count, int cells_cap,
-                                                            const float4* __restrict__ tlist) {
-  grid_count_body(tgt, gs_count(n_tgt_c), flt, bbox, gp, cell_count, cells_cap, tlist, blockIdx.x, gridDim.x);
+                                                            int* __restrict__ cell_count, int* __restrict__ tile_sums,
+                                                            int cells_cap, const float4* __restrict__ tlist) {
+  grid_count_body(tgt, gs_count(n_tgt_c), flt, bbox, gp, cell_count, tile_sums, cells_cap, tlist, blockIdx.x, gridDim.x);
 }
 
 // exclusive scan of cell_count[0 .. ncell] (ncell + 1 entries, the last one is the end sentinel)
-GS_DEV void grid_tile_sum_body(const int* __restrict__ cell_count, const GsGrid* __restrict__ gp,
-                               int* __restrict__ tile_sums, const unsigned blk) {
-  __shared__ int smem[256 / GS_WAVE + 1];
-  const int n = gp->ncell + 1;
-  const int base = blk * GS_GRID_TILE + threadIdx.x * 4;
-  if ((int)(blk * GS_GRID_TILE) >= n) return;
-  int c = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) c += (base + i < n) ? cell_count[base + i] : 0;
-  int total;
-  (void)gs_block_excl_scan<256>(c, smem, &total);
-  if (threadIdx.x == 0) tile_sums[blk] = total;
-}
-__global__ void __launch_bounds__(256) gs_grid_tile_sum_kernel(const int* __restrict__ cell_count,
-                                                               const GsGrid* __restrict__ gp,
-                                                               int* __restrict__ tile_sums) {
-  grid_tile_sum_body(cell_count, gp, tile_sums, blockIdx.x);
-}
 GS_DEV void grid_scan_body(const int* __restrict__ cell_count, const GsGrid* __restrict__ gp,
                            const int* __restrict__ tile_sums, int* __restrict__ cell_start, const unsigned blk) {
   __shared__ int smem[256 / GS_WAVE + 1];
@@ -462,28 +312,12 @@ __global__ void __launch_bounds__(256) gs_grid_scatter_kernel(const float* __res
 
 // ---- batched build: block b of a launch works for sequence b % B on its block b / B ----
 __global__ void __launch_bounds__(GB_BLOCK) gs_gridb_bbox_kernel(const GsGridBatch gb, float u_hi, float v_hi) {
-  const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
-  const unsigned blk = blockIdx.x / gb.B;
-  const GsTargetFilter flt{q.pix, gb.W, gb.ds};
-  if (q.pose16) {
-    __shared__ GsCamera cam;
-    if (threadIdx.x == 0) cam = gs_camera(q.pose16, q.K16);
-    __syncthreads();
-    grid_bbox_body(q.tgt, gs_count(q.n_tgt), flt, &cam, gb.H, u_hi, v_hi, q.pix, q.m.bbox, q.m.unres_count, q.m.tlist,
-                   blk);
-  } else {
-    grid_bbox_body(q.tgt, gs_count(q.n_tgt), flt, nullptr, 0, 0.0f, 0.0f, nullptr, q.m.bbox, q.m.unres_count, q.m.tlist,
-                   blk);
-  }
+  gridb_bbox_block(gb, blockIdx.x, u_hi, v_hi);
 }
 __global__ void __launch_bounds__(256) gs_gridb_count_kernel(const GsGridBatch gb) {
   const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
   grid_count_body(q.tgt, gs_count(q.n_tgt), GsTargetFilter{q.pix, gb.W, gb.ds}, q.m.bbox, q.m.g, q.m.cell_count,
-                  gb.cells_cap, q.m.tlist, blockIdx.x / gb.B, gridDim.x / gb.B);
-}
-__global__ void __launch_bounds__(256) gs_gridb_tile_sum_kernel(const GsGridBatch gb) {
-  const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
-  grid_tile_sum_body(q.m.cell_count, q.m.g, q.m.tile_sums, blockIdx.x / gb.B);
+                  q.m.tile_sums, gb.cells_cap, q.m.tlist, blockIdx.x / gb.B, gridDim.x / gb.B);
 }
 __global__ void __launch_bounds__(256) gs_gridb_scan_kernel(const GsGridBatch gb) {
   const GsGridSeq& q = gb.s[blockIdx.x % gb.B];
@@ -514,13 +348,13 @@ size_t gs_knn_grid_clear_bytes(const GridMem& m, int cells_cap) {
                   4 * (size_t)(cells_cap + 1));
 }
 
-int gs_knn_grid_build_batch(const GsGridBatch& gb, hipStream_t st) {
+int gs_knn_grid_build_batch(const GsGridBatch& gb, hipStream_t st, bool bbox_done) {
   int64_t n_max = 1;
   for (int b = 0; b < gb.B; ++b) n_max = gb.s[b].n_tgt.host > n_max ? gb.s[b].n_tgt.host : n_max;
   const unsigned B = (unsigned)gb.B;
   const float u_hi = (float)((double)gb.W - 0.999), v_hi = (float)((double)gb.H - 0.999);
-  hipLaunchKernelGGL(gs_gridb_bbox_kernel, dim3(B * (unsigned)gs_ceil_div(n_max, GB_BLOCK * GB_ITEMS)), dim3(GB_BLOCK), 0,
-                     st, gb, u_hi, v_hi);
+  if (!bbox_done)   // (else the caller ran gridb_bbox_block for gs_knn_gridb_bbox_blocks(gb) blocks in a launch of its own)
+    hipLaunchKernelGGL(gs_gridb_bbox_kernel, dim3(gs_knn_gridb_bbox_blocks(gb)), dim3(GB_BLOCK), 0, st, gb, u_hi, v_hi);
   // filtered builds walk the compacted target list (a few entries per lattice slot) with a grid-stride loop
   bool listed = true;
   for (int b = 0; b < gb.B; ++b) listed = listed && gb.s[b].pix != nullptr;
@@ -529,7 +363,6 @@ int gs_knn_grid_build_batch(const GsGridBatch& gb, hipStream_t st) {
   if (listed && gb.H > 0 && (unsigned)gs_ceil_div(3 * slots, 256) < nb_pts) nb_pts = (unsigned)gs_ceil_div(3 * slots, 256);
   hipLaunchKernelGGL(gs_gridb_count_kernel, dim3(B * nb_pts), dim3(256), 0, st, gb);
   const unsigned ntile = (unsigned)gs_ceil_div(gb.cells_cap + 1, GS_GRID_TILE);
-  hipLaunchKernelGGL(gs_gridb_tile_sum_kernel, dim3(B * ntile), dim3(256), 0, st, gb);
   hipLaunchKernelGGL(gs_gridb_scan_kernel, dim3(B * ntile), dim3(256), 0, st, gb);
   hipLaunchKernelGGL(gs_gridb_scatter_kernel, dim3(B * nb_pts), dim3(256), 0, st, gb);
   hipError_t e = hipGetLastError();
@@ -551,9 +384,8 @@ int gs_knn_grid_build(const float* tgt, GsCount n_tgt_c, int64_t n_src, void* gr
   hipLaunchKernelGGL(gs_grid_bbox_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, GB_BLOCK * GB_ITEMS)),
                      dim3(GB_BLOCK), 0, st, tgt, n_tgt_c, flt, m.bbox, m.unres_count, m.tlist);
   hipLaunchKernelGGL(gs_grid_count_kernel, dim3((unsigned)gs_ceil_div(n_tgt > 0 ? n_tgt : 1, 256)), dim3(256), 0, st,
-                     tgt, n_tgt_c, flt, m.bbox, m.g, m.cell_count, cells_cap, m.tlist);
+                     tgt, n_tgt_c, flt, m.bbox, m.g, m.cell_count, m.tile_sums, cells_cap, m.tlist);
   const unsigned ntile = (unsigned)gs_ceil_div(cells_cap + 1, GS_GRID_TILE);
-  hipLaunchKernelGGL(gs_grid_tile_sum_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums);
   hipLaunchKernelGGL(gs_grid_scan_kernel, dim3(ntile), dim3(256), 0, st, m.cell_count, m.g, m.tile_sums,
                      m.cell_start);
   hipLaunchKernelGGL(gs_grid_scatter_kernel, dim3((unsigned)gs_ceil_div(n_tgt, 256)), dim3(256), 0, st, tgt,

@@ -350,6 +350,60 @@ def test_two_ranks_sharing_one_gpu_rehearsal():
     assert weak["config"]["poses_sha"] == one["config"]["poses_sha"]
 
 
+_FAR_SCRIPT = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+import gradslam_amd as gs
+from gradslam_amd import ops
+from gradslam_amd.datasets.synthetic import make_sequence
+L, H, W = 4, 240, 320
+s = make_sequence(L, H, W, seed=5)
+depths = s["depths"].copy()
+depths[0, :, int(0.62 * W):] = 0.0          # the map of frame 0 does not cover the right part of the view:
+T = torch.from_numpy                         # the source points there are far from every target
+poses = s["poses"].copy(); poses[1:] = poses[:1]
+frames = gs.RGBDImages(T(s["colors"][None]).cuda(), T(depths[None]).cuda(), T(s["intrinsics"][None]).cuda(), T(poses[None]).cuda())
+slam = gs.slam.PointFusion(odom="gradicp", device="cuda")
+pc, prev, rec, stats = gs.Pointclouds(device="cuda"), None, [], []
+for i in range(L):
+    live = frames[:, i]
+    pc, p = slam.step(pc, live, prev, inplace=True)
+    prev = live
+    rec.append(p[0, 0].cpu().numpy())
+    if i == 1:   # the first localisation: the map is frame 0 only
+        stats = ops.localize_far_stats(torch.device("cuda", 0), 0, H, W, 4, pc._buf["points"][0].shape[0])
+np.savez(sys.argv[1], poses=np.stack(rec), n=np.array([int(pc.points_list[0].shape[0])]), pts=pc.points_list[0].cpu().numpy(),
+         far=np.array(stats))
+"""
+
+
+def test_far_candidate_lists_leave_results_identical(tmp_path):
+    """Source points far from every target (here: 38 % of the view is missing from the map) get candidate lists after
+    the first search of a solve (gs_icp_far_build_kernel) and are then served by 16 gathers instead of a cube scan or
+    a pass over all targets (GRADSLAM_HIP_ICP_FAR=1 forces the lists on at this small size; by default they start at
+    40k source points).  GRADSLAM_HIP_ICP_FAR=0 runs the same frames without lists: poses and the map must be
+    bit-identical, and the lists must actually have been in use.  (This scene is hostile on purpose: half of the far
+    points have more than 16 targets within reach or move out of their list's radius, and fall back to the scans.)"""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for far in ("1", "0"):
+        out = str(tmp_path / ("far%s.npz" % far))
+        subprocess.run([sys.executable, "-c", _FAR_SCRIPT % repo, out], check=True, timeout=600,
+                       env=dict(os.environ, GRADSLAM_HIP_ICP_FAR=far))
+        outs.append(np.load(out))
+    a, b = outs
+    assert a["far"][0] > 300, a["far"]                 # far source points found by the first search ...
+    assert a["far"][1] > 50, a["far"]                  # ... some of which still prove on their list at the last search
+    assert b["far"][0] == 0
+    assert np.array_equal(a["poses"].view(np.int32), b["poses"].view(np.int32))
+    assert a["n"][0] == b["n"][0]
+    assert np.array_equal(a["pts"].view(np.int32), b["pts"].view(np.int32))
+
+
 def test_pointfusion_1296x968_vs_oracle(gs):
     """BASELINE configs[4] shape (ScanNet resolution): 3 frames of PointFusion(gradicp, numiters=6) against the oracle's
     frame loop: 78k ICP queries against ~100k+ binned targets per solve, a map beyond 1.5M surfels: poses within 2e-6,
