@@ -100,6 +100,13 @@ constexpr int FS_BQ = 4;                 // queries per pass of the block-wide b
 constexpr int FS_QPB = FS_BLOCK / GQ_G;  // 96 queries per block, their rows are built by the first two waves
 constexpr int FS_RPG = (FS_QPB / 4) * LIN_NV <= FS_BLOCK ? 4 : 8;  // rows per group in the block reduction
 constexpr int FS_RG = FS_QPB / FS_RPG;                            // row groups
+constexpr int FS_FAR_PASSES = 8;     // list-building launches per solve at most: behind the first halves of iterations
+                                     // 0, 1 (before / after the large first step of a solve) and of every 4th after that
+// pass index of iteration `it`, or -1 (host and device)
+__host__ __device__ inline int fs_far_pass(int it) {
+  const int p = it < 2 ? it : ((it & 3) == 0 ? 1 + it / 4 : -1);
+  return p < FS_FAR_PASSES ? p : -1;
+}
 constexpr int FS_FAR_MIN_RING = 2;   // queries served by a cube of at least this radius get a candidate list (gs_knn.h)
 constexpr int FS_HG = 16;  // lanes per query of the shell search for queries the 2x2x2 stage leaves open
 static_assert(FS_QPB <= 2 * GS_WAVE && FS_QPB % FS_RPG == 0 && FS_RG * LIN_NV <= FS_BLOCK, "block shape");
@@ -148,8 +155,8 @@ struct IcpHalfSeq {
   // anyway (and which the first search of a solve rewrites: nothing of an earlier frame is ever read).
   float4* far_cq;
   uint32_t* far_c;
-  int* far_idx;   // source points the first search of the solve found far from every target, far_n[0] of them
-  int* far_n;
+  int* far_idx;   // [FS_FAR_PASSES][n_src] source points a first half with a list-building pass behind it (fs_far_pass)
+  int* far_n;     // found far from every target, far_n[pass] of them
 };
 
 // index pairs (into [a0..a5, res]) of the 28 accumulated products: 21 upper-triangular a_i a_k, 6 a_i res, res res
@@ -206,6 +213,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
   // (FAR is a template parameter: the kernels sit at their register limit, and the code of the lists costs the
   // variant without them 0.5 us per launch when it is merely present)
   const bool far_on = FAR && far_cq != nullptr && d2prev != nullptr;
+  const int far_pass = (FULL && FAR) ? fs_far_pass(it) : -1;
 
   const int64_t n_src = gs_count(n_src_c), n_tgt = gs_count(q.n_tgt);
   const int nunits = (int)((n_src + FS_QPB - 1) / FS_QPB);
@@ -339,10 +347,13 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
       if (!done) {
         int kdone;
         key = grid_search_rings<FS_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, &kdone);
-        // first search of a solve: queries that needed a cube of radius >= FS_FAR_MIN_RING (or the brute-force pass) are
-        // handed to gs_icp_far_build_kernel, which gives them candidate lists before the next launch
-        if (FULL && it == 0 && far_on && l16 == 0 && (!done || kdone >= FS_FAR_MIN_RING))
-          q.far_idx[atomicAdd(q.far_n, 1)] = (int)sq;
+        // first halves with a list-building pass behind them (fs_far_pass): queries that needed a cube of radius >=
+        // FS_FAR_MIN_RING are handed to gs_icp_far_build_kernel together with what the search found (squared distance,
+        // radius of the last cube); the ones left to the brute-force pass follow below
+        if (FULL && FAR && far_pass >= 0 && far_on && l16 == 0 && done && kdone >= FS_FAR_MIN_RING) {
+          far_cq[sq] = make_float4(__uint_as_float((uint32_t)(key >> 32)), (float)kdone, 0.0f, 0.0f);
+          q.far_idx[(int64_t)far_pass * n_src + atomicAdd(q.far_n + far_pass, 1)] = (int)sq;
+        }
       }
       if (win >= 0) bslot_s[hs] = win;  // a candidate of the list / the cubes beat the 2x2x2 stage
       if (l16 == 0) {
@@ -363,6 +374,13 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
       block_brute_min_sorted_multi<FS_BLOCK, FS_BQ>(qs, unres_q + u, nun - u < FS_BQ ? nun - u : FS_BQ, sorted,
                                                     cell_start[g.ncell], keys_s, bslot_s);
     if (nun) {
+      __syncthreads();
+      if (FULL && FAR && far_pass >= 0 && far_on && (int)threadIdx.x < nun) {   // (see the cube searches above; -1: no cube)
+        const int hs = unres_q[threadIdx.x];
+        const int64_t sq = (int64_t)u0 * FS_QPB + hs;
+        far_cq[sq] = make_float4(__uint_as_float((uint32_t)(keys_s[hs] >> 32)), -1.0f, 0.0f, 0.0f);
+        q.far_idx[(int64_t)far_pass * n_src + atomicAdd(q.far_n + far_pass, 1)] = (int)sq;
+      }
       __syncthreads();
       if (threadIdx.x == 0) unres_n = 0;
       __syncthreads();
@@ -977,7 +995,8 @@ GS_DEV void loc_prep_block(const LocBatch& lb, const unsigned bid, const unsigne
       sm.pad[0] = sm.pad[1] = 0.0f;
       q.state->s[0] = sm;
       q.state->s[1] = sm;
-      if (q.far_n) *q.far_n = 0;
+      if (q.far_n)
+        for (int i = 0; i < FS_FAR_PASSES; ++i) q.far_n[i] = 0;
       if (lb.numiters == 0) icp_write_result(sm, q.pose16, q.out_pose16);
     }
     return;
@@ -1072,29 +1091,36 @@ static ItMem it_carve(void* base, int Hl, int Wl) {
 struct FarMem {
   uint32_t* c;    // [n_lat][GS_FAR_SLOTS] slots of `sorted`
   float4* cq;     // [n_lat] (position the list was built at, exactness radius)
-  int* idx;       // [n_lat] source points handed to the list builder by the first search of the solve
-  int* n;         // [1] how many
+  int* idx;       // [FS_FAR_PASSES][n_lat] source points handed to the list builder
+  int* n;         // [FS_FAR_PASSES] how many
 };
 static size_t far_mem_bytes(int64_t n_lat) {
-  return gs_align(4 * GS_FAR_SLOTS * (size_t)n_lat) + gs_align(16 * (size_t)n_lat) + gs_align(4 * (size_t)n_lat) + 256;
+  return gs_align(4 * GS_FAR_SLOTS * (size_t)n_lat) + gs_align(16 * (size_t)n_lat) +
+         gs_align(4 * FS_FAR_PASSES * (size_t)n_lat) + 256;
 }
 static FarMem far_carve(void* base, int64_t n_lat) {
   char* p = reinterpret_cast<char*>(base);
   FarMem m;
   m.c = reinterpret_cast<uint32_t*>(p); p += gs_align(4 * GS_FAR_SLOTS * (size_t)n_lat);
   m.cq = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)n_lat);
-  m.idx = reinterpret_cast<int*>(p); p += gs_align(4 * (size_t)n_lat);
+  m.idx = reinterpret_cast<int*>(p); p += gs_align(4 * FS_FAR_PASSES * (size_t)n_lat);
   m.n = reinterpret_cast<int*>(p);
   return m;
 }
 
-// Lists for the source points the first search of a solve found far from every target (IcpHalfSeq::far_idx): one launch
-// between the first and the second half-iteration.  A group of FS_HG lanes per point runs the cube search again from
-// the point's position (the transformed cloud of iteration 0) and collects everything within R of it; points the cubes
-// do not reach are finished by the block (brute-force pass + collecting pass, FS_BQ points at a time).  The flag in the
-// sign bit of d2prev[s] tells the following searches that s has a list.
+// Lists for the source points a first half found far from every target (IcpHalfSeq::far_idx): one launch behind the
+// first halves of iterations 0, 1, 4, 8, ... (fs_far_pass; the step of iteration 0 is the large one of a solve: lists
+// built before it often do not survive it; solves that keep wandering by a millimetre per iteration lose lists later
+// too, and a point without a list pays a cube scan or a pass over all targets in EVERY launch until the next pass).
+// The half-iteration hands over what its search found (far_cq[s] = squared distance, radius of the proving cube or -1),
+// so a group of FS_HG lanes per point only collects everything within R of the point's position (the transformed cloud
+// of the iteration) from that cube; points only the brute-force pass served are finished by the block (one collecting
+// pass over the binned targets, FS_BQ points at a time).  The flag in the sign bit of d2prev[s] tells the following
+// searches that s has a list.
 struct FarBuildSeq {
-  const float* src;         // transformed cloud of iteration 0
+  const float* src;         // transformed cloud of the iteration
+  const int* idx;           // the pass's far source points, n[0] of them
+  const int* n;
   const GsGrid* gp;
   const int* cell_start;
   const float4* sorted;
@@ -1106,47 +1132,46 @@ struct FarBuildBatch {
   FarBuildSeq s[GS_MAX_BATCH];
 };
 constexpr int64_t FAR_MIN_LATTICE = 40000;   // source lattices from this size on keep candidate lists by default
-constexpr int FAR_BLOCK = 256;
-constexpr int FAR_BLOCKS_PER_SEQ = 32;
+constexpr int FAR_BLOCK = 512;
+constexpr int FAR_BLOCKS_PER_SEQ = 64;
 __global__ void __launch_bounds__(FAR_BLOCK) gs_icp_far_build_kernel(const FarBuildBatch fb) {
   const FarBuildSeq& q = fb.s[blockIdx.x % fb.B];
   const int blk = (int)(blockIdx.x / fb.B);
-  const int n = *q.m.n;
+  const int n = *q.n;
   if (blk >= n) return;   // (entry i is served by block i % FAR_BLOCKS_PER_SEQ)
   constexpr int NG = FAR_BLOCK / FS_HG;
   __shared__ float qs[NG][3];
-  __shared__ unsigned long long keys_s[NG];
-  __shared__ int bslot_s[NG];
+  __shared__ float d1_s[NG];
   __shared__ uint8_t flag_s[NG];
   __shared__ int unres_q[NG], sq_s[NG];
   __shared__ int unres_n;
   __shared__ uint32_t stage_s[NG][GS_FAR_SLOTS + 4];
   const GsGrid g = *q.gp;
   const int grp = threadIdx.x / FS_HG, l16 = threadIdx.x & (FS_HG - 1);
-  // entries of this block: blk, blk + NBLK, ...; NG of them per round
+  // entries of this block: blk, blk + FAR_BLOCKS_PER_SEQ, ...; NG of them per round
   for (int base = blk; base < n; base += FAR_BLOCKS_PER_SEQ * NG) {   // block-uniform
     if (threadIdx.x == 0) unres_n = 0;
     __syncthreads();
     const int e = base + grp * FAR_BLOCKS_PER_SEQ;
-    int sq = -1;
     if (e < n) {
-      sq = q.m.idx[e];
+      const int sq = q.idx[e];
       const float hx = q.src[3 * (int64_t)sq], hy = q.src[3 * (int64_t)sq + 1], hz = q.src[3 * (int64_t)sq + 2];
-      bool done;
-      int win, kdone;
-      const unsigned long long key = grid_search_rings<FS_HG>(g, q.cell_start, q.sorted, hx, hy, hz, l16, ~0ull, &done, &win,
-                                                              FS_HARD_RINGS, &kdone);
-      if (done) {
-        const float R = far_emit_cube<FS_HG>(g, q.cell_start, q.sorted, hx, hy, hz, l16,
-                                             sqrtf(__uint_as_float((uint32_t)(key >> 32))), kdone, stage_s[grp],
+      // what the search of the half-iteration found for this point: squared distance of its neighbour, radius of the
+      // cube that proved it (-1: the brute-force pass did)
+      const float4 found = q.m.cq[sq];
+      const float d1 = sqrtf(found.x);
+      const int kdone = (int)found.y;
+      if (kdone >= 0) {
+        const float R = far_emit_cube<FS_HG>(g, q.cell_start, q.sorted, hx, hy, hz, l16, d1, kdone, stage_s[grp],
                                              reinterpret_cast<int*>(&stage_s[grp][GS_FAR_SLOTS]));
-        q.m.c[GS_FAR_SLOTS * (int64_t)sq + l16] = stage_s[grp][l16];
+        for (int u = l16; u < GS_FAR_SLOTS; u += FS_HG) q.m.c[GS_FAR_SLOTS * (int64_t)sq + u] = stage_s[grp][u];
         if (l16 == 0) {
           q.m.cq[sq] = make_float4(hx, hy, hz, R);
           if (R > 0.0f) q.d2prev[sq] = __uint_as_float(__float_as_uint(q.d2prev[sq]) | 0x80000000u);
         }
       } else if (l16 == 0) {
         qs[grp][0] = hx; qs[grp][1] = hy; qs[grp][2] = hz;
+        d1_s[grp] = d1;
         sq_s[grp] = sq;
         unres_q[atomicAdd(&unres_n, 1)] = grp;
       }
@@ -1155,13 +1180,9 @@ __global__ void __launch_bounds__(FAR_BLOCK) gs_icp_far_build_kernel(const FarBu
     const int nun = unres_n;   // block-uniform
     for (int u = 0; u < nun; u += FS_BQ) {
       const int nq = nun - u < FS_BQ ? nun - u : FS_BQ;
-      if (threadIdx.x < nq) keys_s[unres_q[u + threadIdx.x]] = ~0ull;
-      __syncthreads();
-      block_brute_min_sorted_multi<FAR_BLOCK, FS_BQ>(qs, unres_q + u, nq, q.sorted, q.cell_start[g.ncell], keys_s, bslot_s);
-      block_brute_collect_multi<FAR_BLOCK, FS_BQ>(qs, unres_q + u, nq, q.sorted, q.cell_start[g.ncell], keys_s,
+      block_brute_collect_multi<FAR_BLOCK, FS_BQ>(qs, unres_q + u, nq, q.sorted, q.cell_start[g.ncell], d1_s,
                                                   GS_FAR_RADD * g.c, sq_s, q.m.cq, q.m.c, flag_s);
-      __syncthreads();
-      if (threadIdx.x < nq) {
+      if ((int)threadIdx.x < nq) {
         const int gq = unres_q[u + threadIdx.x];
         const int s2 = sq_s[gq];
         if (flag_s[gq]) q.d2prev[s2] = __uint_as_float(__float_as_uint(q.d2prev[s2]) | 0x80000000u);
@@ -1531,11 +1552,13 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
                            nullptr, fm[b].cq, fm[b].c, fm[b].idx, fm[b].n};
     }
     icp_half_launch<true>(plan, hb, n_src_c, prm, it, 0, st);
-    if (it == 0 && far_on) {   // lists for the far source points the first search found (one launch per solve)
+    if (far_on && fs_far_pass(it) >= 0) {   // lists for the far source points this search found
+      const int fp = fs_far_pass(it);
       FarBuildBatch fbb;
       fbb.B = B;
       for (int b = 0; b < B; ++b)
-        fbb.s[b] = FarBuildSeq{sc[b].srcA, gm[b].g, gm[b].cell_start, gm[b].sorted, reinterpret_cast<float*>(sc[b].best), fm[b]};
+        fbb.s[b] = FarBuildSeq{(it & 1) ? sc[b].srcB : sc[b].srcA, fm[b].idx + (int64_t)fp * n_lat, fm[b].n + fp, gm[b].g,
+                               gm[b].cell_start, gm[b].sorted, reinterpret_cast<float*>(sc[b].best), fm[b]};
       hipLaunchKernelGGL(gs_icp_far_build_kernel, dim3((unsigned)B * FAR_BLOCKS_PER_SEQ), dim3(FAR_BLOCK), 0, st, fbb);
     }
     ++h;
@@ -1601,17 +1624,22 @@ extern "C" int gs_localize_batch_f32(const gs_localize_seq* seqs_host, int B, in
 }
 
 __global__ void __launch_bounds__(256) gs_far_stats_kernel(const int* __restrict__ far_idx, const int* __restrict__ far_n,
-                                                          const float* __restrict__ d2prev, int* __restrict__ out2) {
-  const int n = *far_n;
-  if (blockIdx.x == 0 && threadIdx.x == 0) out2[0] = n;
-  int c = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+                                                          const float* __restrict__ d2prev, const float4* __restrict__ far_cq,
+                                                          int64_t n_lat, int* __restrict__ out4) {
+  const int n = far_n[0];   // (the first pass: what the first search of the solve found)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { out4[0] = n; out4[2] = far_n[1]; }
+  int c = 0, built = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     c += (__float_as_uint(d2prev[far_idx[i]]) >> 31) ? 1 : 0;
-  if (c) atomicAdd(&out2[1], c);
+    built += far_cq[far_idx[i]].w > 0.0f ? 1 : 0;
+  }
+  if (c) atomicAdd(&out4[1], c);
+  if (built) atomicAdd(&out4[3], built);
+  (void)n_lat;
 }
-extern "C" int gs_localize_far_stats_i64(const void* scratch, int H, int W, int ds, int64_t map_rows, int64_t* out2_host,
+extern "C" int gs_localize_far_stats_i64(const void* scratch, int H, int W, int ds, int64_t map_rows, int64_t* out4_host,
                                          void* stream) {
-  GS_REQUIRE(scratch && out2_host && H > 0 && W > 0 && ds > 0 && map_rows > 0, "bad arguments");
+  GS_REQUIRE(scratch && out4_host && H > 0 && W > 0 && ds > 0 && map_rows > 0, "bad arguments");
   const int64_t n_lat = loc_lattice(H, W, ds);
   gs_localize_seq q;
   memset(&q, 0, sizeof(q));
@@ -1621,14 +1649,20 @@ extern "C" int gs_localize_far_stats_i64(const void* scratch, int H, int W, int 
   const FarMem fm = far_carve(reinterpret_cast<char*>(cv.sc.state) + gs_icp_scratch_bytes(n_lat, map_rows) +
                                   it_mem_bytes((H + ds - 1) / ds, (W + ds - 1) / ds), n_lat);
   hipStream_t st = gs_stream(stream);
-  // (the two result words live behind the counter, in the 256 bytes reserved for it)
-  int* out2 = fm.n + 8;
-  GS_HIP(hipMemsetAsync(out2, 0, 8, st));
-  hipLaunchKernelGGL(gs_far_stats_kernel, dim3(64), dim3(256), 0, st, fm.idx, fm.n, reinterpret_cast<const float*>(cv.sc.best), out2);
-  int h[2] = {0, 0};
-  GS_HIP(hipMemcpyAsync(h, out2, 8, hipMemcpyDeviceToHost, st));
+  // (the result words live behind the counters, in the 256 bytes reserved for them)
+  int* out4 = fm.n + 8;
+  GS_HIP(hipMemsetAsync(out4, 0, 16, st));
+  hipLaunchKernelGGL(gs_far_stats_kernel, dim3(64), dim3(256), 0, st, fm.idx, fm.n, reinterpret_cast<const float*>(cv.sc.best),
+                     fm.cq, n_lat, out4);
+  int h[4] = {0, 0, 0, 0};
+  GsGrid g;
+  GS_HIP(hipMemcpyAsync(h, out4, 16, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(&g, cv.gm.g, sizeof(g), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
-  out2_host[0] = h[0]; out2_host[1] = h[1];
+  for (int i = 0; i < 4; ++i) out4_host[i] = h[i];
+  if (getenv("GRADSLAM_HIP_DEBUG_GRID"))
+    fprintf(stderr, "grid: box (%.3f %.3f %.3f)-(%.3f %.3f %.3f) c %.4f cells %d x %d x %d = %d\n", g.ox, g.oy, g.oz, g.mx,
+            g.my, g.mz, g.c, g.nx, g.ny, g.nz, g.ncell);
   return GS_OK;
 }
 

@@ -320,20 +320,30 @@ GS_DEV unsigned long long grid_search_rings(const GsGrid& g, const int* __restri
 // `sorted`).  A later search from q is exact on the list alone when  sqrt(best list distance) + |q - q0| < R:  every
 // target at least as close to q as the list's best is within R of q0, hence on the list (ties included), and the key
 // order is that of every other engine.
-constexpr int GS_FAR_SLOTS = 16;
+constexpr int GS_FAR_SLOTS = 64;
 constexpr float GS_FAR_RADD = 1.0f;    // R = distance of the neighbour + GS_FAR_RADD cells (reduced until the list fits)
 
-// the list of one query, checked by a group of G >= GS_FAR_SLOTS lanes: returns the minimum key, *proven = exactness
+// the list of one query, checked by a group of G lanes (GS_FAR_SLOTS / G entries each, one 16-byte load of slot numbers
+// per lane): returns the minimum key, *proven = exactness
 template <int G>
 GS_DEV unsigned long long far_list_search(const float4 c0R, const uint32_t* __restrict__ slots,
                                           const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
                                           bool* proven, int* win) {
-  static_assert(G >= GS_FAR_SLOTS, "one lane per list entry");
-  const uint32_t sl = lane < GS_FAR_SLOTS ? slots[lane] : ~0u;
-  const float4 a = sorted[sl != ~0u ? sl : 0u];
-  const unsigned long long k = sl != ~0u ? grid_key(qx, qy, qz, a) : ~0ull;
+  static_assert(GS_FAR_SLOTS == 4 * G, "four list entries per lane");
+  const uint4 sl = reinterpret_cast<const uint4*>(slots)[lane];
+  const uint32_t s4[4] = {sl.x, sl.y, sl.z, sl.w};
+  float4 a[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) a[u] = sorted[s4[u] != ~0u ? s4[u] : 0u];   // (the four gathers are in flight together)
+  unsigned long long k = ~0ull;
+  int bs = -1;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const unsigned long long k2 = s4[u] != ~0u ? grid_key(qx, qy, qz, a[u]) : ~0ull;
+    if (k2 < k) { k = k2; bs = (int)s4[u]; }
+  }
   const unsigned long long kmin = grid_group_min<G>(k);
-  *win = (k == kmin && sl != ~0u) ? (int)sl : -1;
+  *win = (k == kmin) ? bs : -1;
   const float bd = __uint_as_float((uint32_t)(kmin >> 32));
   const float ex = qx - c0R.x, ey = qy - c0R.y, ez = qz - c0R.z;
   const float delta = sqrtf(ex * ex + ey * ey + ez * ez);
@@ -344,7 +354,7 @@ GS_DEV unsigned long long far_list_search(const float4 c0R, const uint32_t* __re
 // list of a query that grid_search_rings served with the cube of radius kdone: every target within
 // R = min(d1 + radd, 0.999 kE cells) of the query, kE = kdone or kdone + 1 (the larger cube when the smaller one leaves
 // less than radd of room); collected by the G lanes into `stage` (GS_FAR_SLOTS x 32 bit + a counter, LDS of the group).
-// Returns R, or 0 when no radius down to d1 + radd / 8 gives a list that fits.
+// Returns R, or 0 when no radius down to d1 + radd / 4 gives a list that fits.
 template <int G>
 GS_DEV float far_emit_cube(const GsGrid& g, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
                            float qx, float qy, float qz, int lane, const float d1, const int kdone, uint32_t* stage,
@@ -355,12 +365,12 @@ GS_DEV float far_emit_cube(const GsGrid& g, const int* __restrict__ cell_start, 
   const int xa = qc.cx - kE < 0 ? 0 : qc.cx - kE, xb = qc.cx + kE >= g.nx ? g.nx - 1 : qc.cx + kE;
   const int side = 2 * kE + 1, nrow = side * side;
   const float rcube = (float)kE * g.c * 0.999f;
-  for (int attempt = 0; attempt < 4; ++attempt, radd *= 0.5f) {
+  for (int attempt = 0; attempt < 3; ++attempt, radd *= 0.5f) {
     float Rt = d1 + radd;
     Rt = Rt < rcube ? Rt : rcube;
     const float R2 = Rt * Rt;
     if (lane == 0) *stage_n = 0;
-    if (lane < GS_FAR_SLOTS) stage[lane] = ~0u;
+    for (int u = lane; u < GS_FAR_SLOTS; u += G) stage[u] = ~0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int r = lane; r < nrow; r += G) {
@@ -456,71 +466,72 @@ GS_DEV void block_brute_min_sorted_multi(const float (*qs)[3], const int* ids, i
   __syncthreads();
 }
 
-// Lists for the queries block_brute_min_sorted_multi just served (same ids; key_out holds their results): one more
-// pass over the binned targets collects, per query, every target within R = d1 + radd; a list that does not fit is
-// retried once with radd / 4, then given up (R = 0: the query is searched again next time).  Writes far_cq[gidx] =
-// (query, R), the GS_FAR_SLOTS slots of far_c[gidx] (gidx[id] = index of query id in those arrays; LDS) and
-// flag_out[id] = the list is valid.
+// Lists for queries only a pass over all binned targets serves (ids: their slots in the LDS arrays of the caller,
+// d1_in[id] = distance of the neighbour the search found): ONE more pass collects, per query, every target within
+// d1 + radd0, d1 + radd0 / 2 and d1 + radd0 / 4 into three lists (the radii are nested; a far query facing a surface
+// has many targets at nearly the same distance, and how many is not known beforehand); the largest radius whose list
+// fits wins.  Writes far_cq[gidx[id]] = (query, R or 0), the GS_FAR_SLOTS slots of far_c[gidx[id]] and flag_out[id] =
+// the list is valid.  Every thread of the block calls it with the same arguments.
 template <int BLOCK, int BQ>
 GS_DEV void block_brute_collect_multi(const float (*qs)[3], const int* ids, int nq, const float4* __restrict__ sorted,
-                                      int n, const unsigned long long* key_in, const float radd0, const int* gidx,
+                                      int n, const float* d1_in, const float radd0, const int* gidx,
                                       float4* __restrict__ far_cq, uint32_t* __restrict__ far_c, uint8_t* flag_out) {
-  __shared__ uint32_t lst[BQ][GS_FAR_SLOTS];
-  __shared__ int cnt[BQ];
-  float q[BQ][3], d1[BQ], Rt[BQ];
-  bool open[BQ];
+  __shared__ uint32_t lst[3][BQ][GS_FAR_SLOTS];
+  __shared__ int cnt[3][BQ];
+  float q[BQ][3], Ra[BQ], Rb[BQ], Rc[BQ];   // the three radii, squared (-1: no list for this query)
 #pragma unroll
   for (int i = 0; i < BQ; ++i) {
     const int id = ids[i < nq ? i : 0];
     q[i][0] = qs[id][0]; q[i][1] = qs[id][1]; q[i][2] = qs[id][2];
-    d1[i] = sqrtf(__uint_as_float((uint32_t)(key_in[id] >> 32)));
-    open[i] = i < nq && d1[i] == d1[i];   // (NaN: nothing was found, no list)
-    Rt[i] = 0.0f;
+    const float d1 = d1_in[id];
+    const bool open = i < nq && d1 == d1;   // (NaN: nothing was found, no list)
+    const float ta = d1 + radd0, tb = d1 + 0.5f * radd0, tc = d1 + 0.25f * radd0;
+    Ra[i] = open ? ta * ta : -1.0f;
+    Rb[i] = open ? tb * tb : -1.0f;
+    Rc[i] = open ? tc * tc : -1.0f;
   }
-  float radd = radd0;
-  for (int attempt = 0; attempt < 2; ++attempt, radd *= 0.25f) {
-    bool any = false;
+  if (threadIdx.x < 3 * BQ) cnt[threadIdx.x / BQ][threadIdx.x % BQ] = 0;
+  for (int t = threadIdx.x; t < 3 * BQ * GS_FAR_SLOTS; t += BLOCK) (&lst[0][0][0])[t] = ~0u;
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += BLOCK) {
+    const float4 p = sorted[j];
 #pragma unroll
-    for (int i = 0; i < BQ; ++i) any = any || open[i];
-    if (!any) break;   // block-uniform
-    if (threadIdx.x < BQ) cnt[threadIdx.x] = 0;
-    if (threadIdx.x < BQ * GS_FAR_SLOTS) lst[threadIdx.x / GS_FAR_SLOTS][threadIdx.x % GS_FAR_SLOTS] = ~0u;
-    __syncthreads();
-    float R2[BQ];
-#pragma unroll
-    for (int i = 0; i < BQ; ++i) { const float r = d1[i] + radd; R2[i] = open[i] ? r * r : -1.0f; }
-    for (int j = threadIdx.x; j < n; j += BLOCK) {
-      const float4 p = sorted[j];
-#pragma unroll
-      for (int i = 0; i < BQ; ++i) {
-        const float dx = q[i][0] - p.x, dy = q[i][1] - p.y, dz = q[i][2] - p.z;
-        float d = dx * dx;
-        d = gs_fma(dy, dy, d);
-        d = gs_fma(dz, dz, d);
-        if (d < R2[i]) {
-          const int pos = atomicAdd(&cnt[i], 1);
-          if (pos < GS_FAR_SLOTS) lst[i][pos] = (uint32_t)j;
+    for (int i = 0; i < BQ; ++i) {
+      const float dx = q[i][0] - p.x, dy = q[i][1] - p.y, dz = q[i][2] - p.z;
+      float d = dx * dx;
+      d = gs_fma(dy, dy, d);
+      d = gs_fma(dz, dz, d);
+      if (d < Ra[i]) {
+        const int pa = atomicAdd(&cnt[0][i], 1);
+        if (pa < GS_FAR_SLOTS) lst[0][i][pa] = (uint32_t)j;
+        if (d < Rb[i]) {
+          const int pb = atomicAdd(&cnt[1][i], 1);
+          if (pb < GS_FAR_SLOTS) lst[1][i][pb] = (uint32_t)j;
+          if (d < Rc[i]) {
+            const int pc = atomicAdd(&cnt[2][i], 1);
+            if (pc < GS_FAR_SLOTS) lst[2][i][pc] = (uint32_t)j;
+          }
         }
       }
     }
-    __syncthreads();
+  }
+  __syncthreads();
 #pragma unroll
-    for (int i = 0; i < BQ; ++i) {
-      if (open[i] && cnt[i] <= GS_FAR_SLOTS) {   // block-uniform
-        open[i] = false;
-        Rt[i] = d1[i] + radd;
-        if (threadIdx.x < GS_FAR_SLOTS) far_c[(int64_t)gidx[ids[i]] * GS_FAR_SLOTS + threadIdx.x] = lst[i][threadIdx.x];
+  for (int i = 0; i < BQ; ++i) {
+    if (i < nq) {   // block-uniform
+      const int r = cnt[0][i] <= GS_FAR_SLOTS ? 0 : (cnt[1][i] <= GS_FAR_SLOTS ? 1 : (cnt[2][i] <= GS_FAR_SLOTS ? 2 : -1));
+      const bool ok = r >= 0 && Ra[i] > 0.0f;
+      if (ok)
+        for (int t = threadIdx.x; t < GS_FAR_SLOTS; t += BLOCK)
+          far_c[(int64_t)gidx[ids[i]] * GS_FAR_SLOTS + t] = r == 0 ? lst[0][i][t] : (r == 1 ? lst[1][i][t] : lst[2][i][t]);
+      if (threadIdx.x == 0) {
+        // (the radius again from its definition: selecting among the register arrays by r would put them in scratch)
+        const float Rsel = d1_in[ids[i]] + (r == 0 ? 1.0f : (r == 1 ? 0.5f : 0.25f)) * radd0;
+        far_cq[gidx[ids[i]]] = make_float4(q[i][0], q[i][1], q[i][2], ok ? Rsel : 0.0f);
+        flag_out[ids[i]] = ok ? 1 : 0;   // (LDS of the caller)
       }
     }
-    __syncthreads();
   }
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < BQ; ++i)
-      if (i < nq) {
-        far_cq[gidx[ids[i]]] = make_float4(q[i][0], q[i][1], q[i][2], Rt[i]);
-        flag_out[ids[i]] = Rt[i] > 0.0f ? 1 : 0;   // (LDS of the caller: the list is valid after this search)
-      }
-  }
+  __syncthreads();
 }
 

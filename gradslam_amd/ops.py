@@ -651,14 +651,15 @@ def localize_batch(vertex, depth, K, prev_poses, maps, ds, mode=1, numiters=20, 
 
 def localize_far_stats(device, b, H, W, ds, capacity):
     """Diagnostics of the last localisation of sequence b on `device` (gs_localize_far_stats_i64): (source points the
-    first search found far from every target, how many of them ended the solve with a proven candidate list)."""
+    first search found far from every target, how many of them ended the solve with a proven candidate list, source
+    points of the second list-building pass, how many of the first have a list that fits)."""
     L = lib()
     scratch = Workspace.get(device).bytes("localize%d" % b, L.gs_localize_scratch_bytes(H, W, int(ds), int(capacity)))
     import ctypes
-    out = (ctypes.c_int64 * 2)()
+    out = (ctypes.c_int64 * 4)()
     check(L.gs_localize_far_stats_i64(scratch.data_ptr(), H, W, int(ds), int(capacity), out, stream(device)),
           "gs_localize_far_stats_i64")
-    return int(out[0]), int(out[1])
+    return tuple(int(v) for v in out)
 
 
 def update_map_fusion_batch_(maps, vertex, normal, depth, rgb, alpha, poses, K, dist_th, dot_th, renorm_all=True,

@@ -96,6 +96,7 @@ class StepPlan(object):
             if bufs is None or bufs[0] is not pc._buf["points"][b] or bounds[b] + P > self.caps[b]:
                 if bounds[b] + P > int(pc._buf["points"][b].shape[0]):
                     pc._reserve(b, P, pc.RESERVE_FRAMES)
+                    bounds = grp.bounds      # (_reserve may have replaced the bounds by the exact counts)
                 if not self._bind_map(pc, b):
                     return None
         # outputs of this frame: one allocation, carved into the local / global maps and the poses

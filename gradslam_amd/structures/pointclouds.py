@@ -80,6 +80,14 @@ class _CountGroup(object):
     def resolve(self):
         return [int(v) for v in self.dev.cpu().tolist()]
 
+    def tighten(self):
+        """One sync: the bounds become the exact counts (used before a buffer would be reallocated: the bounds run a
+        few frames x H*W rows ahead of the counts, which for a 1296x968 frame is millions of rows)."""
+        vals = self.resolve()
+        self.poll()          # every queued copy has landed by now
+        self.bounds = vals
+        return vals
+
 
 class _DeviceCount(object):
     """The count of ONE sequence inside a _CountGroup (the group does the read-backs for all its sequences)."""
@@ -402,6 +410,12 @@ class Pointclouds(object):
         need = n_b + int(extra)
         # (the smallest buffer counts: every attribute is written up to the same row)
         cap = min(self._buf[k][b].shape[0] for k in _ATTRS if self._buf[k] is not None)
+        if need > cap and b in self._dcount:
+            # the host only knows an upper bound of the count: one sync for the exact value is cheaper than copying the
+            # map into buffers twice the size (and re-sizing every scratch that follows the capacity) frames early
+            self._dcount[b].group.tighten()
+            n_b = self._count_of(b)[0]
+            need = n_b + int(extra)
         if need > cap:
             # geometric growth, starting at RESERVE_FRAMES x the request: a surfel map of a few hundred MB is
             # nothing in 288 GB of HBM, and every reallocation (and every size class the bound-sized per-frame

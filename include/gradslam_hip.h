@@ -453,11 +453,12 @@ typedef struct gs_localize_seq {
 GS_API int64_t gs_localize_scratch_bytes(int H, int W, int ds, int64_t n_map_bound);
 GS_API int gs_localize_batch_f32(const gs_localize_seq* seqs_host, int B, int H, int W, int ds,
                                  const gs_icp_params* params_host, void* stream);
-/* Diagnostics of the last solve a scratch was used for (tests, tools; synchronises the stream): out2[0] = number of
+/* Diagnostics of the last solve a scratch was used for (tests, tools; synchronises the stream): out4[0] = number of
  * source points the first search found far from every target and handed to the candidate-list builder (0 when the
- * lists are disabled), out2[1] = how many of them still hold a proven list after the last search.  H, W, ds and
- * map_rows (= max(map.capacity, map.n_bound) of that call) locate the counters in the scratch. */
-GS_API int gs_localize_far_stats_i64(const void* scratch, int H, int W, int ds, int64_t map_rows, int64_t* out2_host,
+ * lists are disabled), out4[1] = how many of them hold a proven list after the last search, out4[2] = source points
+ * handed to the second builder pass, out4[3] = how many of out4[0] have a list that fits (exactness radius > 0).
+ * H, W, ds and map_rows (= max(map.capacity, map.n_bound) of that call) locate the counters in the scratch. */
+GS_API int gs_localize_far_stats_i64(const void* scratch, int H, int W, int ds, int64_t map_rows, int64_t* out4_host,
                                      void* stream);
 
 /* update_map_fusion (slam/fusionutils.py:761-789) for B sequences: gs_update_map_fusion_dc_f32 per sequence, 6
