@@ -412,10 +412,14 @@ class Pointclouds(object):
         cap = min(self._buf[k][b].shape[0] for k in _ATTRS if self._buf[k] is not None)
         if need > cap and b in self._dcount:
             # the host only knows an upper bound of the count: one sync for the exact value is cheaper than copying the
-            # map into buffers twice the size (and re-sizing every scratch that follows the capacity) frames early
-            self._dcount[b].group.tighten()
+            # map into buffers twice the size (and re-sizing every scratch that follows the capacity) frames early --
+            # unless the bound would be back at the capacity within the few frames the host runs ahead (then every one
+            # of those frames would sync here): grow now
+            grp = self._dcount[b].group
+            grp.tighten()
             n_b = self._count_of(b)[0]
-            need = n_b + int(extra)
+            ahead = grp.EVERY * (grp.MAX_AHEAD + 1) + 2
+            need = n_b + int(extra) * (ahead if frames_ahead > 1 else 1)
         if need > cap:
             # geometric growth, starting at RESERVE_FRAMES x the request: a surfel map of a few hundred MB is
             # nothing in 288 GB of HBM, and every reallocation (and every size class the bound-sized per-frame
