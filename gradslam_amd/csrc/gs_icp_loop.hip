@@ -506,7 +506,7 @@ static size_t icp_rows(int64_t n_src) { return (size_t)gs_ceil_div(n_src, FS_QPB
 struct IcpHalfPlan {
   int G, nb, upb;
 };
-static IcpHalfPlan icp_half_plan(int64_t n_src, int B) {
+static IcpHalfPlan icp_half_plan(int64_t n_src, int B, int g_max = 8) {
   static int cus = 0, forced = -1, per_cu = 2;
   if (cus == 0) {
     int dev = 0, v = 0;
@@ -524,9 +524,9 @@ static IcpHalfPlan icp_half_plan(int64_t n_src, int B) {
   const int nunits = (int)icp_rows(n_src);
   const int budget = (per_cu * cus) / B > 0 ? (per_cu * cus) / B : 1;
   IcpHalfPlan pl{2, 1, 1};
-  for (int G = 8; G >= 2; G >>= 1) {
+  for (int G = g_max; G >= 2; G >>= 1) {
     const int NU = FS_BLOCK / G / FS_QPB, need = (nunits + NU - 1) / NU;
-    if ((forced == 0 && need <= budget) || forced == G || (forced == 0 && G == 2)) {
+    if ((forced == 0 && need <= budget) || forced == G || (forced == 0 && G == 2) || (forced > g_max && G == g_max)) {
       pl.G = G;
       pl.nb = need <= budget ? need : budget;
       pl.upb = NU * ((nunits + NU * pl.nb - 1) / (NU * pl.nb));
@@ -557,7 +557,9 @@ static void icp_half_launch(const IcpHalfPlan& pl, IcpHalfBatch& hb, GsCount n_s
 #define GS_HALF_LAUNCH(G_, FAR_)                                                                                        \
   hipLaunchKernelGGL((gs_icp_half_batch_kernel<FULL, G_, FAR_>), grid, block, 0, st, hb, n_src_c, prm->dist_thresh, *prm, \
                      it, rows_in_reduced)
-  if (pl.G == 8) { if (far) GS_HALF_LAUNCH(8, true); else GS_HALF_LAUNCH(8, false); }
+  // (no 8-lane variant with candidate lists: its first half does not fit the register budget; localize_chunk plans
+  // solves with lists for at most 4 lanes per query)
+  if (pl.G == 8) GS_HALF_LAUNCH(8, false);
   else if (pl.G == 4) { if (far) GS_HALF_LAUNCH(4, true); else GS_HALF_LAUNCH(4, false); }
   else { if (far) GS_HALF_LAUNCH(2, true); else GS_HALF_LAUNCH(2, false); }
 #undef GS_HALF_LAUNCH
@@ -1536,7 +1538,7 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   if (icp_tile_enabled() && gm[0].sorted_n)  // (the binned normals are part of the slabs)
     return localize_tiles(seqs, B, (H + ds - 1) / ds, Wl, prm, lb, sc, gm, prof_bytes, st);
   std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
-  const IcpHalfPlan plan = icp_half_plan(n_lat, B);
+  const IcpHalfPlan plan = icp_half_plan(n_lat, B, far_on ? 4 : 8);
   IcpHalfBatch hb;
   hb.B = B;
   int h = 0;
