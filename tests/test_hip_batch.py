@@ -388,6 +388,8 @@ def test_far_candidate_lists_leave_results_identical(tmp_path):
     import os
     import subprocess
     import sys
+    if os.environ.get("GRADSLAM_HIP_ICP_ENGINE") == "tile":
+        pytest.skip("the candidate lists of far queries belong to the row-unit kernels (the tile engine has its own)")
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for far in ("1", "0"):
