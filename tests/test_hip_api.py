@@ -237,6 +237,39 @@ def test_step_api_and_growth(gs):
     assert pc.cpu().device.type == "cpu"
 
 
+def test_map_is_not_reallocated_on_a_loose_count_bound(gs):
+    """The host only keeps an upper bound of a device-side surfel count (it runs a few frames x H*W rows ahead).  When
+    that bound reaches the capacity, `_reserve` first asks for the exact count: buffers with real headroom stay where
+    they are (a reallocation copies the map and re-sizes every scratch that follows the capacity); without headroom for
+    the frames the host runs ahead they grow."""
+    s = make_sequence(5, 48, 64, seed=11)
+    poses = s["poses"].copy()
+    poses[1:] = poses[:1]
+    frames = gs.RGBDImages(T(s["colors"][None]).cuda(), T(s["depths"][None]).cuda(),
+                           T(s["intrinsics"][None]).cuda(), T(poses[None]).cuda())
+    slam = gs.slam.PointFusion(odom="gradicp", device="cuda")
+    pc, prev = gs.Pointclouds(device="cuda"), None
+    for t in range(5):
+        live = frames[:, t]
+        pc, _ = slam.step(pc, live, prev, inplace=True)
+        prev = live
+    P = 48 * 64
+    grp = pc._dcount[0].group            # the counts live on the device in the in-place loop
+    exact = grp.resolve()[0]             # (reading points_list would make the host count exact and drop the group)
+    buf = pc._buf["points"][0]
+    cap = int(buf.shape[0])
+    assert exact + 9 * P < cap           # 16 frames of room were reserved up front
+    pc._dcount[0].group.bounds = [cap - P // 2]          # a bound that has (wrongly) run up to the capacity
+    pc._reserve(0, P, pc.RESERVE_FRAMES)
+    assert pc._buf["points"][0] is buf and pc._dcount[0].group.bounds == [exact]
+    # no headroom for the frames ahead: grows (and keeps the rows)
+    before = buf[:exact].clone()
+    pc._dcount[0].group.bounds = [cap]
+    pc._reserve(0, cap // 4, pc.RESERVE_FRAMES)
+    assert pc._buf["points"][0] is not buf and pc._buf["points"][0].shape[0] >= 2 * cap
+    assert torch.equal(pc._buf["points"][0][:exact], before) and pc.points_list[0].shape[0] == exact
+
+
 def test_scannet_resolution_map_growth(gs):
     """Config C5 shape (1296x968, ScanNet-like): dynamic map growth across capacity doublings with
     gradICP odometry at 78k x ~80k ICP points per frame; poses must track the ground truth."""
