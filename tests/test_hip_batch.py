@@ -407,6 +407,35 @@ def test_far_candidate_lists_leave_results_identical(tmp_path):
     assert np.array_equal(a["pts"].view(np.int32), b["pts"].view(np.int32))
 
 
+def test_pointfusion_1296x968_vs_reference_golden(gs, golden):
+    """BASELINE configs[4] resolution against the REAL reference: 3 frames of PointFusion(gradicp, 20 iterations) at
+    1296x968 (tests/golden/pf1296_s3.npz, oracle/make_golden_640.py --height 968 --width 1296 --seed 3; minutes of CPU
+    per frame there): pose ATE <= 1e-4 m, identical first frame, surfel counts within 0.05 %, point sums as at
+    640x480.  78k ICP source points per frame, so the solves run with the candidate lists of far queries."""
+    g = golden("pf1296_s3")
+    L, H, W = int(g["poses"].shape[0]), int(g["H"]), int(g["W"])
+    assert (H, W) == (968, 1296)
+    s = make_sequence(L, H, W, seed=int(g["seed"]))
+    assert abs(float(s["depths"].astype(np.float64).sum()) - float(g["depth_sum"])) < 1e-6 * float(g["depth_sum"])
+    frames = frames_of(gs, [s])
+    slam = gs.slam.PointFusion(odom="gradicp", device="cuda")
+    pc, prev, counts, sums, rec = gs.Pointclouds(device="cuda"), None, [], [], []
+    for f in range(L):
+        live = frames[:, f]
+        pc, pose = slam.step(pc, live, prev, inplace=True)
+        prev = live
+        rec.append(host(pose[0, 0]))
+        counts.append(pc.points_list[0].shape[0])
+        sums.append(host(pc.points_list[0].double().sum(0)))
+    rec = np.stack(rec)
+    assert ate(rec, g["poses"]) <= 1e-4, ate(rec, g["poses"])
+    diff = np.abs(np.asarray(counts) - g["counts"])
+    assert counts[0] == g["counts"][0]
+    assert diff.max() <= 5e-4 * g["counts"][-1], (counts, g["counts"].tolist())
+    for f in range(L):
+        np.testing.assert_allclose(sums[f], g["sum_points"][f], rtol=0, atol=1e-5 * counts[f] + 4.0 * diff[f] + 1e-3)
+
+
 def test_pointfusion_1296x968_vs_oracle(gs):
     """BASELINE configs[4] shape (ScanNet resolution): 3 frames of PointFusion(gradicp, numiters=6) against the oracle's
     frame loop: 78k ICP queries against ~100k+ binned targets per solve, a map beyond 1.5M surfels: poses within 2e-6,
