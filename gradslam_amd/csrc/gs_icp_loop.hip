@@ -951,7 +951,7 @@ struct LocSeq {
   float* out_pose16;
   char* clear_ptr;       // grid scratch bytes that must be zero before the build
   int64_t* n_valid;      // number of lattice slots with depth (profiling / roofline accounting)
-  int* far_n;            // counter of the far-query list of the solve (NULL: no candidate lists), zeroed here
+  int* far_n;            // [FS_FAR_PASSES] counters of the far-query lists of the solve, zeroed here
 };
 struct LocBatch {
   int B, W, ds, Wl;
@@ -1496,8 +1496,8 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   for (int b = 0; b < B; ++b) {
     fm[b] = far_carve(reinterpret_cast<char*>(sc[b].state) + gs_icp_scratch_bytes(n_lat, loc_rows(seqs[b].map)) +
                           it_mem_bytes((H + ds - 1) / ds, Wl), n_lat);
+    lb.s[b].far_n = fm[b].n;   // (zeroed by the prep launch whether or not this solve keeps lists: gs_localize_far_stats_i64)
     if (!far_on) fm[b] = FarMem{nullptr, nullptr, nullptr, nullptr};
-    lb.s[b].far_n = fm[b].n;
   }
   lb.count_valid = g_gs_prof_on ? 1 : 0;
   lb.clear_bytes = gs_knn_grid_clear_bytes(gm[0], gb.cells_cap);  // same layout offsets for every sequence
@@ -1628,16 +1628,18 @@ extern "C" int gs_localize_batch_f32(const gs_localize_seq* seqs_host, int B, in
 __global__ void __launch_bounds__(256) gs_far_stats_kernel(const int* __restrict__ far_idx, const int* __restrict__ far_n,
                                                           const float* __restrict__ d2prev, const float4* __restrict__ far_cq,
                                                           int64_t n_lat, int* __restrict__ out4) {
-  const int n = far_n[0];   // (the first pass: what the first search of the solve found)
+  // (the first pass: what the first search of the solve found; clamped: a scratch no solve has used holds anything)
+  const int n0 = far_n[0], n = n0 < 0 ? 0 : (n0 > (int)n_lat ? (int)n_lat : n0);
   if (blockIdx.x == 0 && threadIdx.x == 0) { out4[0] = n; out4[2] = far_n[1]; }
   int c = 0, built = 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    c += (__float_as_uint(d2prev[far_idx[i]]) >> 31) ? 1 : 0;
-    built += far_cq[far_idx[i]].w > 0.0f ? 1 : 0;
+    const int s = far_idx[i];
+    if (s < 0 || s >= (int)n_lat) continue;
+    c += (__float_as_uint(d2prev[s]) >> 31) ? 1 : 0;
+    built += far_cq[s].w > 0.0f ? 1 : 0;
   }
   if (c) atomicAdd(&out4[1], c);
   if (built) atomicAdd(&out4[3], built);
-  (void)n_lat;
 }
 extern "C" int gs_localize_far_stats_i64(const void* scratch, int H, int W, int ds, int64_t map_rows, int64_t* out4_host,
                                          void* stream) {

@@ -393,7 +393,7 @@ GS_API int gs_fuse_append_backward_f32(const float* points, const float* normals
 
 /* update_map_fusion (slam/fusionutils.py:761-789) of one sequence as ONE call: global maps of the frame under
  * `pose16` (structures/rgbdimages.py:681-762), projection + association of the map (fusionutils.py:198-577) and
- * the confidence-weighted merge + ordered append (fusionutils.py:580-722), regrouped into 6 launches.  Same
+ * the confidence-weighted merge + ordered append (fusionutils.py:580-722), regrouped into 5 launches.  Same
  * results, bit for bit, as gs_global_maps_f32 + gs_project_map_dc_f32 + gs_associate_dc_f32 +
  * gs_fuse_append_dc_f32.  vertex / normal: LOCAL maps (H, W, 3); alpha (H, W); outputs gvertex / gnormal
  * (H, W, 3), best_pix (H*W) (the correspondence table, -1 = none), new_count_out (must not alias n_map_dev;
@@ -438,9 +438,10 @@ GS_API int gs_frame_maps_batch_f32(const float* depth, int64_t depth_stride_seq,
  * under the previous pose (gs_lattice_source_f32), targets = the map rows that project onto that lattice in the
  * previous frame (gs_project_map_dc_f32 + the selection of gs_select_targets_f32, binned straight from the map),
  * numiters (grad)LM iterations, result composed with the previous pose: out_pose16 = T_icp * prev_pose16
- * (the transform gs_icp_map_dc_f32 returns).  scratch: gs_localize_scratch_bytes(H, W, ds, map.n_bound) bytes per
- * sequence (after the call it holds the solver state / trace at the offset gs_icp_trace_f32 expects + the
- * projection table). */
+ * (the transform gs_icp_map_dc_f32 returns).  scratch: gs_localize_scratch_bytes(H, W, ds, rows) bytes per sequence
+ * with rows = max(map.capacity, map.n_bound): the layout follows the CAPACITY of the map buffers, so that it does not
+ * move from frame to frame while the map grows inside them (after the call the scratch holds the solver state / trace
+ * at the offset gs_icp_trace_f32 expects, the projection table and the candidate lists of far queries). */
 typedef struct gs_localize_seq {
   const float* vertex;      /* live frame, LOCAL vertex map (H, W, 3) */
   const float* depth;       /* live frame depth (H, W) */
