@@ -188,6 +188,27 @@ def test_icpslam_640x480_first_frames(golden):
     np.testing.assert_allclose(m.points.astype(np.float64).sum(0), g["sum_points"][L - 1], rtol=0, atol=1e-5 * len(m))
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_pointfusion_640x480_first_frames_every_seed(golden, seed):
+    """The oracle's PointFusion(odom="gradicp") frame loop against the REAL reference on each of the 8 sequences of the
+    benchmark at 640x480 (tests/golden/pf640.npz, pf640_s1..7.npz, oracle/make_golden_640.py --seed): first 3 frames
+    (5 s per seed here).  Poses within 1e-5 m ATE (measured 5e-7); the surfel counts differ by a handful of threshold
+    flips (float64 fixed-order sums here, float32 sgemm there: DESIGN.md section 2), bounded like the HIP test's."""
+    g = golden("pf640" if seed == 0 else "pf640_s%d" % seed)
+    from gradslam_amd.datasets.synthetic import make_sequence
+    L = 3
+    s = make_sequence(int(g["poses"].shape[0]), int(g["H"]), int(g["W"]), seed=int(g["seed"]))
+    assert int(g["seed"]) == seed
+    poses = s["poses"][:L].copy()
+    poses[1:] = poses[:1]
+    m, rp = oslam.run_sequence(s["colors"][:L], s["depths"][:L], s["intrinsics"][0], poses)
+    assert ate(rp, g["poses"][:L]) <= 1e-5
+    diff = abs(len(m) - int(g["counts"][L - 1]))
+    assert diff <= 5e-4 * int(g["counts"][L - 1])
+    np.testing.assert_allclose(m.points.astype(np.float64).sum(0), g["sum_points"][L - 1], rtol=0,
+                               atol=1e-5 * len(m) + 4.0 * diff + 1e-3)
+
+
 def test_relative_pose_matches_reference(golden):
     """gs_or_relative_pose against GroundTruthOdometryProvider / relative_transformation of the reference
     (torch.inverse in float32 there, double Gauss-Jordan here: equal to a few float32 ulps)."""
