@@ -28,6 +28,39 @@ def test_numpy_backward_oracle_matches_reference_autograd(golden, K, thr, tag):
     assert ibar.shape == (4, 4) and np.all(ibar[3] == 0)
 
 
+def _c3_inputs_cpu(g):
+    """The two ds = 4 clouds of the 640x480 golden, regenerated from the seed with the oracle's (reference-pinned) frame
+    maps and down-sampler; their float64 sums must equal the ones recorded with the golden."""
+    from gradslam_amd.datasets.synthetic import make_sequence
+    from oracle import oracle as o
+    s = make_sequence(2, 480, 640, seed=int(g["seed"]))
+    pts = []
+    for f in range(2):
+        d = s["depths"][f, ..., 0]
+        v, n = o.frame_maps(d, s["intrinsics"][0])[:2]
+        gv, gn = o.global_maps(v, n, d, s["poses"][0])
+        pts.append(o.downsample_frame(gv, gn, None, d, 4)[:2])
+    (tgt, tn), (src, _) = pts
+    for name, x in (("src", src), ("tgt", tgt), ("tn", tn)):
+        assert np.abs(x.astype(np.float64).sum(0) - g["in_sum_" + name]).max() < 1e-9, name
+    return src, tgt, tn
+
+
+def test_numpy_backward_oracle_matches_reference_autograd_at_640x480(golden):
+    """BASELINE config C3 at the benchmarked size against the REAL reference: autograd through 20 iterations of
+    point_to_plane_gradICP on 18 216 x 18 281 points (tests/golden/c3_grad640.npz, oracle/make_golden_c3.py: every 8th
+    gradient row + column sums + norms)."""
+    g = golden("c3_grad640")
+    src, tgt, tn = _c3_inputs_cpu(g)
+    T, tape = ib.icp_forward_tape(src, tgt, tn, numiters=20)
+    np.testing.assert_allclose(T, g["T"], atol=2e-5, rtol=0)
+    sb, tb, nb, _ = ib.icp_backward(tape, tgt, tn, g["W"], src)
+    st = int(g["stride"])
+    for have, name in ((sb, "src"), (tb, "tgt"), (nb, "tn")):
+        assert rel(have[::st], g["grad_" + name]) < 1e-3, name          # measured 1.3e-4 / 7e-5 / 2.9e-4
+        assert abs(np.linalg.norm(have) / float(g["grad_norm_" + name]) - 1.0) < 1e-3, name
+
+
 def test_se3_exp_adjoint_by_finite_differences():
     rng = np.random.default_rng(1)
     # the small-angle branch (|omega| < 1e-6, se3utils.py:89-91) has its own derivative (V = I + w^):
@@ -108,6 +141,36 @@ def test_backward_at_640x480_grid_engine():
     sb, tb, _, _ = ib.icp_backward(tape, tgt.cpu().numpy(), tn.cpu().numpy(), W.cpu().numpy(), src.cpu().numpy())
     assert rel(src_l.grad.cpu().numpy(), sb) < 1e-3
     assert rel(tgt_l.grad.cpu().numpy(), tb) < 1e-3
+
+
+@pytest.mark.gpu
+def test_hip_backward_matches_reference_autograd_at_640x480(golden):
+    """Config C3 at the benchmarked size, HIP against the REAL reference's autograd (tests/golden/c3_grad640.npz): the
+    clouds come from the HIP frame maps and down-sampler (bit-exact: their sums must match the recorded ones), the
+    gradients of <W, T> through 20 gradICP iterations from gs_icp_tape_f32 + gs_icp_backward_f32."""
+    from gradslam_amd import ops
+    from gradslam_amd.datasets.synthetic import make_sequence
+    g = golden("c3_grad640")
+    s = make_sequence(2, 480, 640, seed=int(g["seed"]))
+    K = torch.from_numpy(s["intrinsics"][0]).cuda()
+    pts = []
+    for f in range(2):
+        d = torch.from_numpy(s["depths"][f, ..., 0]).cuda()
+        v, n, _, _ = ops.frame_maps(d, K)
+        gv, gn = ops.global_maps(v, n, d, torch.from_numpy(s["poses"][0]).cuda())
+        pts.append(ops.downsample_frame(gv, gn, None, d, 4)[:2])
+    (tgt, tn), (src, _) = pts
+    for name, x in (("src", src), ("tgt", tgt), ("tn", tn)):
+        assert np.abs(x.double().sum(0).cpu().numpy() - g["in_sum_" + name]).max() < 1e-9, name
+    leaf = [t.clone().requires_grad_(True) for t in (src, tgt, tn)]
+    T, _ = ops.grad_icp(leaf[0], leaf[1], leaf[2], numiters=20)
+    (T * dev(g["W"])).sum().backward()
+    np.testing.assert_allclose(T.detach().cpu().numpy(), g["T"], atol=2e-5, rtol=0)
+    st = int(g["stride"])
+    for t, name in zip(leaf, ("src", "tgt", "tn")):
+        have = t.grad.cpu().numpy()
+        assert rel(have[::st], g["grad_" + name]) < 1e-3, (name, rel(have[::st], g["grad_" + name]))
+        assert abs(np.linalg.norm(have.astype(np.float64)) / float(g["grad_norm_" + name]) - 1.0) < 1e-3, name
 
 
 @pytest.mark.gpu
