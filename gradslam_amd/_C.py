@@ -123,6 +123,7 @@ _PROTOS = {
     "gs_unproject_points_f32": [_vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp],
     "gs_lie_small_f32": [_i32, _vp, _vp, _vp],
     "gs_localize_far_stats_i64": [_vp, _i32, _i32, _i32, _i64, C.POINTER(C.c_int64), _vp],
+    "gs_localize_list_stats_i64": [_vp, _i32, _i32, _i32, _i64, C.POINTER(C.c_int64), _vp],
     "gs_pointfusion_step_batch_f32": [C.POINTER(StepSeq), _i32, _i32, _i32, _i32, C.POINTER(IcpParams), _f, _f, _f, _i32, _vp],
 }
 _RESTYPE = {"gs_last_error": C.c_char_p, "gs_scratch_bytes": _i64, "gs_icp_scratch_bytes": _i64,

@@ -19,7 +19,6 @@
 #include <string.h>
 
 #include <memory>
-#include <mutex>
 
 #include "gs_icp_math.h"
 #include "gs_knn.h"
@@ -44,6 +43,20 @@ GS_DEV void tape_write_sys(float* __restrict__ sys, int it, const double* S, flo
 }
 
 // ---------------------------------------------------------------- fixed-order sums ------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence that also drains the wave's
+// outstanding GLOBAL loads (s_waitcnt vmcnt(0)); the list variants of the half-iteration kernel keep the gathers of
+// their candidate lists in flight across the whole prologue, which is the point of issuing them there.
+GS_DEV void gs_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+template <bool LDS_ONLY>
+GS_DEV void gs_bar() {
+  if (LDS_ONLY) gs_barrier_lds();
+  else __syncthreads();
+}
+
 // Adds up partial rows (nrows x LIN_NV doubles).  Thread t works on value t%32 and the contiguous
 // chunk of CH rows number t/32 (then every STEP*CH rows further): its CH loads are 224 B apart, i.e.
 // one base address with immediate offsets, all in flight together; the chunk sums are then added in
@@ -53,7 +66,7 @@ GS_DEV void icp_sum_rows(const double* __restrict__ partials, int nrows, double*
   constexpr int STEP = BLOCK / 32;
   // CH = rows per thread per round of independent loads: a 640x480 solve of the row-unit engine (200 rows of 96
   // queries, 9 per thread at 768 threads) is ONE round of memory latency with 18; more rows in flight would push
-  // the kernel past 80 VGPRs (2 resident blocks per CU).  The tile engine (50 rows) uses 4.
+  // the kernel past 80 VGPRs (2 resident blocks per CU).
   const int i = threadIdx.x & 31, j = threadIdx.x >> 5;
   double s = 0.0;
   if (i < LIN_NV) {
@@ -77,6 +90,75 @@ GS_DEV void icp_sum_rows(const double* __restrict__ partials, int nrows, double*
   __syncthreads();
 }
 
+// hook(): called by EVERY thread once the first round of loads has been issued and before it is used (the list variants
+// of the half-iteration kernel issue their dependent gathers there: behind the row loads in the queue, in front of the
+// wait for them).
+// The same sums with HALF the loads in flight per thread (9 instead of 18: 18 VGPRs less at the point where the list
+// variants of the half-iteration kernel also hold their gathered candidates), bit for bit: a wave owns chunk j = its
+// index (and chunk j + BLOCK / 64 in a second pass, which only solves of more than 9 * BLOCK / 32 rows need); lanes
+// 0-31 add the first nine rows of the chunk in order, hand the running sum to lanes 32-63, which add the other nine --
+// the order of icp_sum_rows<BLOCK, 18>, whose thread j adds its 18 rows one after the other.
+template <int BLOCK, class Hook>
+GS_DEV void icp_sum_rows_split(const double* __restrict__ partials, int nrows, double* S, double (*sub)[32], Hook hook) {
+  constexpr int CH = 18, HC = CH / 2, STEP = BLOCK / 32, NW = BLOCK / GS_WAVE;
+  static_assert(2 * NW == STEP, "two chunks per wave");
+  // (an opaque copy of the thread index: merged with the uses at the far end of the kernel, the wave index computed
+  // here would be the one value the register allocator spills -- and a spill is a store in the memory queue of the
+  // prologue, behind which every wait for a load drains the queue)
+  unsigned tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int ln = tid & (GS_WAVE - 1), i = ln & 31, half = ln >> 5, w = tid / GS_WAVE;
+  const bool act = i < LIN_NV;
+  double tot[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int j = w + pass * NW;   // wave-uniform
+    double t = 0.0;
+    if (pass == 0 || j * CH < nrows) {
+      for (int b = j * CH, r = 0; r == 0 || b < nrows; b += CH * STEP, ++r) {   // (r > 0: solves of more than 432 rows)
+        // UNCONDITIONAL loads, masked afterwards: a load under a branch may not have been issued, and the compiler then
+        // has to wait for ALL outstanding loads wherever it needs an older one -- here that would drain the gathers the
+        // hook puts in flight.  Rows beyond nrows (at most 24 x 18 of them from the start of the buffer, < 100 KB) are
+        // read from what follows the rows in the caller's scratch (the second row buffer, the grid: megabytes) and never
+        // looked at; one base address + immediate offsets, as in icp_sum_rows.
+        const int b0 = b + half * HC;
+        const int left = act ? nrows - b0 : 0;
+        const double* base = partials + (int64_t)b0 * LIN_NV + i;
+        double a[HC];
+#pragma unroll
+        for (int u = 0; u < HC; ++u) a[u] = base[u * LIN_NV];
+        if (pass == 0 && r == 0) hook();
+#pragma unroll
+        for (int u = 0; u < HC; ++u) a[u] = (u < left) ? a[u] : 0.0;
+        const double carry = __shfl(t, i + 32, GS_WAVE);   // the running sum of the chunk lives in the upper half-wave
+        if (half == 0) {
+          t = carry;
+#pragma unroll
+          for (int u = 0; u < HC; ++u) t += a[u];
+        }
+        const double lo = __shfl(t, i, GS_WAVE);
+        if (half == 1) {
+          t = lo;
+#pragma unroll
+          for (int u = 0; u < HC; ++u) t += a[u];
+        }
+      }
+    }
+    tot[pass] = t;
+  }
+  if (half == 1) {
+    sub[w][i] = tot[0];
+    sub[w + NW][i] = tot[1];
+  }
+  gs_barrier_lds();
+  if (threadIdx.x < LIN_NV) {
+    double t = 0.0;
+    for (int k = 0; k < STEP; ++k) t += sub[k][threadIdx.x];
+    S[threadIdx.x] = t;
+  }
+  gs_barrier_lds();
+}
+
 // Same for the single residual column (value 27): all threads share the rows.
 template <int BLOCK>
 GS_DEV double icp_sum_col27(const double* __restrict__ partials, int nrows, double* red) {
@@ -88,6 +170,26 @@ GS_DEV double icp_sum_col27(const double* __restrict__ partials, int nrows, doub
   double t = 0.0;
   for (int w = 0; w < BLOCK / GS_WAVE; ++w) t += red[w];
   __syncthreads();
+  return t;
+}
+// ... with the hook of icp_sum_rows_split and barriers that order LDS only (the same additions in the same order)
+template <int BLOCK, class Hook>
+GS_DEV double icp_sum_col27_hook(const double* __restrict__ partials, int nrows, double* red, Hook hook) {
+  double s = 0.0;
+  {
+    const bool has = (int)threadIdx.x < nrows;   // (unconditional load, masked afterwards: see icp_sum_rows_split)
+    double a0 = partials[(int64_t)threadIdx.x * LIN_NV + 27];
+    hook();
+    a0 = has ? a0 : 0.0;
+    s += a0;
+  }
+  for (int b = threadIdx.x + BLOCK; b < nrows; b += BLOCK) s += partials[(int64_t)b * LIN_NV + 27];
+  s = gs_wave_sum_f64(s);
+  if ((threadIdx.x & (GS_WAVE - 1)) == 0) red[threadIdx.x / GS_WAVE] = s;
+  gs_barrier_lds();
+  double t = 0.0;
+  for (int w = 0; w < BLOCK / GS_WAVE; ++w) t += red[w];
+  gs_barrier_lds();
   return t;
 }
 
@@ -158,6 +260,18 @@ struct IcpHalfSeq {
   int* far_idx;   // [FS_FAR_PASSES][n_src] source points a first half with a list-building pass behind it (fs_far_pass)
   int* far_n;     // found far from every target, far_n[pass] of them
 };
+// candidate lists of ordinary queries (gs_knn.h: gl_*; lq == NULL: none): lq[s] = (position the list of source point s
+// was built at, exactness radius), ls[GL_SLOTS * s ..] = its slots of `sorted`, lstat = failure counters per launch
+struct IcpHalfLists {
+  float4* lq;
+  uint32_t* ls;
+  int* lstat;
+};
+
+// flags of an entry of the block's list of left-over queries (hard_q)
+constexpr int FS_HQ_FAR = (int)0x80000000;   // the query has a far-candidate list (FAR variants)
+constexpr int FS_HQ_SCAN = 0x40000000;       // (LISTS) its candidate list gave no proof: 2x2x2 scan by the 16-lane group, new list
+constexpr int FS_HQ_SLOT = 0x3fffffff;
 
 // index pairs (into [a0..a5, res]) of the 28 accumulated products: 21 upper-triangular a_i a_k, 6 a_i res, res res
 // (three bits per entry in two 64-bit literals for the 21 matrix products; entries 21..27 are (i - 21, 6).  A table in
@@ -172,17 +286,29 @@ GS_DEV int fs_pb(int i) { return i < 21 ? (int)((FS_PB_BITS >> (3 * i)) & 7ull) 
 // so the normal equations do not depend on G, on the number of blocks or on which block works on which unit: a
 // block owns the contiguous units [lb * upb, (lb + 1) * upb) and walks them NU at a time (grids smaller than the
 // unit count are how a GPU shared by 8 sequences keeps every block resident and pays the prologue once per block).
-template <bool FULL, int G, bool FAR>
-GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const float dist_thresh, const gs_icp_params& prm,
-                          const int it, const int rows_in_reduced, const unsigned lb, const int upb,
-                          unsigned long long* __restrict__ tl_arg = nullptr) {
+// LISTS (round 4): candidate lists of ordinary queries (gs_knn.h: gl_*), lmode = what this launch does with them:
+//   0  nothing (the first search of a solve: the large step of iteration 0 follows)
+//   1  every group builds the list of its point behind the search (the look-ahead of iteration 0)
+//   2  the lists are tried first: their slots, the list centre and the listed points are fetched BEFORE the prologue
+//      waits for the partial rows of the previous launch (the gathers ride behind the row loads and stay in flight
+//      across the scalar stage: its barriers order LDS only), so a launch whose lists all prove has no search on its
+//      critical path.  A list that gives no proof sends its point to the left-over pass, where a 16-lane group
+//      scans the 2x2x2 block and writes a new list.
+// Results do not depend on any of it: a proof is exact, everything else is the search that ran before.
+template <bool FULL, int G, bool FAR, int LMODE>
+GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsCount n_src_c, const float dist_thresh,
+                          const gs_icp_params& prm, const int it, const int rows_in_reduced, const unsigned lb,
+                          const int upb, unsigned long long* __restrict__ tl_arg = nullptr) {
+  constexpr bool LISTS = LMODE != 0;
 #ifdef GS_ICP_TIMELINE
   unsigned long long* __restrict__ tl = tl_arg;
 #else
   constexpr unsigned long long* tl = nullptr;  // per-block timeline stamps: debugging builds only (-DGS_ICP_TIMELINE)
 #endif
+  static_assert(!(FAR && LISTS), "the two kinds of candidate lists are not combined");
   constexpr int NQ = FS_BLOCK / G, NU = NQ / FS_QPB;
-  static_assert(NQ % FS_QPB == 0 && 2 * NU <= FS_BLOCK / GS_WAVE, "block shape");
+  constexpr int LK = gl_k<G>(), LM = G * LK;   // list entries per lane / per source point
+  static_assert(NQ % FS_QPB == 0 && 2 * NU <= FS_BLOCK / GS_WAVE && LM <= GL_SLOTS, "block shape");
   const float* __restrict__ src_in = q.src_in;
   float* __restrict__ src_out = q.src_out;
   const float* __restrict__ tgt = q.tgt;
@@ -204,16 +330,24 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
   __shared__ float qs[NQ][3];
   __shared__ float qa_s[NQ][8];   // a0..a5, residual of every query of the block (zero when filtered out)
   __shared__ double sub_s[NU][FS_RG][LIN_NV];
-  __shared__ int unres_q[NQ], hard_q[NQ];   // (hard_q: bit 31 = the query has a candidate list)
+  __shared__ int unres_q[NQ], hard_q[NQ];   // (hard_q: slot | FS_HQ_* flags)
   __shared__ int unres_n, hard_n;
   __shared__ unsigned long long red[FS_BLOCK / GS_WAVE];
   __shared__ uint8_t far_s[NQ];   // the query's candidate list proved this search (it keeps its flag)
+  __shared__ uint32_t stage_s[LISTS ? NQ * GL_STAGE : 1];   // lists under construction (one per group)
+  // (LMODE 2) source point and (list centre, radius) of every group, parked across the scalar stage of the prologue: its
+  // one-lane float64 code needs the registers, the lanes that wait for it do not
+  __shared__ float4 park_s[LMODE == 2 ? 2 * NQ : 1];
+  __shared__ int build_q[LMODE == 2 ? NQ : 1];   // (LMODE 2) slots of the block whose list is rebuilt behind the left-over pass
+  __shared__ int build_n;
   float4* __restrict__ far_cq = q.far_cq;
   uint32_t* __restrict__ far_c = q.far_c;
   // (FAR is a template parameter: the kernels sit at their register limit, and the code of the lists costs the
   // variant without them 0.5 us per launch when it is merely present)
   const bool far_on = FAR && far_cq != nullptr && d2prev != nullptr;
   const int far_pass = (FULL && FAR) ? fs_far_pass(it) : -1;
+  float4* __restrict__ lq = LISTS ? ql.lq : nullptr;
+  uint32_t* __restrict__ ls = LISTS ? ql.ls : nullptr;
 
   const int64_t n_src = gs_count(n_src_c), n_tgt = gs_count(q.n_tgt);
   const int nunits = (int)((n_src + FS_QPB - 1) / FS_QPB);
@@ -221,13 +355,48 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
   const int nrows_in = rows_in_reduced ? 1 : nunits;
   const int u_first = (int)lb * upb, u_last = (u_first + upb < nunits) ? u_first + upb : nunits;
   if (u_first >= nunits && lb != 0) return;  // beyond the actual count (bound-sized grid)
+  // lists are read by blocks that serve ONE group of units (the host plans it so whenever it asks for them)
+  // (LMODE is a template parameter: one kernel per mode keeps each of them within the register budget)
+  constexpr bool verify = LMODE == 2;
+  constexpr bool build_all = LMODE == 1;
   // the source point of the first slot does not depend on the prologue: issue its load first so that
   // the global-memory latency hides behind the scalar stage
   const int lane = threadIdx.x & (G - 1), slot = threadIdx.x / G;
   float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
-  const bool bounded = d2prev != nullptr && !(FULL && it == 0);  // the first search of a solve has no predecessor
+  // the first search of a solve has no predecessor; a list check needs none
+  const bool bounded = d2prev != nullptr && !(FULL && it == 0) && !verify;
   float dprev = __builtin_inff();
-  {
+  float4 lqv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // (verify) list centre and exactness radius of this group's point
+  uint32_t sl[LK];                                     // (verify) this lane's slots of the list
+  float4 cv[LK];                                       // (verify) the points in those slots
+  typedef float gs_v4f __attribute__((ext_vector_type(4)));
+  gs_v4f stv = {0.0f, 0.0f, 0.0f, 0.0f};             // (verify) this lane's 16 bytes of the state of the previous half
+  static_assert(sizeof(IcpSmall) % 16 == 0, "state copy");
+  const bool st_lane = threadIdx.x >= GS_WAVE && threadIdx.x < GS_WAVE + (int)(sizeof(IcpSmall) / 16);
+  if (LMODE == 2) {
+    // Everything this variant loads before its prologue is UNCONDITIONAL (clamped addresses, masked afterwards): a load
+    // under a branch may not have been issued, so wherever the compiler needs an OLDER load it has to wait for every
+    // outstanding one -- and a conditional load next to a zero-initialised register is waited for on the spot.  The
+    // copy of the state (the one conditional transfer) therefore goes first.
+    // (hand-issued: a DMA into LDS makes the compiler drain the memory queue at every later wait -- it treats the
+    // transfer as a flat access that may complete out of order -- and a plain load is sunk to its use, behind the
+    // gathers.  The hook below waits for it by count and stores it.)
+    if (st_lane)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(stv) : "v"(reinterpret_cast<const float4*>(q.st_in) + (threadIdx.x - GS_WAVE)) : "memory");
+    const int64_t s = (int64_t)u_first * FS_QPB + slot;
+    const bool vlive = slot / FS_QPB + u_first < u_last && s < n_src;
+    const int64_t sc = vlive ? s : 0;   // (source point 0 stands in; masked below)
+    p0 = src_in[3 * sc];
+    p1 = src_in[3 * sc + 1];
+    p2 = src_in[3 * sc + 2];
+    lqv = lq[sc];
+    const uint32_t* __restrict__ w = ls + GL_SLOTS * sc + LK * lane;
+#pragma unroll
+    for (int j = 0; j < LK; ++j) sl[j] = w[j];
+    // (lanes without a source point carry point 0's values until the hook drops its list; they are not `live` below)
+  } else {
+#pragma unroll
+    for (int j = 0; j < LK; ++j) { sl[j] = ~0u; cv[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
     const int64_t s = (int64_t)u_first * FS_QPB + slot;
     if (slot / FS_QPB + u_first < u_last && s < n_src) {
       p0 = src_in[3 * s];
@@ -238,45 +407,99 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
   }
 
   // the state of the previous half and the grid header are fetched while the partial rows are summed
-  // (their latency is off the critical path; the sums' __syncthreads publish sm)
-  const GsGrid g = *q.gp;
+  // (their latency is off the critical path; the sums' barriers publish sm)
+  // (the variant that tries lists first needs the grid for its left-overs only and fetches the header there: twelve
+  // registers less across its prologue)
+  GsGrid g = {};
+  if (LMODE != 2) g = *q.gp;
   // (global -> LDS directly, 16 bytes per lane of the second wave: a copy through registers made that wave wait for
   // its loads before it had even requested the partial rows, and the block waits for its slowest wave)
-  static_assert(sizeof(IcpSmall) % 16 == 0, "state copy");
-  if (threadIdx.x >= GS_WAVE && threadIdx.x < GS_WAVE + (int)(sizeof(IcpSmall) / 16))
-    it_load_lds16(reinterpret_cast<const float4*>(q.st_in) + (threadIdx.x - GS_WAVE), &sm);
+  if (LMODE != 2 && st_lane) it_load_lds16(reinterpret_cast<const float4*>(q.st_in) + (threadIdx.x - GS_WAVE), &sm);
+  // behind the row loads of the prologue: the listed points (the slots have arrived with the source point: same round
+  // trip).  A slot is dereferenced only below the capacity of `sorted` (a list is always written by an earlier launch of
+  // the SAME solve; the clamp costs one compare and keeps a stale word from faulting).
+  const uint32_t nsl = (uint32_t)(q.n_tgt.host < 0x7fffffffll ? q.n_tgt.host : 0x7fffffffll);
+  auto hook = [&]() {
+    if (LISTS) {
+      if (LMODE == 2 && verify) {
+        const bool try_list = (slot / FS_QPB + u_first < u_last && (int64_t)u_first * FS_QPB + slot < n_src) &&
+                              p0 == p0 && lqv.w > 0.0f;
+#pragma unroll
+        for (int j = 0; j < LK; ++j) {
+          if (!try_list || !(sl[j] < nsl)) sl[j] = ~0u;
+#ifndef GS_T_LATEGATHER
+          cv[j] = sorted[sl[j] != ~0u ? sl[j] : 0u];   // (unconditional: slot 0 stands in for an empty entry, never looked at)
+#endif
+        }
+        if (lane == 0) {
+          int slot_p = slot;   // (opaque: merged with the address of qa_s[slot] at the far end of the kernel it would be spilled)
+          asm volatile("" : "+v"(slot_p));
+          park_s[2 * slot_p] = make_float4(p0, p1, p2, 0.0f);
+          park_s[2 * slot_p + 1] = lqv;
+        }
+      }
+      // The barriers of this variant do not drain the memory queue, so the copy of the state (hand-issued before
+      // everything else, or a DMA into LDS in the building variant) is waited for by hand: loads complete in the order
+      // of issue, and exactly LK (verify) vector-memory instructions -- the unconditional gathers right above -- have
+      // been issued since everything else.  The row sums are consumed next anyway, so this wait costs nothing.
+      if (LMODE == 2 && verify) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LK) : "memory");
+        if (st_lane) *reinterpret_cast<gs_v4f*>(reinterpret_cast<float4*>(&sm) + (threadIdx.x - GS_WAVE)) = stv;
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+  };
 
   // ---- prologue: finish the previous half-iteration (identical in every block)
   if (FULL) {
     double e1 = 0.0;
-    if (it > 0) e1 = icp_sum_col27<FS_BLOCK>(partials_in, nrows_in, reinterpret_cast<double*>(red));
-    else __syncthreads();
+    if (LISTS) {
+      // (unconditionally: under `it > 0` the compiler hoists the head of the hook -- the wait for the source point and
+      // the list -- in front of the branch, i.e. in front of the row load.  The sum of a first iteration is not used:
+      // its rows are whatever the buffer holds.)
+      e1 = icp_sum_col27_hook<FS_BLOCK>(partials_in, nrows_in, reinterpret_cast<double*>(red), hook);
+    } else if (it > 0) {
+      e1 = icp_sum_col27<FS_BLOCK>(partials_in, nrows_in, reinterpret_cast<double*>(red));
+    } else {
+      __syncthreads();
+    }
     if (threadIdx.x == 0) {  // scalar stage, in place on the LDS copy of the state
+#ifndef GS_T_NOSCALAR
       if (it > 0)
         icp_update_math((float)e1, sm, prm, (lb == 0 && it - 1 < GS_ICP_MAX_ITERS) ? q.trace + 12 * (it - 1) : nullptr);
+#endif
       unres_n = 0;
       hard_n = 0;
+      build_n = 0;
     }
   } else {
-    icp_sum_rows<FS_BLOCK>(partials_in, nrows_in, S, sub);
+    if (LISTS) icp_sum_rows_split<FS_BLOCK>(partials_in, nrows_in, S, sub, hook);
+    else icp_sum_rows<FS_BLOCK>(partials_in, nrows_in, S, sub);
     if (threadIdx.x < GS_WAVE) gs_solve_spd6_wave(S, sm.damp, sm.xi);  // 6x6 solve across the lanes of wave 0
-    __syncthreads();
+    gs_bar<LISTS>();
     if (threadIdx.x == 0) {
       if (q.tape_sys && lb == 0) tape_write_sys(q.tape_sys, it, S, sm.damp);
+#ifndef GS_T_NOSCALAR
       icp_solve_finish(S, sm);
+#endif
       unres_n = 0;
       hard_n = 0;
+      build_n = 0;
     }
   }
-  __syncthreads();
+  gs_bar<LISTS>();
   if (lb == 0 && threadIdx.x < (int)(sizeof(IcpSmall) / 4))
     reinterpret_cast<float*>(q.st_out)[threadIdx.x] = reinterpret_cast<const float*>(&sm)[threadIdx.x];
   if (tl && threadIdx.x == 0) { tl[4] = wall_clock64(); tl[7] = 0; tl[2] = 0; }
 
-  for (int u0 = u_first; u0 < u_last; u0 += NU) {
+  // (the list variants serve ONE group of units per block -- the host plans them only then -- and say so to the
+  // compiler: nothing is carried around a loop)
+  int u0 = u_first;
+  if (u0 < u_last) do {
     const int64_t s = (int64_t)u0 * FS_QPB + slot;
     const bool live = (u0 + slot / FS_QPB < u_last) && s < n_src;  // this slot holds a source point
-    if (u0 != u_first) {
+    if (!LISTS && u0 != u_first) {
       p0 = p1 = p2 = 0.0f;
       dprev = __builtin_inff();
       if (live) {
@@ -289,6 +512,11 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
     // ---- search: one source point per G-lane group, pending transform applied to the loaded point.
     // A NaN source point (empty slot of an un-compacted lattice, gs_lattice_source_f32) is skipped: it stays
     // NaN through every transform, is never searched and contributes no row.
+    if (LMODE == 2 && live) {   // (parked by this group's first lane: same wave, LDS accesses of a wave are ordered)
+      const float4 pp = park_s[2 * slot];
+      p0 = pp.x; p1 = pp.y; p2 = pp.z;
+      lqv = park_s[2 * slot + 1];
+    }
     if (live && p0 != p0) {
       if (lane == 0) {
         if (FULL) { src_out[3 * s] = p0; src_out[3 * s + 1] = p0; src_out[3 * s + 2] = p0; }
@@ -302,18 +530,60 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
       const float* T = FULL ? sm.T_step : sm.Tr;
       float qx, qy, qz;
       gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
-      // search bound: the previous neighbour of this source point is still a target; the previous query was Tr * p in
-      // the look-ahead half (this half: T_step * p) resp. p itself in the first half (this half: Tr * p)
-      float rball;
-      {
-        float ox = p0, oy = p1, oz = p2;
-        if (FULL) gs_rigid_fma(sm.Tr, p0, p1, p2, ox, oy, oz);
-        const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
-        rball = sqrtf(dprev) + sqrtf(ex * ex + ey * ey + ez * ez);  // inf without a predecessor, NaN after a NaN match
-      }
       bool done;
       int win;
-      const unsigned long long key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win, rball);
+      unsigned long long key;
+      int hq_flags = 0;
+      if (LMODE == 2 && verify) {
+        // the list: every listed point against the query, the same key order as every other engine
+        key = ~0ull;
+        int wsl = -1;
+#ifdef GS_T_LATEGATHER
+#pragma unroll
+        for (int j = 0; j < LK; ++j)
+          if (sl[j] != ~0u) cv[j] = sorted[sl[j]];
+#endif
+#pragma unroll
+        for (int j = 0; j < LK; ++j) {
+          const unsigned long long k2 = sl[j] != ~0u ? grid_key(qx, qy, qz, cv[j]) : ~0ull;
+          if (k2 < key) { key = k2; wsl = (int)sl[j]; }
+        }
+        const unsigned long long kmin = grid_group_min<G>(key);
+        win = (key == kmin && wsl >= 0) ? wsl : -1;
+        key = kmin;
+        const float bd = __uint_as_float((uint32_t)(key >> 32));   // NaN: empty list
+        const float ex = qx - lqv.x, ey = qy - lqv.y, ez = qz - lqv.z;
+        const float delta = sqrtf(ex * ex + ey * ey + ez * ez);
+        done = lqv.w > 0.0f && sqrtf(bd) + delta < lqv.w * 0.9999f;   // false for NaN
+        if (!done) {
+          key = ~0ull;
+          win = -1;
+          // R < 0: the 2x2x2 stage could not prove this point when it was last tried -- straight to the cube scans
+          hq_flags = lqv.w < 0.0f ? 0 : FS_HQ_SCAN;
+          const int hl = 2 * it + (FULL ? 0 : 1);   // launch index within the solve (failure counters)
+          if (lane == 0 && ql.lstat && hl < GL_STAT_LAUNCHES) atomicAdd(ql.lstat + (lqv.w < 0.0f ? GL_STAT_LAUNCHES : 0) + hl, 1);
+        }
+      } else {
+        // search bound: the previous neighbour of this source point is still a target; the previous query was Tr * p in
+        // the look-ahead half (this half: T_step * p) resp. p itself in the first half (this half: Tr * p)
+        float rball;
+        {
+          float ox = p0, oy = p1, oz = p2;
+          if (FULL) gs_rigid_fma(sm.Tr, p0, p1, p2, ox, oy, oz);
+          const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
+          rball = sqrtf(dprev) + sqrtf(ex * ex + ey * ey + ez * ez);  // inf without a predecessor, NaN after a NaN match
+        }
+        key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win, rball);
+        if (build_all) {
+          if (done) {
+            gl_build_block<G>(g, cell_start, sorted, qx, qy, qz, lane, __uint_as_float((uint32_t)(key >> 32)), LM,
+                              stage_s + slot * GL_STAGE, ls + GL_SLOTS * s, lq + s);
+          } else if (lane == 0) {
+            lq[s] = make_float4(qx, qy, qz, -1.0f);
+          }
+        }
+      }
+      (void)hq_flags;
       if (win >= 0 || (lane == 0 && key == ~0ull)) bslot_s[slot] = win;  // one writer: the winning lane
       if (lane == 0) {
         if (FULL) {  // the transformed cloud of this iteration
@@ -324,15 +594,16 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
         qs[slot][0] = qx; qs[slot][1] = qy; qs[slot][2] = qz;
         keys_s[slot] = key;
         if (FAR) far_s[slot] = 0;
-        if (!done) hard_q[atomicAdd(&hard_n, 1)] = slot | (has_far ? (int)0x80000000 : 0);
+        if (!done) hard_q[atomicAdd(&hard_n, 1)] = slot | (LMODE == 2 ? hq_flags : (has_far ? FS_HQ_FAR : 0));
       }
     }
     __syncthreads();
     // ---- the few queries the 2x2x2 stage did not resolve (neighbour farther than ~half a cell): Chebyshev shells
     // by groups of FS_HG lanes, so that they do not hold up the waves of the common case
     const int nh = hard_n;  // block-uniform
+    if (LMODE == 2 && nh) g = *q.gp;
     for (int i = threadIdx.x / FS_HG; i < nh; i += FS_BLOCK / FS_HG) {
-      const int e = hard_q[i], hs = e & 0x7fffffff, l16 = threadIdx.x & (FS_HG - 1);
+      const int e = hard_q[i], hs = e & FS_HQ_SLOT, l16 = threadIdx.x & (FS_HG - 1);
       const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
       const int64_t sq = (int64_t)u0 * FS_QPB + hs;   // the query's source point
       bool done = false, listed = false;
@@ -343,6 +614,18 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
         const unsigned long long kl = far_list_search<FS_HG>(c0R, far_c + GS_FAR_SLOTS * sq, sorted, hx, hy, hz, l16, &done, &win);
         if (done) { key = kl; listed = true; }
         else win = -1;
+      }
+      if (LMODE == 2 && (e & FS_HQ_SCAN)) {   // its list gave no proof: the 2x2x2 block by 16 lanes, and a list for where it is now
+#ifndef GS_T_NOSTAGE16
+        key = grid_search_stage0<FS_HG>(g, cell_start, sorted, hx, hy, hz, l16, &done, &win);
+#endif
+        if (win >= 0) bslot_s[hs] = win;
+        win = -1;
+        // (the new list is written by a pass of its own below: inside this loop its registers come on top of the search's)
+        if (l16 == 0) {
+          if (done) build_q[atomicAdd(&build_n, 1)] = hs;
+          else lq[sq] = make_float4(hx, hy, hz, -1.0f);
+        }
       }
       if (!done) {
         int kdone;
@@ -364,7 +647,17 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
     }
     if (nh) {
       __syncthreads();
-      if (threadIdx.x == 0) hard_n = 0;
+      if (LMODE == 2) {   // new lists for the points whose list gave no proof and whose 2x2x2 scan did (keys_s: what it found)
+        const int nbq = build_n;   // block-uniform
+        for (int i = threadIdx.x / FS_HG; i < nbq; i += FS_BLOCK / FS_HG) {
+          const int hs = build_q[i];
+          const int64_t sq = (int64_t)u0 * FS_QPB + hs;
+          gl_build_block<FS_HG>(g, cell_start, sorted, qs[hs][0], qs[hs][1], qs[hs][2], threadIdx.x & (FS_HG - 1),
+                                __uint_as_float((uint32_t)(keys_s[hs] >> 32)), LM,
+                                stage_s + (threadIdx.x / FS_HG) * GL_STAGE, ls + GL_SLOTS * sq, lq + sq);
+        }
+      }
+      if (threadIdx.x == 0) { hard_n = 0; if (LMODE == 2) build_n = 0; }
       __syncthreads();
     }
     if (tl && threadIdx.x == 0 && u0 == u_first) { tl[5] = wall_clock64(); tl[2] += (unsigned long long)nh; }
@@ -388,6 +681,11 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
 
     // ---- Gauss-Newton row of every query: its own group's first lane gathers the match and leaves [a, res] in LDS
     if (lane == 0) {
+      // (list variants: the index of the source point is formed again here; kept from the top of the kernel it is the
+      // one value the register allocator spills -- the opaque copy keeps the compiler from merging the two)
+      int u0r = u0;
+      if (LISTS) asm volatile("" : "+s"(u0r));
+      const int64_t s = LISTS ? (int64_t)u0r * FS_QPB + slot : (int64_t)u0 * FS_QPB + slot;
       float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, res = 0.0f;
       if (live && qs[slot][0] != qs[slot][0]) {  // skipped (NaN) source point
         if (FULL && out_idx) out_idx[s] = -1;
@@ -463,7 +761,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const GsCount n_src_c, const floa
       }
     }
     __syncthreads();
-  }
+  } while (!LISTS && (u0 += NU) < u_last);
 }
 
 // Batched: block b works for sequence b % B (with B = 8 a sequence lives on one XCD: its binned targets, cell table
@@ -474,8 +772,9 @@ struct IcpHalfBatch {
   int upb;  // row units per block
   unsigned long long* timeline;  // debugging aid (GRADSLAM_HIP_ICP_TIMELINE): per block [start, end, hw id, xcc id]
   IcpHalfSeq s[GS_MAX_BATCH];
+  IcpHalfLists l[GS_MAX_BATCH];   // (read by the list variants only)
 };
-template <bool FULL, int G, bool FAR>
+template <bool FULL, int G, bool FAR, int LMODE>
 __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_batch_kernel(const IcpHalfBatch hb, GsCount n_src_c,
                                                                         float dist_thresh, gs_icp_params prm, int it,
                                                                         int rows_in_reduced) {
@@ -485,8 +784,9 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_batch_kernel(const Ic
   unsigned long long t0 = 0;
   if (hb.timeline && threadIdx.x == 0) t0 = wall_clock64();
 #endif
-  icp_half_body<FULL, G, FAR>(hb.s[blockIdx.x % B], n_src_c, dist_thresh, prm, it, rows_in_reduced,
-                         gs_xcd_block(blk, nblk, X), hb.upb, hb.timeline ? hb.timeline + 72 * (size_t)blockIdx.x : nullptr);
+  icp_half_body<FULL, G, FAR, LMODE>(hb.s[blockIdx.x % B], hb.l[blockIdx.x % B], n_src_c, dist_thresh, prm, it, rows_in_reduced,
+                                     gs_xcd_block(blk, nblk, X), hb.upb,
+                                     hb.timeline ? hb.timeline + 72 * (size_t)blockIdx.x : nullptr);
 #ifdef GS_ICP_TIMELINE
   if (hb.timeline && threadIdx.x == 0) {
     unsigned long long* r = hb.timeline + 72 * (size_t)blockIdx.x;
@@ -536,9 +836,10 @@ static IcpHalfPlan icp_half_plan(int64_t n_src, int B, int g_max = 8) {
   }
   return pl;
 }
+// lmode: what the launch does with the candidate lists of ordinary queries (icp_half_body; 0 = the variant without them)
 template <bool FULL>
 static void icp_half_launch(const IcpHalfPlan& pl, IcpHalfBatch& hb, GsCount n_src_c, const gs_icp_params* prm, int it,
-                            int rows_in_reduced, hipStream_t st) {
+                            int rows_in_reduced, hipStream_t st, int lmode = 0) {
   hb.upb = pl.upb;
   static const char* tl_path = getenv("GRADSLAM_HIP_ICP_TIMELINE");
   static unsigned long long* tl_buf = nullptr;
@@ -554,14 +855,23 @@ static void icp_half_launch(const IcpHalfPlan& pl, IcpHalfBatch& hb, GsCount n_s
   }
   const dim3 grid((unsigned)(hb.B * pl.nb)), block(FS_BLOCK);
   const bool far = hb.s[0].far_cq != nullptr;   // candidate lists of far queries: the same for all sequences of a batch
-#define GS_HALF_LAUNCH(G_, FAR_)                                                                                        \
-  hipLaunchKernelGGL((gs_icp_half_batch_kernel<FULL, G_, FAR_>), grid, block, 0, st, hb, n_src_c, prm->dist_thresh, *prm, \
-                     it, rows_in_reduced)
-  // (no 8-lane variant with candidate lists: its first half does not fit the register budget; localize_chunk plans
-  // solves with lists for at most 4 lanes per query)
-  if (pl.G == 8) GS_HALF_LAUNCH(8, false);
-  else if (pl.G == 4) { if (far) GS_HALF_LAUNCH(4, true); else GS_HALF_LAUNCH(4, false); }
-  else { if (far) GS_HALF_LAUNCH(2, true); else GS_HALF_LAUNCH(2, false); }
+#define GS_HALF_LAUNCH(G_, FAR_, LMODE_)                                                                               \
+  hipLaunchKernelGGL((gs_icp_half_batch_kernel<FULL, G_, FAR_, LMODE_>), grid, block, 0, st, hb, n_src_c,              \
+                     prm->dist_thresh, *prm, it, rows_in_reduced)
+#define GS_HALF_LAUNCH_L(G_)                                                 \
+  do {                                                                       \
+    if (lmode == 2) GS_HALF_LAUNCH(G_, false, 2);                            \
+    else if (lmode == 1) GS_HALF_LAUNCH(G_, false, 1);                       \
+    else GS_HALF_LAUNCH(G_, false, 0);                                       \
+  } while (0)
+  // (no 8-lane variant with far-candidate lists: its first half does not fit the register budget; localize_chunk plans
+  // solves with such lists for at most 4 lanes per query)
+  const bool lists = lmode != 0 && !far && hb.l[0].lq != nullptr;
+  if (!lists) lmode = 0;
+  if (pl.G == 8) GS_HALF_LAUNCH_L(8);
+  else if (pl.G == 4) { if (far) GS_HALF_LAUNCH(4, true, 0); else GS_HALF_LAUNCH_L(4); }
+  else { if (far) GS_HALF_LAUNCH(2, true, 0); else GS_HALF_LAUNCH_L(2); }
+#undef GS_HALF_LAUNCH_L
 #undef GS_HALF_LAUNCH
   if (hb.timeline) {  // debugging aid: synchronous dump of this launch's block records
     std::unique_ptr<unsigned long long[]> h(new unsigned long long[tl_n]);
@@ -840,6 +1150,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
     const IcpHalfPlan plan = icp_half_plan(n_src, 1);
     IcpHalfBatch hb;
     hb.B = 1;
+    hb.l[0] = IcpHalfLists{nullptr, nullptr, nullptr};
     for (int it = 0; it < prm->numiters; ++it) {
       float* cur = cloud(it);
       hb.s[0] = IcpHalfSeq{cur_in, cur, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, gm.sorted_n,
@@ -934,7 +1245,6 @@ extern "C" int gs_icp_map_dc_f32(const float* src, int64_t n_src_bound, const in
                  icp_scratch, nullptr, stream, n_src_dev, n_map_dev, GsTargetFilter{pix, W, ds});
 }
 
-#include "gs_icp_tile.h"
 
 // ---------------------------------------------------------------- batched localisation -----
 // ICPSLAM._localize (slam/icpslam.py:238-247) for B independent sequences in ONE chain of launches: every kernel
@@ -952,6 +1262,7 @@ struct LocSeq {
   char* clear_ptr;       // grid scratch bytes that must be zero before the build
   int64_t* n_valid;      // number of lattice slots with depth (profiling / roofline accounting)
   int* far_n;            // [FS_FAR_PASSES] counters of the far-query lists of the solve, zeroed here
+  int* lstat;            // [2 * GL_STAT_LAUNCHES] failure counters of the ordinary candidate lists, zeroed here
 };
 struct LocBatch {
   int B, W, ds, Wl;
@@ -999,6 +1310,8 @@ GS_DEV void loc_prep_block(const LocBatch& lb, const unsigned bid, const unsigne
       q.state->s[1] = sm;
       if (q.far_n)
         for (int i = 0; i < FS_FAR_PASSES; ++i) q.far_n[i] = 0;
+      if (q.lstat)
+        for (int i = 0; i < 2 * GL_STAT_LAUNCHES; ++i) q.lstat[i] = 0;
       if (lb.numiters == 0) icp_write_result(sm, q.pose16, q.out_pose16);
     }
     return;
@@ -1063,33 +1376,26 @@ __global__ void __launch_bounds__(FS_BLOCK) gs_icp_finish_batch_kernel(const Icp
 
 static int64_t loc_lattice(int H, int W, int ds) { return (int64_t)((H + ds - 1) / ds) * ((W + ds - 1) / ds); }
 
-// what the tile engine adds behind the ICP scratch of a sequence: the slabs, two partial-row buffers (one row per tile)
-// and the reduced row of large solves
-struct ItMem {
-  char* slabs;
-  uint32_t* cand;   // candidate lists, 16 bytes per lattice slot
-  float4* cq;       // list centre + exactness radius, 16 bytes per lattice slot
-  float4* cn;       // normal of the previous match, 16 bytes per lattice slot
-  double* partials[2];
-  double* rowred;
+// candidate lists of ordinary queries (gs_knn.h: gl_*), behind the ICP scratch of a sequence
+struct ListMem {
+  float4* lq;      // [n_lat] (position the list was built at, exactness radius; 0: no list, < 0: no list and the 2x2x2
+                   // stage cannot prove this point -- cube scans)
+  uint32_t* ls;    // [n_lat][GL_SLOTS] slots of `sorted` (~0: empty)
+  int* stat;       // [2 * GL_STAT_LAUNCHES] per launch of the solve: lists that failed their proof, points without a list
 };
-static size_t it_row_bytes(int Hl, int Wl) { return gs_align(sizeof(double) * LIN_NV * (size_t)it_tiles(Hl, Wl)); }
-static size_t it_mem_bytes(int Hl, int Wl) {
-  return it_slab_bytes(Hl, Wl) + 3 * gs_align(16 * (size_t)Hl * Wl) + 2 * it_row_bytes(Hl, Wl) + 256;
+static size_t list_mem_bytes(int64_t n_lat) {
+  return gs_align(16 * (size_t)n_lat) + gs_align(4 * GL_SLOTS * (size_t)n_lat) + gs_align(4 * 2 * GL_STAT_LAUNCHES);
 }
-static ItMem it_carve(void* base, int Hl, int Wl) {
+static ListMem list_carve(void* base, int64_t n_lat) {
   char* p = reinterpret_cast<char*>(base);
-  ItMem m;
-  m.slabs = p; p += it_slab_bytes(Hl, Wl);
-  m.cand = reinterpret_cast<uint32_t*>(p); p += gs_align(16 * (size_t)Hl * Wl);
-  m.cq = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)Hl * Wl);
-  m.cn = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)Hl * Wl);
-  for (int k = 0; k < 2; ++k) { m.partials[k] = reinterpret_cast<double*>(p); p += it_row_bytes(Hl, Wl); }
-  m.rowred = reinterpret_cast<double*>(p);
+  ListMem m;
+  m.lq = reinterpret_cast<float4*>(p); p += gs_align(16 * (size_t)n_lat);
+  m.ls = reinterpret_cast<uint32_t*>(p); p += gs_align(4 * GL_SLOTS * (size_t)n_lat);
+  m.stat = reinterpret_cast<int*>(p);
   return m;
 }
 
-// candidate lists of far queries (gs_knn.h), behind the tile engine's part of a sequence's scratch
+// candidate lists of far queries (gs_knn.h), behind the lists of the ordinary ones
 struct FarMem {
   uint32_t* c;    // [n_lat][GS_FAR_SLOTS] slots of `sorted`
   float4* cq;     // [n_lat] (position the list was built at, exactness radius)
@@ -1198,230 +1504,11 @@ extern "C" int64_t gs_localize_scratch_bytes(int H, int W, int ds, int64_t n_map
   if (H < 1 || W < 1 || ds < 1) return 0;
   const int64_t n_lat = loc_lattice(H, W, ds);
   return (int64_t)(gs_align(12 * (size_t)n_lat) + gs_align(4 * (size_t)(n_map_bound > 0 ? n_map_bound : 1)) + 256) +
-         gs_icp_scratch_bytes(n_lat, n_map_bound) + (int64_t)it_mem_bytes((H + ds - 1) / ds, (W + ds - 1) / ds) +
+         gs_icp_scratch_bytes(n_lat, n_map_bound) + (int64_t)list_mem_bytes(n_lat) +
          (int64_t)far_mem_bytes(n_lat);
 }
 
-static GsCount n_src_rows(int nrows) { return GsCount{(int64_t)nrows * FS_QPB, nullptr}; }  // a count that yields nrows rows
-
-// GRADSLAM_HIP_ICP_ENGINE=tile: the tile engine (gs_icp_tile.h: LDS slabs + candidate lists) instead of the row-unit
-// kernels (gs_icp_half_batch_kernel).  Bit-identical results; measured in round 3: 11.6 / 13.5 us per
-// launch in the steady state of a solve against 17.3 us, but the launches that (re)build lists in the first iterations
-// cost what the steady state saves -- 6 640 against 6 740 frames/s end to end at 8 sequences per GPU -- so the row-unit
-// kernels stay the default.
-static bool icp_tile_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("GRADSLAM_HIP_ICP_ENGINE");
-    v = (e && strcmp(e, "tile") == 0) ? 1 : 0;
-  }
-  return v == 1;
-}
-
 static int64_t loc_rows(const gs_map_view& m) { return m.capacity > m.n_bound ? m.capacity : m.n_bound; }
-
-// ---- replaying the half-iteration launches of a solve as a hipGraph.  Their kernel arguments depend on the scratch
-// layout, the map buffers and the solver parameters only (not on the frame), so the 2 x numiters launches of a chunk
-// are captured once and replayed every frame: one graph launch instead of 40 kernel launches on the host
-// (GRADSLAM_HIP_GRAPH=0: plain launches; profiling passes and debugging builds always use plain launches).
-struct ItGraphKey {
-  int dev, B, Hl, Wl;
-  gs_icp_params prm;
-  const void* ptr[GS_MAX_BATCH][3];   // scratch, map points, map normals
-  int64_t rows[GS_MAX_BATCH];
-};
-struct ItGraphEntry {
-  bool used;
-  ItGraphKey key;
-  hipGraph_t graph;
-  hipGraphExec_t exec;
-  unsigned long long stamp;
-};
-constexpr int IT_GRAPH_SLOTS = 16;
-static ItGraphEntry g_it_graphs[IT_GRAPH_SLOTS];
-static unsigned long long g_it_graph_clock = 0;
-static std::mutex g_it_graph_mutex;
-static bool it_graphs_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("GRADSLAM_HIP_GRAPH");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v == 1;
-}
-static hipStream_t it_capture_stream(int dev) {
-  static hipStream_t cs[64] = {};
-  if (dev < 0 || dev >= 64) return nullptr;
-  if (!cs[dev] && hipStreamCreateWithFlags(&cs[dev], hipStreamNonBlocking) != hipSuccess) cs[dev] = nullptr;
-  return cs[dev];
-}
-
-// The 2 x numiters half-iterations + the final update of one chunk on the tile engine.  The grid of every sequence is
-// built; lattice / state / d2prev live where the row-unit engine keeps them.
-static int localize_tiles(const gs_localize_seq* seqs, int B, int Hl, int Wl, const gs_icp_params* prm, const LocBatch& lb,
-                          const IcpScratch* sc, const GridMem* gm, double prof_bytes, hipStream_t st) {
-  ItMem im[GS_MAX_BATCH];
-  ItBuildBatch bb;
-  ItBatch hb;
-  bb.B = hb.B = B;
-  bb.Wl = hb.Wl = Wl; bb.Hl = hb.Hl = Hl;
-  bb.tiles_x = hb.tiles_x = it_tiles_x(Wl);
-  static const int force_scan = getenv("GRADSLAM_HIP_ICP_FORCE_SCAN") ? atoi(getenv("GRADSLAM_HIP_ICP_FORCE_SCAN")) : 0;
-  hb.force_scan = force_scan;
-  const int ntiles = hb.ntiles = it_tiles(Hl, Wl);
-  const int64_t n_lat = (int64_t)Hl * Wl;
-  for (int b = 0; b < B; ++b) {
-    const gs_localize_seq& q = seqs[b];
-    im[b] = it_carve(reinterpret_cast<char*>(sc[b].state) + gs_icp_scratch_bytes(n_lat, loc_rows(q.map)), Hl, Wl);
-    bb.s[b] = ItBuildSeq{lb.s[b].lattice, gm[b].g, gm[b].cell_start, gm[b].sorted, gm[b].sorted_n, im[b].slabs};
-  }
-  {
-    GsProf prof(GS_PROF_COMPACT, 0.0, st);
-    hipLaunchKernelGGL(gs_it_slab_build_kernel, dim3((unsigned)(B * ntiles)), dim3(IT_NQ), 0, st, bb);
-  }
-  const bool reduce_rows = ntiles > FS_REDUCE_ROWS;
-  const dim3 grid((unsigned)(B * ntiles)), block(IT_BLOCK);
-  int h = 0;
-  auto enqueue_halves = [&](hipStream_t st) {
-  h = 0;
-  for (int it = 0; it < prm->numiters; ++it) {
-    for (int b = 0; b < B; ++b) {
-      const gs_localize_seq& q = seqs[b];
-      const float* cur_in = it == 0 ? lb.s[b].lattice : (((it - 1) & 1) ? sc[b].srcB : sc[b].srcA);
-      float* cur = (it & 1) ? sc[b].srcB : sc[b].srcA;
-      hb.s[b] = ItSeq{cur_in, cur, q.map.points, q.map.normals, gm[b].g,
-                      gm[b].cell_start, gm[b].sorted, gm[b].sorted_n, im[b].slabs, reinterpret_cast<float*>(sc[b].best),
-                      im[b].cand, im[b].cq, im[b].cn, im[b].partials[(h + 1) & 1], im[b].partials[h & 1], &sc[b].state->s[h & 1],
-                      &sc[b].state->s[(h + 1) & 1], sc[b].state->trace};
-    }
-#ifdef GS_ICP_TIMELINE
-    // debugging builds (GRADSLAM_HIP_ICP_TIMELINE=<path>): record every launch of the solve (the file holds the last
-    // solve of the process)
-    static const char* tl_path = getenv("GRADSLAM_HIP_ICP_TIMELINE");
-    static unsigned long long* tl_buf = nullptr;
-    const size_t tl_n = 8 * (size_t)B * ntiles;   // words per launch
-    const size_t tl_cap = (size_t)64 << 20;
-    hb.tl = nullptr;
-    if (tl_path) {
-      if (!tl_buf && hipMalloc(&tl_buf, tl_cap) != hipSuccess) tl_buf = nullptr;
-      if (tl_buf && 8 * tl_n * 2 * (size_t)prm->numiters <= tl_cap) {
-        if (it == 0) (void)hipMemsetAsync(tl_buf, 0, 8 * tl_n * 2 * (size_t)prm->numiters, st);
-        hb.tl = tl_buf + tl_n * (2 * (size_t)it);
-      }
-    }
-#endif
-    hipLaunchKernelGGL((gs_icp_tile_half_kernel<true>), grid, block, 0, st, hb, prm->dist_thresh, *prm, it, 0);
-    ++h;
-    if (reduce_rows) {
-      ItRowsBatch rb;
-      rb.B = B; rb.nrows = ntiles;
-      for (int b = 0; b < B; ++b) { rb.in[b] = im[b].partials[(h + 1) & 1]; rb.out[b] = im[b].rowred; }
-      hipLaunchKernelGGL(gs_icp_tile_reduce_rows_kernel, dim3((unsigned)B), dim3(IT_BLOCK), 0, st, rb);
-    }
-    for (int b = 0; b < B; ++b) {
-      ItSeq& u = hb.s[b];
-      u.src_in = (it & 1) ? sc[b].srcB : sc[b].srcA;
-      u.src_out = nullptr;
-      u.partials_in = reduce_rows ? im[b].rowred : im[b].partials[(h + 1) & 1];
-      u.partials_out = im[b].partials[h & 1];
-      u.st_in = &sc[b].state->s[h & 1];
-      u.st_out = &sc[b].state->s[(h + 1) & 1];
-    }
-#ifdef GS_ICP_TIMELINE
-    if (hb.tl) hb.tl += tl_n;
-#endif
-    hipLaunchKernelGGL((gs_icp_tile_half_kernel<false>), grid, block, 0, st, hb, prm->dist_thresh, *prm, it,
-                       reduce_rows ? 1 : 0);
-    ++h;
-#ifdef GS_ICP_TIMELINE
-    if (hb.tl && it == prm->numiters - 1) {
-      const size_t nw = tl_n * 2 * (size_t)prm->numiters;
-      std::unique_ptr<unsigned long long[]> hbuf(new unsigned long long[nw]);
-      if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hbuf.get(), tl_buf, 8 * nw, hipMemcpyDeviceToHost) == hipSuccess) {
-        FILE* f = fopen(tl_path, "w");
-        if (f) {
-          fprintf(f, "# tile engine B=%d tiles=%d: launch(2 it + half) block start issued prologue lists scans leftovers end counts\n", B, ntiles);
-          for (size_t i = 0; i < nw / 8; ++i) {
-            fprintf(f, "%zu %zu", i / (tl_n / 8), i % (tl_n / 8));
-            for (int k = 0; k < 8; ++k) fprintf(f, " %llu", hbuf[8 * i + k]);
-            fprintf(f, "\n");
-          }
-          fclose(f);
-        }
-      }
-    }
-    hb.tl = nullptr;
-#endif
-  }
-  };
-  bool plain = true;
-#ifndef GS_ICP_TIMELINE
-  if (it_graphs_enabled() && !g_gs_prof_on && !force_scan && prm->numiters > 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    ItGraphKey key;
-    memset(&key, 0, sizeof(key));
-    key.dev = dev; key.B = B; key.Hl = Hl; key.Wl = Wl; key.prm = *prm;
-    for (int b = 0; b < B; ++b) {
-      key.ptr[b][0] = seqs[b].scratch; key.ptr[b][1] = seqs[b].map.points; key.ptr[b][2] = seqs[b].map.normals;
-      key.rows[b] = loc_rows(seqs[b].map);
-    }
-    std::lock_guard<std::mutex> lock(g_it_graph_mutex);
-    ItGraphEntry* hit = nullptr;
-    ItGraphEntry* victim = &g_it_graphs[0];
-    for (int i = 0; i < IT_GRAPH_SLOTS; ++i) {
-      ItGraphEntry& e = g_it_graphs[i];
-      if (e.used && memcmp(&e.key, &key, sizeof(key)) == 0) { hit = &e; break; }
-      if (!e.used || (victim->used && e.stamp < victim->stamp)) victim = &e;
-    }
-    if (!hit) {
-      hipStream_t cs = it_capture_stream(dev);
-      if (cs && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        enqueue_halves(cs);
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        if (hipStreamEndCapture(cs, &graph) == hipSuccess && graph &&
-            hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-          if (victim->used) { (void)hipGraphExecDestroy(victim->exec); (void)hipGraphDestroy(victim->graph); }
-          victim->used = true; victim->key = key; victim->graph = graph; victim->exec = exec;
-          hit = victim;
-        } else {
-          if (graph) (void)hipGraphDestroy(graph);
-          (void)hipGetLastError();
-        }
-      }
-    }
-    if (hit) {
-      hit->stamp = ++g_it_graph_clock;
-      if (hipGraphLaunch(hit->exec, st) == hipSuccess) {
-        plain = false;
-        h = 2 * prm->numiters;
-      } else {
-        (void)hipGetLastError();
-      }
-    }
-  }
-#endif
-  if (plain) {
-    std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
-    enqueue_halves(st);
-  }
-  {
-    GsProf prof(GS_PROF_SOLVE, 1.0, st);
-    IcpFinishBatch fb;
-    fb.B = B;
-    for (int b = 0; b < B; ++b) {
-      fb.partials_in[b] = im[b].partials[(h + 1) & 1];
-      fb.st[b] = sc[b].state;
-      fb.compose16[b] = seqs[b].prev_pose16;
-      fb.out_T16[b] = seqs[b].out_pose16;
-    }
-    hipLaunchKernelGGL(gs_icp_finish_batch_kernel, dim3((unsigned)B), dim3(FS_BLOCK), 0, st, fb, n_src_rows(ntiles), h & 1,
-                       *prm);
-  }
-  GS_LAUNCH_CHECK();
-  return GS_OK;
-}
 
 // scratch of one sequence: lattice | pix | n_valid | ICP scratch (which holds the grid)
 struct LocCarve {
@@ -1469,7 +1556,7 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
     sc[b] = cv.sc;
     gm[b] = cv.gm;
     lb.s[b] = LocSeq{q.vertex, q.depth, q.prev_pose16, lattice, sc[b].state, q.out_pose16,
-                     reinterpret_cast<char*>(gm[b].g), n_valid, nullptr};
+                     reinterpret_cast<char*>(gm[b].g), n_valid, nullptr, nullptr};
     static int binned_normals = -1;  // GRADSLAM_HIP_ICP_BINNED_NORMALS=0: gather the matches' normals from the map (A/B)
     if (binned_normals < 0) {
       const char* e = getenv("GRADSLAM_HIP_ICP_BINNED_NORMALS");
@@ -1480,8 +1567,7 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
                         binned_normals ? q.map.normals : nullptr, gm[b]};
     if (g_gs_prof_on) GS_HIP(hipMemsetAsync(n_valid, 0, 8, st));
   }
-  // candidate lists of far queries (gs_knn.h; the results do not depend on them), row-unit kernels only, behind the tile
-  // engine's part of the scratch.
+  // candidate lists of far queries (gs_knn.h; the results do not depend on them), behind the ordinary lists in the scratch.
   // Policy (measured): at 1296x968 (78k source points, clusters of far ones at the frame borders)
   // +4 % frames/s over 200 frames; at 640x480 the handful of far points does not pay for the list checks (-2 %).
   // GRADSLAM_HIP_ICP_FAR=1 / 0 forces the lists on / off.
@@ -1490,14 +1576,25 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
     const char* e = getenv("GRADSLAM_HIP_ICP_FAR");
     far_lists = e ? (atoi(e) != 0 ? 1 : 0) : 2;
   }
-  const bool far_on = (far_lists == 1 || (far_lists == 2 && n_lat >= FAR_MIN_LATTICE)) && prm->numiters > 0 &&
-                      !(icp_tile_enabled() && gm[0].sorted_n);
+  const bool far_on = (far_lists == 1 || (far_lists == 2 && n_lat >= FAR_MIN_LATTICE)) && prm->numiters > 0;
   FarMem fm[GS_MAX_BATCH];
   for (int b = 0; b < B; ++b) {
     fm[b] = far_carve(reinterpret_cast<char*>(sc[b].state) + gs_icp_scratch_bytes(n_lat, loc_rows(seqs[b].map)) +
-                          it_mem_bytes((H + ds - 1) / ds, Wl), n_lat);
+                          list_mem_bytes(n_lat), n_lat);
     lb.s[b].far_n = fm[b].n;   // (zeroed by the prep launch whether or not this solve keeps lists: gs_localize_far_stats_i64)
     if (!far_on) fm[b] = FarMem{nullptr, nullptr, nullptr, nullptr};
+  }
+  // candidate lists of ordinary queries (gs_knn.h: gl_*; the results do not depend on them): every solve that keeps no
+  // far lists.  GRADSLAM_HIP_ICP_LISTS=0 switches them off (A/B runs).
+  static int ord_lists = -1;
+  if (ord_lists < 0) {
+    const char* e = getenv("GRADSLAM_HIP_ICP_LISTS");
+    ord_lists = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  ListMem lm[GS_MAX_BATCH];
+  for (int b = 0; b < B; ++b) {
+    lm[b] = list_carve(reinterpret_cast<char*>(sc[b].state) + gs_icp_scratch_bytes(n_lat, loc_rows(seqs[b].map)), n_lat);
+    lb.s[b].lstat = lm[b].stat;   // (zeroed by the prep launch whether or not this solve keeps lists)
   }
   lb.count_valid = g_gs_prof_on ? 1 : 0;
   lb.clear_bytes = gs_knn_grid_clear_bytes(gm[0], gb.cells_cap);  // same layout offsets for every sequence
@@ -1535,10 +1632,10 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
       prof_bytes += icp_alg_bytes(prm->numiters, n_lat, nv, hits);
     }
   }
-  if (icp_tile_enabled() && gm[0].sorted_n)  // (the binned normals are part of the slabs)
-    return localize_tiles(seqs, B, (H + ds - 1) / ds, Wl, prm, lb, sc, gm, prof_bytes, st);
   std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
   const IcpHalfPlan plan = icp_half_plan(n_lat, B, far_on ? 4 : 8);
+  // (a block reads the lists of ONE group of row units: solves whose blocks walk several groups keep none)
+  const bool lists_on = ord_lists == 1 && !far_on && plan.upb * plan.G * FS_QPB <= FS_BLOCK;
   IcpHalfBatch hb;
   hb.B = B;
   int h = 0;
@@ -1552,8 +1649,10 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
                            sc[b].partials[(h + 1) & 1], sc[b].partials[h & 1],
                            &sc[b].state->s[h & 1], &sc[b].state->s[(h + 1) & 1], sc[b].state->trace, nullptr, nullptr,
                            nullptr, fm[b].cq, fm[b].c, fm[b].idx, fm[b].n};
+      hb.l[b] = lists_on ? IcpHalfLists{lm[b].lq, lm[b].ls, lm[b].stat} : IcpHalfLists{nullptr, nullptr, nullptr};
     }
-    icp_half_launch<true>(plan, hb, n_src_c, prm, it, 0, st);
+    // lists: nothing in the first search of a solve (the large step follows), built behind the second, tried from then on
+    icp_half_launch<true>(plan, hb, n_src_c, prm, it, 0, st, lists_on ? (h == 0 ? 0 : 2) : 0);
     if (far_on && fs_far_pass(it) >= 0) {   // lists for the far source points this search found
       const int fp = fs_far_pass(it);
       FarBuildBatch fbb;
@@ -1579,7 +1678,7 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
       u.st_in = &sc[b].state->s[h & 1];
       u.st_out = &sc[b].state->s[(h + 1) & 1];
     }
-    icp_half_launch<false>(plan, hb, n_src_c, prm, it, reduce_rows ? 1 : 0, st);
+    icp_half_launch<false>(plan, hb, n_src_c, prm, it, reduce_rows ? 1 : 0, st, lists_on ? (h == 1 ? 1 : 2) : 0);
     ++h;
   }
   prof_loop.reset();
@@ -1651,7 +1750,7 @@ extern "C" int gs_localize_far_stats_i64(const void* scratch, int H, int W, int 
   q.map.capacity = map_rows; q.map.n_bound = map_rows;
   const LocCarve cv = loc_carve(q, n_lat);
   const FarMem fm = far_carve(reinterpret_cast<char*>(cv.sc.state) + gs_icp_scratch_bytes(n_lat, map_rows) +
-                                  it_mem_bytes((H + ds - 1) / ds, (W + ds - 1) / ds), n_lat);
+                                  list_mem_bytes(n_lat), n_lat);
   hipStream_t st = gs_stream(stream);
   // (the result words live behind the counters, in the 256 bytes reserved for them)
   int* out4 = fm.n + 8;
@@ -1667,6 +1766,24 @@ extern "C" int gs_localize_far_stats_i64(const void* scratch, int H, int W, int 
   if (getenv("GRADSLAM_HIP_DEBUG_GRID"))
     fprintf(stderr, "grid: box (%.3f %.3f %.3f)-(%.3f %.3f %.3f) c %.4f cells %d x %d x %d = %d\n", g.ox, g.oy, g.oz, g.mx,
             g.my, g.mz, g.c, g.nx, g.ny, g.nz, g.ncell);
+  return GS_OK;
+}
+
+extern "C" int gs_localize_list_stats_i64(const void* scratch, int H, int W, int ds, int64_t map_rows, int64_t* out128_host,
+                                          void* stream) {
+  GS_REQUIRE(scratch && out128_host && H > 0 && W > 0 && ds > 0 && map_rows > 0, "bad arguments");
+  const int64_t n_lat = loc_lattice(H, W, ds);
+  gs_localize_seq q;
+  memset(&q, 0, sizeof(q));
+  q.scratch = const_cast<void*>(scratch);
+  q.map.capacity = map_rows; q.map.n_bound = map_rows;
+  const LocCarve cv = loc_carve(q, n_lat);
+  const ListMem lm = list_carve(reinterpret_cast<char*>(cv.sc.state) + gs_icp_scratch_bytes(n_lat, map_rows), n_lat);
+  int h[2 * GL_STAT_LAUNCHES];
+  hipStream_t st = gs_stream(stream);
+  GS_HIP(hipMemcpyAsync(h, lm.stat, sizeof(h), hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < 2 * GL_STAT_LAUNCHES; ++i) out128_host[i] = h[i];
   return GS_OK;
 }
 

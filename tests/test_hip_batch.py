@@ -389,8 +389,6 @@ def test_far_candidate_lists_leave_results_identical(tmp_path):
     import os
     import subprocess
     import sys
-    if os.environ.get("GRADSLAM_HIP_ICP_ENGINE") == "tile":
-        pytest.skip("the candidate lists of far queries belong to the row-unit kernels (the tile engine has its own)")
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for far in ("1", "0"):
@@ -405,6 +403,63 @@ def test_far_candidate_lists_leave_results_identical(tmp_path):
     assert np.array_equal(a["poses"].view(np.int32), b["poses"].view(np.int32))
     assert a["n"][0] == b["n"][0]
     assert np.array_equal(a["pts"].view(np.int32), b["pts"].view(np.int32))
+
+
+_LIST_SCRIPT = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+import gradslam_amd as gs
+from gradslam_amd import ops
+from gradslam_amd.datasets.synthetic import make_sequence
+B, L, H, W = int(sys.argv[2]), 4, int(sys.argv[3]), int(sys.argv[4])
+seqs = [make_sequence(L, H, W, seed=3 + b) for b in range(B)]
+st = lambda k: torch.from_numpy(np.stack([s[k] for s in seqs])).cuda()
+poses = st("poses"); poses[:, 1:] = poses[:, :1]
+frames = gs.RGBDImages(st("colors"), st("depths"), st("intrinsics"), poses)
+slam = gs.slam.PointFusion(odom="gradicp", device="cuda")
+pc, prev, rec, stats = gs.Pointclouds(device="cuda"), None, [], []
+for i in range(L):
+    live = frames[:, i]
+    pc, p = slam.step(pc, live, prev, inplace=True)
+    prev = live
+    rec.append(p[:, 0].cpu().numpy())
+    if i >= 1:
+        stats.append([ops.localize_list_stats(torch.device("cuda", 0), b, H, W, 4, pc._buf["points"][b].shape[0]) for b in range(B)])
+np.savez(sys.argv[1], poses=np.stack(rec), n=np.array([int(x.shape[0]) for x in pc.points_list]),
+         pts=np.concatenate([x.cpu().numpy() for x in pc.points_list]), stats=np.array(stats))
+"""
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 480, 640), (8, 480, 640), (3, 240, 320), (2, 67, 131)])
+def test_candidate_lists_leave_results_identical(tmp_path, B, H, W):
+    """Round 4: the half-iteration kernels keep a candidate list per source point (every target within R of where the
+    point was searched from) and, from the third launch of a solve on, try the list before any search
+    (gs_knn.h: gl_*; the listed points are fetched while the prologue waits for the partial rows).  A proof on the list
+    is exact and everything else is the search that ran before, so GRADSLAM_HIP_ICP_LISTS=0 must give the same bits:
+    poses, surfel counts, points -- at 8 / 4 / 2 lanes per source point (one, three / two, eight sequences per GPU).
+    And the lists must carry the solve: in its second half no launch may re-search more than 2 % of the points."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for on in ("1", "0"):
+        out = str(tmp_path / ("lists%s.npz" % on))
+        subprocess.run([sys.executable, "-c", _LIST_SCRIPT % repo, out, str(B), str(H), str(W)], check=True, timeout=900,
+                       env=dict(os.environ, GRADSLAM_HIP_ICP_LISTS=on))
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.array_equal(a["poses"].view(np.int32), b["poses"].view(np.int32))
+    assert np.array_equal(a["n"], b["n"])
+    assert np.array_equal(a["pts"].view(np.int32), b["pts"].view(np.int32))
+    assert not b["stats"].any()                                  # no lists, no counters
+    st = a["stats"]                                              # (frames - 1, B, 2, 64)
+    n_lat = ((H + 3) // 4) * ((W + 3) // 4)
+    assert st[:, :, :, :2].sum() == 0                            # launches 0 and 1 try no lists
+    late = st[:, :, :, 20:40].sum(axis=2)                        # failed + without a list, launches 20 .. 39
+    assert late.max() <= 0.02 * n_lat, late.max()
+    assert st[:, :, 0, 2:40].sum() > 0 or n_lat < 2000           # some list failed somewhere (the counters are alive)
 
 
 def test_pointfusion_1296x968_vs_reference_golden(gs, golden):

@@ -1,0 +1,31 @@
+"""Per-launch failure counters of the candidate lists of ordinary ICP queries (gs_localize_list_stats_i64) on the
+benchmark workload:  python tools/list_stats_probe.py [B] [frames]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gradslam_amd as gs
+from gradslam_amd import ops
+from gradslam_amd.datasets.synthetic import make_sequence
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+H, W = 480, 640
+seqs = [make_sequence(L, H, W, seed=b) for b in range(B)]
+st = lambda k: torch.from_numpy(np.stack([s[k] for s in seqs])).cuda()
+poses = st("poses"); poses[:, 1:] = poses[:, :1]
+frames = gs.RGBDImages(st("colors"), st("depths"), st("intrinsics"), poses)
+slam = gs.slam.PointFusion(odom="gradicp", device="cuda")
+pc, prev = gs.Pointclouds(device="cuda"), None
+tot = np.zeros((2, 64), np.int64)
+worst = np.zeros(64, np.int64)
+for f in range(L):
+    live = frames[:, f]; pc, _ = slam.step(pc, live, prev, inplace=True); prev = live
+    if f >= 1:
+        for b in range(B):
+            fa, op = ops.localize_list_stats(torch.device("cuda", 0), b, H, W, 4, pc._buf["points"][b].shape[0])
+            tot[0] += fa; tot[1] += op
+            worst = np.maximum(worst, np.array(fa) + np.array(op))
+n = (L - 1) * B
+print("mean per solve over %d solves (19200 lattice slots): launch: failed lists / points without a list / worst solve (failed + without)" % n)
+for h in range(40):
+    print("  launch %2d: %8.1f %8.1f %6d" % (h, tot[0, h] / n, tot[1, h] / n, worst[h]))
