@@ -334,7 +334,8 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
   __shared__ int unres_n, hard_n;
   __shared__ unsigned long long red[FS_BLOCK / GS_WAVE];
   __shared__ uint8_t far_s[NQ];   // the query's candidate list proved this search (it keeps its flag)
-  __shared__ uint32_t stage_s[LISTS ? NQ * GL_STAGE : 1];   // lists under construction (one per group)
+  // lists under construction: one per group of the search (LMODE 1) / per 16-lane group of the left-over pass (LMODE 2)
+  __shared__ uint32_t stage_s[LMODE == 1 ? NQ * GL_STAGE : (LMODE == 2 ? (FS_BLOCK / FS_HG) * GL_STAGE : 1)];
   // (LMODE 2) source point and (list centre, radius) of every group, parked across the scalar stage of the prologue: its
   // one-lane float64 code needs the registers, the lanes that wait for it do not
   __shared__ float4 park_s[LMODE == 2 ? 2 * NQ : 1];
@@ -576,8 +577,8 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win, rball);
         if (build_all) {
           if (done) {
-            gl_build_block<G>(g, cell_start, sorted, qx, qy, qz, lane, __uint_as_float((uint32_t)(key >> 32)), LM,
-                              stage_s + slot * GL_STAGE, ls + GL_SLOTS * s, lq + s);
+            gl_build<G>(g, cell_start, sorted, qx, qy, qz, lane, __uint_as_float((uint32_t)(key >> 32)), 0, LM,
+                        stage_s + slot * GL_STAGE, ls + GL_SLOTS * s, lq + s);
           } else if (lane == 0) {
             lq[s] = make_float4(qx, qy, qz, -1.0f);
           }
@@ -622,10 +623,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         if (win >= 0) bslot_s[hs] = win;
         win = -1;
         // (the new list is written by a pass of its own below: inside this loop its registers come on top of the search's)
-        if (l16 == 0) {
-          if (done) build_q[atomicAdd(&build_n, 1)] = hs;
-          else lq[sq] = make_float4(hx, hy, hz, -1.0f);
-        }
+        if (l16 == 0 && done) build_q[atomicAdd(&build_n, 1)] = hs;
       }
       if (!done) {
         int kdone;
@@ -636,6 +634,17 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         if (FULL && FAR && far_pass >= 0 && far_on && l16 == 0 && done && kdone >= FS_FAR_MIN_RING) {
           far_cq[sq] = make_float4(__uint_as_float((uint32_t)(key >> 32)), (float)kdone, 0.0f, 0.0f);
           q.far_idx[(int64_t)far_pass * n_src + atomicAdd(q.far_n + far_pass, 1)] = (int)sq;
+        }
+        // (LMODE 2) a point the cubes served gets its list from the cube (one cell wider when the neighbour sits close to
+        // the cube's bound); what is left to the brute-force pass keeps none and comes back here in every launch
+        if (LMODE == 2 && l16 == 0) {
+          if (done) {
+            const float d1 = sqrtf(__uint_as_float((uint32_t)(key >> 32)));
+            const int kE = kdone + ((d1 + 0.1f * g.c > (float)kdone * g.c * 0.999f) ? 1 : 0);
+            build_q[atomicAdd(&build_n, 1)] = hs | (kE << 16);
+          } else {
+            lq[sq] = make_float4(hx, hy, hz, -1.0f);
+          }
         }
       }
       if (win >= 0) bslot_s[hs] = win;  // a candidate of the list / the cubes beat the 2x2x2 stage
@@ -650,11 +659,11 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
       if (LMODE == 2) {   // new lists for the points whose list gave no proof and whose 2x2x2 scan did (keys_s: what it found)
         const int nbq = build_n;   // block-uniform
         for (int i = threadIdx.x / FS_HG; i < nbq; i += FS_BLOCK / FS_HG) {
-          const int hs = build_q[i];
+          const int hs = build_q[i] & 0xffff, kE = build_q[i] >> 16;   // (kE = 0: the 2x2x2 block, else the cube's radius)
           const int64_t sq = (int64_t)u0 * FS_QPB + hs;
-          gl_build_block<FS_HG>(g, cell_start, sorted, qs[hs][0], qs[hs][1], qs[hs][2], threadIdx.x & (FS_HG - 1),
-                                __uint_as_float((uint32_t)(keys_s[hs] >> 32)), LM,
-                                stage_s + (threadIdx.x / FS_HG) * GL_STAGE, ls + GL_SLOTS * sq, lq + sq);
+          gl_build<FS_HG>(g, cell_start, sorted, qs[hs][0], qs[hs][1], qs[hs][2], threadIdx.x & (FS_HG - 1),
+                          __uint_as_float((uint32_t)(keys_s[hs] >> 32)), kE, LM,
+                          stage_s + (threadIdx.x / FS_HG) * GL_STAGE, ls + GL_SLOTS * sq, lq + sq);
         }
       }
       if (threadIdx.x == 0) { hard_n = 0; if (LMODE == 2) build_n = 0; }

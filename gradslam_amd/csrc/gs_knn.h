@@ -403,7 +403,9 @@ GS_DEV float far_emit_cube(const GsGrid& g, const int* __restrict__ cell_start, 
 // targets from positions that move by millimetres, then by micrometres.  After a source point's search from q0 its
 // group re-walks the 2x2x2 block it has just scanned and keeps EVERY target within R of q0 (slots of `sorted`, at most
 // M = lanes x entries per lane), R = (distance of the neighbour + GL_MARGIN cells), capped by the distance to the nearest
-// block face with cells behind it (beyond that the block says nothing) and by the nearest target that did not fit.
+// block face with cells behind it (beyond that the block says nothing) and narrowed until the targets fit the slots.
+// Points the block cannot prove (a neighbour farther than half a cell: frame borders, holes) are served by cube scans and
+// get their list from the cube.
 // A later search from q is EXACT on the list alone when
 //     sqrt(best list distance) + |q - q0| < 0.9999 R:
 // every target outside the list is at least R from q0, hence farther than R - |q - q0| from q, hence farther than the
@@ -413,59 +415,108 @@ GS_DEV float far_emit_cube(const GsGrid& g, const int* __restrict__ cell_start, 
 // the point is now (16-lane groups, with the other leftovers).  tools/icp_list_sim.py is the CPU study behind the
 // constants: on the benchmark's solves 32-36 of the 40 launches have no failing list at all.
 constexpr int GL_SLOTS = 8;            // list slots of a source point in memory (32 bytes)
-constexpr float GL_MARGIN = 0.4f;      // cells
-constexpr int GL_STAGE = GL_SLOTS + 2; // LDS words of a list under construction: the slots, a counter, the overflow minimum
+constexpr float GL_MARGIN = 0.4f;      // cells: the widest of the GL_RADII nested radii tried (each half the one before)
+constexpr int GL_RADII = 4;
+constexpr int GL_STAGE = GL_SLOTS + GL_RADII + 1;   // LDS words of a list under construction: slots, one counter per radius, fill
 constexpr int GL_STAT_LAUNCHES = 64;   // launches of a solve with their own failure counters (diagnostics)
 // entries per lane of a G-lane group (M = G x entries <= GL_SLOTS)
 // (2 lanes x 2: a third entry per lane costs the first-half kernel eight spilled registers, and any spill costs a
 // dependent launch microseconds; tools/icp_list_sim.py: 4 slots leave two launches of a solve with 5 % failures)
 template <int G> constexpr int gl_k() { return G == 8 ? 1 : 2; }
 
-// Builds the list of the query (qx, qy, qz) whose neighbour (squared distance d1sq) the 2x2x2 stage has just proven:
-// the GB lanes of the group (same wave) re-walk the un-pruned block.  stage = GL_STAGE words of LDS owned by the group.
-// Writes slots[0 .. GL_SLOTS) and *lq = (q, R); M = capacity the READING groups use (their lanes x entries per lane).
+// Builds the list of the query (qx, qy, qz) whose neighbour (squared distance d1sq) a search has just proven: the GB
+// lanes of the group (same wave) re-walk the region that search covered, twice.
+//   kE = 0: the 2x2x2 block of grid_search_stage0 (un-pruned); every target outside it is at least as far as the nearest
+//           block face with cells behind it;
+//   kE > 0: the cube of Chebyshev radius kE cells around the query's cell (grid_search_rings); every target outside it is
+//           at least kE cells away.
+// Pass 1 counts the targets within d1 + GL_MARGIN / 2^k cells (k = 0 .. GL_RADII - 1), each capped by that bound; the
+// widest radius whose targets fit the M slots wins (a point on a dense patch keeps a list, a short one); pass 2 collects
+// them.  stage = GL_STAGE words of LDS owned by the group.  Writes slots[0 .. GL_SLOTS) and *lq = (q, R) (R = 0:
+// nothing fits); M = capacity the READING groups use (their lanes x entries per lane).
 template <int GB>
-GS_DEV void gl_build_block(const GsGrid& g, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
-                           float qx, float qy, float qz, int lane, const float d1sq, const int M, uint32_t* stage,
-                           uint32_t* __restrict__ slots, float4* __restrict__ lq) {
+GS_DEV void gl_build(const GsGrid& g, const int* __restrict__ cell_start, const float4* __restrict__ sorted, float qx,
+                     float qy, float qz, int lane, const float d1sq, const int kE, const int M, uint32_t* stage,
+                     uint32_t* __restrict__ slots, float4* __restrict__ lq) {
   const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
   const int cx = qc.cx, cy = qc.cy, cz = qc.cz;
-  const float fx = (qc.px - g.ox) * g.inv_c - (float)cx, fy = (qc.py - g.oy) * g.inv_c - (float)cy,
-              fz = (qc.pz - g.oz) * g.inv_c - (float)cz;
-  const int x0 = (fx < 0.5f) ? cx - 1 : cx, y0 = (fy < 0.5f) ? cy - 1 : cy, z0 = (fz < 0.5f) ? cz - 1 : cz;
-  const float BIG = 3.0e38f;
-  const float ax = fminf(x0 >= 1 ? fx + (float)(cx - x0) : BIG, x0 + 2 < g.nx ? (float)(x0 + 2 - cx) - fx : BIG);
-  const float ay = fminf(y0 >= 1 ? fy + (float)(cy - y0) : BIG, y0 + 2 < g.ny ? (float)(y0 + 2 - cy) - fy : BIG);
-  const float az = fminf(z0 >= 1 ? fz + (float)(cz - z0) : BIG, z0 + 2 < g.nz ? (float)(z0 + 2 - cz) - fz : BIG);
-  const float amin = fminf(ax, fminf(ay, az));
-  // (the same face distance as grid_search_stage0; a query outside the bounding box is measured from its projection,
-  // which is at most as far from every target: the ball around q0 is then only smaller than claimed -- still exact)
-  const float rb = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
-  float R = sqrtf(d1sq) + GL_MARGIN * g.c;
-  R = R < rb ? R : rb;
-  if (!(R > 0.0f)) R = 0.0f;   // (NaN distance: nothing found)
-  const float R2 = R * R;
-  for (int u = lane; u < GL_STAGE; u += GB) stage[u] = u < GL_SLOTS ? ~0u : (u == GL_SLOTS ? 0u : 0x7f800000u);
+  int xa, xb, zlo, ylo, side;
+  float rcov;
+  if (kE == 0) {
+    const float fx = (qc.px - g.ox) * g.inv_c - (float)cx, fy = (qc.py - g.oy) * g.inv_c - (float)cy,
+                fz = (qc.pz - g.oz) * g.inv_c - (float)cz;
+    const int x0 = (fx < 0.5f) ? cx - 1 : cx, y0 = (fy < 0.5f) ? cy - 1 : cy, z0 = (fz < 0.5f) ? cz - 1 : cz;
+    const float BIG = 3.0e38f;
+    const float ax = fminf(x0 >= 1 ? fx + (float)(cx - x0) : BIG, x0 + 2 < g.nx ? (float)(x0 + 2 - cx) - fx : BIG);
+    const float ay = fminf(y0 >= 1 ? fy + (float)(cy - y0) : BIG, y0 + 2 < g.ny ? (float)(y0 + 2 - cy) - fy : BIG);
+    const float az = fminf(z0 >= 1 ? fz + (float)(cz - z0) : BIG, z0 + 2 < g.nz ? (float)(z0 + 2 - cz) - fz : BIG);
+    const float amin = fminf(ax, fminf(ay, az));
+    // (the same face distance as grid_search_stage0; a query outside the bounding box is measured from its projection,
+    // which is at most as far from every target as the query itself: the claim about the ball around q0 still holds)
+    rcov = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
+    xa = x0 >= 0 ? x0 : x0 + 1; xb = x0 + 1 < g.nx ? x0 + 1 : x0;
+    zlo = z0; ylo = y0; side = 2;
+  } else {
+    rcov = (float)kE * g.c * 0.999f;   // (the bound of grid_search_rings)
+    xa = cx - kE < 0 ? 0 : cx - kE; xb = cx + kE >= g.nx ? g.nx - 1 : cx + kE;
+    zlo = cz - kE; ylo = cy - kE; side = 2 * kE + 1;
+  }
+  const int nrow = side * side;
+  const float d1 = sqrtf(d1sq);
+  float R2[GL_RADII];
+#pragma unroll
+  for (int k = 0; k < GL_RADII; ++k) {
+    float R = d1 + (GL_MARGIN / (float)(1 << k)) * g.c;
+    R = R < rcov ? R : rcov;
+    R2[k] = (R > 0.0f) ? R * R : 0.0f;   // (NaN distance: nothing found, nothing listed)
+  }
+  for (int u = lane; u < GL_STAGE; u += GB) stage[u] = u < GL_SLOTS ? ~0u : 0u;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (R > 0.0f) {
-    const int xa = x0 >= 0 ? x0 : x0 + 1, xb = x0 + 1 < g.nx ? x0 + 1 : x0;
+  {  // pass 1: how many targets within each radius
+    int cnt[GL_RADII];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int zz = z0 + (r >> 1), yy = y0 + (r & 1);
+    for (int k = 0; k < GL_RADII; ++k) cnt[k] = 0;
+    for (int r = 0; r < nrow; ++r) {
+      const int zz = zlo + r / side, yy = ylo + r % side;
       if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
       const int row = (zz * g.ny + yy) * g.nx;
-      const int jb = cell_start[row + xa], je = cell_start[row + xb + 1];
-      for (int j = jb + lane; j < je; j += GB) {
+      const int je = cell_start[row + xb + 1];
+      for (int j = cell_start[row + xa] + lane; j < je; j += GB) {
         const float4 c = sorted[j];
         const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
         float d = dx * dx;
         d = gs_fma(dy, dy, d);
         d = gs_fma(dz, dz, d);
-        if (d < R2) {
-          const int pos = (int)atomicAdd(&stage[GL_SLOTS], 1u);
-          if (pos < M) stage[pos] = (uint32_t)j;
-          else atomicMin(&stage[GL_SLOTS + 1], __float_as_uint(d));   // (d >= 0: the bit patterns order like the values)
+#pragma unroll
+        for (int k = 0; k < GL_RADII; ++k) cnt[k] += d < R2[k] ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GL_RADII; ++k)
+      if (cnt[k]) atomicAdd(&stage[GL_SLOTS + k], (uint32_t)cnt[k]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float Rsel2 = 0.0f;   // the widest radius that fits (group-uniform: every lane reads the same counters)
+#pragma unroll
+  for (int k = GL_RADII - 1; k >= 0; --k)
+    if ((int)stage[GL_SLOTS + k] <= M && R2[k] > 0.0f) Rsel2 = R2[k];
+  if (Rsel2 > 0.0f) {  // pass 2: collect
+    for (int r = 0; r < nrow; ++r) {
+      const int zz = zlo + r / side, yy = ylo + r % side;
+      if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
+      const int row = (zz * g.ny + yy) * g.nx;
+      const int je = cell_start[row + xb + 1];
+      for (int j = cell_start[row + xa] + lane; j < je; j += GB) {
+        const float4 c = sorted[j];
+        const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+        float d = dx * dx;
+        d = gs_fma(dy, dy, d);
+        d = gs_fma(dz, dz, d);
+        if (d < Rsel2) {
+          const int pos = (int)atomicAdd(&stage[GL_SLOTS + GL_RADII], 1u);
+          if (pos < GL_SLOTS) stage[pos] = (uint32_t)j;   // (pos < M by the count of pass 1)
         }
       }
     }
@@ -473,11 +524,7 @@ GS_DEV void gl_build_block(const GsGrid& g, const int* __restrict__ cell_start, 
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   for (int u = lane; u < GL_SLOTS; u += GB) slots[u] = stage[u];
-  if (lane == 0) {
-    const float dov = __uint_as_float(stage[GL_SLOTS + 1]);   // +inf: everything within R fitted
-    const float Rv = sqrtf(dov);
-    *lq = make_float4(qx, qy, qz, Rv < R ? Rv : R);
-  }
+  if (lane == 0) *lq = make_float4(qx, qy, qz, sqrtf(Rsel2));
   __builtin_amdgcn_wave_barrier();
 }
 

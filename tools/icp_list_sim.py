@@ -77,22 +77,19 @@ def face_bound(q):
 
 
 def build(q):
-    d1, _ = tree.query(q, k=1)
+    """gl_build_block: the widest of the nested radii d1 + margin / 2^k (capped by the block-face bound) whose targets
+    fit the M slots"""
+    dd, ii = tree.query(q, k=M + 1)
+    d1 = dd[:, 0]
     rb = face_bound(q)
     open_ = d1 > rb                     # stage 0 cannot prove it: cube scans, no list
-    R = np.minimum(d1 + margin_cells * c, rb)
-    dd, ii = tree.query(q, k=M + 1)
-    over = dd[:, M] < R                 # more than M targets within R: the list ends below the (M+1)-th
-    R = np.where(over, dd[:, M], R)
+    R = np.zeros(len(q))
+    for k in (3, 2, 1, 0):              # the widest that fits wins
+        Rk = np.minimum(d1 + margin_cells * c / (1 << k), rb)
+        fits = dd[:, M] >= Rk           # at most M targets within Rk
+        R = np.where(fits, Rk, R)
     lists = np.where(dd[:, :M] < R[:, None], ii[:, :M], -1)
-    if CUBE_LISTS:   # open queries: served by a cube of radius k cells (every target outside it is >= k c away): list within that
-        k = np.ceil(d1 / (c * 0.999))
-        Rc = np.minimum(d1 + margin_cells * c, k * c * 0.999)
-        Rc = np.where(dd[:, M] < Rc, dd[:, M], Rc)
-        R = np.where(open_, Rc, R)
-        lists = np.where(dd[:, :M] < R[:, None], ii[:, :M], -1)
-    else:
-        R = np.where(open_, 0.0, R)
+    R = np.where(open_, 0.0, R)
     return lists, R
 
 
