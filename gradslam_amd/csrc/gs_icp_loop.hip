@@ -211,6 +211,7 @@ __host__ __device__ inline int fs_far_pass(int it) {
 }
 constexpr int FS_FAR_MIN_RING = 2;   // queries served by a cube of at least this radius get a candidate list (gs_knn.h)
 constexpr int FS_HG = 16;  // lanes per query of the shell search for queries the 2x2x2 stage leaves open
+constexpr int FS_LISTS_FROM = 6;   // iteration behind whose look-ahead search the candidate lists of ordinary queries are built
 static_assert(FS_QPB <= 2 * GS_WAVE && FS_QPB % FS_RPG == 0 && FS_RG * LIN_NV <= FS_BLOCK, "block shape");
 
 // FULL = true : first half of iteration `it`  (prologue: LM update of iteration it-1, then search
@@ -1595,10 +1596,16 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   }
   // candidate lists of ordinary queries (gs_knn.h: gl_*; the results do not depend on them): every solve that keeps no
   // far lists.  GRADSLAM_HIP_ICP_LISTS=0 switches them off (A/B runs).
-  static int ord_lists = -1;
+  // GRADSLAM_HIP_ICP_LISTS_FROM=k: the lists are built behind the look-ahead search of iteration k and tried from
+  // iteration k + 1 on.  Default FS_LISTS_FROM: the first iterations of a solve move the cloud by millimetres, a list
+  // built there fails in the next launch, and a failing list costs a 16-lane re-scan plus a new list (measured, DESIGN.md
+  // section 4: launches with thousands of failing lists take 25-45 us instead of 17).
+  static int ord_lists = -1, lists_from = FS_LISTS_FROM;
   if (ord_lists < 0) {
     const char* e = getenv("GRADSLAM_HIP_ICP_LISTS");
     ord_lists = (e && atoi(e) == 0) ? 0 : 1;
+    const char* f = getenv("GRADSLAM_HIP_ICP_LISTS_FROM");
+    if (f && atoi(f) >= 0) lists_from = atoi(f);
   }
   ListMem lm[GS_MAX_BATCH];
   for (int b = 0; b < B; ++b) {
@@ -1660,8 +1667,8 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
                            nullptr, fm[b].cq, fm[b].c, fm[b].idx, fm[b].n};
       hb.l[b] = lists_on ? IcpHalfLists{lm[b].lq, lm[b].ls, lm[b].stat} : IcpHalfLists{nullptr, nullptr, nullptr};
     }
-    // lists: nothing in the first search of a solve (the large step follows), built behind the second, tried from then on
-    icp_half_launch<true>(plan, hb, n_src_c, prm, it, 0, st, lists_on ? (h == 0 ? 0 : 2) : 0);
+    // lists: built behind the look-ahead search of iteration lists_from, tried from then on
+    icp_half_launch<true>(plan, hb, n_src_c, prm, it, 0, st, lists_on && it > lists_from ? 2 : 0);
     if (far_on && fs_far_pass(it) >= 0) {   // lists for the far source points this search found
       const int fp = fs_far_pass(it);
       FarBuildBatch fbb;
@@ -1687,7 +1694,8 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
       u.st_in = &sc[b].state->s[h & 1];
       u.st_out = &sc[b].state->s[(h + 1) & 1];
     }
-    icp_half_launch<false>(plan, hb, n_src_c, prm, it, reduce_rows ? 1 : 0, st, lists_on ? (h == 1 ? 1 : 2) : 0);
+    icp_half_launch<false>(plan, hb, n_src_c, prm, it, reduce_rows ? 1 : 0, st,
+                           lists_on ? (it == lists_from ? 1 : (it > lists_from ? 2 : 0)) : 0);
     ++h;
   }
   prof_loop.reset();

@@ -417,6 +417,8 @@ GS_DEV float far_emit_cube(const GsGrid& g, const int* __restrict__ cell_start, 
 constexpr int GL_SLOTS = 8;            // list slots of a source point in memory (32 bytes)
 constexpr float GL_MARGIN = 0.4f;      // cells: the widest of the GL_RADII nested radii tried (each half the one before)
 constexpr int GL_RADII = 4;
+constexpr int GL_MAX_CUBE = 6;         // no list from a cube wider than this (13 x 13 rows of cells)
+constexpr float GL_MIN_ROOM = 0.1f;    // cells between the neighbour and the bound of the scanned region, at least
 constexpr int GL_STAGE = GL_SLOTS + GL_RADII + 1;   // LDS words of a list under construction: slots, one counter per radius, fill
 constexpr int GL_STAT_LAUNCHES = 64;   // launches of a solve with their own failure counters (diagnostics)
 // entries per lane of a G-lane group (M = G x entries <= GL_SLOTS)
@@ -436,12 +438,13 @@ template <int G> constexpr int gl_k() { return G == 8 ? 1 : 2; }
 // nothing fits); M = capacity the READING groups use (their lanes x entries per lane).
 template <int GB>
 GS_DEV void gl_build(const GsGrid& g, const int* __restrict__ cell_start, const float4* __restrict__ sorted, float qx,
-                     float qy, float qz, int lane, const float d1sq, const int kE, const int M, uint32_t* stage,
+                     float qy, float qz, int lane, const float d1sq, int kE, const int M, uint32_t* stage,
                      uint32_t* __restrict__ slots, float4* __restrict__ lq) {
   const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
   const int cx = qc.cx, cy = qc.cy, cz = qc.cz;
-  int xa, xb, zlo, ylo, side;
-  float rcov;
+  const float d1 = sqrtf(d1sq);
+  int xa = 0, xb = 0, zlo = 0, ylo = 0, side = 0;
+  float rcov = 0.0f;
   if (kE == 0) {
     const float fx = (qc.px - g.ox) * g.inv_c - (float)cx, fy = (qc.py - g.oy) * g.inv_c - (float)cy,
                 fz = (qc.pz - g.oz) * g.inv_c - (float)cz;
@@ -456,19 +459,23 @@ GS_DEV void gl_build(const GsGrid& g, const int* __restrict__ cell_start, const 
     rcov = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
     xa = x0 >= 0 ? x0 : x0 + 1; xb = x0 + 1 < g.nx ? x0 + 1 : x0;
     zlo = z0; ylo = y0; side = 2;
-  } else {
+    // a neighbour that sits right at the block's bound leaves its list no room: such a point would fail its proof, be
+    // re-scanned and get the same list in EVERY launch (a handful per solve, and a launch is as slow as its slowest
+    // block).  It takes its list from the smallest cube that leaves GL_MIN_ROOM cells of room instead.
+    if (rcov < d1 + GL_MIN_ROOM * g.c) kE = (int)((d1 + GL_MIN_ROOM * g.c) * g.inv_c * (1.0f / 0.999f)) + 1;
+  }
+  if (kE > 0) {
     rcov = (float)kE * g.c * 0.999f;   // (the bound of grid_search_rings)
     xa = cx - kE < 0 ? 0 : cx - kE; xb = cx + kE >= g.nx ? g.nx - 1 : cx + kE;
     zlo = cz - kE; ylo = cy - kE; side = 2 * kE + 1;
   }
   const int nrow = side * side;
-  const float d1 = sqrtf(d1sq);
   float R2[GL_RADII];
 #pragma unroll
   for (int k = 0; k < GL_RADII; ++k) {
     float R = d1 + (GL_MARGIN / (float)(1 << k)) * g.c;
     R = R < rcov ? R : rcov;
-    R2[k] = (R > 0.0f) ? R * R : 0.0f;   // (NaN distance: nothing found, nothing listed)
+    R2[k] = (R > 0.0f && kE <= GL_MAX_CUBE) ? R * R : 0.0f;   // (NaN distance: nothing found, nothing listed)
   }
   for (int u = lane; u < GL_STAGE; u += GB) stage[u] = u < GL_SLOTS ? ~0u : 0u;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -26,6 +26,7 @@ for cfg in ${R4_CFGS:-"L1" "L0" "L1K"}; do
     L0) envs="GRADSLAM_HIP_ICP_LISTS=0";;
     L1K) envs="GRADSLAM_HIP_ICP_LISTS=1 HIP_FORCE_DEV_KERNARG=1";;
     L0K) envs="GRADSLAM_HIP_ICP_LISTS=0 HIP_FORCE_DEV_KERNARG=1";;
+    F*) envs="GRADSLAM_HIP_ICP_LISTS=1 GRADSLAM_HIP_ICP_LISTS_FROM=${cfg#F}";;
     L1K0) envs="GRADSLAM_HIP_ICP_LISTS=1 HIP_FORCE_DEV_KERNARG=0";;
   esac
   for b in ${R4_B:-8 1}; do
