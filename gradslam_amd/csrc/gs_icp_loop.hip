@@ -494,6 +494,9 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
   if (lb == 0 && threadIdx.x < (int)(sizeof(IcpSmall) / 4))
     reinterpret_cast<float*>(q.st_out)[threadIdx.x] = reinterpret_cast<const float*>(&sm)[threadIdx.x];
   if (tl && threadIdx.x == 0) { tl[4] = wall_clock64(); tl[7] = 0; tl[2] = 0; }
+#ifndef GS_T_LATEGRID
+  if (LMODE == 2) g = *q.gp;   // (in flight while the lists are checked; the left-over pass needs it)
+#endif
 
   // (the list variants serve ONE group of units per block -- the host plans them only then -- and say so to the
   // compiler: nothing is carried around a loop)
@@ -515,9 +518,11 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
     // A NaN source point (empty slot of an un-compacted lattice, gs_lattice_source_f32) is skipped: it stays
     // NaN through every transform, is never searched and contributes no row.
     if (LMODE == 2 && live) {   // (parked by this group's first lane: same wave, LDS accesses of a wave are ordered)
-      const float4 pp = park_s[2 * slot];
+      int slot_p = slot;   // (opaque, as where it was parked)
+      asm volatile("" : "+v"(slot_p));
+      const float4 pp = park_s[2 * slot_p];
       p0 = pp.x; p1 = pp.y; p2 = pp.z;
-      lqv = park_s[2 * slot + 1];
+      lqv = park_s[2 * slot_p + 1];
     }
     if (live && p0 != p0) {
       if (lane == 0) {
@@ -563,7 +568,8 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
           // R < 0: the 2x2x2 stage could not prove this point when it was last tried -- straight to the cube scans
           hq_flags = lqv.w < 0.0f ? 0 : FS_HQ_SCAN;
           const int hl = 2 * it + (FULL ? 0 : 1);   // launch index within the solve (failure counters)
-          if (lane == 0 && ql.lstat && hl < GL_STAT_LAUNCHES) atomicAdd(ql.lstat + (lqv.w < 0.0f ? GL_STAT_LAUNCHES : 0) + hl, 1);
+          if (lane == 0 && ql.lstat && hl < GL_STAT_LAUNCHES)
+            atomicAdd(ql.lstat + (lqv.w < 0.0f ? 2 * GL_STAT_LAUNCHES : (lqv.w == 0.0f ? GL_STAT_LAUNCHES : 0)) + hl, 1);
         }
       } else {
         // search bound: the previous neighbour of this source point is still a target; the previous query was Tr * p in
@@ -603,7 +609,9 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
     // ---- the few queries the 2x2x2 stage did not resolve (neighbour farther than ~half a cell): Chebyshev shells
     // by groups of FS_HG lanes, so that they do not hold up the waves of the common case
     const int nh = hard_n;  // block-uniform
+#ifdef GS_T_LATEGRID
     if (LMODE == 2 && nh) g = *q.gp;
+#endif
     for (int i = threadIdx.x / FS_HG; i < nh; i += FS_BLOCK / FS_HG) {
       const int e = hard_q[i], hs = e & FS_HQ_SLOT, l16 = threadIdx.x & (FS_HG - 1);
       const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
@@ -846,21 +854,26 @@ static IcpHalfPlan icp_half_plan(int64_t n_src, int B, int g_max = 8) {
   }
   return pl;
 }
+static unsigned long long* g_icp_tl_buf = nullptr;
 // lmode: what the launch does with the candidate lists of ordinary queries (icp_half_body; 0 = the variant without them)
 template <bool FULL>
 static void icp_half_launch(const IcpHalfPlan& pl, IcpHalfBatch& hb, GsCount n_src_c, const gs_icp_params* prm, int it,
                             int rows_in_reduced, hipStream_t st, int lmode = 0) {
   hb.upb = pl.upb;
+  // debugging aid (library built with -DGS_ICP_TIMELINE): per-block time stamps of the LAST iteration's two launches,
+  // the first half into <path>, the look-ahead that follows it back to back into <path>.next (their first block starts
+  // are one launch period apart); both are written after the second launch
   static const char* tl_path = getenv("GRADSLAM_HIP_ICP_TIMELINE");
-  static unsigned long long* tl_buf = nullptr;
+  unsigned long long*& tl_buf = g_icp_tl_buf;   // (one buffer for both instantiations of this template)
+  constexpr size_t TL_HALF = 72 * 7000;
   hb.timeline = nullptr;
   const size_t tl_n = 72 * (size_t)hb.B * pl.nb;
-  const bool tl = tl_path && FULL && it == prm->numiters - 1;  // record the last full half-iteration of a solve
+  const bool tl = tl_path && it == prm->numiters - 1;
   if (tl) {
-    if (!tl_buf && hipMalloc(&tl_buf, 8 * 64 * 8192) != hipSuccess) tl_buf = nullptr;
-    if (tl_buf && tl_n <= 72 * 7000) {
-      hb.timeline = tl_buf;
-      (void)hipMemsetAsync(tl_buf, 0, 8 * tl_n, st);
+    if (!tl_buf && hipMalloc(&tl_buf, 8 * 2 * TL_HALF) != hipSuccess) tl_buf = nullptr;
+    if (tl_buf && tl_n <= TL_HALF) {
+      hb.timeline = tl_buf + (FULL ? 0 : TL_HALF);
+      if (FULL) (void)hipMemsetAsync(tl_buf, 0, 8 * 2 * TL_HALF, st);
     }
   }
   const dim3 grid((unsigned)(hb.B * pl.nb)), block(FS_BLOCK);
@@ -883,22 +896,25 @@ static void icp_half_launch(const IcpHalfPlan& pl, IcpHalfBatch& hb, GsCount n_s
   else { if (far) GS_HALF_LAUNCH(2, true, 0); else GS_HALF_LAUNCH_L(2); }
 #undef GS_HALF_LAUNCH_L
 #undef GS_HALF_LAUNCH
-  if (hb.timeline) {  // debugging aid: synchronous dump of this launch's block records
-    std::unique_ptr<unsigned long long[]> h(new unsigned long long[tl_n]);
-    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.get(), tl_buf, 8 * tl_n, hipMemcpyDeviceToHost) == hipSuccess) {
-      FILE* f = fopen(tl_path, "w");
-      if (f) {
-        fprintf(f, "# B=%d G=%d nb=%d upb=%d: block start end(100MHz ticks) hw_id xcc_id after_prologue after_search after_unres n_unres\n", hb.B, pl.G, pl.nb, pl.upb);
+  if (hb.timeline && !FULL) {  // debugging aid: synchronous dump of the two launches' block records
+    std::unique_ptr<unsigned long long[]> h(new unsigned long long[2 * TL_HALF]);
+    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.get(), tl_buf, 8 * 2 * TL_HALF, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int part = 0; part < 2; ++part) {
+        char path[1024];
+        snprintf(path, sizeof(path), "%s%s", tl_path, part ? ".next" : "");
+        FILE* f = fopen(path, "w");
+        if (!f) continue;
+        fprintf(f, "# B=%d G=%d nb=%d upb=%d lmode=%d: block start end(100MHz ticks) hw_id xcc_id after_prologue after_search after_unres n_unres\n", hb.B, pl.G, pl.nb, pl.upb, lmode);
         for (size_t i = 0; i < tl_n / 72; ++i) {
           fprintf(f, "%zu", i);
-          for (int k = 0; k < 72; ++k) fprintf(f, " %llu", h[72 * i + k]);
+          for (int k = 0; k < 72; ++k) fprintf(f, " %llu", h[part * TL_HALF + 72 * i + k]);
           fprintf(f, "\n");
         }
         fclose(f);
       }
     }
-    hb.timeline = nullptr;
   }
+  hb.timeline = nullptr;
 }
 
 // Large solves (more rows than FS_REDUCE_ROWS): every block of the next kernel adding up all rows is
@@ -1272,7 +1288,7 @@ struct LocSeq {
   char* clear_ptr;       // grid scratch bytes that must be zero before the build
   int64_t* n_valid;      // number of lattice slots with depth (profiling / roofline accounting)
   int* far_n;            // [FS_FAR_PASSES] counters of the far-query lists of the solve, zeroed here
-  int* lstat;            // [2 * GL_STAT_LAUNCHES] failure counters of the ordinary candidate lists, zeroed here
+  int* lstat;            // [3 * GL_STAT_LAUNCHES] failure counters of the ordinary candidate lists, zeroed here
 };
 struct LocBatch {
   int B, W, ds, Wl;
@@ -1321,7 +1337,7 @@ GS_DEV void loc_prep_block(const LocBatch& lb, const unsigned bid, const unsigne
       if (q.far_n)
         for (int i = 0; i < FS_FAR_PASSES; ++i) q.far_n[i] = 0;
       if (q.lstat)
-        for (int i = 0; i < 2 * GL_STAT_LAUNCHES; ++i) q.lstat[i] = 0;
+        for (int i = 0; i < 3 * GL_STAT_LAUNCHES; ++i) q.lstat[i] = 0;
       if (lb.numiters == 0) icp_write_result(sm, q.pose16, q.out_pose16);
     }
     return;
@@ -1391,10 +1407,11 @@ struct ListMem {
   float4* lq;      // [n_lat] (position the list was built at, exactness radius; 0: no list, < 0: no list and the 2x2x2
                    // stage cannot prove this point -- cube scans)
   uint32_t* ls;    // [n_lat][GL_SLOTS] slots of `sorted` (~0: empty)
-  int* stat;       // [2 * GL_STAT_LAUNCHES] per launch of the solve: lists that failed their proof, points without a list
+  int* stat;       // [3 * GL_STAT_LAUNCHES] per launch of the solve: lists that failed their proof, points whose list
+                   // is empty (nothing fitted), points the 2x2x2 stage cannot prove (no list)
 };
 static size_t list_mem_bytes(int64_t n_lat) {
-  return gs_align(16 * (size_t)n_lat) + gs_align(4 * GL_SLOTS * (size_t)n_lat) + gs_align(4 * 2 * GL_STAT_LAUNCHES);
+  return gs_align(16 * (size_t)n_lat) + gs_align(4 * GL_SLOTS * (size_t)n_lat) + gs_align(4 * 3 * GL_STAT_LAUNCHES);
 }
 static ListMem list_carve(void* base, int64_t n_lat) {
   char* p = reinterpret_cast<char*>(base);
@@ -1786,9 +1803,9 @@ extern "C" int gs_localize_far_stats_i64(const void* scratch, int H, int W, int 
   return GS_OK;
 }
 
-extern "C" int gs_localize_list_stats_i64(const void* scratch, int H, int W, int ds, int64_t map_rows, int64_t* out128_host,
+extern "C" int gs_localize_list_stats_i64(const void* scratch, int H, int W, int ds, int64_t map_rows, int64_t* out192_host,
                                           void* stream) {
-  GS_REQUIRE(scratch && out128_host && H > 0 && W > 0 && ds > 0 && map_rows > 0, "bad arguments");
+  GS_REQUIRE(scratch && out192_host && H > 0 && W > 0 && ds > 0 && map_rows > 0, "bad arguments");
   const int64_t n_lat = loc_lattice(H, W, ds);
   gs_localize_seq q;
   memset(&q, 0, sizeof(q));
@@ -1796,11 +1813,11 @@ extern "C" int gs_localize_list_stats_i64(const void* scratch, int H, int W, int
   q.map.capacity = map_rows; q.map.n_bound = map_rows;
   const LocCarve cv = loc_carve(q, n_lat);
   const ListMem lm = list_carve(reinterpret_cast<char*>(cv.sc.state) + gs_icp_scratch_bytes(n_lat, map_rows), n_lat);
-  int h[2 * GL_STAT_LAUNCHES];
+  int h[3 * GL_STAT_LAUNCHES];
   hipStream_t st = gs_stream(stream);
   GS_HIP(hipMemcpyAsync(h, lm.stat, sizeof(h), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
-  for (int i = 0; i < 2 * GL_STAT_LAUNCHES; ++i) out128_host[i] = h[i];
+  for (int i = 0; i < 3 * GL_STAT_LAUNCHES; ++i) out192_host[i] = h[i];
   return GS_OK;
 }
 

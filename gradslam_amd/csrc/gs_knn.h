@@ -415,8 +415,9 @@ GS_DEV float far_emit_cube(const GsGrid& g, const int* __restrict__ cell_start, 
 // the point is now (16-lane groups, with the other leftovers).  tools/icp_list_sim.py is the CPU study behind the
 // constants: on the benchmark's solves 32-36 of the 40 launches have no failing list at all.
 constexpr int GL_SLOTS = 8;            // list slots of a source point in memory (32 bytes)
-constexpr float GL_MARGIN = 0.4f;      // cells: the widest of the GL_RADII nested radii tried (each half the one before)
+constexpr float GL_MARGIN = 0.4f;      // cells: the widest of the GL_RADII nested radii tried (each a fifth of the one before)
 constexpr int GL_RADII = 4;
+static_assert(GL_RADII == 4, "gl_build spells out the ladder");
 constexpr int GL_MAX_CUBE = 6;         // no list from a cube wider than this (13 x 13 rows of cells)
 constexpr float GL_MIN_ROOM = 0.1f;    // cells between the neighbour and the bound of the scanned region, at least
 constexpr int GL_STAGE = GL_SLOTS + GL_RADII + 1;   // LDS words of a list under construction: slots, one counter per radius, fill
@@ -432,7 +433,7 @@ template <int G> constexpr int gl_k() { return G == 8 ? 1 : 2; }
 //           block face with cells behind it;
 //   kE > 0: the cube of Chebyshev radius kE cells around the query's cell (grid_search_rings); every target outside it is
 //           at least kE cells away.
-// Pass 1 counts the targets within d1 + GL_MARGIN / 2^k cells (k = 0 .. GL_RADII - 1), each capped by that bound; the
+// Pass 1 counts the targets within d1 + GL_MARGIN / 5^k cells (k = 0 .. GL_RADII - 1), each capped by that bound; the
 // widest radius whose targets fit the M slots wins (a point on a dense patch keeps a list, a short one); pass 2 collects
 // them.  stage = GL_STAGE words of LDS owned by the group.  Writes slots[0 .. GL_SLOTS) and *lq = (q, R) (R = 0:
 // nothing fits); M = capacity the READING groups use (their lanes x entries per lane).
@@ -473,59 +474,88 @@ GS_DEV void gl_build(const GsGrid& g, const int* __restrict__ cell_start, const 
   float R2[GL_RADII];
 #pragma unroll
   for (int k = 0; k < GL_RADII; ++k) {
-    float R = d1 + (GL_MARGIN / (float)(1 << k)) * g.c;
+    // room above the neighbour: GL_MARGIN, then a fifth of the one before (0.4, 0.08, 0.016, 0.0032 cells: the last one
+    // -- a tenth of a millimetre at 640x480 -- still covers the micrometre steps of a converged solve, and lets a point
+    // among near-coincident map surfels keep a list)
+    const float room = k == 0 ? GL_MARGIN : (k == 1 ? GL_MARGIN * 0.2f : (k == 2 ? GL_MARGIN * 0.04f : GL_MARGIN * 0.008f));
+    float R = d1 + room * g.c;
     R = R < rcov ? R : rcov;
     R2[k] = (R > 0.0f && kE <= GL_MAX_CUBE) ? R * R : 0.0f;   // (NaN distance: nothing found, nothing listed)
   }
   for (int u = lane; u < GL_STAGE; u += GB) stage[u] = u < GL_SLOTS ? ~0u : 0u;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  {  // pass 1: how many targets within each radius
+  // The region as a flat candidate list.  kE = 0: the 4 row segments of the block, their 8 bounds fetched together
+  // (one round trip), then 2 or 4 independent gathers in flight per lane and pass -- a rebuilt list costs three round trips,
+  // and a block with ONE failing list is what a launch waits for.  Cubes (rare) walk their rows one after the other.
+  int sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, e1 = 0, e2 = 0, e3 = 0, total = 0;
+  if (kE == 0) {
+    const bool zl = zlo >= 0, zh = zlo + 1 < g.nz, yl = ylo >= 0, yh = ylo + 1 < g.ny;
+    const int r0 = (zlo * g.ny + ylo) * g.nx, r1 = r0 + g.nx, r2 = r0 + g.ny * g.nx, r3 = r2 + g.nx;
+    int se0 = 0, se1 = 0, se2 = 0, se3 = 0;
+    if (zl && yl) { sb0 = cell_start[r0 + xa]; se0 = cell_start[r0 + xb + 1]; }
+    if (zl && yh) { sb1 = cell_start[r1 + xa]; se1 = cell_start[r1 + xb + 1]; }
+    if (zh && yl) { sb2 = cell_start[r2 + xa]; se2 = cell_start[r2 + xb + 1]; }
+    if (zh && yh) { sb3 = cell_start[r3 + xa]; se3 = cell_start[r3 + xb + 1]; }
+    e1 = se0 - sb0;
+    e2 = e1 + (se1 - sb1);
+    e3 = e2 + (se2 - sb2);
+    total = e3 + (se3 - sb3);
+  }
+  float Rsel2 = 0.0f;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {   // pass 0: how many targets within each radius; pass 1: collect within the chosen one
     int cnt[GL_RADII];
 #pragma unroll
     for (int k = 0; k < GL_RADII; ++k) cnt[k] = 0;
-    for (int r = 0; r < nrow; ++r) {
-      const int zz = zlo + r / side, yy = ylo + r % side;
-      if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
-      const int row = (zz * g.ny + yy) * g.nx;
-      const int je = cell_start[row + xb + 1];
-      for (int j = cell_start[row + xa] + lane; j < je; j += GB) {
-        const float4 c = sorted[j];
-        const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-        float d = dx * dx;
-        d = gs_fma(dy, dy, d);
-        d = gs_fma(dz, dz, d);
+    if (pass == 1 && !(Rsel2 > 0.0f)) break;
+    auto visit = [&](const int j, const float4 c) {
+      const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+      float d = dx * dx;
+      d = gs_fma(dy, dy, d);
+      d = gs_fma(dz, dz, d);
+      if (pass == 0) {
 #pragma unroll
         for (int k = 0; k < GL_RADII; ++k) cnt[k] += d < R2[k] ? 1 : 0;
+      } else if (d < Rsel2) {
+        const int pos = (int)atomicAdd(&stage[GL_SLOTS + GL_RADII], 1u);
+        if (pos < GL_SLOTS) stage[pos] = (uint32_t)j;   // (pos < M by the count of pass 0)
+      }
+    };
+    if (kE == 0) {
+      constexpr int NF = GB >= 16 ? 2 : 4;   // gathers in flight per lane (32 candidates per round either way or more)
+      for (int t0 = lane; t0 < total; t0 += NF * GB) {
+        float4 p[NF];
+        int ix[NF];
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+          const int t = t0 + u * GB, tt = t < total ? t : 0;   // total > 0 here: position 0 is valid
+          ix[u] = tt < e1 ? sb0 + tt : (tt < e2 ? sb1 + (tt - e1) : (tt < e3 ? sb2 + (tt - e2) : sb3 + (tt - e3)));
+          p[u] = sorted[ix[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < NF; ++u)
+          if (t0 + u * GB < total) visit(ix[u], p[u]);
+      }
+    } else {
+      for (int r = 0; r < nrow; ++r) {
+        const int zz = zlo + r / side, yy = ylo + r % side;
+        if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
+        const int row = (zz * g.ny + yy) * g.nx;
+        const int je = cell_start[row + xb + 1];
+        for (int j = cell_start[row + xa] + lane; j < je; j += GB) visit(j, sorted[j]);
       }
     }
+    if (pass == 0) {
 #pragma unroll
-    for (int k = 0; k < GL_RADII; ++k)
-      if (cnt[k]) atomicAdd(&stage[GL_SLOTS + k], (uint32_t)cnt[k]);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  float Rsel2 = 0.0f;   // the widest radius that fits (group-uniform: every lane reads the same counters)
+      for (int k = 0; k < GL_RADII; ++k)
+        if (cnt[k]) atomicAdd(&stage[GL_SLOTS + k], (uint32_t)cnt[k]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // the widest radius that fits (group-uniform: every lane reads the same counters)
 #pragma unroll
-  for (int k = GL_RADII - 1; k >= 0; --k)
-    if ((int)stage[GL_SLOTS + k] <= M && R2[k] > 0.0f) Rsel2 = R2[k];
-  if (Rsel2 > 0.0f) {  // pass 2: collect
-    for (int r = 0; r < nrow; ++r) {
-      const int zz = zlo + r / side, yy = ylo + r % side;
-      if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
-      const int row = (zz * g.ny + yy) * g.nx;
-      const int je = cell_start[row + xb + 1];
-      for (int j = cell_start[row + xa] + lane; j < je; j += GB) {
-        const float4 c = sorted[j];
-        const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-        float d = dx * dx;
-        d = gs_fma(dy, dy, d);
-        d = gs_fma(dz, dz, d);
-        if (d < Rsel2) {
-          const int pos = (int)atomicAdd(&stage[GL_SLOTS + GL_RADII], 1u);
-          if (pos < GL_SLOTS) stage[pos] = (uint32_t)j;   // (pos < M by the count of pass 1)
-        }
-      }
+      for (int k = GL_RADII - 1; k >= 0; --k)
+        if ((int)stage[GL_SLOTS + k] <= M && R2[k] > 0.0f) Rsel2 = R2[k];
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

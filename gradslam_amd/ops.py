@@ -664,16 +664,16 @@ def localize_far_stats(device, b, H, W, ds, capacity):
 
 def localize_list_stats(device, b, H, W, ds, capacity):
     """Diagnostics of the candidate lists of ordinary source points in the last localisation of sequence b on `device`
-    (gs_localize_list_stats_i64): (failed[64], without_list[64]) per launch of the solve (launch = 2 x iteration +
-    half).  All zero when the solve kept no lists."""
+    (gs_localize_list_stats_i64): (failed[64], empty_list[64], without_list[64]) per launch of the solve (launch = 2 x
+    iteration + half).  All zero when the solve kept no lists."""
     L = lib()
     scratch = Workspace.get(device).bytes("localize%d" % b, L.gs_localize_scratch_bytes(H, W, int(ds), int(capacity)))
     import ctypes
-    out = (ctypes.c_int64 * 128)()
+    out = (ctypes.c_int64 * 192)()
     check(L.gs_localize_list_stats_i64(scratch.data_ptr(), H, W, int(ds), int(capacity), out, stream(device)),
           "gs_localize_list_stats_i64")
     v = [int(x) for x in out]
-    return v[:64], v[64:]
+    return v[:64], v[64:128], v[128:]
 
 
 def update_map_fusion_batch_(maps, vertex, normal, depth, rgb, alpha, poses, K, dist_th, dot_th, renorm_all=True,

@@ -463,11 +463,12 @@ GS_API int gs_localize_far_stats_i64(const void* scratch, int H, int W, int ds, 
                                      void* stream);
 /* Diagnostics of the candidate lists of ordinary source points (round 4; tests, tools; synchronises the stream) for the
  * last solve a scratch was used for: out[h] = source points whose list gave no proof in launch h of the solve (h = 2 x
- * iteration + half; they were re-searched by the 2x2x2 scan and got a new list), out[64 + h] = source points that had no
- * list in launch h because the 2x2x2 stage could not prove them (cube scans, as without lists).  All zero when the solve
- * kept no lists (GRADSLAM_HIP_ICP_LISTS=0, far-candidate lists in use, blocks walking several groups of row units).
- * out_host holds 128 values. */
-GS_API int gs_localize_list_stats_i64(const void* scratch, int H, int W, int ds, int64_t map_rows, int64_t* out128_host,
+ * iteration + half; they were re-searched by the 2x2x2 scan and got a new list), out[64 + h] = source points whose list
+ * was empty (no radius fitted the slots: re-searched as well), out[128 + h] = source points that had no list in launch h
+ * because neither the 2x2x2 stage nor the cubes could prove them (as without lists).  All zero when the solve kept no
+ * lists (GRADSLAM_HIP_ICP_LISTS=0, far-candidate lists in use, blocks walking several groups of row units) and for the
+ * launches before the lists start (GRADSLAM_HIP_ICP_LISTS_FROM).  out_host holds 192 values. */
+GS_API int gs_localize_list_stats_i64(const void* scratch, int H, int W, int ds, int64_t map_rows, int64_t* out192_host,
                                       void* stream);
 
 /* update_map_fusion (slam/fusionutils.py:761-789) for B sequences: gs_update_map_fusion_dc_f32 per sequence, 6

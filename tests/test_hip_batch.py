@@ -456,12 +456,13 @@ def test_candidate_lists_leave_results_identical(tmp_path, B, H, W):
     assert np.array_equal(a["n"], b["n"])
     assert np.array_equal(a["pts"].view(np.int32), b["pts"].view(np.int32))
     assert not b["stats"].any()                                  # no lists, no counters
-    st = a["stats"]                                              # (frames - 1, B, 2, 64)
+    st = a["stats"]                                              # (frames - 1, B, 3, 64)
     n_lat = ((H + 3) // 4) * ((W + 3) // 4)
     assert st[:, :, :, :2].sum() == 0                            # launches 0 and 1 try no lists
-    late = st[:, :, :, 20:40].sum(axis=2)                        # failed + without a list, launches 20 .. 39
+    late = st[:, :, :, 20:40].sum(axis=2)                        # failed + empty + without a list, launches 20 .. 39
     assert late.max() <= 0.02 * n_lat, late.max()
-    assert st[:, :, 0, 2:40].sum() > 0 or n_lat < 2000           # some list failed somewhere (the counters are alive)
+    if n_lat >= 19200:
+        assert st[:, :, 0, 2:40].sum() > 0                       # some list failed somewhere (the counters are alive)
 
 
 def test_pointfusion_1296x968_vs_reference_golden(gs, golden):

@@ -16,16 +16,16 @@ poses = st("poses"); poses[:, 1:] = poses[:, :1]
 frames = gs.RGBDImages(st("colors"), st("depths"), st("intrinsics"), poses)
 slam = gs.slam.PointFusion(odom="gradicp", device="cuda")
 pc, prev = gs.Pointclouds(device="cuda"), None
-tot = np.zeros((2, 64), np.int64)
+tot = np.zeros((3, 64), np.int64)
 worst = np.zeros(64, np.int64)
 for f in range(L):
     live = frames[:, f]; pc, _ = slam.step(pc, live, prev, inplace=True); prev = live
     if f >= 1:
         for b in range(B):
-            fa, op = ops.localize_list_stats(torch.device("cuda", 0), b, H, W, 4, pc._buf["points"][b].shape[0])
-            tot[0] += fa; tot[1] += op
-            worst = np.maximum(worst, np.array(fa) + np.array(op))
+            fa, em, op = ops.localize_list_stats(torch.device("cuda", 0), b, H, W, 4, pc._buf["points"][b].shape[0])
+            tot[0] += fa; tot[1] += em; tot[2] += op
+            worst = np.maximum(worst, np.array(fa) + np.array(em) + np.array(op))
 n = (L - 1) * B
-print("mean per solve over %d solves (19200 lattice slots): launch: failed lists / points without a list / worst solve (failed + without)" % n)
+print("mean per solve over %d solves (19200 lattice slots): launch: failed lists / empty lists / points without a list / worst solve (sum)" % n)
 for h in range(40):
-    print("  launch %2d: %8.1f %8.1f %6d" % (h, tot[0, h] / n, tot[1, h] / n, worst[h]))
+    print("  launch %2d: %8.1f %8.1f %8.1f %6d" % (h, tot[0, h] / n, tot[1, h] / n, tot[2, h] / n, worst[h]))
