@@ -335,13 +335,9 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
   __shared__ int unres_n, hard_n;
   __shared__ unsigned long long red[FS_BLOCK / GS_WAVE];
   __shared__ uint8_t far_s[NQ];   // the query's candidate list proved this search (it keeps its flag)
-  // lists under construction: one per group of the search (LMODE 1) / per 16-lane group of the left-over pass (LMODE 2)
-  __shared__ uint32_t stage_s[LMODE == 1 ? NQ * GL_STAGE : (LMODE == 2 ? (FS_BLOCK / FS_HG) * GL_STAGE : 1)];
   // (LMODE 2) source point and (list centre, radius) of every group, parked across the scalar stage of the prologue: its
   // one-lane float64 code needs the registers, the lanes that wait for it do not
   __shared__ float4 park_s[LMODE == 2 ? 2 * NQ : 1];
-  __shared__ int build_q[LMODE == 2 ? NQ : 1];   // (LMODE 2) slots of the block whose list is rebuilt behind the left-over pass
-  __shared__ int build_n;
   float4* __restrict__ far_cq = q.far_cq;
   uint32_t* __restrict__ far_c = q.far_c;
   // (FAR is a template parameter: the kernels sit at their register limit, and the code of the lists costs the
@@ -366,13 +362,14 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
   const int lane = threadIdx.x & (G - 1), slot = threadIdx.x / G;
   float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
   // the first search of a solve has no predecessor; a list check needs none
-  const bool bounded = d2prev != nullptr && !(FULL && it == 0) && !verify;
+  const bool bounded = d2prev != nullptr && !(FULL && it == 0) && !LISTS;   // (the list variants scan whole regions)
   float dprev = __builtin_inff();
   float4 lqv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // (verify) list centre and exactness radius of this group's point
   uint32_t sl[LK];                                     // (verify) this lane's slots of the list
   float4 cv[LK];                                       // (verify) the points in those slots
   typedef float gs_v4f __attribute__((ext_vector_type(4)));
   gs_v4f stv = {0.0f, 0.0f, 0.0f, 0.0f};             // (verify) this lane's 16 bytes of the state of the previous half
+  int st_idx = 0;
   static_assert(sizeof(IcpSmall) % 16 == 0, "state copy");
   const bool st_lane = threadIdx.x >= GS_WAVE && threadIdx.x < GS_WAVE + (int)(sizeof(IcpSmall) / 16);
   if (LMODE == 2) {
@@ -383,8 +380,12 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
     // (hand-issued: a DMA into LDS makes the compiler drain the memory queue at every later wait -- it treats the
     // transfer as a flat access that may complete out of order -- and a plain load is sunk to its use, behind the
     // gathers.  The hook below waits for it by count and stores it.)
+    // (an opaque copy of the thread index for the state's addresses: 16 x index merged with its uses at the far end of
+    // the kernel is what the register allocator would spill -- a store in the memory queue of the prologue)
+    st_idx = (int)threadIdx.x - GS_WAVE;
+    asm volatile("" : "+v"(st_idx));
     if (st_lane)
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(stv) : "v"(reinterpret_cast<const float4*>(q.st_in) + (threadIdx.x - GS_WAVE)) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(stv) : "v"(reinterpret_cast<const float4*>(q.st_in) + st_idx) : "memory");
     const int64_t s = (int64_t)u_first * FS_QPB + slot;
     const bool vlive = slot / FS_QPB + u_first < u_last && s < n_src;
     const int64_t sc = vlive ? s : 0;   // (source point 0 stands in; masked below)
@@ -446,7 +447,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
       // been issued since everything else.  The row sums are consumed next anyway, so this wait costs nothing.
       if (LMODE == 2 && verify) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LK) : "memory");
-        if (st_lane) *reinterpret_cast<gs_v4f*>(reinterpret_cast<float4*>(&sm) + (threadIdx.x - GS_WAVE)) = stv;
+        if (st_lane) *reinterpret_cast<gs_v4f*>(reinterpret_cast<float4*>(&sm) + st_idx) = stv;
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -473,7 +474,6 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
 #endif
       unres_n = 0;
       hard_n = 0;
-      build_n = 0;
     }
   } else {
     if (LISTS) icp_sum_rows_split<FS_BLOCK>(partials_in, nrows_in, S, sub, hook);
@@ -487,7 +487,6 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
 #endif
       unres_n = 0;
       hard_n = 0;
-      build_n = 0;
     }
   }
   gs_bar<LISTS>();
@@ -572,23 +571,25 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
             atomicAdd(ql.lstat + (lqv.w < 0.0f ? 2 * GL_STAT_LAUNCHES : (lqv.w == 0.0f ? GL_STAT_LAUNCHES : 0)) + hl, 1);
         }
       } else {
-        // search bound: the previous neighbour of this source point is still a target; the previous query was Tr * p in
-        // the look-ahead half (this half: T_step * p) resp. p itself in the first half (this half: Tr * p)
-        float rball;
-        {
-          float ox = p0, oy = p1, oz = p2;
-          if (FULL) gs_rigid_fma(sm.Tr, p0, p1, p2, ox, oy, oz);
-          const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
-          rball = sqrtf(dprev) + sqrtf(ex * ex + ey * ey + ez * ez);  // inf without a predecessor, NaN after a NaN match
-        }
-        key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win, rball);
         if (build_all) {
-          if (done) {
-            gl_build<G>(g, cell_start, sorted, qx, qy, qz, lane, __uint_as_float((uint32_t)(key >> 32)), 0, LM,
-                        stage_s + slot * GL_STAGE, ls + GL_SLOTS * s, lq + s);
-          } else if (lane == 0) {
-            lq[s] = make_float4(qx, qy, qz, -1.0f);
+          // the whole 2x2x2 block, every lane remembering its nearest candidates: the list is a by-product of the search
+          GlTop<LK> top;
+          gl_top_reset<LK>(top);
+          float rc2;
+          key = grid_search_stage0_top<G, LK>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win, top, &rc2);
+          if (done) gl_write_lanes<G, LK>(top, rc2, qx, qy, qz, lane, ls + GL_SLOTS * s, lq + s);
+          else if (lane == 0) lq[s] = make_float4(qx, qy, qz, -1.0f);   // (the cubes below may still give it a list)
+        } else {
+          // search bound: the previous neighbour of this source point is still a target; the previous query was Tr * p
+          // in the look-ahead half (this half: T_step * p) resp. p itself in the first half (this half: Tr * p)
+          float rball;
+          {
+            float ox = p0, oy = p1, oz = p2;
+            if (FULL) gs_rigid_fma(sm.Tr, p0, p1, p2, ox, oy, oz);
+            const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
+            rball = sqrtf(dprev) + sqrtf(ex * ex + ey * ey + ez * ez);  // inf without a predecessor, NaN after a NaN match
           }
+          key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win, rball);
         }
       }
       (void)hq_flags;
@@ -625,18 +626,19 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         if (done) { key = kl; listed = true; }
         else win = -1;
       }
+      constexpr int KH = 2;   // candidates a lane of the 16-lane group remembers for the new list
+      GlTop<KH> top;
+      float rc2 = 0.0f;
       if (LMODE == 2 && (e & FS_HQ_SCAN)) {   // its list gave no proof: the 2x2x2 block by 16 lanes, and a list for where it is now
-#ifndef GS_T_NOSTAGE16
-        key = grid_search_stage0<FS_HG>(g, cell_start, sorted, hx, hy, hz, l16, &done, &win);
-#endif
+        gl_top_reset<KH>(top);
+        key = grid_search_stage0_top<FS_HG, KH>(g, cell_start, sorted, hx, hy, hz, l16, &done, &win, top, &rc2);
         if (win >= 0) bslot_s[hs] = win;
         win = -1;
-        // (the new list is written by a pass of its own below: inside this loop its registers come on top of the search's)
-        if (l16 == 0 && done) build_q[atomicAdd(&build_n, 1)] = hs;
       }
       if (!done) {
-        int kdone;
-        key = grid_search_rings<FS_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, &kdone);
+        int kdone = 0;
+        if (LISTS) key = grid_search_rings_top<FS_HG, KH>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, top, &rc2);
+        else key = grid_search_rings<FS_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, &kdone);
         // first halves with a list-building pass behind them (fs_far_pass): queries that needed a cube of radius >=
         // FS_FAR_MIN_RING are handed to gs_icp_far_build_kernel together with what the search found (squared distance,
         // radius of the last cube); the ones left to the brute-force pass follow below
@@ -644,17 +646,11 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
           far_cq[sq] = make_float4(__uint_as_float((uint32_t)(key >> 32)), (float)kdone, 0.0f, 0.0f);
           q.far_idx[(int64_t)far_pass * n_src + atomicAdd(q.far_n + far_pass, 1)] = (int)sq;
         }
-        // (LMODE 2) a point the cubes served gets its list from the cube (one cell wider when the neighbour sits close to
-        // the cube's bound); what is left to the brute-force pass keeps none and comes back here in every launch
-        if (LMODE == 2 && l16 == 0) {
-          if (done) {
-            const float d1 = sqrtf(__uint_as_float((uint32_t)(key >> 32)));
-            const int kE = kdone + ((d1 + 0.1f * g.c > (float)kdone * g.c * 0.999f) ? 1 : 0);
-            build_q[atomicAdd(&build_n, 1)] = hs | (kE << 16);
-          } else {
-            lq[sq] = make_float4(hx, hy, hz, -1.0f);
-          }
-        }
+      }
+      // (list variants) the scan that served the point leaves its list; what only the brute-force pass can serve keeps none
+      if (LISTS) {
+        if (done) gl_select_write<FS_HG, KH>(top, rc2, hx, hy, hz, l16, LM, ls + GL_SLOTS * sq, lq + sq);
+        else if (l16 == 0) lq[sq] = make_float4(hx, hy, hz, -1.0f);
       }
       if (win >= 0) bslot_s[hs] = win;  // a candidate of the list / the cubes beat the 2x2x2 stage
       if (l16 == 0) {
@@ -665,17 +661,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
     }
     if (nh) {
       __syncthreads();
-      if (LMODE == 2) {   // new lists for the points whose list gave no proof and whose 2x2x2 scan did (keys_s: what it found)
-        const int nbq = build_n;   // block-uniform
-        for (int i = threadIdx.x / FS_HG; i < nbq; i += FS_BLOCK / FS_HG) {
-          const int hs = build_q[i] & 0xffff, kE = build_q[i] >> 16;   // (kE = 0: the 2x2x2 block, else the cube's radius)
-          const int64_t sq = (int64_t)u0 * FS_QPB + hs;
-          gl_build<FS_HG>(g, cell_start, sorted, qs[hs][0], qs[hs][1], qs[hs][2], threadIdx.x & (FS_HG - 1),
-                          __uint_as_float((uint32_t)(keys_s[hs] >> 32)), kE, LM,
-                          stage_s + (threadIdx.x / FS_HG) * GL_STAGE, ls + GL_SLOTS * sq, lq + sq);
-        }
-      }
-      if (threadIdx.x == 0) { hard_n = 0; if (LMODE == 2) build_n = 0; }
+      if (threadIdx.x == 0) hard_n = 0;
       __syncthreads();
     }
     if (tl && threadIdx.x == 0 && u0 == u_first) { tl[5] = wall_clock64(); tl[2] += (unsigned long long)nh; }

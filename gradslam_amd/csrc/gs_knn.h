@@ -400,98 +400,86 @@ GS_DEV float far_emit_cube(const GsGrid& g, const int* __restrict__ cell_start, 
 }
 
 // ---- candidate lists of ORDINARY queries (round 4).  The 2 x numiters searches of a solve look at the SAME binned
-// targets from positions that move by millimetres, then by micrometres.  After a source point's search from q0 its
-// group re-walks the 2x2x2 block it has just scanned and keeps EVERY target within R of q0 (slots of `sorted`, at most
-// M = lanes x entries per lane), R = (distance of the neighbour + GL_MARGIN cells), capped by the distance to the nearest
-// block face with cells behind it (beyond that the block says nothing) and narrowed until the targets fit the slots.
-// Points the block cannot prove (a neighbour farther than half a cell: frame borders, holes) are served by cube scans and
-// get their list from the cube.
-// A later search from q is EXACT on the list alone when
+// targets from positions that move by millimetres, then by micrometres.  A search that scans a whole region (the
+// un-pruned 2x2x2 block, or a cube of cells) lets every lane remember, besides the minimum, the KT nearest candidates it
+// has seen and the distance of the next one (GlTop: a few compares and selects per candidate).  Behind the scan
+//     list = the nearest candidates of the lanes (M slots of `sorted`),
+//     R    = min(distance of the nearest candidate that did NOT make the list, bound of the scanned region):
+// every target closer than R to the search position q0 is on the list.  A later search from q is EXACT on the list alone
+// when
 //     sqrt(best list distance) + |q - q0| < 0.9999 R:
 // every target outside the list is at least R from q0, hence farther than R - |q - q0| from q, hence farther than the
 // list's best; ties are inside the list, and the packed (distance bits, index) order is that of every other engine.
-// The half-iteration kernels fetch the list's points into LDS while their prologue waits for the partial rows of the
-// previous launch, so a proving launch has no search on its critical path at all.  Lists that fail are rebuilt where
-// the point is now (16-lane groups, with the other leftovers).  tools/icp_list_sim.py is the CPU study behind the
-// constants: on the benchmark's solves 32-36 of the 40 launches have no failing list at all.
+// The half-iteration kernels fetch the listed points while their prologue waits for the partial rows of the previous
+// launch, so a launch whose lists all prove has no search on its critical path.  A list that fails is replaced where the
+// point is now by the 16-lane scan that serves it (the same pass).  tools/icp_list_sim.py is the CPU study behind it.
 constexpr int GL_SLOTS = 8;            // list slots of a source point in memory (32 bytes)
-constexpr float GL_MARGIN = 0.4f;      // cells: the widest of the GL_RADII nested radii tried (each a fifth of the one before)
-constexpr int GL_RADII = 4;
-static_assert(GL_RADII == 4, "gl_build spells out the ladder");
-constexpr int GL_MAX_CUBE = 6;         // no list from a cube wider than this (13 x 13 rows of cells)
-constexpr float GL_MIN_ROOM = 0.1f;    // cells between the neighbour and the bound of the scanned region, at least
-constexpr int GL_STAGE = GL_SLOTS + GL_RADII + 1;   // LDS words of a list under construction: slots, one counter per radius, fill
 constexpr int GL_STAT_LAUNCHES = 64;   // launches of a solve with their own failure counters (diagnostics)
+constexpr float GL_MIN_ROOM = 0.1f;    // cells between the neighbour and the bound of a cube scan, at least (else the next cube)
 // entries per lane of a G-lane group (M = G x entries <= GL_SLOTS)
 // (2 lanes x 2: a third entry per lane costs the first-half kernel eight spilled registers, and any spill costs a
-// dependent launch microseconds; tools/icp_list_sim.py: 4 slots leave two launches of a solve with 5 % failures)
+// dependent launch microseconds)
 template <int G> constexpr int gl_k() { return G == 8 ? 1 : 2; }
 
-// Builds the list of the query (qx, qy, qz) whose neighbour (squared distance d1sq) a search has just proven: the GB
-// lanes of the group (same wave) re-walk the region that search covered, twice.
-//   kE = 0: the 2x2x2 block of grid_search_stage0 (un-pruned); every target outside it is at least as far as the nearest
-//           block face with cells behind it;
-//   kE > 0: the cube of Chebyshev radius kE cells around the query's cell (grid_search_rings); every target outside it is
-//           at least kE cells away.
-// Pass 1 counts the targets within d1 + GL_MARGIN / 5^k cells (k = 0 .. GL_RADII - 1), each capped by that bound; the
-// widest radius whose targets fit the M slots wins (a point on a dense patch keeps a list, a short one); pass 2 collects
-// them.  stage = GL_STAGE words of LDS owned by the group.  Writes slots[0 .. GL_SLOTS) and *lq = (q, R) (R = 0:
-// nothing fits); M = capacity the READING groups use (their lanes x entries per lane).
-template <int GB>
-GS_DEV void gl_build(const GsGrid& g, const int* __restrict__ cell_start, const float4* __restrict__ sorted, float qx,
-                     float qy, float qz, int lane, const float d1sq, int kE, const int M, uint32_t* stage,
-                     uint32_t* __restrict__ slots, float4* __restrict__ lq) {
-  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
-  const int cx = qc.cx, cy = qc.cy, cz = qc.cz;
-  const float d1 = sqrtf(d1sq);
-  int xa = 0, xb = 0, zlo = 0, ylo = 0, side = 0;
-  float rcov = 0.0f;
-  if (kE == 0) {
-    const float fx = (qc.px - g.ox) * g.inv_c - (float)cx, fy = (qc.py - g.oy) * g.inv_c - (float)cy,
-                fz = (qc.pz - g.oz) * g.inv_c - (float)cz;
-    const int x0 = (fx < 0.5f) ? cx - 1 : cx, y0 = (fy < 0.5f) ? cy - 1 : cy, z0 = (fz < 0.5f) ? cz - 1 : cz;
-    const float BIG = 3.0e38f;
-    const float ax = fminf(x0 >= 1 ? fx + (float)(cx - x0) : BIG, x0 + 2 < g.nx ? (float)(x0 + 2 - cx) - fx : BIG);
-    const float ay = fminf(y0 >= 1 ? fy + (float)(cy - y0) : BIG, y0 + 2 < g.ny ? (float)(y0 + 2 - cy) - fy : BIG);
-    const float az = fminf(z0 >= 1 ? fz + (float)(cz - z0) : BIG, z0 + 2 < g.nz ? (float)(z0 + 2 - cz) - fz : BIG);
-    const float amin = fminf(ax, fminf(ay, az));
-    // (the same face distance as grid_search_stage0; a query outside the bounding box is measured from its projection,
-    // which is at most as far from every target as the query itself: the claim about the ball around q0 still holds)
-    rcov = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
-    xa = x0 >= 0 ? x0 : x0 + 1; xb = x0 + 1 < g.nx ? x0 + 1 : x0;
-    zlo = z0; ylo = y0; side = 2;
-    // a neighbour that sits right at the block's bound leaves its list no room: such a point would fail its proof, be
-    // re-scanned and get the same list in EVERY launch (a handful per solve, and a launch is as slow as its slowest
-    // block).  It takes its list from the smallest cube that leaves GL_MIN_ROOM cells of room instead.
-    if (rcov < d1 + GL_MIN_ROOM * g.c) kE = (int)((d1 + GL_MIN_ROOM * g.c) * g.inv_c * (1.0f / 0.999f)) + 1;
-  }
-  if (kE > 0) {
-    rcov = (float)kE * g.c * 0.999f;   // (the bound of grid_search_rings)
-    xa = cx - kE < 0 ? 0 : cx - kE; xb = cx + kE >= g.nx ? g.nx - 1 : cx + kE;
-    zlo = cz - kE; ylo = cy - kE; side = 2 * kE + 1;
-  }
-  const int nrow = side * side;
-  float R2[GL_RADII];
+// the KT nearest candidates a lane has seen (squared distances ascending, slots of `sorted`) and the squared distance of
+// the next nearest one (d[KT], +inf while fewer were seen)
+template <int KT>
+struct GlTop {
+  float d[KT + 1];
+  int s[KT];
+};
+template <int KT>
+GS_DEV void gl_top_reset(GlTop<KT>& t) {
 #pragma unroll
-  for (int k = 0; k < GL_RADII; ++k) {
-    // room above the neighbour: GL_MARGIN, then a fifth of the one before (0.4, 0.08, 0.016, 0.0032 cells: the last one
-    // -- a tenth of a millimetre at 640x480 -- still covers the micrometre steps of a converged solve, and lets a point
-    // among near-coincident map surfels keep a list)
-    const float room = k == 0 ? GL_MARGIN : (k == 1 ? GL_MARGIN * 0.2f : (k == 2 ? GL_MARGIN * 0.04f : GL_MARGIN * 0.008f));
-    float R = d1 + room * g.c;
-    R = R < rcov ? R : rcov;
-    R2[k] = (R > 0.0f && kE <= GL_MAX_CUBE) ? R * R : 0.0f;   // (NaN distance: nothing found, nothing listed)
+  for (int k = 0; k <= KT; ++k) t.d[k] = __builtin_inff();
+#pragma unroll
+  for (int k = 0; k < KT; ++k) t.s[k] = -1;
+}
+// (branch-free insertion; a NaN distance fails every compare and changes nothing)
+template <int KT>
+GS_DEV void gl_top_push(GlTop<KT>& t, const float d, const int slot) {
+#pragma unroll
+  for (int k = KT; k >= 0; --k) {   // from the far end: entry k takes entry k - 1 when d goes in front of it
+    const bool before_prev = k > 0 && d < t.d[k - 1];
+    const bool before_this = d < t.d[k];
+    if (k < KT) t.s[k] = before_prev ? t.s[k - 1] : (before_this ? slot : t.s[k]);
+    t.d[k] = before_prev ? t.d[k - 1] : (before_this ? d : t.d[k]);
   }
-  for (int u = lane; u < GL_STAGE; u += GB) stage[u] = u < GL_SLOTS ? ~0u : 0u;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  // The region as a flat candidate list.  kE = 0: the 4 row segments of the block, their 8 bounds fetched together
-  // (one round trip), then 2 or 4 independent gathers in flight per lane and pass -- a rebuilt list costs three round trips,
-  // and a block with ONE failing list is what a launch waits for.  Cubes (rare) walk their rows one after the other.
+}
+template <int G>
+GS_DEV float gl_group_minf(float v) {
+#pragma unroll
+  for (int d = G / 2; d > 0; d >>= 1) {
+    const float o = __shfl_xor(v, d, G);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// grid_search_stage0 without a search bound (the whole 2x2x2 block is scanned, so that it bounds the list) and with the
+// lanes' trackers.  *rcov2 = squared distance within which the block holds every target (+inf: no cells behind any face).
+template <int G, int KT>
+GS_DEV unsigned long long grid_search_stage0_top(const GsGrid& g, const int* __restrict__ cell_start,
+                                                 const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
+                                                 bool* resolved, int* win, GlTop<KT>& top, float* rcov2) {
+  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
+  const float px = qc.px, py = qc.py, pz = qc.pz;
+  const int cx = qc.cx, cy = qc.cy, cz = qc.cz;
+  unsigned long long key = ~0ull;
+  int bt = -1;
+  const float fx = (px - g.ox) * g.inv_c - (float)cx, fy = (py - g.oy) * g.inv_c - (float)cy,
+              fz = (pz - g.oz) * g.inv_c - (float)cz;
+  const int x0 = (fx < 0.5f) ? cx - 1 : cx, y0 = (fy < 0.5f) ? cy - 1 : cy, z0 = (fz < 0.5f) ? cz - 1 : cz;
+  const float BIG = 3.0e38f;
+  const float ax = fminf(x0 >= 1 ? fx + (float)(cx - x0) : BIG, x0 + 2 < g.nx ? (float)(x0 + 2 - cx) - fx : BIG);
+  const float ay = fminf(y0 >= 1 ? fy + (float)(cy - y0) : BIG, y0 + 2 < g.ny ? (float)(y0 + 2 - cy) - fy : BIG);
+  const float az = fminf(z0 >= 1 ? fz + (float)(cz - z0) : BIG, z0 + 2 < g.nz ? (float)(z0 + 2 - cz) - fz : BIG);
+  const float amin = fminf(ax, fminf(ay, az));
   int sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, e1 = 0, e2 = 0, e3 = 0, total = 0;
-  if (kE == 0) {
-    const bool zl = zlo >= 0, zh = zlo + 1 < g.nz, yl = ylo >= 0, yh = ylo + 1 < g.ny;
-    const int r0 = (zlo * g.ny + ylo) * g.nx, r1 = r0 + g.nx, r2 = r0 + g.ny * g.nx, r3 = r2 + g.nx;
+  {
+    const int xa = x0 >= 0 ? x0 : x0 + 1, xb = x0 + 1 < g.nx ? x0 + 1 : x0;
+    const bool zl = z0 >= 0, zh = z0 + 1 < g.nz, yl = y0 >= 0, yh = y0 + 1 < g.ny;
+    const int r0 = (z0 * g.ny + y0) * g.nx, r1 = r0 + g.nx, r2 = r0 + g.ny * g.nx, r3 = r2 + g.nx;
     int se0 = 0, se1 = 0, se2 = 0, se3 = 0;
     if (zl && yl) { sb0 = cell_start[r0 + xa]; se0 = cell_start[r0 + xb + 1]; }
     if (zl && yh) { sb1 = cell_start[r1 + xa]; se1 = cell_start[r1 + xb + 1]; }
@@ -502,67 +490,129 @@ GS_DEV void gl_build(const GsGrid& g, const int* __restrict__ cell_start, const 
     e3 = e2 + (se2 - sb2);
     total = e3 + (se3 - sb3);
   }
-  float Rsel2 = 0.0f;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {   // pass 0: how many targets within each radius; pass 1: collect within the chosen one
-    int cnt[GL_RADII];
+  constexpr int NF = G >= 16 ? 2 : 4;   // gathers in flight per lane (the 16-lane groups see 32 candidates per round)
+  for (int t0 = lane; t0 < total; t0 += NF * G) {
+    float4 p[NF];
+    int ix[NF];
 #pragma unroll
-    for (int k = 0; k < GL_RADII; ++k) cnt[k] = 0;
-    if (pass == 1 && !(Rsel2 > 0.0f)) break;
-    auto visit = [&](const int j, const float4 c) {
-      const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-      float d = dx * dx;
-      d = gs_fma(dy, dy, d);
-      d = gs_fma(dz, dz, d);
-      if (pass == 0) {
-#pragma unroll
-        for (int k = 0; k < GL_RADII; ++k) cnt[k] += d < R2[k] ? 1 : 0;
-      } else if (d < Rsel2) {
-        const int pos = (int)atomicAdd(&stage[GL_SLOTS + GL_RADII], 1u);
-        if (pos < GL_SLOTS) stage[pos] = (uint32_t)j;   // (pos < M by the count of pass 0)
-      }
-    };
-    if (kE == 0) {
-      constexpr int NF = GB >= 16 ? 2 : 4;   // gathers in flight per lane (32 candidates per round either way or more)
-      for (int t0 = lane; t0 < total; t0 += NF * GB) {
-        float4 p[NF];
-        int ix[NF];
-#pragma unroll
-        for (int u = 0; u < NF; ++u) {
-          const int t = t0 + u * GB, tt = t < total ? t : 0;   // total > 0 here: position 0 is valid
-          ix[u] = tt < e1 ? sb0 + tt : (tt < e2 ? sb1 + (tt - e1) : (tt < e3 ? sb2 + (tt - e2) : sb3 + (tt - e3)));
-          p[u] = sorted[ix[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < NF; ++u)
-          if (t0 + u * GB < total) visit(ix[u], p[u]);
-      }
-    } else {
-      for (int r = 0; r < nrow; ++r) {
-        const int zz = zlo + r / side, yy = ylo + r % side;
-        if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
-        const int row = (zz * g.ny + yy) * g.nx;
-        const int je = cell_start[row + xb + 1];
-        for (int j = cell_start[row + xa] + lane; j < je; j += GB) visit(j, sorted[j]);
-      }
+    for (int u = 0; u < NF; ++u) {
+      const int t = t0 + u * G, tt = t < total ? t : 0;  // total > 0 here: position 0 is valid
+      ix[u] = tt < e1 ? sb0 + tt : (tt < e2 ? sb1 + (tt - e1) : (tt < e3 ? sb2 + (tt - e2) : sb3 + (tt - e3)));
+      p[u] = sorted[ix[u]];
     }
-    if (pass == 0) {
 #pragma unroll
-      for (int k = 0; k < GL_RADII; ++k)
-        if (cnt[k]) atomicAdd(&stage[GL_SLOTS + k], (uint32_t)cnt[k]);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // the widest radius that fits (group-uniform: every lane reads the same counters)
-#pragma unroll
-      for (int k = GL_RADII - 1; k >= 0; --k)
-        if ((int)stage[GL_SLOTS + k] <= M && R2[k] > 0.0f) Rsel2 = R2[k];
+    for (int u = 0; u < NF; ++u) {
+      const bool in = t0 + u * G < total;
+      const unsigned long long k2 = in ? grid_key(qx, qy, qz, p[u]) : ~0ull;
+      const bool better = k2 < key;
+      key = better ? k2 : key;
+      bt = better ? ix[u] : bt;
+      // (the distance the key carries; NaN for a masked or NaN candidate: ignored by the tracker)
+      gl_top_push<KT>(top, __uint_as_float((uint32_t)(k2 >> 32)), ix[u]);
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  for (int u = lane; u < GL_SLOTS; u += GB) slots[u] = stage[u];
-  if (lane == 0) *lq = make_float4(qx, qy, qz, sqrtf(Rsel2));
-  __builtin_amdgcn_wave_barrier();
+  {
+    const unsigned long long kmin = grid_group_min<G>(key);
+    *win = (key == kmin && bt >= 0) ? bt : -1;
+    key = kmin;
+  }
+  const float rb = (amin < 1.0e30f) ? (amin - 0.001f) * g.c : BIG;
+  const float bd = __uint_as_float((uint32_t)(key >> 32));  // NaN while nothing was found
+  *resolved = rb > 0.0f && (rb >= 1.0e30f ? bd == bd : bd <= rb * rb);
+  *rcov2 = rb >= 1.0e30f ? __builtin_inff() : (rb > 0.0f ? rb * rb : 0.0f);
+  return key;
+}
+
+// grid_search_rings with the lanes' trackers (reset per cube: a cube re-scans the cells of the one before).  A cube that
+// proves the neighbour but leaves it less than GL_MIN_ROOM cells of room is followed by the next one, for the list's
+// sake.  *rcov2 = squared radius within which the last cube scanned holds every target (0: not resolved).
+template <int G, int KT>
+GS_DEV unsigned long long grid_search_rings_top(const GsGrid& g, const int* __restrict__ cell_start,
+                                                const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
+                                                unsigned long long key, bool* resolved, int* win, const int kmax,
+                                                GlTop<KT>& top, float* rcov2) {
+  const GsQueryCell qc = grid_query_cell(g, qx, qy, qz);
+  bool done = false;
+  int bs = -1;
+  float cov2 = 0.0f;
+  for (int k = 1; k <= kmax + 1; ++k) {
+    if (k > kmax && !done) break;
+    gl_top_reset<KT>(top);
+    const int side = 2 * k + 1, nrow = side * side;
+    const int xa = qc.cx - k < 0 ? 0 : qc.cx - k, xb = qc.cx + k >= g.nx ? g.nx - 1 : qc.cx + k;
+    for (int r = lane; r < nrow; r += G) {
+      const int zz = qc.cz + r / side - k, yy = qc.cy + r % side - k;
+      if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
+      const int row = (zz * g.ny + yy) * g.nx;
+      const int je = cell_start[row + xb + 1];
+      for (int j = cell_start[row + xa]; j < je; ++j) {
+        const unsigned long long k2 = grid_key(qx, qy, qz, sorted[j]);
+        if (k2 < key) { key = k2; bs = j; }
+        gl_top_push<KT>(top, __uint_as_float((uint32_t)(k2 >> 32)), j);
+      }
+    }
+    {
+      const unsigned long long own = key;
+      key = grid_group_min<G>(key);
+      if (own != key) bs = -1;
+    }
+    const float rb = (float)k * g.c * 0.999f;
+    const float bd = __uint_as_float((uint32_t)(key >> 32));  // NaN while nothing was found
+    if (done) { cov2 = rb * rb; break; }                      // the extra cube: room for the list
+    done = bd <= rb * rb;
+    if (done) {
+      cov2 = rb * rb;
+      if (sqrtf(bd) + GL_MIN_ROOM * g.c <= rb) break;
+    }
+  }
+  *resolved = done;
+  *win = bs;
+  *rcov2 = done ? cov2 : 0.0f;
+  return key;
+}
+
+// The list of a point searched by its own G lanes (the readers: lane l keeps entries l * KT ..): every lane writes the
+// candidates it remembers; R from what the lanes left out and the bound of the scan.  All lanes of the group call it.
+template <int G, int KT>
+GS_DEV void gl_write_lanes(const GlTop<KT>& top, const float rcov2, float qx, float qy, float qz, int lane,
+                           uint32_t* __restrict__ slots, float4* __restrict__ lq) {
+  const float out2 = gl_group_minf<G>(top.d[KT]);
+  const float R2 = out2 < rcov2 ? out2 : rcov2;
+#pragma unroll
+  for (int k = 0; k < KT; ++k) slots[lane * KT + k] = top.s[k] >= 0 ? (uint32_t)top.s[k] : ~0u;
+  if (lane == 0) *lq = make_float4(qx, qy, qz, sqrtf(R2));
+}
+
+// The list of a point searched by a group of GB lanes for readers that keep M slots: the M nearest of everything the
+// lanes remember (M rounds of a group minimum; the winner hands over its head), R from the nearest candidate left out -- a
+// lane's own next one or the best head that stays behind -- and the bound of the scan.  All lanes of the group call it.
+template <int GB, int KT>
+GS_DEV void gl_select_write(GlTop<KT> top, const float rcov2, float qx, float qy, float qz, int lane, const int M,
+                            uint32_t* __restrict__ slots, float4* __restrict__ lq) {
+  float out2 = gl_group_minf<GB>(top.d[KT]);
+  for (int e = 0; e < GL_SLOTS; ++e) {
+    const unsigned long long mine = ((unsigned long long)__float_as_uint(top.d[0]) << 32) | (unsigned)lane;  // d >= 0
+    const unsigned long long best = grid_group_min<GB>(mine);
+    const float bd = __uint_as_float((uint32_t)(best >> 32));
+    if (e >= M) {   // the nearest one that stays behind bounds the list (and the unused slots are cleared)
+      if (e == M) out2 = bd < out2 ? bd : out2;
+      if (lane == 0) slots[e] = ~0u;
+      continue;
+    }
+    if (best == mine) {
+      slots[e] = (bd < __builtin_inff() && top.s[0] >= 0) ? (uint32_t)top.s[0] : ~0u;
+#pragma unroll
+      for (int k = 0; k + 1 < KT; ++k) { top.d[k] = top.d[k + 1]; top.s[k] = top.s[k + 1]; }
+      top.d[KT - 1] = __builtin_inff();   // (what came behind the remembered ones is in out2 already)
+      top.s[KT - 1] = -1;
+    }
+  }
+  if (M >= GL_SLOTS) {   // no slot left to look at the next head in the loop
+    const float nb = gl_group_minf<GB>(top.d[0]);
+    out2 = nb < out2 ? nb : out2;
+  }
+  const float R2 = out2 < rcov2 ? out2 : rcov2;
+  if (lane == 0) *lq = make_float4(qx, qy, qz, sqrtf(R2));
 }
 
 template <int G = GQ_G>

@@ -1,0 +1,24 @@
+"""Build-time invariants of the ICP half-iteration kernels (no GPU needed: hipcc cross-compiles and reports the register
+allocation).  A kernel of the 2 x numiters dependent launches of a solve that touches its private segment costs every
+launch microseconds, and a register spill in the prologue of the list variants is a store in the
+memory queue behind which every wait for a load drains the gathers in flight -- so ScratchSize 0 is checked, not hoped
+for."""
+import os
+import re
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_half_iteration_kernels_use_no_scratch_and_fit_two_blocks_per_cu():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "kernel_resources.py"), "gs_icp_loop.hip", "gs_icp_half_batch_kernel"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [ln.split(None, 7) for ln in r.stdout.splitlines() if "gs_icp_half_batch_kernel" in ln]
+    assert len(rows) == 22, r.stdout            # 2 halves x (3 lane counts x 3 list modes + 2 far-list variants)
+    for vgpr, sgpr, scratch, occ, sspill, vspill, lds, name in rows:
+        assert int(scratch) == 0 and int(vspill) == 0, (name, scratch, vspill)
+        assert int(vgpr) <= 80 and int(occ) >= 6, (name, vgpr, occ)          # 2 blocks of 12 waves per CU
+        assert int(lds) <= 80 * 1024, (name, lds)                             # ... and of the 160 KB of LDS
+    assert re.search(r"<true, 2, false, 2>", r.stdout) and re.search(r"<false, 8, false, 1>", r.stdout)
