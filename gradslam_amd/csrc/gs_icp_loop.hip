@@ -338,6 +338,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
   // (LMODE 2) source point and (list centre, radius) of every group, parked across the scalar stage of the prologue: its
   // one-lane float64 code needs the registers, the lanes that wait for it do not
   __shared__ float4 park_s[LMODE == 2 ? 2 * NQ : 1];
+  __shared__ uint8_t rowdone_s[LMODE == 2 ? NQ : 1];   // (LMODE 2) the row of this slot was built by the lane that won its list check
   float4* __restrict__ far_cq = q.far_cq;
   uint32_t* __restrict__ far_c = q.far_c;
   // (FAR is a template parameter: the kernels sit at their register limit, and the code of the lists costs the
@@ -357,6 +358,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
   // (LMODE is a template parameter: one kernel per mode keeps each of them within the register budget)
   constexpr bool verify = LMODE == 2;
   constexpr bool build_all = LMODE == 1;
+  constexpr bool NPREF = LMODE == 2 && !FULL;   // the list check also fetches the normal of the likely match
   // the source point of the first slot does not depend on the prologue: issue its load first so that
   // the global-memory latency hides behind the scalar stage
   const int lane = threadIdx.x & (G - 1), slot = threadIdx.x / G;
@@ -367,6 +369,8 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
   float4 lqv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // (verify) list centre and exactness radius of this group's point
   uint32_t sl[LK];                                     // (verify) this lane's slots of the list
   float4 cv[LK];                                       // (verify) the points in those slots
+  float4 cn0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // (verify) the normal of the first of them (the list's nearest
+                                                       // when it was built: almost always the match again)
   typedef float gs_v4f __attribute__((ext_vector_type(4)));
   gs_v4f stv = {0.0f, 0.0f, 0.0f, 0.0f};             // (verify) this lane's 16 bytes of the state of the previous half
   int st_idx = 0;
@@ -434,11 +438,14 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
           cv[j] = sorted[sl[j] != ~0u ? sl[j] : 0u];   // (unconditional: slot 0 stands in for an empty entry, never looked at)
 #endif
         }
+        // (look-ahead half only: in the first half the four registers do not fit next to its scalar stage)
+        if (NPREF && sorted_n) cn0 = sorted_n[sl[0] != ~0u ? sl[0] : 0u];   // (block-uniform: every lane issues it or none)
         if (lane == 0) {
           int slot_p = slot;   // (opaque: merged with the address of qa_s[slot] at the far end of the kernel it would be spilled)
           asm volatile("" : "+v"(slot_p));
           park_s[2 * slot_p] = make_float4(p0, p1, p2, 0.0f);
           park_s[2 * slot_p + 1] = lqv;
+          rowdone_s[slot_p] = 0;
         }
       }
       // The barriers of this variant do not drain the memory queue, so the copy of the state (hand-issued before
@@ -446,7 +453,8 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
       // of issue, and exactly LK (verify) vector-memory instructions -- the unconditional gathers right above -- have
       // been issued since everything else.  The row sums are consumed next anyway, so this wait costs nothing.
       if (LMODE == 2 && verify) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LK) : "memory");
+        if (NPREF && sorted_n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LK + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LK) : "memory");
         if (st_lane) *reinterpret_cast<gs_v4f*>(reinterpret_cast<float4*>(&sm) + st_idx) = stv;
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -467,6 +475,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
     } else {
       __syncthreads();
     }
+    if (tl && threadIdx.x == 0) { tl[8] = wall_clock64(); tl[9] = tl[8]; }   // sums done (no solve in this half)
     if (threadIdx.x == 0) {  // scalar stage, in place on the LDS copy of the state
 #ifndef GS_T_NOSCALAR
       if (it > 0)
@@ -478,8 +487,10 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
   } else {
     if (LISTS) icp_sum_rows_split<FS_BLOCK>(partials_in, nrows_in, S, sub, hook);
     else icp_sum_rows<FS_BLOCK>(partials_in, nrows_in, S, sub);
+    if (tl && threadIdx.x == 0) tl[8] = wall_clock64();   // sums done
     if (threadIdx.x < GS_WAVE) gs_solve_spd6_wave(S, sm.damp, sm.xi);  // 6x6 solve across the lanes of wave 0
     gs_bar<LISTS>();
+    if (tl && threadIdx.x == 0) tl[9] = wall_clock64();   // solve done
     if (threadIdx.x == 0) {
       if (q.tape_sys && lb == 0) tape_write_sys(q.tape_sys, it, S, sm.damp);
 #ifndef GS_T_NOSCALAR
@@ -544,6 +555,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         // the list: every listed point against the query, the same key order as every other engine
         key = ~0ull;
         int wsl = -1;
+        bool first = false;   // this lane's best is its first entry (whose normal it holds)
 #ifdef GS_T_LATEGATHER
 #pragma unroll
         for (int j = 0; j < LK; ++j)
@@ -552,7 +564,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
 #pragma unroll
         for (int j = 0; j < LK; ++j) {
           const unsigned long long k2 = sl[j] != ~0u ? grid_key(qx, qy, qz, cv[j]) : ~0ull;
-          if (k2 < key) { key = k2; wsl = (int)sl[j]; }
+          if (k2 < key) { key = k2; wsl = (int)sl[j]; first = j == 0; }
         }
         const unsigned long long kmin = grid_group_min<G>(key);
         win = (key == kmin && wsl >= 0) ? wsl : -1;
@@ -561,6 +573,17 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         const float ex = qx - lqv.x, ey = qy - lqv.y, ez = qz - lqv.z;
         const float delta = sqrtf(ex * ex + ey * ey + ez * ez);
         done = lqv.w > 0.0f && sqrtf(bd) + delta < lqv.w * 0.9999f;   // false for NaN
+        // the lane that holds the match and its normal builds the Gauss-Newton row right here (the same operations on the
+        // same values as the row pass below, which then has nothing to gather for this slot)
+        if (NPREF && done && win >= 0 && first && sorted_n) {
+          float a[6], res;
+          gn_row_pn(qx, qy, qz, cv[0], cn0, a, res);
+          const bool keep = (dist_thresh < 0.0f) || (bd < dist_thresh);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) qa_s[slot][i] = keep ? a[i] : 0.0f;
+          qa_s[slot][6] = keep ? res : 0.0f;
+          rowdone_s[slot] = 1;
+        }
         if (!done) {
           key = ~0ull;
           win = -1;
@@ -691,6 +714,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
       if (LISTS) asm volatile("" : "+s"(u0r));
       const int64_t s = LISTS ? (int64_t)u0r * FS_QPB + slot : (int64_t)u0 * FS_QPB + slot;
       float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, res = 0.0f;
+      bool rowdone = false;
       if (live && qs[slot][0] != qs[slot][0]) {  // skipped (NaN) source point
         if (FULL && out_idx) out_idx[s] = -1;
         if (tape_idx) tape_idx[s] = -1;
@@ -707,7 +731,8 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         const float d2 = __uint_as_float((uint32_t)(bb >> 32));
         const bool keep = (dist_thresh < 0.0f) || (d2 < dist_thresh);
         const int bsl = bslot_s[slot];
-        if (sorted_n && bsl >= 0 && bb != ~0ull)   // matched point and normal from the binned copies (same bits)
+        if (NPREF && rowdone_s[slot]) rowdone = true;   // (built by the lane that won the list check)
+        else if (sorted_n && bsl >= 0 && bb != ~0ull)   // matched point and normal from the binned copies (same bits)
           gn_row_pn(qs[slot][0], qs[slot][1], qs[slot][2], sorted[bsl], sorted_n[bsl], a, res);
         else
           gn_row(qs[slot][0], qs[slot][1], qs[slot][2], tgt, tn, j, a, res);
@@ -719,9 +744,11 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
           res = 0.0f;
         }
       }
+      if (!rowdone) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) qa_s[slot][i] = a[i];
-      qa_s[slot][6] = res;
+        for (int i = 0; i < 6; ++i) qa_s[slot][i] = a[i];
+        qa_s[slot][6] = res;
+      }
     }
     __syncthreads();
     if (!FULL) {  // residual only: per unit the wave-sum tree over its 96 values (64 + 32), then the two wave sums

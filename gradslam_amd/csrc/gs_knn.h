@@ -591,6 +591,10 @@ GS_DEV void gl_select_write(GlTop<KT> top, const float rcov2, float qx, float qy
                             uint32_t* __restrict__ slots, float4* __restrict__ lq) {
   float out2 = gl_group_minf<GB>(top.d[KT]);
   for (int e = 0; e < GL_SLOTS; ++e) {
+    if (e > M) {   // (M is the same for every lane of the kernel) nothing more to look at: clear the slot
+      if (lane == 0) slots[e] = ~0u;
+      continue;
+    }
     const unsigned long long mine = ((unsigned long long)__float_as_uint(top.d[0]) << 32) | (unsigned)lane;  // d >= 0
     const unsigned long long best = grid_group_min<GB>(mine);
     const float bd = __uint_as_float((uint32_t)(best >> 32));

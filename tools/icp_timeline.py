@@ -40,6 +40,10 @@ for part, label in (("", "first half"), (".next", "look-ahead")):
     nun = (rows[:, 8] & 0xffffffff).astype(np.int64)
     print("phases (us, mean / max over blocks): prologue %.2f / %.2f   search (list check) + left-overs %.2f / %.2f   rows %.2f / %.2f" % (
         pro.mean(), pro.max(), sea.mean(), sea.max(), rest.mean(), rest.max()))
+    s1 = (rows[:, 9] - rows[:, 1]).astype(np.float64) / 100.0    # start -> row sums done
+    s2 = (rows[:, 10] - rows[:, 9]).astype(np.float64) / 100.0   # -> 6x6 solve done (look-ahead half)
+    s3 = (rows[:, 5] - rows[:, 10]).astype(np.float64) / 100.0   # -> scalar stage done, state published
+    print("prologue (us, mean over blocks): loads + sums %.2f   solve %.2f   scalar stage + barrier %.2f" % (s1.mean(), s2.mean(), s3.mean()))
     print("left-over queries: total %d, blocks with any %d, per block max %d; brute-force queries %d" % (
         csum.sum(), (csum > 0).sum(), csum.max(), nun.sum()))
     order = np.argsort(end)[::-1][:5]
