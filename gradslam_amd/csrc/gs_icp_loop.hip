@@ -271,7 +271,6 @@ struct IcpHalfLists {
 
 // flags of an entry of the block's list of left-over queries (hard_q)
 constexpr int FS_HQ_FAR = (int)0x80000000;   // the query has a far-candidate list (FAR variants)
-constexpr int FS_HQ_SCAN = 0x40000000;       // (LISTS) its candidate list gave no proof: 2x2x2 scan by the 16-lane group, new list
 constexpr int FS_HQ_SLOT = 0x3fffffff;
 
 // index pairs (into [a0..a5, res]) of the 28 accumulated products: 21 upper-triangular a_i a_k, 6 a_i res, res res
@@ -550,7 +549,6 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
       bool done;
       int win;
       unsigned long long key;
-      int hq_flags = 0;
       if (LMODE == 2 && verify) {
         // the list: every listed point against the query, the same key order as every other engine
         key = ~0ull;
@@ -587,11 +585,22 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         if (!done) {
           key = ~0ull;
           win = -1;
-          // R < 0: the 2x2x2 stage could not prove this point when it was last tried -- straight to the cube scans
-          hq_flags = lqv.w < 0.0f ? 0 : FS_HQ_SCAN;
           const int hl = 2 * it + (FULL ? 0 : 1);   // launch index within the solve (failure counters)
           if (lane == 0 && ql.lstat && hl < GL_STAT_LAUNCHES)
             atomicAdd(ql.lstat + (lqv.w < 0.0f ? 2 * GL_STAT_LAUNCHES : (lqv.w == 0.0f ? GL_STAT_LAUNCHES : 0)) + hl, 1);
+          // No proof from the list: the group scans the 2x2x2 block itself, right here, and leaves a new list for where
+          // the point is now (as the building launch does).  A launch in which many lists fail -- the cloud has moved by
+          // millimetres -- then costs what a launch without lists costs, not more; sending the failures to the 16-lane
+          // left-over pass instead made such launches two to three times as long.
+          // (R < 0: the 2x2x2 stage could not prove this point when it was last tried -- straight to the cube scans)
+          if (lqv.w >= 0.0f) {
+            GlTop<LK> top;
+            gl_top_reset<LK>(top);
+            float rc2;
+            key = grid_search_stage0_top<G, LK>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win, top, &rc2);
+            if (done) gl_write_lanes<G, LK>(top, rc2, qx, qy, qz, lane, ls + GL_SLOTS * s, lq + s);
+            else if (lane == 0) lq[s] = make_float4(qx, qy, qz, -1.0f);   // (the cubes below may still give it a list)
+          }
         }
       } else {
         if (build_all) {
@@ -615,7 +624,6 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
           key = grid_search_stage0<G>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win, rball);
         }
       }
-      (void)hq_flags;
       if (win >= 0 || (lane == 0 && key == ~0ull)) bslot_s[slot] = win;  // one writer: the winning lane
       if (lane == 0) {
         if (FULL) {  // the transformed cloud of this iteration
@@ -626,7 +634,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         qs[slot][0] = qx; qs[slot][1] = qy; qs[slot][2] = qz;
         keys_s[slot] = key;
         if (FAR) far_s[slot] = 0;
-        if (!done) hard_q[atomicAdd(&hard_n, 1)] = slot | (LMODE == 2 ? hq_flags : (has_far ? FS_HQ_FAR : 0));
+        if (!done) hard_q[atomicAdd(&hard_n, 1)] = slot | (has_far ? FS_HQ_FAR : 0);
       }
     }
     __syncthreads();
@@ -652,12 +660,6 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
       constexpr int KH = 2;   // candidates a lane of the 16-lane group remembers for the new list
       GlTop<KH> top;
       float rc2 = 0.0f;
-      if (LMODE == 2 && (e & FS_HQ_SCAN)) {   // its list gave no proof: the 2x2x2 block by 16 lanes, and a list for where it is now
-        gl_top_reset<KH>(top);
-        key = grid_search_stage0_top<FS_HG, KH>(g, cell_start, sorted, hx, hy, hz, l16, &done, &win, top, &rc2);
-        if (win >= 0) bslot_s[hs] = win;
-        win = -1;
-      }
       if (!done) {
         int kdone = 0;
         if (LISTS) key = grid_search_rings_top<FS_HG, KH>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, top, &rc2);

@@ -417,9 +417,9 @@ constexpr int GL_SLOTS = 8;            // list slots of a source point in memory
 constexpr int GL_STAT_LAUNCHES = 64;   // launches of a solve with their own failure counters (diagnostics)
 constexpr float GL_MIN_ROOM = 0.1f;    // cells between the neighbour and the bound of a cube scan, at least (else the next cube)
 // entries per lane of a G-lane group (M = G x entries <= GL_SLOTS)
-// (2 lanes x 2: a third entry per lane costs the first-half kernel eight spilled registers, and any spill costs a
-// dependent launch microseconds)
-template <int G> constexpr int gl_k() { return G == 8 ? 1 : 2; }
+// (2 lanes x 2, 4 x 1, 8 x 1: one more entry per lane makes the first-half kernel spill next to its scalar stage --
+// which wants ~60 registers for one lane's float64 code -- and any spill costs a dependent launch microseconds)
+template <int G> constexpr int gl_k() { return G == 2 ? 2 : 1; }
 
 // the KT nearest candidates a lane has seen (squared distances ascending, slots of `sorted`) and the squared distance of
 // the next nearest one (d[KT], +inf while fewer were seen)
