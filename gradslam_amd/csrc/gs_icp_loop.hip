@@ -337,6 +337,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
   // (LMODE 2) source point and (list centre, radius) of every group, parked across the scalar stage of the prologue: its
   // one-lane float64 code needs the registers, the lanes that wait for it do not
   __shared__ float4 park_s[LMODE == 2 ? 2 * NQ : 1];
+  __shared__ int lfail_s[3];   // (LMODE 2) lists of this block that gave no proof / were empty / points without a list
   __shared__ uint8_t rowdone_s[LMODE == 2 ? NQ : 1];   // (LMODE 2) the row of this slot was built by the lane that won its list check
   float4* __restrict__ far_cq = q.far_cq;
   uint32_t* __restrict__ far_c = q.far_c;
@@ -482,6 +483,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
 #endif
       unres_n = 0;
       hard_n = 0;
+      lfail_s[0] = lfail_s[1] = lfail_s[2] = 0;
     }
   } else {
     if (LISTS) icp_sum_rows_split<FS_BLOCK>(partials_in, nrows_in, S, sub, hook);
@@ -497,6 +499,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
 #endif
       unres_n = 0;
       hard_n = 0;
+      lfail_s[0] = lfail_s[1] = lfail_s[2] = 0;
     }
   }
   gs_bar<LISTS>();
@@ -585,9 +588,9 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         if (!done) {
           key = ~0ull;
           win = -1;
-          const int hl = 2 * it + (FULL ? 0 : 1);   // launch index within the solve (failure counters)
-          if (lane == 0 && ql.lstat && hl < GL_STAT_LAUNCHES)
-            atomicAdd(ql.lstat + (lqv.w < 0.0f ? 2 * GL_STAT_LAUNCHES : (lqv.w == 0.0f ? GL_STAT_LAUNCHES : 0)) + hl, 1);
+          // (failure counters: per block in LDS, three global atomics per block below -- thousands of failing groups
+          // adding to ONE global word serialise at ~12 ns each, which made a launch with many failures three times as long)
+          if (lane == 0) atomicAdd(&lfail_s[lqv.w < 0.0f ? 2 : (lqv.w == 0.0f ? 1 : 0)], 1);
           // No proof from the list: the group scans the 2x2x2 block itself, right here, and leaves a new list for where
           // the point is now (as the building launch does).  A launch in which many lists fail -- the cloud has moved by
           // millimetres -- then costs what a launch without lists costs, not more; sending the failures to the 16-lane
@@ -638,6 +641,11 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
       }
     }
     __syncthreads();
+    if (LMODE == 2 && threadIdx.x < 3 && ql.lstat) {   // failure counters of this launch (diagnostics)
+      const int hl = 2 * it + (FULL ? 0 : 1);         // launch index within the solve
+      const int c = lfail_s[threadIdx.x];
+      if (c && hl < GL_STAT_LAUNCHES) atomicAdd(ql.lstat + threadIdx.x * GL_STAT_LAUNCHES + hl, c);
+    }
     // ---- the few queries the 2x2x2 stage did not resolve (neighbour farther than ~half a cell): Chebyshev shells
     // by groups of FS_HG lanes, so that they do not hold up the waves of the common case
     const int nh = hard_n;  // block-uniform
@@ -883,7 +891,9 @@ static void icp_half_launch(const IcpHalfPlan& pl, IcpHalfBatch& hb, GsCount n_s
   constexpr size_t TL_HALF = 72 * 7000;
   hb.timeline = nullptr;
   const size_t tl_n = 72 * (size_t)hb.B * pl.nb;
-  const bool tl = tl_path && it == prm->numiters - 1;
+  static const char* tl_it_env = getenv("GRADSLAM_HIP_ICP_TIMELINE_IT");   // the iteration recorded (default: the last)
+  const int tl_it = tl_it_env ? atoi(tl_it_env) : prm->numiters - 1;
+  const bool tl = tl_path && it == tl_it;
   if (tl) {
     if (!tl_buf && hipMalloc(&tl_buf, 8 * 2 * TL_HALF) != hipSuccess) tl_buf = nullptr;
     if (tl_buf && tl_n <= TL_HALF) {
