@@ -211,7 +211,7 @@ __host__ __device__ inline int fs_far_pass(int it) {
 }
 constexpr int FS_FAR_MIN_RING = 2;   // queries served by a cube of at least this radius get a candidate list (gs_knn.h)
 constexpr int FS_HG = 16;  // lanes per query of the shell search for queries the 2x2x2 stage leaves open
-constexpr int FS_LISTS_FROM = 6;   // iteration behind whose look-ahead search the candidate lists of ordinary queries are built
+constexpr int FS_LISTS_FROM = 1;   // iteration behind whose look-ahead search the candidate lists of ordinary queries are built
 static_assert(FS_QPB <= 2 * GS_WAVE && FS_QPB % FS_RPG == 0 && FS_RG * LIN_NV <= FS_BLOCK, "block shape");
 
 // FULL = true : first half of iteration `it`  (prologue: LM update of iteration it-1, then search
@@ -434,9 +434,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
 #pragma unroll
         for (int j = 0; j < LK; ++j) {
           if (!try_list || !(sl[j] < nsl)) sl[j] = ~0u;
-#ifndef GS_T_LATEGATHER
           cv[j] = sorted[sl[j] != ~0u ? sl[j] : 0u];   // (unconditional: slot 0 stands in for an empty entry, never looked at)
-#endif
         }
         // (look-ahead half only: in the first half the four registers do not fit next to its scalar stage)
         if (NPREF && sorted_n) cn0 = sorted_n[sl[0] != ~0u ? sl[0] : 0u];   // (block-uniform: every lane issues it or none)
@@ -477,10 +475,8 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
     }
     if (tl && threadIdx.x == 0) { tl[8] = wall_clock64(); tl[9] = tl[8]; }   // sums done (no solve in this half)
     if (threadIdx.x == 0) {  // scalar stage, in place on the LDS copy of the state
-#ifndef GS_T_NOSCALAR
       if (it > 0)
         icp_update_math((float)e1, sm, prm, (lb == 0 && it - 1 < GS_ICP_MAX_ITERS) ? q.trace + 12 * (it - 1) : nullptr);
-#endif
       unres_n = 0;
       hard_n = 0;
       lfail_s[0] = lfail_s[1] = lfail_s[2] = 0;
@@ -494,9 +490,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
     if (tl && threadIdx.x == 0) tl[9] = wall_clock64();   // solve done
     if (threadIdx.x == 0) {
       if (q.tape_sys && lb == 0) tape_write_sys(q.tape_sys, it, S, sm.damp);
-#ifndef GS_T_NOSCALAR
       icp_solve_finish(S, sm);
-#endif
       unres_n = 0;
       hard_n = 0;
       lfail_s[0] = lfail_s[1] = lfail_s[2] = 0;
@@ -506,9 +500,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
   if (lb == 0 && threadIdx.x < (int)(sizeof(IcpSmall) / 4))
     reinterpret_cast<float*>(q.st_out)[threadIdx.x] = reinterpret_cast<const float*>(&sm)[threadIdx.x];
   if (tl && threadIdx.x == 0) { tl[4] = wall_clock64(); tl[7] = 0; tl[2] = 0; }
-#ifndef GS_T_LATEGRID
-  if (LMODE == 2) g = *q.gp;   // (in flight while the lists are checked; the left-over pass needs it)
-#endif
+  if (LMODE == 2) g = *q.gp;   // (in flight while the lists are checked; re-scans and the left-over pass need it)
 
   // (the list variants serve ONE group of units per block -- the host plans them only then -- and say so to the
   // compiler: nothing is carried around a loop)
@@ -557,11 +549,6 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         key = ~0ull;
         int wsl = -1;
         bool first = false;   // this lane's best is its first entry (whose normal it holds)
-#ifdef GS_T_LATEGATHER
-#pragma unroll
-        for (int j = 0; j < LK; ++j)
-          if (sl[j] != ~0u) cv[j] = sorted[sl[j]];
-#endif
 #pragma unroll
         for (int j = 0; j < LK; ++j) {
           const unsigned long long k2 = sl[j] != ~0u ? grid_key(qx, qy, qz, cv[j]) : ~0ull;
@@ -649,9 +636,6 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
     // ---- the few queries the 2x2x2 stage did not resolve (neighbour farther than ~half a cell): Chebyshev shells
     // by groups of FS_HG lanes, so that they do not hold up the waves of the common case
     const int nh = hard_n;  // block-uniform
-#ifdef GS_T_LATEGRID
-    if (LMODE == 2 && nh) g = *q.gp;
-#endif
     for (int i = threadIdx.x / FS_HG; i < nh; i += FS_BLOCK / FS_HG) {
       const int e = hard_q[i], hs = e & FS_HQ_SLOT, l16 = threadIdx.x & (FS_HG - 1);
       const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
@@ -1639,9 +1623,9 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   // candidate lists of ordinary queries (gs_knn.h: gl_*; the results do not depend on them): every solve that keeps no
   // far lists.  GRADSLAM_HIP_ICP_LISTS=0 switches them off (A/B runs).
   // GRADSLAM_HIP_ICP_LISTS_FROM=k: the lists are built behind the look-ahead search of iteration k and tried from
-  // iteration k + 1 on.  Default FS_LISTS_FROM: the first iterations of a solve move the cloud by millimetres, a list
-  // built there fails in the next launch, and a failing list costs a 16-lane re-scan plus a new list (measured, DESIGN.md
-  // section 4: launches with thousands of failing lists take 25-45 us instead of 17).
+  // iteration k + 1 on.  Default FS_LISTS_FROM = 1: the step of iteration 0 is the large one of a solve (millimetres);
+  // a list built before it would not survive it.  Later starts were measured too: 0 / 1 / 4 / 8 give
+  // 7.40 / 7.42 / 7.42 / 7.31 k frames/s at 8 sequences per GPU.
   static int ord_lists = -1, lists_from = FS_LISTS_FROM;
   if (ord_lists < 0) {
     const char* e = getenv("GRADSLAM_HIP_ICP_LISTS");
