@@ -307,8 +307,84 @@ def secondary_measurements(gs, args, frames, device, barrier, Wm, K):
                                      "calls_timed": 10,
                                      "what": "point_to_plane_gradICP between frames 0 and 2 of sequence 0 on the ds = 4 "
                                              "lattice; backward = d(sum T)/d(src) through all 20 iterations"}
+        # configs[2] as SURVEY states it: depth.requires_grad_(); PointFusion(gradicp) over two frames through the driver;
+        # recovered_poses.sum().backward() -> depth.grad (ICP, down-sampler, frame-map and map-append backward kernels)
+        col, K4 = dv(seq["colors"][None, :2]), dv(seq["intrinsics"][None])
+        pp = dv(seq["poses"][None, :2]).clone()
+        pp[:, 1:] = pp[:, :1]
+        dd = dv(seq["depths"][None, :2]).requires_grad_(True)
+        slam3 = gs.slam.PointFusion(odom=args.odom, device=device)
+
+        def chain_fwd():
+            with torch.no_grad():
+                slam3(gs.RGBDImages(col, dd.detach(), K4, pp))
+
+        def chain():
+            dd.grad = None
+            _, rp = slam3(gs.RGBDImages(col, dd, K4, pp))
+            rp.sum().backward()
+
+        out["c3_gradicp_640x480"].update({
+            "driver_forward_ms": timeit(chain_fwd), "driver_forward_plus_backward_ms": timeit(chain),
+            "driver_what": "depth.requires_grad_(); PointFusion(odom).__call__ on 2 frames of 640x480 (frame maps, map "
+                           "init, localisation, fusion); recovered_poses.sum().backward(); depth.grad of both frames",
+            "driver_depth_grad_norm": [float(dd.grad[0, f].double().norm()) for f in (0, 1)]})
     except Exception as e:   # noqa: BLE001  (a secondary number must not take the headline down)
         out["c3_gradicp_640x480"] = {"error": repr(e)}
+
+    # ---- the same workload with the frames STREAMED from pinned host memory (uint16 depth, uint8
+    # colour, one asynchronous copy per sequence and modality on a copy stream + one conversion launch per frame,
+    # overlapped with the previous step) next to the same quantised frames resident in HBM
+    try:
+        from gradslam_amd.datasets.streaming import FrameStreamer, quantize_sequences
+        Bs = len(frames._rgb_image)
+        seqs_s = make_sequences(list(range(Bs)), Wm + K, 480, 640)
+        d16, c8 = quantize_sequences(seqs_s, 5000.0)
+        Ks = torch.from_numpy(np.stack([s["intrinsics"] for s in seqs_s])).to(device)
+        P0 = torch.from_numpy(np.stack([s["poses"][:1] for s in seqs_s])).to(device)
+
+        def stream_run(resident):
+            slam_s = gs.slam.PointFusion(odom=args.odom, device=device)
+            if resident:
+                dres = torch.empty((Wm + K, Bs, 480, 640, 1), dtype=torch.float32, device=device)   # time-major, as the raw frames
+                cres = torch.empty((Wm + K, Bs, 480, 640, 3), dtype=torch.float32, device=device)
+                ops.ingest_frames_native(d16.to(device), c8.to(device), dres, cres, 5000.0)
+                fr = gs.RGBDImages(cres.transpose(0, 1), dres.transpose(0, 1), Ks, P0.repeat(1, Wm + K, 1, 1))
+                get = lambda t: fr[:, t]   # noqa: E731
+            else:
+                st = FrameStreamer(d16, c8, Ks, P0, scale_div=5000.0, device=device)
+                get = st.frame
+            pc_s, prev_s, rec = gs.Pointclouds(device=device), None, []
+            for t in range(Wm):
+                live = get(t)
+                pc_s, p = slam_s.step(pc_s, live, prev_s, inplace=True)
+                prev_s = live
+            barrier()
+            t0 = time.perf_counter()
+            for t in range(Wm, Wm + K):
+                live = get(t)
+                pc_s, p = slam_s.step(pc_s, live, prev_s, inplace=True)
+                prev_s = live
+                rec.append(p[:, 0])
+            barrier()
+            el = time.perf_counter() - t0
+            import hashlib
+            return el, hashlib.sha256(torch.stack(rec, 1).cpu().numpy().tobytes()).hexdigest()[:16]
+
+        el_r, sha_r = stream_run(True)
+        el_s, sha_s = stream_run(False)
+        raw_mb = Bs * 480 * 640 * 5 / 1e6
+        out["stream_b%d_640x480" % Bs] = {
+            "frames_per_s_streamed": Bs * K / el_s, "frames_per_s_resident": Bs * K / el_r, "ratio": el_r / el_s,
+            "ms_per_step_streamed": el_s / K * 1e3, "ms_per_step_resident": el_r / K * 1e3,
+            "raw_megabytes_per_step": raw_mb, "pcie_gb_per_s_needed": raw_mb / 1e3 / (el_s / K),
+            "poses_sha_streamed": sha_s, "poses_sha_resident": sha_r, "identical": sha_s == sha_r,
+            "what": "uint16 depth (metres x 5000) + uint8 colour in pinned host memory -> hipMemcpyAsync on a copy stream -> "
+                    "gs_ingest_frames_native_f32 -> PointFusion.step; frame t + 1 in flight while step t computes "
+                    "(gradslam_amd/datasets/streaming.py); resident = the same quantised frames as float32 in HBM"}
+        del d16, c8
+    except Exception as e:   # noqa: BLE001
+        out["stream_640x480"] = {"error": repr(e)}
 
     # ---- configs[4] shape: 1296x968, 60 timed frames, growing map
     try:
@@ -395,14 +471,19 @@ def main():
     barrier()
     g0 = time.perf_counter()
     all_poses = multigpu.gather_poses(poses_local)
+    barrier()
+    g1 = time.perf_counter()
     all_maps = multigpu.gather_maps(pc, dst=0) if world > 1 else pc   # (the maps go to rank 0 only)
     barrier()
     gather_ms = (time.perf_counter() - g0) * 1e3
+    gather_poses_ms, gather_maps_ms = (g1 - g0) * 1e3, (time.perf_counter() - g1) * 1e3
+    gather_peak = int(multigpu.GATHER_PEAK_BYTES) if world > 1 else 0
     assert all_poses.shape[0] == args.batch and (rank != 0 or len(all_maps) == args.batch)
     # fingerprint of the gathered result: the same for every N (sequences do not interact; tests/test_hip_batch.py)
     import hashlib
     sha = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:16]  # noqa: E731
     poses_sha = sha(all_poses)
+    poses_sha_by_sequence = [sha(all_poses[b:b + 1]) for b in range(all_poses.shape[0])]
     n_map_all = [int(p.shape[0]) for p in all_maps.points_list] if rank == 0 else None
     # what every rank saw: its own clock around the K steps, its sequences, the fingerprint of its poses
     mine_info = {"rank": rank, "sequences": mine, "elapsed_s": elapsed_local, "ms_per_step": elapsed_local / K * 1e3,
@@ -494,7 +575,9 @@ def main():
                        "sequences_total": args.batch, "sequences_per_gpu": B_local, "frames_timed_per_sequence": K,
                        "map_surfels_end_rank0": n_map, "map_surfels_all": n_map_all, "poses_sha": poses_sha,
                        "parity_mode": "renormalize_unmatched=True (reference-identical merge)",
-                       "final_gather_ms": gather_ms, "api": "gradslam_amd.slam.PointFusion.step",
+                       "poses_sha_by_sequence": poses_sha_by_sequence,
+                       "final_gather_ms": gather_ms, "gather_poses_ms": gather_poses_ms, "gather_maps_to_rank0_ms": gather_maps_ms,
+                       "gather_peak_bytes_rank0": gather_peak, "api": "gradslam_amd.slam.PointFusion.step",
                        "host_enqueue_ms_per_step": (t_enq - run["waits"]) / K * 1e3,
                        "host_wait_ms_per_step": run["waits"] / K * 1e3,
                        "host_note": "host_enqueue = Python + launches of a step; host_wait = what the host spends blocked on "

@@ -85,3 +85,55 @@ extern "C" int gs_ingest_color_u8_f32(const uint8_t* raw, int H0, int W0, float*
   GS_LAUNCH_CHECK();
   return GS_OK;
 }
+
+// ---- streaming ingest (round 4): n native-size frames (depth and colour) in ONE launch, the arithmetic of the two
+// kernels above for H == H0, W == W0.  A thread converts 4 consecutive pixels: 8 B + 12 B read, 16 B + 48 B written, every
+// access 8 / 16 bytes wide.  For raw frames that arrive over PCIe while the previous step computes
+// (gradslam_amd/datasets/streaming.py).
+__global__ void __launch_bounds__(256) gs_ingest_native4_kernel(const uint16_t* __restrict__ depth_raw,
+                                                                const uint8_t* __restrict__ color_raw, int64_t n_quads,
+                                                                float* __restrict__ depth_out, float* __restrict__ color_out,
+                                                                double scale_div, int normalize) {
+  const int64_t qd = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (qd >= n_quads) return;
+  if (depth_raw) {
+    const uint2 r = reinterpret_cast<const uint2*>(depth_raw)[qd];
+    float4 o;
+    o.x = (float)((double)(r.x & 0xffffu) / scale_div);
+    o.y = (float)((double)(r.x >> 16) / scale_div);
+    o.z = (float)((double)(r.y & 0xffffu) / scale_div);
+    o.w = (float)((double)(r.y >> 16) / scale_div);
+    reinterpret_cast<float4*>(depth_out)[qd] = o;
+  }
+  if (color_raw) {
+    const uint32_t* c = reinterpret_cast<const uint32_t*>(color_raw) + 3 * qd;
+    const uint32_t w0 = c[0], w1 = c[1], w2 = c[2];
+    float v[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const uint32_t w = k < 4 ? w0 : (k < 8 ? w1 : w2);
+      const double b = (double)((w >> (8 * (k & 3))) & 0xffu);
+      v[k] = (float)(normalize ? b / 255.0 : b);
+    }
+    float4* o = reinterpret_cast<float4*>(color_out) + 3 * qd;
+    o[0] = make_float4(v[0], v[1], v[2], v[3]);
+    o[1] = make_float4(v[4], v[5], v[6], v[7]);
+    o[2] = make_float4(v[8], v[9], v[10], v[11]);
+  }
+}
+
+extern "C" int gs_ingest_frames_native_f32(const uint16_t* depth_raw, const uint8_t* color_raw, int64_t n_frames, int H,
+                                           int W, double scale_div, int normalize, float* depth_out, float* color_out,
+                                           void* stream) {
+  GS_REQUIRE(n_frames > 0 && H > 0 && W > 0 && scale_div != 0.0, "bad arguments");
+  GS_REQUIRE((depth_raw == nullptr) == (depth_out == nullptr) && (color_raw == nullptr) == (color_out == nullptr) &&
+                 (depth_raw || color_raw), "raw / out pointers must come in pairs");
+  const int64_t px = n_frames * (int64_t)H * W;
+  GS_REQUIRE(px % 4 == 0, "the pixel count must be a multiple of 4 (use the per-frame entry points otherwise)");
+  GS_REQUIRE(((uintptr_t)depth_raw % 8 == 0) && ((uintptr_t)color_raw % 4 == 0) && ((uintptr_t)depth_out % 16 == 0) &&
+                 ((uintptr_t)color_out % 16 == 0), "misaligned buffers");
+  hipLaunchKernelGGL(gs_ingest_native4_kernel, dim3((unsigned)gs_ceil_div(px / 4, 256)), dim3(256), 0, gs_stream(stream),
+                     depth_raw, color_raw, px / 4, depth_out, color_out, scale_div, normalize);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}

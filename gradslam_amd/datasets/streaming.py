@@ -1,0 +1,98 @@
+"""Streaming ingest (datasets/tum.py:352-434, datasets/datautils.py:73-118 do this per item on the
+host): raw sensor frames -- uint16 depth, uint8 colour, as decoded from the PNGs -- wait in PINNED host memory; while the
+GPU works on frame t, frame t + 1 crosses PCIe on a copy stream (one asynchronous copy per modality for the whole batch:
+the host array is time-major)
+and is converted to the float32 images the SLAM step consumes by one launch (gs_ingest_frames_native_f32, on the copy
+stream as well).  The compute stream only waits for an event; a ring of RING device buffers keeps a frame alive until the
+step after the next has been enqueued.
+
+    st = FrameStreamer(depth_u16, color_u8, intrinsics, first_poses, scale_div=5000.0, device="cuda")
+    for t in range(len(st)):
+        live = st.frame(t)          # RGBDImages (B, 1, H, W, .), frame t + 1 already on its way
+        pc, live.poses = slam.step(pc, live, prev, inplace=True); prev = live
+
+PyTorch is used for what it is here for: pinned / device memory, streams, events."""
+import torch
+
+from .. import ops
+from ..structures.rgbdimages import RGBDImages
+
+__all__ = ["FrameStreamer", "quantize_sequences"]
+
+
+def quantize_sequences(seqs, scale_div=5000.0):
+    """synthetic float sequences (datasets/synthetic.py) -> what a sensor would have stored: depth uint16 (metres x
+    scale_div, rounded; TUM's png_depth_scale), colour uint8.  Returns pinned, TIME-MAJOR (L, B, H, W) uint16 and
+    (L, B, H, W, 3) uint8: the frame of all sequences at time t is one contiguous block, i.e. one copy per modality."""
+    import numpy as np
+    d = np.stack([np.clip(np.rint(s["depths"][..., 0].astype(np.float64) * scale_div), 0, 65535).astype(np.uint16) for s in seqs], 1)
+    c = np.stack([np.clip(np.floor(s["colors"]), 0, 255).astype(np.uint8) for s in seqs], 1)
+    d, c = np.ascontiguousarray(d), np.ascontiguousarray(c)
+    return torch.from_numpy(d.view(np.int16)).view(torch.uint16).pin_memory(), torch.from_numpy(c).pin_memory()
+
+
+class FrameStreamer(object):
+    RING = 3
+
+    def __init__(self, depth_u16, color_u8, intrinsics, first_poses, scale_div, device="cuda", normalize_color=False):
+        """depth_u16 (L, B, H, W) uint16 and color_u8 (L, B, H, W, 3) uint8, time-major and contiguous in pinned host
+        memory; intrinsics (B, 1, 4, 4) and first_poses (B, 1, 4, 4) on the device (every frame carries them: the SLAM
+        step reads the first frame's pose and overwrites the others)."""
+        if not (depth_u16.is_pinned() and color_u8.is_pinned()):
+            raise ValueError("FrameStreamer: the raw frames must live in pinned host memory (tensor.pin_memory())")
+        if depth_u16.dtype not in (torch.uint16, torch.int16) or color_u8.dtype != torch.uint8:
+            raise TypeError("FrameStreamer: depth must be uint16 and colour uint8")
+        L, B, H, W = depth_u16.shape
+        if tuple(color_u8.shape) != (L, B, H, W, 3) or not depth_u16.is_contiguous() or not color_u8.is_contiguous():
+            raise ValueError("FrameStreamer: contiguous time-major frames expected: depth (L, B, H, W), colour (L, B, H, W, 3)")
+        self.device = torch.device(device)
+        self.B, self.L, self.H, self.W = B, L, H, W
+        self.depth_u16, self.color_u8 = depth_u16, color_u8
+        self.K, self.P0 = intrinsics, first_poses
+        self.scale_div, self.normalize = float(scale_div), bool(normalize_color)
+        dev = self.device
+        R = self.RING
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.raw_d = [torch.empty((B, H, W), dtype=depth_u16.dtype, device=dev) for _ in range(R)]
+        self.raw_c = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(R)]
+        self.f_d = [torch.empty((B, 1, H, W, 1), dtype=torch.float32, device=dev) for _ in range(R)]
+        self.f_c = [torch.empty((B, 1, H, W, 3), dtype=torch.float32, device=dev) for _ in range(R)]
+        self.ready = [torch.cuda.Event() for _ in range(R)]     # copy + conversion of the slot's frame done
+        self.released = [None] * R                                # compute stream done with what the slot held before
+        self.in_slot = [-1] * R
+        self._prefetch(0)
+
+    def __len__(self):
+        return self.L
+
+    def _prefetch(self, t):
+        if t >= self.L:
+            return
+        k = t % self.RING
+        if self.in_slot[k] == t:
+            return
+        cs = self.copy_stream
+        if self.released[k] is not None:
+            cs.wait_event(self.released[k])   # the step that read this slot's previous frame has finished
+        with torch.cuda.stream(cs):
+            # (one contiguous block per modality: two copies per frame of the batch; pinned, so true asynchronous DMA)
+            self.raw_d[k].copy_(self.depth_u16[t], non_blocking=True)
+            self.raw_c[k].copy_(self.color_u8[t], non_blocking=True)
+            ops.ingest_frames_native(self.raw_d[k], self.raw_c[k], self.f_d[k], self.f_c[k], self.scale_div,
+                                     self.normalize, on_stream=cs)
+            self.ready[k].record(cs)
+        self.in_slot[k] = t
+
+    def frame(self, t):
+        """RGBDImages of frame t for all sequences (float32 on the device); starts the transfer of frame t + 1."""
+        self._prefetch(t)
+        k = t % self.RING
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self.ready[k])
+        # the slot that frame t + 1 will use held frame t + 1 - RING: everything enqueued so far has read it
+        nk = (t + 1) % self.RING
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.released[nk] = ev
+        self._prefetch(t + 1)
+        return RGBDImages(self.f_c[k], self.f_d[k], self.K, self.P0)

@@ -98,6 +98,7 @@ def _gather_to(recv, send, dst):
         dist.gather(send, recv if me == dst else None, dst=dst)
 
 
+GATHER_PEAK_BYTES = 0            # bytes the last gather_maps call held at its peak on this rank (buffers + result so far)
 ALL_GATHER_MAX_BYTES = 2 << 30   # per rank: beyond this an all-to-all map gather is refused (gather to one rank instead)
 
 
@@ -108,8 +109,8 @@ def gather_maps(pointclouds: Pointclouds, dst: Optional[int] = None,
     dst=None: on every rank (all_gather: every rank receives world x the largest rank's map, so this is for maps of
     benchmark size; above `max_bytes` (default ALL_GATHER_MAX_BYTES) received bytes per rank it falls back to dst=0 with
     a warning).  dst=r: on rank r only, the other ranks get None (gather: 1/world of the traffic and memory).
-    Two collectives: the per-sequence counts and attribute widths of every rank (a small object gather), then ONE
-    padded (all_)gather of each rank's surfels packed row-wise as [points | normals | colors | features]."""
+    The per-sequence counts and attribute widths of every rank travel first (a small object gather), then one padded
+    (all_)gather per attribute (points, normals, colors, features)."""
     world = _world()
     if world == 1:
         return pointclouds.clone()   # (a new object, as with world > 1: callers may mutate the result)
@@ -129,32 +130,35 @@ def gather_maps(pointclouds: Pointclouds, dst: Optional[int] = None,
         warnings.warn("gather_maps: %.1f GB per rank for an all_gather of the maps; gathering to rank 0 only"
                       % (world * cap * width * 4 / 1e9))
         dst = 0
-    packed = torch.zeros((rows, width), dtype=torch.float32, device=dev)
-    col = 0
-    for k in ("points", "normals", "colors", "features"):
-        if w[k] and widths[k] and rows:
-            packed[:, col:col + w[k]] = torch.cat(lists[k], 0)
-        col += w[k]
-    send = torch.zeros((cap, width), dtype=torch.float32, device=dev)
-    send[:rows] = packed
+    # One padded (all_)gather PER ATTRIBUTE: the receiving rank then holds world x the widest attribute (3 floats per
+    # surfel) at a time next to the result, instead of world x all 10 floats of every rank's padded map plus a packed and
+    # a padded copy of its own (the peak of the one-collective form; GATHER_PEAK_BYTES reports what this call held).
+    global GATHER_PEAK_BYTES
     me = dist.get_rank()
-    if dst is None:
-        recv = [torch.empty_like(send) for _ in range(world)]
-        _all_gather(recv, send)
-    else:
-        recv = [torch.empty_like(send) for _ in range(world)] if me == dst else None
-        _gather_to(recv, send, dst)
-        if me != dst:
-            return None
     out = {k: [] for k in w}
-    for r, (cnts, _) in enumerate(meta):
-        per_seq = torch.split(recv[r][: sum(cnts)], cnts, 0) if cnts else []
-        for t in per_seq:
-            col = 0
-            for k in ("points", "normals", "colors", "features"):
-                if w[k]:
-                    out[k].append(t[:, col:col + w[k]].contiguous())
-                col += w[k]
+    peak = 0
+    for k in ("points", "normals", "colors", "features"):
+        if not w[k]:
+            continue
+        send = torch.zeros((cap, w[k]), dtype=torch.float32, device=dev)
+        if widths[k] and rows:
+            torch.cat(lists[k], 0, out=send[:rows])
+        if dst is None:
+            recv = [torch.empty_like(send) for _ in range(world)]
+            _all_gather(recv, send)
+        else:
+            recv = [torch.empty_like(send) for _ in range(world)] if me == dst else None
+            _gather_to(recv, send, dst)
+        held = send.numel() * 4 * (1 + (world if recv is not None else 0)) + sum(t.numel() * 4 for v in out.values() for t in v)
+        peak = max(peak, held)
+        if recv is not None:
+            for r, (cnts, _) in enumerate(meta):
+                if cnts:
+                    out[k].extend(t.clone() for t in torch.split(recv[r][: sum(cnts)], cnts, 0))
+        del send, recv
+    GATHER_PEAK_BYTES = peak
+    if dst is not None and me != dst:
+        return None
     if not out["points"]:
         return Pointclouds(device=dev)
     return Pointclouds(out["points"], out["normals"] or None, out["colors"] or None, out["features"] or None)

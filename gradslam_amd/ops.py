@@ -337,6 +337,29 @@ def ingest_color(raw_u8, H, W, normalize=False):
     return out
 
 
+def ingest_frames_native(depth_raw, color_raw, depth_out, color_out, scale_div, normalize=False, on_stream=None):
+    """n native-size raw frames -> float32 images in ONE launch (gs_ingest_frames_native_f32): depth_raw (..., H, W) uint16
+    -> depth_out (same pixels) float32 metres, color_raw (..., H, W, 3) uint8 -> color_out float32; either pair may be
+    None.  All tensors contiguous, on one device; `on_stream`: a torch stream to launch on (default: the current one)."""
+    ref = depth_raw if depth_raw is not None else color_raw
+    dev = require_device(ref)
+    H, W = (depth_raw.shape[-2:] if depth_raw is not None else color_raw.shape[-3:-1])
+    n = (depth_raw.numel() if depth_raw is not None else color_raw.numel() // 3) // (H * W)
+    for raw, out, dt, c in ((depth_raw, depth_out, (torch.uint16, torch.int16), 1), (color_raw, color_out, (torch.uint8,), 3)):
+        if raw is None:
+            continue
+        if raw.dtype not in dt or out.dtype != f32 or not raw.is_contiguous() or not out.is_contiguous() or \
+                out.numel() != raw.numel() or raw.numel() != n * H * W * c or out.device != dev:
+            raise _C.HipExtensionError("ingest_frames_native: raw / out buffers do not match")
+    st = stream(dev) if on_stream is None else _C.C.c_void_p(on_stream.cuda_stream)
+    check(lib().gs_ingest_frames_native_f32(ptr(depth_raw) if depth_raw is not None else None,
+                                            ptr(color_raw) if color_raw is not None else None, n, int(H), int(W),
+                                            float(scale_div), 1 if normalize else 0,
+                                            ptr(depth_out) if depth_raw is not None else None,
+                                            ptr(color_out) if color_raw is not None else None, st),
+          "gs_ingest_frames_native_f32")
+
+
 def relative_pose(T01, T02):
     """(n, 4, 4) x (n, 4, 4) -> compose(inv(T01), T02) (relative_transformation of the reference)."""
     T01, T02 = _c(T01), _c(T02)

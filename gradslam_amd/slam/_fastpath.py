@@ -6,7 +6,8 @@ on container bookkeeping around its three batched entry points, which is as long
 itself (8 sequences of 640x480).  A `StepPlan` keeps everything that does not change between frames (the descriptor
 array of gs_pointfusion_step_batch_f32, scratch, solver parameters, two device count buffers) and per frame only
 rewrites the pointers that move: frame slices, pose buffers, count bounds.  The kernels and their order are those of
-the generic path (same C functions), so the results are bit-identical (tests/test_hip_batch.py).
+the generic path (same C functions), so the results are bit-identical
+(tests/test_hip_batch.py::test_fast_path_equals_generic_path).
 
 Used by `PointFusion.step(..., inplace=True)` when nothing is on the autograd tape and the map already holds surfels
 with device-side counts; everything else takes the generic path."""
@@ -22,6 +23,15 @@ __all__ = ["try_step"]
 
 f32 = torch.float32
 FASTPATH = os.environ.get("GRADSLAM_HIP_FASTPATH", "1") != "0"   # 0: always the generic path (A/B runs)
+
+
+def _kwargs_key(kw):
+    """hashable, comparable form of the solver keywords (a tensor-valued dist_thresh compares element-wise otherwise)"""
+    def norm(v):
+        if torch.is_tensor(v):
+            return tuple(float(x) for x in v.detach().reshape(-1).cpu())
+        return v
+    return tuple(sorted((k, norm(v)) for k, v in kw.items()))
 
 
 def _dense_frames(t, inner):
@@ -46,13 +56,11 @@ class StepPlan(object):
         self.prm = _C.IcpParams(int(prov._mode), int(kw.get("numiters", 20)), float(kw.get("damp", 1e-8)),
                                 ops._thresh(kw.get("dist_thresh")), float(kw.get("lambda_max", 2.0)),
                                 float(kw.get("B", 1.0)), float(kw.get("B2", 1.0)), float(kw.get("nu", 200.0)))
-        self.key = (float(slam.sigma), float(slam.dist_th), float(slam.dot_th), int(slam.dsratio), tuple(sorted(kw.items())),
+        self.key = (float(slam.sigma), float(slam.dist_th), float(slam.dot_th), int(slam.dsratio), _kwargs_key(kw),
                     int(prov._mode))
         self.sigma = float(slam.sigma)
         self.tss = ops.two_sigma_sq(slam.sigma)
         self.dist_th, self.dot_th, self.ds = float(slam.dist_th), float(slam.dot_th), int(slam.dsratio)
-        self.cnt = [torch.zeros(B, dtype=torch.int64, device=device) for _ in range(2)]
-        self.flip = 0
         self.caps = [-1] * B          # capacity the descriptors / scratch of sequence b were set up for
         self.bufs = [None] * B        # (points, normals, colors, features) tensors behind the descriptors
         self.scratch = [None] * B     # (localize, update) scratch tensors
@@ -93,7 +101,10 @@ class StepPlan(object):
         # room for this frame's appends (geometric growth; the descriptors follow the new buffers)
         for b in range(B):
             bufs = self.bufs[b]
-            if bufs is None or bufs[0] is not pc._buf["points"][b] or bounds[b] + P > self.caps[b]:
+            # (every attribute by identity: a setter of normals / colors / features swaps that buffer alone, and another
+            # map stepped with the same slam object brings four other buffers)
+            if (bufs is None or any(bufs[i] is not pc._buf[k][b] for i, k in enumerate(_ATTRS)) or
+                    bounds[b] + P > self.caps[b]):
                 if bounds[b] + P > int(pc._buf["points"][b].shape[0]):
                     pc._reserve(b, P, pc.RESERVE_FRAMES)
                     bounds = grp.bounds      # (_reserve may have replaced the bounds by the exact counts)
@@ -104,11 +115,12 @@ class StepPlan(object):
         best = torch.empty((B, P), dtype=torch.int32, device=dev)
         o = out.data_ptr()
         v0, n0, a0, gv0, gn0, po0 = o, o + 12 * P * B, o + 24 * P * B, o + 28 * P * B, o + 40 * P * B, o + 52 * P * B
-        cnt_new = self.cnt[self.flip]
-        if cnt_new.data_ptr() == grp.dev.data_ptr():
-            self.flip ^= 1
-            cnt_new = self.cnt[self.flip]
-        self.flip ^= 1
+        # the new counts go to a buffer the MAP owns (two per count group, alternating): a plan serves whatever map it is
+        # handed, and a map's live device count must not be a word some other map's next frame writes
+        pair = getattr(grp, "_step_counts", None)
+        if pair is None or pair[0].shape[0] != B or pair[0].device != dev:
+            pair = grp._step_counts = [torch.zeros(B, dtype=torch.int64, device=dev) for _ in range(2)]
+        cnt_new = pair[0] if pair[0].data_ptr() != grp.dev.data_ptr() else pair[1]
         d0, ds_ = d
         r0, rs_ = r
         k0, p0, c0, n_dev0, b0 = K.data_ptr(), pp.data_ptr(), cnt_new.data_ptr(), grp.dev.data_ptr(), best.data_ptr()
@@ -154,6 +166,8 @@ def try_step(slam, pointclouds, live_frame, prev_frame):
         return None
     if prev_frame._poses is None or live_frame._intrinsics.data_ptr() != prev_frame._intrinsics.data_ptr():
         return None
+    if tuple(prev_frame._poses.shape) != (B, 1, 4, 4):   # (poses are addressed as base + 64 b)
+        return None
     dev = live_frame.device
     if dev.type != "cuda" or pointclouds.device != dev or prev_frame.device != dev:
         return None
@@ -171,7 +185,7 @@ def try_step(slam, pointclouds, live_frame, prev_frame):
     H, W = live_frame.h, live_frame.w
     plan = getattr(slam, "_step_plan", None)
     key = (float(slam.sigma), float(slam.dist_th), float(slam.dot_th), int(slam.dsratio),
-           tuple(sorted(slam.odomprov._kwargs().items())), int(slam.odomprov._mode))
+           _kwargs_key(slam.odomprov._kwargs()), int(slam.odomprov._mode))
     if (plan is None or (plan.B, plan.H, plan.W, plan.device) != (B, H, W, dev) or plan.key != key or
             plan.stream_id != torch.cuda.current_stream(dev).cuda_stream):
         plan = slam._step_plan = StepPlan(slam, B, H, W, dev)

@@ -124,7 +124,8 @@ class RGBDImages(object):
             other.__dict__.update(self.__dict__)
             other._rgb_image = new_rgb
             other._depth_image = self._depth_image[slices[0], slices[1]]
-            other._intrinsics = self._intrinsics if slices[0] == slice(None, None) else self._intrinsics[slices[0], :]
+            whole = isinstance(slices[0], slice) and slices[0] == slice(None, None)
+            other._intrinsics = self._intrinsics if whole else self._intrinsics[slices[0], :]
             for k in self._INTERNAL_TENSORS:
                 if k in ("_rgb_image", "_depth_image", "_intrinsics"):
                     continue
@@ -140,7 +141,8 @@ class RGBDImages(object):
             other._depth_shape = other._depth_image_shape = full[:c] + (1,) + full[c + 1:]
             other._intrinsics_shape = (full[0], 1, 4, 4)
             other._poses_shape = full[:2] + (4, 4)
-            other._pixel_pos_shape = full[:c] + full[c + 1:] + (3,)
+            other._pixel_pos_shape = ((full[:c] + (3,) + full[c + 1:]) if other._channels_first
+                                      else (full[:c] + full[c + 1:] + (3,)))   # (as the constructor)
             other._B, other._L = full[0], full[1]
             other.shape = (other._B, other._L, other.h, other.w)
             return other

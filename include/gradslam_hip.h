@@ -346,6 +346,12 @@ GS_API int gs_ingest_depth_u16_f32(const uint16_t* raw, int H0, int W0, float* o
                                    double scale_div, void* stream);
 GS_API int gs_ingest_color_u8_f32(const uint8_t* raw, int H0, int W0, float* out, int H, int W, int normalize,
                                   void* stream);
+/* Streaming ingest (round 4; datasets/tum.py:352-434 per frame, datasets/datautils.py:73-118): n_frames native-size frames
+ * in one launch -- depth uint16 (n, H, W) -> float32 metres (raw / scale_div in float64, then float32), colour uint8
+ * (n, H, W, 3) -> float32 (optionally / 255): the arithmetic of the two entry points above without a resize.  Either pair
+ * may be NULL.  n_frames * H * W must be a multiple of 4. */
+GS_API int gs_ingest_frames_native_f32(const uint16_t* depth_raw, const uint8_t* color_raw, int64_t n_frames, int H, int W,
+                                       double scale_div, int normalize, float* depth_out, float* color_out, void* stream);
 
 /* ---- the per-frame map pipeline with the surfel count kept ON THE DEVICE -------------------
  * Same kernels and results as the functions they are named after; `n_map_bound` (host) is an

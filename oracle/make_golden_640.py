@@ -12,6 +12,9 @@ Build-container only (minutes of CPU).  Outputs (committed, travel to the GPU bo
   tests/golden/cpu_ref_timing.json   seconds per frame of the unmodified reference on `cores` host cores
     python -m oracle.make_golden_640 --slam icpslam --odom icp --frames 8 --tag icpslam640
   tests/golden/icpslam640.npz        the same for ICPSLAM (hard-LM ICP odometry, aggregate mapping)
+    python -m oracle.make_golden_640 --odom gt --frames 8 --tag pf640_gt
+  tests/golden/pf640_gt.npz          PointFusion with GROUND-TRUTH odometry: the fusion path (K5 / K6) across frames with
+                                     no ICP in the loop (+ sha256 of the first map's tables, which are exact)
 """
 import argparse
 import json
@@ -37,7 +40,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tag", default="pf640")
     ap.add_argument("--slam", default="pointfusion", choices=["pointfusion", "icpslam"])
-    ap.add_argument("--odom", default="gradicp", choices=["gradicp", "icp"])
+    ap.add_argument("--odom", default="gradicp", choices=["gradicp", "icp", "gt"])
     args = ap.parse_args()
     refimport.import_reference()
     import torch
@@ -53,7 +56,8 @@ def main():
     s = make_sequence(L, H, W, seed=args.seed)
     T = torch.from_numpy
     poses = T(s["poses"][None]).clone()
-    poses[:, 1:] = poses[:, :1]
+    if args.odom != "gt":   # (ground-truth odometry reads the frames' own poses: slam/icpslam.py:231-236)
+        poses[:, 1:] = poses[:, :1]
     frames = RGBDImages(T(s["colors"][None]), T(s["depths"][None]), T(s["intrinsics"][None]), poses)
     slam = (PointFusion if args.slam == "pointfusion" else ICPSLAM)(odom=args.odom)
     pc = Pointclouds()
@@ -62,6 +66,8 @@ def main():
     counts = np.zeros(L, np.int64)
     sums = {k: np.zeros((L, c), np.float64) for k, c in (("points", 3), ("normals", 3), ("colors", 3), ("ccounts", 1))}
     secs = np.zeros(L)
+    import hashlib
+    sha0 = {}
     with torch.no_grad():
         for f in range(L):   # slam/icpslam.py:124-137, one step() per frame so that every frame can be recorded
             live = frames[:, f]
@@ -71,6 +77,9 @@ def main():
             prev = live
             rec[f] = live.poses[0, 0].numpy()
             counts[f] = pc.points_list[0].shape[0]
+            if f == 0:   # the first map is exact (no fusion yet): fingerprints of its tables
+                for k, lst in (("points", pc.points_list), ("normals", pc.normals_list), ("colors", pc.colors_list)):
+                    sha0[k] = hashlib.sha256(lst[0].numpy().tobytes()).hexdigest()
             for k, lst in (("points", pc.points_list), ("normals", pc.normals_list), ("colors", pc.colors_list),
                            ("ccounts", pc.features_list)):
                 if lst is not None:   # ICPSLAM's aggregate map carries no confidence counts
@@ -80,7 +89,9 @@ def main():
                         depth_sum=np.float64(s["depths"].astype(np.float64).sum()),
                         color_sum=np.float64(s["colors"].astype(np.float64).sum()),
                         seed=np.int64(args.seed), H=np.int64(H), W=np.int64(W),
-                        last_points=pc.points_list[0][-4096:].numpy(), **{"sum_" + k: v for k, v in sums.items()})
+                        last_points=pc.points_list[0][-4096:].numpy(),
+                        sha_frame0=np.array([sha0.get(k, "") for k in ("points", "normals", "colors")]),
+                        **{"sum_" + k: v for k, v in sums.items()})
     timing = {"what": "unmodified gradslam v0.1.0 %s(odom='%s').step on CPU (torch %s), synthetic %dx%d "
                       "sequence seed %d; chamferdist.knn_points replaced by an OpenMP brute-force stand-in "
                       "(oracle/shims), everything else is the reference's own PyTorch code"

@@ -506,3 +506,49 @@ def check_pointclouds_algebra(golden, device, tol):
 
 def test_pointclouds_algebra_vs_reference_golden_cpu(golden):
     check_pointclouds_algebra(golden, "cpu", 2e-6)
+
+
+def test_structutils_list_to_padded_and_back():
+    """structures/structutils.py:47-124 of the reference (its own tests: tests/structures/test_structutils.py): padding
+    to the largest item or to a given size, equisized stacking, cutting back by rows or by (rows, columns), the
+    reference's error messages."""
+    from gradslam_amd.structures.structutils import list_to_padded, padded_to_list
+    g = torch.Generator().manual_seed(3)
+    items = [torch.rand(n, c, generator=g) for n, c in ((5, 3), (2, 3), (0, 3), (7, 2))]
+    pad = list_to_padded(items)
+    assert pad.shape == (4, 7, 3) and pad.dtype == items[0].dtype
+    for b, t in enumerate(items):
+        assert torch.equal(pad[b, : t.shape[0], : t.shape[1]], t)
+        assert float(pad[b, t.shape[0]:].abs().sum()) == 0.0 and float(pad[b, :, t.shape[1]:].abs().sum()) == 0.0
+    big = list_to_padded(items, pad_size=(9, 4), pad_value=-1.0)
+    assert big.shape == (4, 9, 4) and float(big[2].max()) == -1.0 and torch.equal(big[3, :7, :2], items[3])
+    same = [torch.rand(4, 3, generator=g) for _ in range(3)]
+    assert torch.equal(list_to_padded(same, equisized=True), torch.stack(same, 0))
+    with pytest.raises(ValueError, match="Pad size must contain target size for 1st and 2nd dim"):
+        list_to_padded(items, pad_size=(9,))
+    with pytest.raises(ValueError, match="Supports only 2-dimensional tensor items"):
+        list_to_padded([torch.rand(2, 3, 1)], pad_size=(2, 3))
+    back = padded_to_list(pad, [t.shape[0] for t in items])
+    assert all(torch.equal(a[:, : b.shape[1]], b) for a, b in zip(back, items))
+    back2 = padded_to_list(pad, [tuple(t.shape) for t in items])
+    assert all(torch.equal(a, b) for a, b in zip(back2, items))
+    assert back2[0].data_ptr() == pad.data_ptr()                      # views, not copies
+    assert len(padded_to_list(pad)) == 4 and padded_to_list(pad)[1].shape == (7, 3)
+    with pytest.raises(ValueError, match="Supports only 3-dimensional input tensors"):
+        padded_to_list(pad[0])
+    with pytest.raises(ValueError, match="Split size must be of same length as inputs first dimension"):
+        padded_to_list(pad, [1, 2])
+    with pytest.raises(ValueError, match="Support only for 2-dimensional unbinded tensor"):
+        padded_to_list(pad, [(1, 2, 3)] * 4)
+
+
+def test_rgbdimages_slice_keeps_the_channels_first_pixel_pos_shape():
+    rgb, depth = torch.rand(2, 3, 3, 4, 5), torch.rand(2, 3, 1, 4, 5)
+    K = torch.eye(4).repeat(2, 1, 1, 1)
+    r = gs.RGBDImages(rgb, depth, K, channels_first=True)
+    s = r[:, 1]
+    assert s._pixel_pos_shape == (2, 1, 3, 4, 5) and s._rgb_image_shape == (2, 1, 3, 4, 5)
+    s2 = r[torch.tensor([1]), 0]     # (a tensor index is not mistaken for "all sequences")
+    assert s2._intrinsics.shape == (1, 1, 4, 4) and s2._B == 1
+    c = gs.RGBDImages(rgb.permute(0, 1, 3, 4, 2).contiguous(), depth.permute(0, 1, 3, 4, 2).contiguous(), K)
+    assert c[:, 2]._pixel_pos_shape == (2, 1, 4, 5, 3)

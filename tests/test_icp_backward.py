@@ -263,6 +263,45 @@ def test_pointfusion_driver_pose_gradient_wrt_live_depth(golden):
     assert (err0 < 1e-2 * np.abs(ref0).max()).mean() > 0.999
 
 
+@pytest.mark.gpu
+def test_config_c3_as_stated_at_640x480_vs_reference_autograd(golden):
+    """BASELINE configs[2] / SURVEY C3 exactly as stated: depth.requires_grad_(); PointFusion(odom="gradicp") over two
+    640x480 frames; recovered_poses.sum().backward(); depth.grad of both frames against the REAL reference's autograd
+    (tests/golden/c3_driver640.npz, oracle/make_golden_c3.py --driver: every 8th image row, norms, sums, supports).
+    The whole backward chain runs: ICP (20 iterations) -> down-sampler -> global / local frame maps for frame 1; ICP
+    targets and normals -> map append -> frame maps for frame 0.  Tolerances as at 96x128 (the per-pixel gradients of
+    frame 0 pass through sums over thousands of matches): frame 1 relative error < 5e-3; frame 0 median error < 1e-3 of
+    the largest gradient, 99.9 % of the pixels within 1e-2 of it; norms within 1 %."""
+    import gradslam_amd as gs
+    from gradslam_amd.datasets.synthetic import make_sequence
+    g = golden("c3_driver640")
+    s = make_sequence(2, 480, 640, seed=int(g["seed"]))
+    assert abs(float(s["depths"].astype(np.float64).sum()) - float(g["depth_sum"])) < 1e-6 * float(g["depth_sum"])
+    dd = dev(s["depths"][None]).requires_grad_(True)
+    pp = dev(s["poses"][None]).clone()
+    pp[:, 1:] = pp[:, :1]
+    frames = gs.RGBDImages(dev(s["colors"][None]), dd, dev(s["intrinsics"][None]), pp)
+    _, rp = gs.slam.PointFusion(odom="gradicp", device="cuda")(frames)
+    np.testing.assert_allclose(rp[0].detach().cpu().numpy(), g["poses"], atol=2e-5, rtol=0)
+    rp.sum().backward()
+    got = dd.grad[0, :, :, :, 0].cpu().numpy()               # (2, H, W)
+    st = int(g["stride"])
+    ref = g["grad_rows"]
+    # frame 1: only the ICP source lattice carries gradient
+    assert int((got[1] != 0).sum()) == int(g["support"][1])
+    assert rel(got[1][::st], ref[1]) < 5e-3
+    # frame 0: through the map (targets and their normals)
+    assert abs(int((got[0] != 0).sum()) - int(g["support"][0])) <= 0.01 * int(g["support"][0])
+    err0 = np.abs(got[0][::st] - ref[0])
+    big = float(g["grad_absmax"][0])
+    assert np.median(err0[ref[0] != 0]) < 1e-3 * big
+    assert (err0 < 1e-2 * big).mean() > 0.999
+    for f in (0, 1):
+        nrm = float(np.sqrt((got[f].astype(np.float64) ** 2).sum()))
+        assert abs(nrm - float(g["grad_norm"][f])) <= 1e-2 * float(g["grad_norm"][f]), (f, nrm, float(g["grad_norm"][f]))
+        assert abs(float(got[f].astype(np.float64).sum()) - float(g["grad_sum"][f])) <= 2e-2 * float(g["grad_norm"][f])
+
+
 # ------------------------------------------------------------------------------------------ hard-LM ICP (mode 0)
 @pytest.mark.parametrize("K,thr,tag", CASES)
 def test_numpy_backward_oracle_matches_reference_autograd_hard_lm(golden, K, thr, tag):
