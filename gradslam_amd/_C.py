@@ -98,6 +98,7 @@ _PROTOS = {
     "gs_ingest_depth_u16_f32": [_vp, _i32, _i32, _vp, _i32, _i32, C.c_double, _vp],
     "gs_ingest_color_u8_f32": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     "gs_ingest_frames_native_f32": [_vp, _vp, _i64, _i32, _i32, C.c_double, _i32, _vp, _vp, _vp],
+    "gs_host_device_pointer": [_vp, C.POINTER(C.c_void_p)],
     "gs_global_maps_pose_backward_scratch_bytes": [_i32, _i32],
     "gs_global_maps_pose_backward_f32": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gs_fuse_append_backward_f32": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp,

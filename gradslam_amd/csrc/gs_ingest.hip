@@ -90,35 +90,35 @@ extern "C" int gs_ingest_color_u8_f32(const uint8_t* raw, int H0, int W0, float*
 // kernels above for H == H0, W == W0.  A thread converts 4 consecutive pixels: 8 B + 12 B read, 16 B + 48 B written, every
 // access 8 / 16 bytes wide.  For raw frames that arrive over PCIe while the previous step computes
 // (gradslam_amd/datasets/streaming.py).
+constexpr int GS_INGEST_BLOCKS = 128;   // 512 waves on 1024 SIMDs, ~400 KB of loads in flight per sweep (PCIe needs ~100 KB)
+// One work item = 4 depth pixels (8 B -> 16 B) or 4 colour BYTES (4 B -> 16 B): items [0, n_quads) are depth quads, items
+// [n_quads, 4 n_quads) colour words.  A SMALL grid walks them: the launch overlaps the ICP chain of the previous frame,
+// whose blocks need every SIMD's register file almost entirely (6 waves x 80 VGPRs of 512); a full-size grid of
+// fat waves parked on PCIe loads took the second block's place on their CUs and cost the chain 0.17 ms per step.
 __global__ void __launch_bounds__(256) gs_ingest_native4_kernel(const uint16_t* __restrict__ depth_raw,
                                                                 const uint8_t* __restrict__ color_raw, int64_t n_quads,
                                                                 float* __restrict__ depth_out, float* __restrict__ color_out,
                                                                 double scale_div, int normalize) {
-  const int64_t qd = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (qd >= n_quads) return;
-  if (depth_raw) {
-    const uint2 r = reinterpret_cast<const uint2*>(depth_raw)[qd];
+  const int64_t first = depth_raw ? 0 : n_quads, last = color_raw ? 4 * n_quads : n_quads;
+  for (int64_t i = first + (int64_t)blockIdx.x * 256 + threadIdx.x; i < last; i += (int64_t)gridDim.x * 256) {
     float4 o;
-    o.x = (float)((double)(r.x & 0xffffu) / scale_div);
-    o.y = (float)((double)(r.x >> 16) / scale_div);
-    o.z = (float)((double)(r.y & 0xffffu) / scale_div);
-    o.w = (float)((double)(r.y >> 16) / scale_div);
-    reinterpret_cast<float4*>(depth_out)[qd] = o;
-  }
-  if (color_raw) {
-    const uint32_t* c = reinterpret_cast<const uint32_t*>(color_raw) + 3 * qd;
-    const uint32_t w0 = c[0], w1 = c[1], w2 = c[2];
-    float v[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      const uint32_t w = k < 4 ? w0 : (k < 8 ? w1 : w2);
-      const double b = (double)((w >> (8 * (k & 3))) & 0xffu);
-      v[k] = (float)(normalize ? b / 255.0 : b);
+    if (i < n_quads) {
+      const uint2 r = reinterpret_cast<const uint2*>(depth_raw)[i];
+      o.x = (float)((double)(r.x & 0xffffu) / scale_div);
+      o.y = (float)((double)(r.x >> 16) / scale_div);
+      o.z = (float)((double)(r.y & 0xffffu) / scale_div);
+      o.w = (float)((double)(r.y >> 16) / scale_div);
+      reinterpret_cast<float4*>(depth_out)[i] = o;
+    } else {
+      const int64_t w = i - n_quads;
+      const uint32_t c = reinterpret_cast<const uint32_t*>(color_raw)[w];
+      const double b0 = (double)(c & 0xffu), b1 = (double)((c >> 8) & 0xffu), b2 = (double)((c >> 16) & 0xffu), b3 = (double)(c >> 24);
+      o.x = (float)(normalize ? b0 / 255.0 : b0);
+      o.y = (float)(normalize ? b1 / 255.0 : b1);
+      o.z = (float)(normalize ? b2 / 255.0 : b2);
+      o.w = (float)(normalize ? b3 / 255.0 : b3);
+      reinterpret_cast<float4*>(color_out)[w] = o;
     }
-    float4* o = reinterpret_cast<float4*>(color_out) + 3 * qd;
-    o[0] = make_float4(v[0], v[1], v[2], v[3]);
-    o[1] = make_float4(v[4], v[5], v[6], v[7]);
-    o[2] = make_float4(v[8], v[9], v[10], v[11]);
   }
 }
 
@@ -132,8 +132,25 @@ extern "C" int gs_ingest_frames_native_f32(const uint16_t* depth_raw, const uint
   GS_REQUIRE(px % 4 == 0, "the pixel count must be a multiple of 4 (use the per-frame entry points otherwise)");
   GS_REQUIRE(((uintptr_t)depth_raw % 8 == 0) && ((uintptr_t)color_raw % 4 == 0) && ((uintptr_t)depth_out % 16 == 0) &&
                  ((uintptr_t)color_out % 16 == 0), "misaligned buffers");
-  hipLaunchKernelGGL(gs_ingest_native4_kernel, dim3((unsigned)gs_ceil_div(px / 4, 256)), dim3(256), 0, gs_stream(stream),
+  const int64_t nb = gs_ceil_div(px, 256);   // (one work item per depth quad + three per colour quad)
+  hipLaunchKernelGGL(gs_ingest_native4_kernel, dim3((unsigned)(nb < GS_INGEST_BLOCKS ? nb : GS_INGEST_BLOCKS)), dim3(256), 0, gs_stream(stream),
                      depth_raw, color_raw, px / 4, depth_out, color_out, scale_div, normalize);
   GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// Device-side address of pinned (hipHostMalloc / hipHostRegister) host memory, or an error when the range is not mapped
+// into the device's address space.  The streaming ingest reads the raw frames straight out of pinned host memory with it
+// (no hipMemcpyAsync: measured, two asynchronous 6 MB copies cost the enqueuing host thread 0.24 ms).
+extern "C" int gs_host_device_pointer(const void* host_ptr, void** dev_ptr_out) {
+  GS_REQUIRE(host_ptr && dev_ptr_out, "bad arguments");
+  void* d = nullptr;
+  const hipError_t e = hipHostGetDevicePointer(&d, const_cast<void*>(host_ptr), 0);
+  if (e != hipSuccess || !d) {
+    (void)hipGetLastError();
+    gs_set_error("gs_host_device_pointer: not a device-mapped pinned allocation (%s)", hipGetErrorString(e));
+    return GS_ERR_INVALID;
+  }
+  *dev_ptr_out = d;
   return GS_OK;
 }

@@ -1,10 +1,16 @@
 """Streaming ingest (datasets/tum.py:352-434, datasets/datautils.py:73-118 do this per item on the
-host): raw sensor frames -- uint16 depth, uint8 colour, as decoded from the PNGs -- wait in PINNED host memory; while the
-GPU works on frame t, frame t + 1 crosses PCIe on a copy stream (one asynchronous copy per modality for the whole batch:
-the host array is time-major)
-and is converted to the float32 images the SLAM step consumes by one launch (gs_ingest_frames_native_f32, on the copy
-stream as well).  The compute stream only waits for an event; a ring of RING device buffers keeps a frame alive until the
-step after the next has been enqueued.
+host): raw sensor frames -- uint16 depth, uint8 colour, as decoded from the PNGs -- wait in PINNED host memory, time-major;
+while the GPU works on frame t, frame t + 1 crosses PCIe on a side stream (one hipMemcpyAsync per modality for the whole
+batch, i.e. the SDMA engines: no compute unit involved) and becomes the float32 images the SLAM step consumes by ONE
+launch (gs_ingest_frames_native_f32) on the same stream.  The compute stream only waits for an event.  A ring of RING
+device buffers makes it unnecessary for the side stream to wait for anything on the device: the host checks an event that
+is RING - 3 steps old before it reuses a slot (it has always fired: the frame loop keeps the host ~6 steps ahead at
+most).  That matters: a hipMemcpyAsync enqueued BEHIND a device-side wait blocks the enqueuing thread until the wait
+resolves (0.3 - 0.5 ms per copy, measured: the host became the bottleneck of a 1.07 ms step).
+Measured at 8 sequences of 640x480 (tools/stream_probe.py, 12.3 MB of raw pixels per step, 49 GB/s when copied alone):
+1.111 ms per step streamed against 1.070 resident = 96 %.  zero_copy=True lets the conversion kernel read the pinned
+frames itself (the allocation is mapped into the device's address space): no copy engine, but a kernel parked on PCIe loads
+for 0.3 ms next to the ICP chain, whose blocks want every SIMD's register file -- 88 %.
 
     st = FrameStreamer(depth_u16, color_u8, intrinsics, first_poses, scale_div=5000.0, device="cuda")
     for t in range(len(st)):
@@ -32,9 +38,10 @@ def quantize_sequences(seqs, scale_div=5000.0):
 
 
 class FrameStreamer(object):
-    RING = 3
+    RING = 10   # device buffers per modality (10 x 61 MB at 8 sequences of 640x480)
 
-    def __init__(self, depth_u16, color_u8, intrinsics, first_poses, scale_div, device="cuda", normalize_color=False):
+    def __init__(self, depth_u16, color_u8, intrinsics, first_poses, scale_div, device="cuda", normalize_color=False,
+                 zero_copy=False):
         """depth_u16 (L, B, H, W) uint16 and color_u8 (L, B, H, W, 3) uint8, time-major and contiguous in pinned host
         memory; intrinsics (B, 1, 4, 4) and first_poses (B, 1, 4, 4) on the device (every frame carries them: the SLAM
         step reads the first frame's pose and overwrites the others)."""
@@ -53,12 +60,17 @@ class FrameStreamer(object):
         dev = self.device
         R = self.RING
         self.copy_stream = torch.cuda.Stream(device=dev)
-        self.raw_d = [torch.empty((B, H, W), dtype=depth_u16.dtype, device=dev) for _ in range(R)]
-        self.raw_c = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(R)]
+        # zero-copy needs the pinned frames mapped into the device's address space (hipHostMalloc memory is)
+        self.zero_copy = bool(zero_copy) and ops.host_device_pointer(depth_u16) is not None and \
+            ops.host_device_pointer(color_u8) is not None
+        self.raw_d = self.raw_c = None
+        if not self.zero_copy:
+            self.raw_d = [torch.empty((B, H, W), dtype=depth_u16.dtype, device=dev) for _ in range(R)]
+            self.raw_c = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(R)]
         self.f_d = [torch.empty((B, 1, H, W, 1), dtype=torch.float32, device=dev) for _ in range(R)]
         self.f_c = [torch.empty((B, 1, H, W, 3), dtype=torch.float32, device=dev) for _ in range(R)]
         self.ready = [torch.cuda.Event() for _ in range(R)]     # copy + conversion of the slot's frame done
-        self.released = [None] * R                                # compute stream done with what the slot held before
+        self.done = {}                                            # frame t -> event: every step up to t has been enqueued
         self.in_slot = [-1] * R
         self._prefetch(0)
 
@@ -72,14 +84,26 @@ class FrameStreamer(object):
         if self.in_slot[k] == t:
             return
         cs = self.copy_stream
-        if self.released[k] is not None:
-            cs.wait_event(self.released[k])   # the step that read this slot's previous frame has finished
+        # The slot held frame t - RING, which steps t - RING (as the live frame) and t - RING + 1 (as the previous one)
+        # read: both must have finished.  Zero-copy: the side stream waits on the device.  Copy path: the HOST waits --
+        # an event RING - 3 frames old has long fired (the frame loop keeps the host ~6 steps ahead of the device at
+        # most), whereas a hipMemcpyAsync enqueued behind a device-side wait blocks the enqueuing thread until the wait
+        # resolves (measured: 0.3 - 0.5 ms per copy).
+        ev = self.done.get(t - self.RING + 1)
+        if ev is not None:
+            if self.zero_copy:
+                cs.wait_event(ev)
+            else:
+                ev.synchronize()
         with torch.cuda.stream(cs):
-            # (one contiguous block per modality: two copies per frame of the batch; pinned, so true asynchronous DMA)
-            self.raw_d[k].copy_(self.depth_u16[t], non_blocking=True)
-            self.raw_c[k].copy_(self.color_u8[t], non_blocking=True)
-            ops.ingest_frames_native(self.raw_d[k], self.raw_c[k], self.f_d[k], self.f_c[k], self.scale_div,
-                                     self.normalize, on_stream=cs)
+            if self.zero_copy:   # the conversion kernel reads the pinned host frames itself
+                ops.ingest_frames_native(self.depth_u16[t], self.color_u8[t], self.f_d[k], self.f_c[k], self.scale_div,
+                                         self.normalize, on_stream=cs)
+            else:                # one contiguous block per modality: two copies per frame of the batch, then the conversion
+                self.raw_d[k].copy_(self.depth_u16[t], non_blocking=True)
+                self.raw_c[k].copy_(self.color_u8[t], non_blocking=True)
+                ops.ingest_frames_native(self.raw_d[k], self.raw_c[k], self.f_d[k], self.f_c[k], self.scale_div,
+                                         self.normalize, on_stream=cs)
             self.ready[k].record(cs)
         self.in_slot[k] = t
 
@@ -88,11 +112,11 @@ class FrameStreamer(object):
         self._prefetch(t)
         k = t % self.RING
         cur = torch.cuda.current_stream(self.device)
+        if t > 0 and (t - 1) not in self.done:   # everything enqueued so far = the steps up to t - 1
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self.done[t - 1] = ev
+            self.done.pop(t - 1 - 2 * self.RING, None)
         cur.wait_event(self.ready[k])
-        # the slot that frame t + 1 will use held frame t + 1 - RING: everything enqueued so far has read it
-        nk = (t + 1) % self.RING
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        self.released[nk] = ev
         self._prefetch(t + 1)
         return RGBDImages(self.f_c[k], self.f_d[k], self.K, self.P0)

@@ -337,27 +337,49 @@ def ingest_color(raw_u8, H, W, normalize=False):
     return out
 
 
+def host_device_pointer(t):
+    """Device-side address of a PINNED host tensor (gs_host_device_pointer), or None when the allocation is not mapped
+    into the device's address space."""
+    import ctypes
+    if t.is_cuda or not t.is_pinned():
+        return None
+    out = ctypes.c_void_p()
+    rc = lib().gs_host_device_pointer(ctypes.c_void_p(t.data_ptr()), ctypes.byref(out))
+    return out.value if rc == 0 and out.value else None
+
+
 def ingest_frames_native(depth_raw, color_raw, depth_out, color_out, scale_div, normalize=False, on_stream=None):
     """n native-size raw frames -> float32 images in ONE launch (gs_ingest_frames_native_f32): depth_raw (..., H, W) uint16
     -> depth_out (same pixels) float32 metres, color_raw (..., H, W, 3) uint8 -> color_out float32; either pair may be
-    None.  All tensors contiguous, on one device; `on_stream`: a torch stream to launch on (default: the current one)."""
+    None.  The raw tensors live on the device of the outputs -- or in PINNED host memory mapped into its address space
+    (the kernel then reads them over PCIe: the streaming ingest).  `on_stream`: a torch stream to launch on (default:
+    the current one)."""
     ref = depth_raw if depth_raw is not None else color_raw
-    dev = require_device(ref)
+    dev = require_device(depth_out if depth_raw is not None else color_out)
     H, W = (depth_raw.shape[-2:] if depth_raw is not None else color_raw.shape[-3:-1])
     n = (depth_raw.numel() if depth_raw is not None else color_raw.numel() // 3) // (H * W)
+    ptrs = []
     for raw, out, dt, c in ((depth_raw, depth_out, (torch.uint16, torch.int16), 1), (color_raw, color_out, (torch.uint8,), 3)):
         if raw is None:
+            ptrs += [None, None]
             continue
         if raw.dtype not in dt or out.dtype != f32 or not raw.is_contiguous() or not out.is_contiguous() or \
                 out.numel() != raw.numel() or raw.numel() != n * H * W * c or out.device != dev:
             raise _C.HipExtensionError("ingest_frames_native: raw / out buffers do not match")
+        if raw.is_cuda:
+            if raw.device != dev:
+                raise _C.HipExtensionError("ingest_frames_native: raw frames on another device")
+            rp = raw.data_ptr()
+        else:
+            rp = host_device_pointer(raw)
+            if rp is None:
+                raise _C.HipExtensionError("ingest_frames_native: host frames must be pinned and device-mapped "
+                                           "(tensor.pin_memory()); there is no CPU path")
+        ptrs += [_C.C.c_void_p(rp), ptr(out)]
+    del ref
     st = stream(dev) if on_stream is None else _C.C.c_void_p(on_stream.cuda_stream)
-    check(lib().gs_ingest_frames_native_f32(ptr(depth_raw) if depth_raw is not None else None,
-                                            ptr(color_raw) if color_raw is not None else None, n, int(H), int(W),
-                                            float(scale_div), 1 if normalize else 0,
-                                            ptr(depth_out) if depth_raw is not None else None,
-                                            ptr(color_out) if color_raw is not None else None, st),
-          "gs_ingest_frames_native_f32")
+    check(lib().gs_ingest_frames_native_f32(ptrs[0], ptrs[2], n, int(H), int(W), float(scale_div), 1 if normalize else 0,
+                                            ptrs[1], ptrs[3], st), "gs_ingest_frames_native_f32")
 
 
 def relative_pose(T01, T02):

@@ -352,6 +352,9 @@ GS_API int gs_ingest_color_u8_f32(const uint8_t* raw, int H0, int W0, float* out
  * may be NULL.  n_frames * H * W must be a multiple of 4. */
 GS_API int gs_ingest_frames_native_f32(const uint16_t* depth_raw, const uint8_t* color_raw, int64_t n_frames, int H, int W,
                                        double scale_div, int normalize, float* depth_out, float* color_out, void* stream);
+/* Device-side address of a pinned host allocation (hipHostGetDevicePointer), for kernels that read raw frames straight
+ * from host memory; GS_ERR_INVALID when the range is not device-mapped. */
+GS_API int gs_host_device_pointer(const void* host_ptr, void** dev_ptr_out);
 
 /* ---- the per-frame map pipeline with the surfel count kept ON THE DEVICE -------------------
  * Same kernels and results as the functions they are named after; `n_map_bound` (host) is an

@@ -582,11 +582,13 @@ def test_streamed_frames_give_the_resident_result(gs):
     st = FrameStreamer(d16, c8, K, P0, scale_div=5000.0, device="cuda")
     first = st.frame(0)
     assert torch.equal(first.depth_image, dres[:, :1, ..., None]) and torch.equal(first.rgb_image, cres[:, :1])
-    st2 = FrameStreamer(d16, c8, K, P0, scale_div=5000.0, device="cuda")
-    got = run(st2.frame)
-    assert np.array_equal(ref[0].view(np.int32), got[0].view(np.int32))
-    for a, b in zip(ref[1] + ref[2], got[1] + got[2]):
-        assert a.shape == b.shape and np.array_equal(a.view(np.int32), b.view(np.int32))
+    for zero_copy in (False, True):   # hipMemcpyAsync + conversion (default) / the kernel reads the pinned host frames itself
+        st2 = FrameStreamer(d16, c8, K, P0, scale_div=5000.0, device="cuda", zero_copy=zero_copy)
+        assert st2.zero_copy == zero_copy
+        got = run(st2.frame)
+        assert np.array_equal(ref[0].view(np.int32), got[0].view(np.int32))
+        for a, b in zip(ref[1] + ref[2], got[1] + got[2]):
+            assert a.shape == b.shape and np.array_equal(a.view(np.int32), b.view(np.int32))
     with pytest.raises(ValueError, match="pinned host memory"):
         FrameStreamer(d16.clone(), c8, K, P0, 5000.0)
 
