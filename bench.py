@@ -194,7 +194,15 @@ def pmc_traffic(kernel_prefix):
             c, fetch_kb, write_kb = int(f[-5]), float(f[-3]), float(f[-2])
             tot += c * (fetch_kb + write_kb) * 1024.0
             calls += c
-    return (tot / calls, "profiles/" + os.path.basename(files[-1])) if calls else (None, None)
+    if not calls:
+        return None, None
+    import re
+    head = "".join(open(files[-1]).readlines()[:4])
+    cmd = re.search(r"`([^`]*)`", head)
+    # the file and the command line of the run it came from: NOT this run (rocprofv3 cannot wrap a run from inside)
+    return tot / calls, {"file": "profiles/" + os.path.basename(files[-1]), "command": cmd.group(1) if cmd else None,
+                         "note": "separate rocprofv3 --pmc passes of that command (shorter run, smaller maps): valid for the "
+                                 "ICP kernel, whose traffic does not depend on the map size"}
 
 
 def read_profile(lib, kind):
@@ -385,6 +393,25 @@ def secondary_measurements(gs, args, frames, device, barrier, Wm, K):
         del d16, c8
     except Exception as e:   # noqa: BLE001
         out["stream_640x480"] = {"error": repr(e)}
+
+    # ---- the headline workload over a LONG timed region (the default 20 steps are a growth-phase average):
+    # 200 timed steps after 30 warm-up frames, maps growing from 1.2 M to ~3 M surfels per sequence and then saturating
+    # (the synthetic camera turns back at frame 150)
+    try:
+        Bs = len(frames._rgb_image)
+        Ls, Ws = 230, 30
+        fr_l = frames_on_device(gs, make_sequences(list(range(Bs)), Ls, 480, 640), device)
+        slam_l = gs.slam.PointFusion(odom=args.odom, device=device)
+        r = timed_steps(gs, slam_l, fr_l, Ws, Ls - Ws, device, barrier, seg_every=50)
+        out["steady_b%d_200_steps" % Bs] = {
+            "frames_per_s": Bs * (Ls - Ws) / r["elapsed"], "ms_per_step": r["elapsed"] / (Ls - Ws) * 1e3,
+            "ms_per_step_first_quartile": r["ms_first_quartile"], "ms_per_step_last_quartile": r["ms_last_quartile"],
+            "segments": r["segments"], "steps": Ls - Ws, "warmup": Ws,
+            "map_surfels_end": [int(p.shape[0]) for p in r["pc"].points_list],
+            "what": "the headline workload (B sequences of 640x480, resident) over 200 timed steps"}
+        del fr_l, r
+    except Exception as e:   # noqa: BLE001
+        out["steady_200_steps"] = {"error": repr(e)}
 
     # ---- configs[4] shape: 1296x968, 60 timed frames, growing map
     try:

@@ -43,7 +43,8 @@ def test_sequences_generated_in_process_under_a_profiler(monkeypatch):
 
 def test_pmc_summary_parser_and_committed_bench_lines():
     traffic, src = bench.pmc_traffic("gs_icp_half_batch_kernel")
-    assert src is not None and src.startswith("profiles/") and 1e6 < traffic < 1e9
+    assert src is not None and src["file"].startswith("profiles/") and 1e6 < traffic < 1e9
+    assert src["command"] and "bench.py" in src["command"]          # the run the counters came from, on record
     lines = sorted(glob.glob(os.path.join(REPO, "profiles", "r02_*_bench_line.json")))
     assert lines
     for path in lines:
