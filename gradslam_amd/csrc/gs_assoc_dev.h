@@ -84,6 +84,15 @@ GS_DEV bool gs_is_similar(const float* __restrict__ points, const float* __restr
   return (dist < dist_th) && (dot > dot_th);
 }
 
+// the same test on the pixel's global vertex f and normal g held in registers
+GS_DEV bool gs_is_similar_v(const float* __restrict__ points, const float* __restrict__ normals, const float* f,
+                            const float* g, int64_t n, float dist_th, float dot_th) {
+  const float q0 = points[3 * n], q1 = points[3 * n + 1], q2 = points[3 * n + 2];
+  const float dist = gs_norm3(f[0] - q0, f[1] - q1, f[2] - q2);
+  const float dot = gs_dot3_plain(g[0], g[1], g[2], normals[3 * n], normals[3 * n + 1], normals[3 * n + 2]);
+  return (dist < dist_th) && (dot > dot_th);
+}
+
 // slam/fusionutils.py:491-517: (1/(ccount+1e-20), |p - f|^2) packed so that unsigned order ==
 // lexicographic float order (both are >= 0).
 GS_DEV uint64_t gs_assoc_key(const float* __restrict__ points, const float* __restrict__ ccounts,
@@ -96,4 +105,14 @@ GS_DEV uint64_t gs_assoc_key(const float* __restrict__ points, const float* __re
   ray = ray + d2 * d2;
   return ((uint64_t)__float_as_uint(inv) << 32) | (uint64_t)__float_as_uint(ray);
 }
-
+// the same key with the pixel's global vertex f in registers
+GS_DEV uint64_t gs_assoc_key_v(const float* __restrict__ points, const float* __restrict__ ccounts, const float* f,
+                               int64_t n) {
+  const float inv = 1.0f / (ccounts[n] + 1e-20f);
+  const float d0 = points[3 * n] - f[0];
+  const float d1 = points[3 * n + 1] - f[1];
+  const float d2 = points[3 * n + 2] - f[2];
+  float ray = d0 * d0 + d1 * d1;
+  ray = ray + d2 * d2;
+  return ((uint64_t)__float_as_uint(inv) << 32) | (uint64_t)__float_as_uint(ray);
+}

@@ -26,10 +26,27 @@ struct GsClearJob {
   char* ptr[GS_MAX_BATCH];
 };
 constexpr int GS_CLEAR_ITEMS = 8;  // 16-byte stores per thread of a clearing block (32 KB per block)
-// gs_frame_maps_batch_f32 + the clear job in the same launch (library-internal)
+// Per-pixel tables of the map update that the frame-map launch of the one-call step initialises on the side (its threads
+// are per pixel already): key = ~0, winner = -1 for frame f of the launch, the "any match" flag of that sequence and the
+// flag of the call = 0.  The update then starts at its projection pass (no per-pixel pass of its own).
+struct GsPixelTables {
+  int n;   // frames with tables (0: none)
+  uint64_t* key_pix[GS_MAX_BATCH];
+  int32_t* best_pix[GS_MAX_BATCH];
+  int32_t* any_flag[GS_MAX_BATCH];
+  int32_t* call_flag;   // may be NULL (not the first chunk of the call)
+};
+// gs_frame_maps_batch_f32 + the clear job (+ the update's pixel tables) in the same launch (library-internal)
 int gs_frame_maps_batch_clear(const float* depth, int64_t depth_stride_seq, int64_t depth_stride_frame, const float* K16,
                               int n_frames, int frames_per_K, int H, int W, float two_sigma_sq, float* vertex,
-                              float* normal, float* alpha, const GsClearJob* job, void* stream);
+                              float* normal, float* alpha, const GsClearJob* job, void* stream,
+                              const GsPixelTables* tables = nullptr);
+
+// the batched map update behind gs_update_map_fusion_batch_f32 (gs_fuse.hip); tables_ready: see GsPixelTables
+int gs_update_map_fusion_batch_impl(const gs_update_seq* seqs_host, int B, int H, int W, float dist_th, float dot_th,
+                                    int renorm_all, void* stream, bool tables_ready);
+int32_t* gs_update_map_call_flag(void* scratch_of_first_sequence);
+void gs_update_map_tables(void* scratch, int32_t** any_flag, uint64_t** key_pix);
 
 // ---------------------------------------------------------------- error plumbing -------
 void gs_set_error(const char* fmt, ...);

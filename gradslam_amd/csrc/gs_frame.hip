@@ -140,7 +140,8 @@ struct GsRow3 {
 };
 GS_DEV void frame_maps_body(const float* __restrict__ depth, const float* __restrict__ K16, int H, int W,
                             float two_sigma_sq, float* __restrict__ vertex, float* __restrict__ normal,
-                            float* __restrict__ alpha, uint8_t* __restrict__ valid) {
+                            float* __restrict__ alpha, uint8_t* __restrict__ valid,
+                            uint64_t* __restrict__ key_pix = nullptr, int32_t* __restrict__ best_pix = nullptr) {
   __shared__ float tile[FM_LH][FM_LW];
   const int w_base = blockIdx.x * FM_TW, h_base = blockIdx.y * FM_TH;
   // stage depth tile with a one-pixel halo on every side (coordinates clamped into the image;
@@ -169,6 +170,7 @@ GS_DEV void frame_maps_body(const float* __restrict__ depth, const float* __rest
     if (vertex) reinterpret_cast<GsRow3*>(vertex)[p] = GsRow3{vx, vy, vz};   // one 12-byte store per row (dwordx3)
     if (valid) valid[p] = d > 0.0f ? 1 : 0;
     if (alpha) alpha[p] = gs_alpha_of(vx, vy, vz, two_sigma_sq, 1e-7f);
+    if (key_pix) { key_pix[p] = ~0ull; best_pix[p] = -1; }   // (GsPixelTables: the map update's per-pixel tables)
     if (normal) {
       // forward differences; the last column / row reuse the previous difference
       // (structures/rgbdimages.py:724-731)
@@ -205,7 +207,7 @@ __global__ void __launch_bounds__(256) gs_frame_maps_kernel(
 __global__ void __launch_bounds__(256) gs_frame_maps_batch_kernel(
     const float* __restrict__ depth, int64_t stride_seq, int64_t stride_frame, const float* __restrict__ K16,
     int frames_per_K, int H, int W, float two_sigma_sq, float* __restrict__ vertex, float* __restrict__ normal,
-    float* __restrict__ alpha, const int n_frames, const GsClearJob job) {
+    float* __restrict__ alpha, const int n_frames, const GsClearJob job, const GsPixelTables tabs) {
   if ((int)blockIdx.z >= n_frames) {
     const size_t blk = ((size_t)(blockIdx.z - n_frames) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const size_t n16 = job.bytes / 16, per = (n16 + 256 * GS_CLEAR_ITEMS - 1) / (256 * GS_CLEAR_ITEMS);
@@ -222,8 +224,14 @@ __global__ void __launch_bounds__(256) gs_frame_maps_batch_kernel(
   }
   const size_t f = blockIdx.z, P = (size_t)H * W;
   const size_t b = f / frames_per_K, l = f % frames_per_K;
+  const bool tb = (int)f < tabs.n;
+  if (tb && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    *tabs.any_flag[f] = 0;
+    if (f == 0 && tabs.call_flag) *tabs.call_flag = 0;
+  }
   frame_maps_body(depth + b * stride_seq + l * stride_frame, K16 + 16 * b, H, W, two_sigma_sq, vertex + 3 * f * P,
-                  normal ? normal + 3 * f * P : nullptr, alpha ? alpha + f * P : nullptr, nullptr);
+                  normal ? normal + 3 * f * P : nullptr, alpha ? alpha + f * P : nullptr, nullptr,
+                  tb ? tabs.key_pix[f] : nullptr, tb ? tabs.best_pix[f] : nullptr);
 }
 
 extern "C" int gs_frame_maps_f32(const float* depth, const float* K16, int H, int W,
@@ -242,8 +250,15 @@ extern "C" int gs_frame_maps_f32(const float* depth, const float* K16, int H, in
 
 int gs_frame_maps_batch_clear(const float* depth, int64_t depth_stride_seq, int64_t depth_stride_frame, const float* K16,
                               int n_frames, int frames_per_K, int H, int W, float two_sigma_sq, float* vertex,
-                              float* normal, float* alpha, const GsClearJob* job, void* stream) {
+                              float* normal, float* alpha, const GsClearJob* job, void* stream,
+                              const GsPixelTables* tables) {
   GS_REQUIRE(depth && K16 && vertex, "depth, K16 and vertex must not be NULL");
+  GsPixelTables tabs;
+  tabs.n = 0; tabs.call_flag = nullptr;
+  if (tables && tables->n > 0) {
+    GS_REQUIRE(tables->n <= GS_MAX_BATCH && tables->n <= n_frames, "bad pixel tables");
+    tabs = *tables;
+  }
   GS_REQUIRE(H >= 2 && W >= 2, "image must be at least 2x2");
   GS_REQUIRE(n_frames > 0 && n_frames <= 65535 && frames_per_K > 0 && n_frames % frames_per_K == 0, "bad frame count");
   GS_REQUIRE(depth_stride_frame >= (int64_t)H * W && depth_stride_seq >= 0, "bad depth strides");
@@ -259,10 +274,11 @@ int gs_frame_maps_batch_clear(const float* depth, int64_t depth_stride_seq, int6
   } else {
     job = &none;
   }
-  const double bytes = (double)n_frames * H * W * (4.0 + 12.0 + (normal ? 12 : 0) + (alpha ? 4 : 0));
+  const double bytes = (double)n_frames * H * W * (4.0 + 12.0 + (normal ? 12 : 0) + (alpha ? 4 : 0)) +
+                       (double)tabs.n * H * W * 12.0;
   GsProf prof(GS_PROF_FRAME, bytes, gs_stream(stream));
   hipLaunchKernelGGL(gs_frame_maps_batch_kernel, grid, dim3(256), 0, gs_stream(stream), depth, depth_stride_seq,
-                     depth_stride_frame, K16, frames_per_K, H, W, two_sigma_sq, vertex, normal, alpha, n_frames, *job);
+                     depth_stride_frame, K16, frames_per_K, H, W, two_sigma_sq, vertex, normal, alpha, n_frames, *job, tabs);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

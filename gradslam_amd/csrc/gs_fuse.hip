@@ -32,9 +32,81 @@ __global__ void __launch_bounds__(256) gs_fuse_scatter_kernel(const int32_t* __r
 // All loads first, then the arithmetic, then the stores: the three floats of an attribute then travel as ONE 12-byte
 // access (interleaved loads and stores compile to 21 + 10 single-dword accesses, and the scattered frame gathers of
 // the matched rows make the kernel address-rate bound).
+// `frame(p, fp, fn)` yields the global vertex and normal of pixel p: from the materialised global maps (FrameGlobalMaps)
+// or computed on the spot from the local maps and the pose (FrameLocalMaps: the same operations, so the same bits).
+struct FrameGlobalMaps {
+  const float* __restrict__ gvertex;
+  const float* __restrict__ gnormal;
+  __device__ void operator()(const int64_t p, float* fp, float* fn) const {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      fp[k] = gvertex[3 * p + k];
+      fn[k] = gnormal[3 * p + k];
+    }
+  }
+  __device__ void vertex_of(const int64_t p, float* fp) const {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fp[k] = gvertex[3 * p + k];
+  }
+  __device__ void normal_of(const int64_t p, float* fn) const {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fn[k] = gnormal[3 * p + k];
+  }
+};
+// rgbdimages.py:700-708 / :760-762 for ONE pixel, as gs_global_maps_kernel / gs_mu_pixel_init_kernel compute it.
+// The validity mask is read off the local vertex: for a vertex map made by the frame-map kernel (gs_frame.hip, fm_vertex:
+// z = (1.0f * d) * (d > 0 ? 1 : 0)) `z > 0` holds exactly when `d > 0` does -- d <= 0 gives +-0 or NaN, NaN gives NaN.
+// (A gather of depth[p] instead was measured: these passes are bound by the number of scattered accesses, and that
+// fifth one cost 15 us in the projection pass and 5 us in the merge at 8 x 640x480.)  Only the one-call step, which makes
+// the vertex map itself, uses this form.
+struct FrameLocalMaps {
+  const float* __restrict__ vertex;
+  const float* __restrict__ normal;
+  float T[12];
+  __device__ void operator()(const int64_t p, float* fp, float* fn) const {
+    float v[3], n[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      v[k] = vertex[3 * p + k];
+      n[k] = normal[3 * p + k];
+    }
+    const float validf = v[2] > 0.0f ? 1.0f : 0.0f;
+    float g0, g1, g2;
+    gs_rigid_fma(T, v[0], v[1], v[2], g0, g1, g2);
+    fp[0] = g0 * validf; fp[1] = g1 * validf; fp[2] = g2 * validf;
+    fn[0] = gs_dot3_fma(T[0], T[1], T[2], n[0], n[1], n[2]);
+    fn[1] = gs_dot3_fma(T[4], T[5], T[6], n[0], n[1], n[2]);
+    fn[2] = gs_dot3_fma(T[8], T[9], T[10], n[0], n[1], n[2]);
+  }
+  __device__ void vertex_of(const int64_t p, float* fp) const {
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = vertex[3 * p + k];
+    const float validf = v[2] > 0.0f ? 1.0f : 0.0f;
+    float g0, g1, g2;
+    gs_rigid_fma(T, v[0], v[1], v[2], g0, g1, g2);
+    fp[0] = g0 * validf; fp[1] = g1 * validf; fp[2] = g2 * validf;
+  }
+  __device__ void normal_of(const int64_t p, float* fn) const {
+    float n[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) n[k] = normal[3 * p + k];
+    fn[0] = gs_dot3_fma(T[0], T[1], T[2], n[0], n[1], n[2]);
+    fn[1] = gs_dot3_fma(T[4], T[5], T[6], n[0], n[1], n[2]);
+    fn[2] = gs_dot3_fma(T[8], T[9], T[10], n[0], n[1], n[2]);
+  }
+};
+GS_DEV FrameLocalMaps frame_local_maps(const float* vertex, const float* normal, const float* pose16) {
+  FrameLocalMaps f;
+  f.vertex = vertex; f.normal = normal;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) f.T[i] = pose16[i];
+  return f;
+}
+
+template <class Frame>
 GS_DEV void fuse_merge_row(float* __restrict__ points, float* __restrict__ normals, float* __restrict__ colors,
-                           float* __restrict__ ccounts, const int64_t n, const int32_t p,
-                           const float* __restrict__ gvertex, const float* __restrict__ gnormal,
+                           float* __restrict__ ccounts, const int64_t n, const int32_t p, const Frame& frame,
                            const float* __restrict__ rgb, const float* __restrict__ alpha) {
   const float a = p >= 0 ? alpha[p] : 0.0f;
   const float cc = ccounts[n];
@@ -46,12 +118,9 @@ GS_DEV void fuse_merge_row(float* __restrict__ points, float* __restrict__ norma
     C[k] = colors[3 * n + k];
   }
   if (p >= 0) {
+    frame((int64_t)p, fp, fn);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      fp[k] = gvertex[3 * (int64_t)p + k];
-      fn[k] = gnormal[3 * (int64_t)p + k];
-      fc[k] = rgb[3 * (int64_t)p + k];
-    }
+    for (int k = 0; k < 3; ++k) fc[k] = rgb[3 * (int64_t)p + k];
   }
   const float cc2 = cc + a;
   const float inv = 1.0f / (cc2 == 0.0f ? 1.0f : cc2);
@@ -85,7 +154,7 @@ __global__ void __launch_bounds__(256) gs_fuse_merge_kernel(
   if (*any_flag == 0 && renorm_all != 2) return;
   const int32_t p = pix_of[n];
   if (p < 0 && !renorm_all) return;
-  fuse_merge_row(points, normals, colors, ccounts, n, p, gvertex, gnormal, rgb, alpha);
+  fuse_merge_row(points, normals, colors, ccounts, n, p, FrameGlobalMaps{gvertex, gnormal}, rgb, alpha);
 }
 
 struct PredNewPixel {
@@ -95,25 +164,21 @@ struct PredNewPixel {
     return depth[p] > 0.0f && (best_pix == nullptr || best_pix[p] < 0);
   }
 };
-struct EmitAppend {
+template <class Frame>
+struct EmitAppendT {
   float* points;
   float* normals;
   float* colors;
   float* ccounts;
   GsCount n_map;
-  const float* gvertex;
-  const float* gnormal;
+  Frame frame;   // global vertex / normal of a pixel (FrameGlobalMaps | FrameLocalMaps)
   const float* rgb;
   const float* alpha;
   __device__ void operator()(int64_t p, int64_t pos) const {
     const int64_t r = gs_count(n_map) + pos;
     float v[3], nn[3] = {0.0f, 0.0f, 0.0f}, c[3] = {0.0f, 0.0f, 0.0f};  // loads, then stores: 12-byte accesses
-#pragma unroll
-    for (int k = 0; k < 3; ++k) v[k] = gvertex[3 * p + k];
-    if (normals) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) nn[k] = gnormal[3 * p + k];
-    }
+    frame.vertex_of(p, v);
+    if (normals) frame.normal_of(p, nn);
     if (colors) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) c[k] = rgb[3 * p + k];
@@ -132,6 +197,7 @@ struct EmitAppend {
     if (ccounts) ccounts[r] = a;
   }
 };
+typedef EmitAppendT<FrameGlobalMaps> EmitAppend;
 
 static int fuse_append(float* points, float* normals, float* colors, float* ccounts, GsCount n_map_c,
                        int64_t capacity, const int32_t* best_pix, const float* gvertex, const float* gnormal,
@@ -161,7 +227,7 @@ static int fuse_append(float* points, float* normals, float* colors, float* ccou
                        alpha, renorm_all);
     GS_LAUNCH_CHECK();
   }
-  EmitAppend emit{points, normals, colors, ccounts, n_map_c, gvertex, gnormal, rgb, alpha};
+  EmitAppend emit{points, normals, colors, ccounts, n_map_c, FrameGlobalMaps{gvertex, gnormal}, rgb, alpha};
   return gs_compact(GsCount{P, nullptr}, PredNewPixel{depth, best_pix}, emit, new_count_out, n_map_c, capacity,
                     scratch, st);
 }
@@ -191,7 +257,7 @@ static int append_valid(float* points, float* normals, float* colors, float* cco
   GS_REQUIRE(H > 0 && W > 0 && n_map_c.host >= 0 && capacity >= n_map_c.host, "bad sizes");
   GS_REQUIRE(points && gvertex && depth && new_count_out && scratch, "NULL pointer");
   EmitAppend emit{points, gnormal ? normals : nullptr, rgb ? colors : nullptr, alpha ? ccounts : nullptr,
-                  n_map_c, gvertex, gnormal, rgb, alpha};
+                  n_map_c, FrameGlobalMaps{gvertex, gnormal}, rgb, alpha};
   return gs_compact(GsCount{(int64_t)H * W, nullptr}, PredNewPixel{depth, nullptr}, emit, new_count_out, n_map_c,
                     capacity, scratch, gs_stream(stream));
 }
@@ -414,11 +480,18 @@ __global__ void __launch_bounds__(256) gs_mu_project_key_kernel(const MuBatch mb
   // pix[n] = the pixel this row competes for, or -1 (not in the frame, or not similar to the pixel): the pick pass
   // then reads 4 bytes of most rows instead of 12, and the key is only stored for the rows that have one
   int32_t pk = -1;
-  if (p >= 0 && gs_is_similar(q.points, q.normals, q.gvertex, q.gnormal, n, p, mb.dist_th, mb.dot_th)) {
-    const uint64_t k = gs_assoc_key(q.points, q.ccounts, q.gvertex, n, p);
-    atomicMin(reinterpret_cast<unsigned long long*>(&q.key_pix[p]), (unsigned long long)k);
-    q.key_pt[n] = k;
-    pk = p;
+  if (p >= 0) {
+    // the pixel's global vertex / normal: materialised by the pixel pass, or computed here (MuSeq::gvertex == NULL: the
+    // one-call step, whose frame-map launch initialised the tables -- there is no pixel pass then)
+    float fp[3], fn[3];
+    if (q.gvertex) FrameGlobalMaps{q.gvertex, q.gnormal}((int64_t)p, fp, fn);
+    else frame_local_maps(q.vertex, q.normal, q.pose16)((int64_t)p, fp, fn);
+    if (gs_is_similar_v(q.points, q.normals, fp, fn, n, mb.dist_th, mb.dot_th)) {
+      const uint64_t k = gs_assoc_key_v(q.points, q.ccounts, fp, n);
+      atomicMin(reinterpret_cast<unsigned long long*>(&q.key_pix[p]), (unsigned long long)k);
+      q.key_pt[n] = k;
+      pk = p;
+    }
   }
   q.pix[n] = pk;
   q.pix_of[n] = -1;
@@ -478,7 +551,8 @@ GS_DEV void mu_merge_body(const MuBatch& mb, const unsigned bid) {
   if (*mb.call_flag == 0) return;
   const int32_t p = q.pix_of[n];
   if (p < 0 && !mb.renorm_all) return;
-  fuse_merge_row(q.points, q.normals, q.colors, q.ccounts, n, p, q.gvertex, q.gnormal, q.rgb, q.alpha);
+  if (q.gvertex) fuse_merge_row(q.points, q.normals, q.colors, q.ccounts, n, p, FrameGlobalMaps{q.gvertex, q.gnormal}, q.rgb, q.alpha);
+  else fuse_merge_row(q.points, q.normals, q.colors, q.ccounts, n, p, frame_local_maps(q.vertex, q.normal, q.pose16), q.rgb, q.alpha);
 }
 
 // ordered append without a scan launch: block b adds up the counts of the tiles before it (fixed order)
@@ -524,11 +598,20 @@ GS_DEV void mu_append_body(const MuBatch& mb, const unsigned bid) {
     if (keep[i]) loc_s[w++] = (unsigned short)(threadIdx.x * GS_CP_ITEMS + i);
   }
   __syncthreads();
-  const EmitAppend emit{q.points, q.normals, q.colors, q.ccounts, q.n_map, q.gvertex, q.gnormal, q.rgb, q.alpha};
   const int64_t tile_base = (int64_t)blk * GS_CP_TILE;
-  for (int r = threadIdx.x; r < tile_new; r += GS_CP_BLOCK) {
-    const int64_t pos = (int64_t)tile_prefix + r;
-    if (n_map + pos < q.capacity) emit(tile_base + loc_s[r], pos);
+  if (q.gvertex) {
+    const EmitAppend emit{q.points, q.normals, q.colors, q.ccounts, q.n_map, FrameGlobalMaps{q.gvertex, q.gnormal}, q.rgb, q.alpha};
+    for (int r = threadIdx.x; r < tile_new; r += GS_CP_BLOCK) {
+      const int64_t pos = (int64_t)tile_prefix + r;
+      if (n_map + pos < q.capacity) emit(tile_base + loc_s[r], pos);
+    }
+  } else {
+    const EmitAppendT<FrameLocalMaps> emit{q.points, q.normals, q.colors, q.ccounts, q.n_map,
+                                           frame_local_maps(q.vertex, q.normal, q.pose16), q.rgb, q.alpha};
+    for (int r = threadIdx.x; r < tile_new; r += GS_CP_BLOCK) {
+      const int64_t pos = (int64_t)tile_prefix + r;
+      if (n_map + pos < q.capacity) emit(tile_base + loc_s[r], pos);
+    }
   }
 }
 
@@ -548,9 +631,17 @@ extern "C" int64_t gs_update_map_scratch_bytes(int64_t n_map_bound, int H, int W
                    2 * gs_align(4 * (size_t)(n_map_bound > 0 ? n_map_bound : 1)) + 4096);
 }
 
+// where the tables the frame-map launch of the one-call step initialises live inside an update scratch (as update_chunk
+// carves it); the call flag is the second flag word of the FIRST sequence of the call (see MuBatch::call_flag)
+int32_t* gs_update_map_call_flag(void* scratch0) { return reinterpret_cast<int32_t*>(scratch0) + 32; }
+void gs_update_map_tables(void* scratch, int32_t** any_flag, uint64_t** key_pix) {
+  *any_flag = reinterpret_cast<int32_t*>(scratch);
+  *key_pix = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(scratch) + 256);
+}
+
 // phase 0: global maps, association, winner / tile counts; phase 1: merge + append (after phase 0 of every chunk)
 static int update_chunk(const gs_update_seq* seqs, int B, int H, int W, float dist_th, float dot_th, int renorm_all,
-                        hipStream_t st, int phase, int32_t* call_flag, bool first_chunk) {
+                        hipStream_t st, int phase, int32_t* call_flag, bool first_chunk, bool tables_ready) {
   MuBatch mb;
   mb.B = B; mb.H = H; mb.W = W; mb.renorm_all = renorm_all;
   mb.call_flag = call_flag; mb.zero_call_flag = first_chunk ? 1 : 0;
@@ -584,7 +675,7 @@ static int update_chunk(const gs_update_seq* seqs, int B, int H, int W, float di
   const unsigned uB = (unsigned)B;
   const unsigned pb = uB * (unsigned)gs_ceil_div(mb.P, 256), nb = uB * (unsigned)gs_ceil_div(n_max > 0 ? n_max : 1, 256);
   if (phase == 0) {
-    {
+    if (!tables_ready) {   // (the one-call step: the frame-map launch initialised the tables, the global maps stay implicit)
       GsProf prof(GS_PROF_FRAME, (double)B * (double)mb.P * 64.0, st);   // 28 B read + 24 B + 12 B written per pixel
       hipLaunchKernelGGL(gs_mu_pixel_init_kernel, dim3(pb), dim3(256), 0, st, mb);
     }
@@ -604,8 +695,11 @@ static int update_chunk(const gs_update_seq* seqs, int B, int H, int W, float di
   return GS_OK;
 }
 
-extern "C" int gs_update_map_fusion_batch_f32(const gs_update_seq* seqs_host, int B, int H, int W, float dist_th,
-                                              float dot_th, int renorm_all, void* stream) {
+// tables_ready: the caller's frame-map launch has initialised key_pix / best_pix / the flags (gs_update_map_tables says
+// where they live); gvertex / gnormal may then be NULL -- the global vertex and normal of a pixel are computed where they
+// are used (the same operations as the pixel pass: the same bits) and never written to memory.
+int gs_update_map_fusion_batch_impl(const gs_update_seq* seqs_host, int B, int H, int W, float dist_th, float dot_th,
+                                    int renorm_all, void* stream, bool tables_ready) {
   GS_REQUIRE(seqs_host && B > 0 && H > 0 && W > 0, "bad arguments");
   GS_REQUIRE((int64_t)H * W < (1ll << 31), "too large for int32 indices");
   for (int b = 0; b < B; ++b) {
@@ -613,21 +707,27 @@ extern "C" int gs_update_map_fusion_batch_f32(const gs_update_seq* seqs_host, in
     GS_REQUIRE(u.map.n_bound >= 0 && u.map.n_bound < 0x7fffffff, "bad map size");
     GS_REQUIRE(u.map.capacity >= u.map.n_bound + (int64_t)H * W, "capacity must cover n_bound + H*W rows");
     GS_REQUIRE(u.map.points && u.map.normals && u.map.colors && u.map.ccounts && u.vertex && u.normal && u.depth && u.rgb &&
-                   u.alpha && u.pose16 && u.K16 && u.gvertex && u.gnormal && u.best_pix && u.new_count_out && u.scratch,
+                   u.alpha && u.pose16 && u.K16 && u.best_pix && u.new_count_out && u.scratch,
                "NULL pointer");
+    GS_REQUIRE((u.gvertex && u.gnormal) || (tables_ready && !u.gvertex && !u.gnormal), "gvertex / gnormal: both or none");
     GS_REQUIRE(u.new_count_out != u.map.n_dev, "new_count_out must not alias the map's device count");
   }
   hipStream_t st = gs_stream(stream);
-  // (second word of the first sequence's flag area: see MuBatch::call_flag)
-  int32_t* call_flag = reinterpret_cast<int32_t*>(seqs_host[0].scratch) + 32;
+  int32_t* call_flag = gs_update_map_call_flag(seqs_host[0].scratch);
   for (int phase = 0; phase < 2; ++phase) {
     for (int c0 = 0; c0 < B; c0 += GS_MAX_BATCH) {
       const int nb = B - c0 < GS_MAX_BATCH ? B - c0 : GS_MAX_BATCH;
-      const int rc = update_chunk(seqs_host + c0, nb, H, W, dist_th, dot_th, renorm_all, st, phase, call_flag, c0 == 0);
+      const int rc = update_chunk(seqs_host + c0, nb, H, W, dist_th, dot_th, renorm_all, st, phase, call_flag, c0 == 0,
+                                  tables_ready);
       if (rc != GS_OK) return rc;
     }
   }
   return GS_OK;
+}
+
+extern "C" int gs_update_map_fusion_batch_f32(const gs_update_seq* seqs_host, int B, int H, int W, float dist_th,
+                                              float dot_th, int renorm_all, void* stream) {
+  return gs_update_map_fusion_batch_impl(seqs_host, B, H, W, dist_th, dot_th, renorm_all, stream, false);
 }
 
 extern "C" int gs_update_map_fusion_dc_f32(float* points, float* normals, float* colors, float* ccounts,

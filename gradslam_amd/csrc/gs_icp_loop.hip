@@ -358,7 +358,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
   // (LMODE is a template parameter: one kernel per mode keeps each of them within the register budget)
   constexpr bool verify = LMODE == 2;
   constexpr bool build_all = LMODE == 1;
-  constexpr bool NPREF = LMODE == 2 && !FULL;   // the list check also fetches the normal of the likely match
+  constexpr bool NPREF = LMODE == 2;   // the list check also fetches the normal of the likely match
   // the source point of the first slot does not depend on the prologue: issue its load first so that
   // the global-memory latency hides behind the scalar stage
   const int lane = threadIdx.x & (G - 1), slot = threadIdx.x / G;
@@ -474,26 +474,30 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
       __syncthreads();
     }
     if (tl && threadIdx.x == 0) { tl[8] = wall_clock64(); tl[9] = tl[8]; }   // sums done (no solve in this half)
-    if (threadIdx.x == 0) {  // scalar stage, in place on the LDS copy of the state
+    if (threadIdx.x < GS_WAVE) {  // scalar stage by wave 0, in place on the LDS copy of the state
       if (it > 0)
-        icp_update_math((float)e1, sm, prm, (lb == 0 && it - 1 < GS_ICP_MAX_ITERS) ? q.trace + 12 * (it - 1) : nullptr);
-      unres_n = 0;
-      hard_n = 0;
-      lfail_s[0] = lfail_s[1] = lfail_s[2] = 0;
+        icp_update_math_wave((float)e1, sm, prm,
+                             (lb == 0 && it - 1 < GS_ICP_MAX_ITERS) ? q.trace + 12 * (it - 1) : nullptr, (int)threadIdx.x);
+      if (threadIdx.x == 0) {
+        unres_n = 0;
+        hard_n = 0;
+        lfail_s[0] = lfail_s[1] = lfail_s[2] = 0;
+      }
     }
   } else {
     if (LISTS) icp_sum_rows_split<FS_BLOCK>(partials_in, nrows_in, S, sub, hook);
     else icp_sum_rows<FS_BLOCK>(partials_in, nrows_in, S, sub);
     if (tl && threadIdx.x == 0) tl[8] = wall_clock64();   // sums done
-    if (threadIdx.x < GS_WAVE) gs_solve_spd6_wave(S, sm.damp, sm.xi);  // 6x6 solve across the lanes of wave 0
-    gs_bar<LISTS>();
-    if (tl && threadIdx.x == 0) tl[9] = wall_clock64();   // solve done
-    if (threadIdx.x == 0) {
-      if (q.tape_sys && lb == 0) tape_write_sys(q.tape_sys, it, S, sm.damp);
-      icp_solve_finish(S, sm);
-      unres_n = 0;
-      hard_n = 0;
-      lfail_s[0] = lfail_s[1] = lfail_s[2] = 0;
+    if (threadIdx.x < GS_WAVE) {   // 6x6 solve and the exponential of the step across the lanes of wave 0
+      gs_solve_spd6_wave(S, sm.damp, sm.xi);
+      if (tl && threadIdx.x == 0) tl[9] = wall_clock64();   // solve done
+      icp_solve_finish_wave(S, sm, (int)threadIdx.x);
+      if (threadIdx.x == 0) {
+        if (q.tape_sys && lb == 0) tape_write_sys(q.tape_sys, it, S, sm.damp);
+        unres_n = 0;
+        hard_n = 0;
+        lfail_s[0] = lfail_s[1] = lfail_s[2] = 0;
+      }
     }
   }
   gs_bar<LISTS>();
@@ -1839,8 +1843,10 @@ extern "C" int gs_pointfusion_step_batch_f32(const gs_step_seq* seqs_host, int B
   const int64_t dstride = B > 1 ? seqs_host[1].depth - s0.depth : P;
   for (int b = 0; b < B; ++b) {
     const gs_step_seq& q = seqs_host[b];
-    GS_REQUIRE(q.depth && q.rgb && q.K16 && q.prev_pose16 && q.out_pose16 && q.vertex && q.normal && q.alpha && q.gvertex &&
-                   q.gnormal && q.best_pix && q.new_count_out && q.loc_scratch && q.upd_scratch, "NULL pointer");
+    GS_REQUIRE(q.depth && q.rgb && q.K16 && q.prev_pose16 && q.out_pose16 && q.vertex && q.normal && q.alpha &&
+                   q.best_pix && q.new_count_out && q.loc_scratch && q.upd_scratch, "NULL pointer");
+    GS_REQUIRE((q.gvertex != nullptr) == (q.gnormal != nullptr) && (q.gvertex != nullptr) == (s0.gvertex != nullptr),
+               "gvertex / gnormal: both or none, the same choice for every sequence");
     GS_REQUIRE(q.out_pose16 != q.prev_pose16, "out_pose16 must not alias prev_pose16");
     GS_REQUIRE(q.vertex == s0.vertex + 3 * P * b && q.normal == s0.normal + 3 * P * b && q.alpha == s0.alpha + P * b,
                "vertex / normal / alpha of the batch must be dense");
@@ -1849,6 +1855,10 @@ extern "C" int gs_pointfusion_step_batch_f32(const gs_step_seq* seqs_host, int B
   GS_REQUIRE(dstride >= P || B == 1, "overlapping depth images");
   // the sequences are independent: chunk by chunk through the frame maps and the localisation; the map update is ONE
   // call for the whole batch (its merge looks at the correspondences of every sequence of the call)
+  // Global maps not asked for (gvertex == NULL): they are never written -- the update computes the global vertex / normal
+  // of a pixel where it uses them -- and the frame-map launch initialises the update's per-pixel tables, so that the
+  // update has no per-pixel pass at all (it was 26 us of a 1.05 ms frame at 8 x 640x480).
+  const bool implicit_global = s0.gvertex == nullptr;
   std::unique_ptr<gs_update_seq[]> us(new gs_update_seq[B]);
   for (int c0 = 0; c0 < B; c0 += GS_MAX_BATCH) {
     const int nb = B - c0 < GS_MAX_BATCH ? B - c0 : GS_MAX_BATCH;
@@ -1875,13 +1885,20 @@ extern "C" int gs_pointfusion_step_batch_f32(const gs_step_seq* seqs_host, int B
       job.ptr[b] = reinterpret_cast<char*>(cv.gm.g);
       if (b == 0) job.bytes = gs_knn_grid_clear_bytes(cv.gm, gs_knn_grid_cells_cap(n_lat));
     }
+    GsPixelTables tabs{};
+    tabs.n = implicit_global ? nb : 0;
+    tabs.call_flag = c0 == 0 ? gs_update_map_call_flag(seqs_host[0].upd_scratch) : nullptr;
+    for (int b = 0; b < tabs.n; ++b) {
+      gs_update_map_tables(sq[b].upd_scratch, &tabs.any_flag[b], &tabs.key_pix[b]);
+      tabs.best_pix[b] = sq[b].best_pix;
+    }
     int rc = gs_frame_maps_batch_clear(sq[0].depth, dstride, P, sq[0].K16, nb, 1, H, W, two_sigma_sq, sq[0].vertex,
-                                       sq[0].normal, sq[0].alpha, &job, stream);
+                                       sq[0].normal, sq[0].alpha, &job, stream, &tabs);
     if (rc != GS_OK) return rc;
     rc = localize_batch(ls, nb, H, W, ds, prm, stream, true);
     if (rc != GS_OK) return rc;
   }
-  return gs_update_map_fusion_batch_f32(us.get(), B, H, W, dist_th, dot_th, renorm_all, stream);
+  return gs_update_map_fusion_batch_impl(us.get(), B, H, W, dist_th, dot_th, renorm_all, stream, implicit_global);
 }
 
 extern "C" int64_t gs_icp_tape_bytes(int64_t n_src, int numiters) { return (int64_t)gs_icp_tape_size(n_src, numiters); }

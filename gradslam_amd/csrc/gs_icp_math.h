@@ -220,6 +220,72 @@ GS_DEV void gs_se3_exp_dev(const float* xi6, float* T16) {
   T16[12] = 0; T16[13] = 0; T16[14] = 0; T16[15] = 1;
 }
 
+// The same exponential spread over the lanes of ONE wave (round 4: the scalar stage of the half-iteration kernels is
+// 2 us of one lane's float64 code on the critical path of every launch).  Every lane computes the common scalars (theta,
+// sin, cos, A, B, C: the same operations, so the same bits); lane i < 3 then computes row i of R and V -- every entry sees
+// exactly the operations of gs_se3_exp_dev in the same order (the hat matrix is materialised, so that the products with
+// its zeros are the same products) -- and lane 3 the constant row.  T16 may live in LDS; all 64 lanes must call it.
+GS_DEV void gs_se3_exp_wave(const float* xi6, float* T16, const int lane) {
+  const double v[3] = {xi6[0], xi6[1], xi6[2]}, w[3] = {xi6[3], xi6[4], xi6[5]};
+  const double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  const bool small = (float)theta < 1e-6f;
+  double Ac = 0.0, Bc = 0.0, Cc = 0.0;
+  if (!small) {
+    double sn, cs;
+    gs_sincos_fast(theta, &sn, &cs);
+    Ac = sn / theta; Bc = (1 - cs) / (theta * theta); Cc = (theta - sn) / (theta * theta * theta);
+  }
+  // hat matrix wh[k][j] (the values gs_se3_exp_dev selects entry by entry)
+  const double wh[3][3] = {{0.0, -w[2], w[1]}, {w[2], 0.0, -w[0]}, {-w[1], w[0], 0.0}};
+  if (lane < 3) {
+    const int i = lane;
+    double whi[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) whi[j] = i == 0 ? wh[0][j] : (i == 1 ? wh[1][j] : wh[2][j]);
+    double Vi[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double I = (i == j) ? 1.0 : 0.0;
+      double Rij;
+      if (small) {
+        Rij = I + whi[j];
+        Vi[j] = Rij;
+      } else {
+        double s2 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s2 += whi[k] * wh[k][j];
+        Rij = I + Ac * whi[j] + Bc * s2;
+        Vi[j] = I + Bc * whi[j] + Cc * s2;
+      }
+      T16[4 * i + j] = (float)Rij;
+    }
+    T16[4 * i + 3] = (float)(Vi[0] * v[0] + Vi[1] * v[1] + Vi[2] * v[2]);
+  } else if (lane == 3) {
+    T16[12] = 0; T16[13] = 0; T16[14] = 0; T16[15] = 1;
+  }
+}
+
+// LDS traffic of one wave is ordered; these keep the compiler from reordering it (all lanes of the wave call them)
+GS_DEV void gs_wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// gs_mm4(A, B, C = B) by 16 lanes of one wave on operands in LDS: lane e computes entry e with the operations of gs_mm4
+// (plain multiply / add, k ascending); every entry is read before any is written.  All 64 lanes must call it.
+GS_DEV void gs_mm4_wave_inplace(const float* A, float* B, const int lane) {
+  float acc = 0.0f;
+  if (lane < 16) {
+    const int i = lane >> 2, j = lane & 3;
+    acc = A[4 * i] * B[j];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) acc = acc + A[4 * i + k] * B[4 * k + j];
+  }
+  gs_wave_sync_lds();
+  if (lane < 16) B[lane] = acc;
+}
+
 // torch.mm of two 4x4 (odometry/icputils.py:362,543): tiny matmul, plain, ascending k.
 GS_DEV void gs_mm4(const float* A, const float* B, float* C) {
   float t[16];
@@ -364,6 +430,59 @@ GS_DEV void icp_update_math(float new_err, IcpSmall& s, const gs_icp_params& prm
 #pragma unroll
     for (int k = 0; k < 6; ++k) trace_row[4 + k] = s.xi[k];
     trace_row[10] = 0; trace_row[11] = 0;
+  }
+}
+
+// The two scalar stages by ONE WAVE on a state that lives in LDS (the half-iteration kernels): the scalars are computed
+// by every lane (same operations, same bits), the 12 + 16 matrix entries by one lane each.  All 64 lanes must call them;
+// the caller publishes `s` with a workgroup barrier afterwards.
+GS_DEV void icp_solve_finish_wave(const double* S, IcpSmall& s, const int lane) {
+  gs_wave_sync_lds();   // (s.xi was written by gs_solve_spd6_wave's lanes)
+  gs_se3_exp_wave(s.xi, s.Tr, lane);
+  if (lane == 0) s.err = (float)S[27];
+}
+GS_DEV void icp_update_math_wave(float new_err, IcpSmall& s, const gs_icp_params& prm, float* trace_row, const int lane) {
+  const float err = s.err;
+  float damp = s.damp;
+  float sig = 1.0f;
+  float xi[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) xi[k] = s.xi[k];
+  if (prm.mode == 0) {
+    const bool accept = new_err < err;   // (the same for every lane)
+    float tr = 0.0f;
+    if (lane < 16) tr = s.Tr[lane];
+    gs_wave_sync_lds();
+    if (lane < 16) s.T_step[lane] = accept ? tr : ((lane % 5 == 0) ? 1.0f : 0.0f);
+    damp = accept ? damp / 2 : damp * 2;
+    gs_wave_sync_lds();
+    if (accept) gs_mm4_wave_inplace(s.T_step, s.T_total, lane);
+  } else {
+    const float lmin = (float)(1.0 / (double)prm.lambda_max);
+    const float lrange = (float)((double)prm.lambda_max - 1.0 / (double)prm.lambda_max);
+    float errdiff = new_err - err;
+    errdiff = errdiff < -70.0f ? -70.0f : (errdiff > 70.0f ? 70.0f : errdiff);
+    const float e_b = (float)gs_exp_fast((double)((float)(-(double)prm.B) * errdiff));
+    const float damp_new = lmin + lrange / (1.0f + e_b);
+    damp = damp * damp_new;
+    const float e_b2 = (float)gs_exp_fast((double)((float)(-(double)prm.B2) * errdiff));
+    const float pw = (float)gs_exp_fast((double)(float)(1.0 / (double)prm.nu) * gs_log_fast((double)(1.0f + e_b2)));
+    sig = 1.0f / pw;
+    float xs[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xs[k] = sig * xi[k];
+    gs_se3_exp_wave(xs, s.T_step, lane);
+    gs_wave_sync_lds();
+    gs_mm4_wave_inplace(s.T_step, s.T_total, lane);
+  }
+  if (lane == 0) {
+    s.damp = damp;
+    if (trace_row) {
+      trace_row[0] = err; trace_row[1] = new_err; trace_row[2] = damp; trace_row[3] = sig;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) trace_row[4 + k] = xi[k];
+      trace_row[10] = 0; trace_row[11] = 0;
+    }
   }
 }
 

@@ -450,8 +450,14 @@ class Pointclouds(object):
         return dc.bound, dc.dev
 
     def _tighten_counts(self):
-        """Reads the device-side counts back (one sync): host counts exact again (used by profiling passes)."""
-        return list(self._n)
+        """Reads the device-side counts back (one sync) and makes the host-side BOUNDS exact, keeping the device counts in
+        charge: the next step takes the same path as without this call (used by profiling passes, whose byte counts come
+        from the bounds)."""
+        if not self._dcount:
+            return list(self._n_host)
+        for grp in {id(dc.group): dc.group for dc in self._dcount.values()}.values():
+            grp.tighten()
+        return [self._dcount[b].bound if b in self._dcount else self._n_host[b] for b in range(len(self._n_host))]
 
     def _set_count_dev(self, b, dev_count, max_growth):
         """The kernels wrote the new count of sequence b to `dev_count`; at most `max_growth` rows

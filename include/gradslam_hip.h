@@ -516,8 +516,9 @@ typedef struct gs_step_seq {
   float* vertex;             /* out: LOCAL vertex / normal maps (H, W, 3), sample confidences (H, W) */
   float* normal;
   float* alpha;
-  float* gvertex;            /* out: global maps under the recovered pose */
-  float* gnormal;
+  float* gvertex;            /* out, optional: global maps under the recovered pose.  Both NULL (for every sequence of the */
+  float* gnormal;            /* call): not written -- the update computes the global vertex / normal of a pixel where it   */
+                             /* uses them (same bits) and skips its per-pixel pass; gs_global_maps_f32 gives them on demand */
   int32_t* best_pix;         /* out: correspondence table (H*W) */
   int64_t* new_count_out;    /* out: device int64[1], must not alias map.n_dev */
   gs_map_view map;           /* all four attributes; n_bound > 0; capacity >= n_bound + H*W */
