@@ -551,7 +551,7 @@ def main():
                                 "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                 "(FETCH x2 per MI355X_MICROARCH.md)."}
         groups = {}
-        for kind, name in ((2, "K1 frame maps + global maps"), (6, "K2/K3 lattice + projection + grid build"),
+        for kind, name in ((2, "K1 frame maps + update tables"), (6, "K2/K3 lattice + projection + grid build"),
                            (4, "K5 association"), (5, "K6 fuse+append")):
             gms, gn, gbytes = read_profile(lib, kind)
             if gn > 0:
@@ -560,7 +560,7 @@ def main():
                                 "avg_us_per_launch": gms * 1e3 / gn, "alg_bytes_per_launch": gbytes / gn}
         tot = {k: read_profile(lib, k)[0] for k in range(9)}
         step_ms = {n_: tot[k] / K for k, n_ in ((8, "icp_search_linearise"), (7, "icp_finish"), (6, "prep_project_grid_build"),
-                                                (2, "frame_maps_global_maps"), (4, "associate"), (5, "fuse"))}
+                                                (2, "frame_maps_update_tables"), (4, "associate"), (5, "fuse"))}
         roofline_hbm = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "groups": groups,
                         "gpu_ms_per_step_by_group": step_ms,
                         "hbm_frac_whole_step": (sum(read_profile(lib, k)[2] for k in (2, 4, 5, 6, 8)) / K) /

@@ -23,6 +23,9 @@ __all__ = ["try_step"]
 
 f32 = torch.float32
 FASTPATH = os.environ.get("GRADSLAM_HIP_FASTPATH", "1") != "0"   # 0: always the generic path (A/B runs)
+# 1: the step also writes the live frame's GLOBAL vertex / normal maps (one more per-pixel pass per frame).  Default 0:
+# the update computes them where it uses them and the container computes them when somebody asks (the same bits).
+STEP_GLOBAL_MAPS = os.environ.get("GRADSLAM_HIP_STEP_GLOBAL_MAPS", "0") == "1"
 
 
 def _kwargs_key(kw):
@@ -113,10 +116,12 @@ class StepPlan(object):
         # outputs of this frame: one allocation, carved into the local / global maps and the poses
         # (no global maps: the step computes them where the update uses them and never writes them; the container
         # computes them from the local maps and the pose when somebody asks -- the same bits)
-        out = torch.empty(B * (7 * P + 16), dtype=f32, device=dev)
+        gm = STEP_GLOBAL_MAPS
+        out = torch.empty(B * ((13 if gm else 7) * P + 16), dtype=f32, device=dev)
         best = torch.empty((B, P), dtype=torch.int32, device=dev)
         o = out.data_ptr()
         v0, n0, a0, po0 = o, o + 12 * P * B, o + 24 * P * B, o + 28 * P * B
+        gv0, gn0 = po0 + 64 * B, po0 + 64 * B + 12 * P * B
         # the new counts go to a buffer the MAP owns (two per count group, alternating): a plan serves whatever map it is
         # handed, and a map's live device count must not be a word some other map's next frame writes
         pair = getattr(grp, "_step_counts", None)
@@ -132,7 +137,8 @@ class StepPlan(object):
             q.depth, q.rgb = d0 + 4 * ds_ * b, r0 + 4 * rs_ * b
             q.K16, q.prev_pose16, q.out_pose16 = k0 + 64 * b, p0 + 64 * b, po0 + 64 * b
             q.vertex, q.normal, q.alpha = v0 + 12 * P * b, n0 + 12 * P * b, a0 + 4 * P * b
-            q.gvertex, q.gnormal, q.best_pix = None, None, b0 + 4 * P * b
+            q.gvertex, q.gnormal = (gv0 + 12 * P * b, gn0 + 12 * P * b) if gm else (None, None)
+            q.best_pix = b0 + 4 * P * b
             q.new_count_out = c0 + 8 * b
             q.map.n_bound = bounds[b]
             q.map.n_dev = n_dev0 + 8 * b
@@ -143,8 +149,13 @@ class StepPlan(object):
         live._vertex_map = out[:n3].view(B, 1, H, W, 3)
         live._normal_map = out[n3:2 * n3].view(B, 1, H, W, 3)
         live._alpha_cache = (self.sigma, out[2 * n3:2 * n3 + P * B].view(B, 1, H, W, 1))
-        live._global_vertex_map = live._global_normal_map = None    # (recomputed on demand under the new pose)
-        live._poses = out[7 * P * B:].view(B, 1, 4, 4)
+        live._poses = out[7 * P * B:7 * P * B + 16 * B].view(B, 1, 4, 4)
+        if gm:
+            g = 7 * P * B + 16 * B
+            live._global_vertex_map = out[g:g + n3].view(B, 1, H, W, 3)
+            live._global_normal_map = out[g + n3:g + 2 * n3].view(B, 1, H, W, 3)
+        else:
+            live._global_vertex_map = live._global_normal_map = None    # (computed on demand under the new pose)
         grp.advance(cnt_new, P)
         pc._padded_cache.clear()
         pc.equisized = True if B == 1 else None

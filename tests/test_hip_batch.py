@@ -467,6 +467,35 @@ def test_fast_path_equals_generic_path(tmp_path):
     assert np.array_equal(a["n"], b["n"])
 
 
+def test_step_without_materialised_global_maps_gives_the_same_bits(gs, monkeypatch):
+    """gs_pointfusion_step_batch_f32 with gvertex = gnormal = NULL (the default of the fused step): the frame-map launch
+    initialises the update's per-pixel tables and the projection / merge / append passes transform a pixel where they
+    use it, so the global maps are never written.  Poses, map and -- computed on demand by the container -- the global
+    maps themselves must equal, bit for bit, the step that materialises them (GRADSLAM_HIP_STEP_GLOBAL_MAPS=1)."""
+    from gradslam_amd.slam import _fastpath
+    B, L, H, W = 2, 5, 120, 160
+    seqs = [make_sequence(L, H, W, seed=41 + b) for b in range(B)]
+
+    def run(materialise):
+        monkeypatch.setattr(_fastpath, "STEP_GLOBAL_MAPS", materialise)
+        frames = frames_of(gs, seqs)
+        slam = gs.slam.PointFusion(odom="gradicp", device="cuda")
+        pc, prev, rec = gs.Pointclouds(device="cuda"), None, []
+        for i in range(L):
+            live = frames[:, i]
+            pc, p = slam.step(pc, live, prev, inplace=True)
+            if i >= 2:   # (frame 0 has no previous frame, frame 1 finds the counts not yet grouped: generic path)
+                assert (live._global_vertex_map is not None) == materialise
+            rec += [host(p[:, 0]), host(live.global_vertex_map), host(live.global_normal_map)]
+            prev = live
+        return rec + [np.concatenate([host(x) for x in getattr(pc, k)]) for k in
+                      ("points_list", "normals_list", "colors_list", "features_list")]
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(x.view(np.int32), y.view(np.int32))
+
+
 def test_one_slam_object_steps_two_maps_alternately(gs):
     """the device count buffers of the fast path belonged to the plan cached on the slam object, so a second
     map stepped with the same object overwrote the first map's live count.  They belong to the map now: two maps
