@@ -346,3 +346,28 @@ def test_resize_known_answers_with_border_clamps():
     assert np.array_equal(o.ingest_depth(d, 4, 6, 1000.0)[::2, ::2], d.astype(np.float32) / 1000)   # floor(dst / 2)
     assert np.array_equal(o.ingest_depth(d, 4, 6, 1000.0)[1::2, 1::2], d.astype(np.float32) / 1000)
     assert np.array_equal(o.ingest_depth(d, 1, 2, 5000.0), np.array([[0.2, 0.4]], np.float32))      # floor(dst * 1.5)
+
+
+def test_validity_mask_can_be_read_off_the_local_vertex():
+    """The fused step does not store the live frame's global maps; where the map update needs the global vertex of a pixel
+    it transforms the local one and re-masks it with `vertex.z > 0` instead of `depth > 0` (gs_fuse.hip: FrameLocalMaps --
+    one scattered access less per surfel).  That is the same mask for a vertex map made by the frame-map arithmetic
+    (rgbdimages.py:643-679: z = (1 * d) * [d > 0]), whatever the depth holds: zeros, negatives, NaN, infinities,
+    denormals, and whatever the intrinsics are."""
+    rng = np.random.default_rng(5)
+    H, W = 12, 16
+    depth = rng.uniform(0.3, 4.0, (H, W)).astype(np.float32)
+    special = np.array([0.0, -0.0, -1.5, np.nan, np.inf, -np.inf, 1e-45, -1e-45, 1e-38, 3.4e38], np.float32)
+    depth.reshape(-1)[:special.size * 3] = np.tile(special, 3)
+    rng.shuffle(depth.reshape(-1))
+    for K in (np.array([[525, 0, 8.5, 0], [0, 525, 6.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32),
+              np.array([[-3.25, 0, 100.0, 0], [0, -120.0, -59.9, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)):
+        with np.errstate(all="ignore"):
+            v, n, a, valid = o.frame_maps(depth, K, 0.6)
+            assert np.array_equal(v[..., 2] > 0, depth > 0) and np.array_equal(valid, depth > 0)
+            # ... and the global vertex re-masked either way has the same bits
+            pose = np.eye(4, dtype=np.float32)
+            pose[:3, 3] = (0.3, -0.2, 0.1)
+            gv, _ = o.global_maps(v, n, depth, pose)
+            gz, _ = o.global_maps(v, n, np.where(v[..., 2] > 0, np.float32(1), np.float32(0)), pose)
+        assert np.array_equal(gv.view(np.int32), gz.view(np.int32))
