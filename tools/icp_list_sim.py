@@ -1,12 +1,15 @@
-"""CPU study behind the candidate lists of the ICP half-iteration kernels.
+"""CPU study of the candidate lists of the ICP half-iteration kernels (DESIGN.md sections 4 and 7).
 
-Replays one gradICP solve of the benchmark workload with the ORACLE (its per-iteration trace gives every query position of
-the 2 x numiters searches), then simulates the list scheme on those positions: a list = every target within R of the
-position q0 it was built at (at most M slots), a later search from q is exact on the list alone when
-sqrt(best list distance) + |q - q0| < 0.9999 R.  Prints, per launch, how many queries fail that proof and how many
-blocks of 384 queries contain a failing one (a launch is as slow as its slowest block).
+Replays one gradICP solve of the benchmark workload with the ORACLE (bit-identical to the HIP path; its per-iteration
+trace gives every query position of the 2 x numiters searches) and simulates the list scheme on those positions:
+a list = the M nearest targets of the position q0 it was built at, R = distance of the (M+1)-th nearest (the scan that
+builds a list covers more than that), a later search from q is exact on the list alone when
+    sqrt(best list distance) + |q - q0| < 0.9999 R;
+a list that gives no proof is rebuilt where the point is now.  Printed per launch: lists without a proof for M = 4 (what
+2 lanes per point keep today), M = 8, and for a two-level list (4 slots checked first, 4 more and their radius fetched
+only when the first four give no proof).
 
-    python tools/icp_list_sim.py [seed] [frame] [margin_cells] [M] [gt|gradicp] [cube_lists 0|1]
+    python tools/icp_list_sim.py [seed] [frame] [gt|gradicp]      (the replay is cached under /tmp)
 """
 import os
 import sys
@@ -20,24 +23,28 @@ from gradslam_amd.datasets.synthetic import make_sequence   # noqa: E402
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 frame = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-margin_cells = float(sys.argv[3]) if len(sys.argv) > 3 else 0.25
-M = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-ODOM = sys.argv[5] if len(sys.argv) > 5 else "gt"
-CUBE_LISTS = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+ODOM = sys.argv[3] if len(sys.argv) > 3 else "gradicp"
 H, W, ds = 480, 640, 4
+cache = "/tmp/icp_list_sim_s%d_f%d_%s.npz" % (seed, frame, ODOM)
 
-seq = make_sequence(frame + 1, H, W, seed=seed)
-K = seq["intrinsics"][0]
-m, poses = osl.run_sequence(seq["colors"][:frame], seq["depths"][:frame], K, seq["poses"][:frame], odom=ODOM)
-depth = seq["depths"][frame].reshape(H, W)
-prev_pose = poses[frame - 1]
-v, n, a, _ = o.frame_maps(depth, K, 0.6)
-gv, gn = o.global_maps(v, n, depth, prev_pose)
-src, _, _ = o.downsample_frame(gv, gn, seq["colors"][frame], depth, ds)
-pix = o.project_map(m.points, prev_pose, K, H, W)
-tgt, tgtn, _ = o.select_targets(pix, W, ds, m.points, m.normals)
-T, idx, trace = o.icp(src, tgt, tgtn, init=None, compose=prev_pose, mode=1, numiters=20, return_trace=True)
-print("map %d surfels, src %d, tgt %d" % (len(m), len(src), len(tgt)))
+if os.path.exists(cache):
+    z = np.load(cache)
+    src, tgt, trace, n_map = z["src"], z["tgt"], z["trace"], int(z["n_map"])
+else:
+    seq = make_sequence(frame + 1, H, W, seed=seed)
+    K = seq["intrinsics"][0]
+    m, poses = osl.run_sequence(seq["colors"][:frame], seq["depths"][:frame], K, seq["poses"][:frame], odom=ODOM)
+    depth = seq["depths"][frame].reshape(H, W)
+    prev_pose = poses[frame - 1]
+    v, n, a, _ = o.frame_maps(depth, K, 0.6)
+    gv, gn = o.global_maps(v, n, depth, prev_pose)
+    src, _, _ = o.downsample_frame(gv, gn, seq["colors"][frame], depth, ds)
+    pix = o.project_map(m.points, prev_pose, K, H, W)
+    tgt, tgtn, _ = o.select_targets(pix, W, ds, m.points, m.normals)
+    T, idx, trace = o.icp(src, tgt, tgtn, init=None, compose=prev_pose, mode=1, numiters=20, return_trace=True)
+    n_map = len(m)
+    np.savez(cache, src=src, tgt=tgt, trace=trace, n_map=n_map)
+print("seed %d frame %d (%s): map %d surfels, %d source points, %d targets" % (seed, frame, ODOM, n_map, len(src), len(tgt)))
 
 # query positions of the 40 searches
 pos = []
@@ -50,82 +57,44 @@ for k in range(20):
     pos.append(A @ Tr[:3, :3].T + Tr[:3, 3])          # look-ahead
     A = A @ Ts[:3, :3].T + Ts[:3, 3]
 print("|xi_t| per iteration (mm):", " ".join("%.3f" % (1e3 * np.linalg.norm(trace[k, 4:7])) for k in range(20)))
-print("mean displacement between consecutive searches (mm):",
-      " ".join("%.3f" % (1e3 * np.linalg.norm(pos[h + 1] - pos[h], axis=1).mean()) for h in range(39)))
-
-# the grid of gs_knn.hip:grid_from_bbox
-lo, hi = tgt.min(0).astype(np.float64), tgt.max(0).astype(np.float64)
-e = (hi - lo) + 1e-6
-c = 1.5 * np.sqrt((e[0] * e[1] + e[1] * e[2] + e[0] * e[2]) / len(tgt))
-nxyz = (e / c).astype(int) + 1
-print("cell edge %.2f mm, grid %s" % (1e3 * c, nxyz))
 tree = cKDTree(tgt.astype(np.float64))
+dd, _ = tree.query(pos[0], k=9)
+print("distance of the 1st / 5th / 9th nearest target (mm, median over the source points): %.2f / %.2f / %.2f" %
+      tuple(1e3 * np.median(dd[:, j]) for j in (0, 4, 8)))
 
 
-def face_bound(q):
-    """(amin - 0.001) * c of grid_search_stage0: distance to the nearest face of the 2x2x2 block that has cells behind"""
-    p = np.clip(q, lo, hi)
-    f = (p - lo) / c
-    cell = np.minimum(np.maximum(f.astype(int), 0), nxyz - 1)
-    fr = f - cell
-    x0 = np.where(fr < 0.5, cell - 1, cell)
-    big = 3e38
-    lo_d = np.where(x0 >= 1, fr + (cell - x0), big)
-    hi_d = np.where(x0 + 2 < nxyz, (x0 + 2 - cell) - fr, big)
-    amin = np.minimum(lo_d, hi_d).min(1)
-    return (amin - 0.001) * c
+def simulate(levels):
+    """levels = (4,), (8,) or (4, 8): slots checked first, then (optionally) the longer list"""
+    Mmax = max(levels)
+    out = []
+    q0 = nn = None
+    for h in range(1, 40):
+        q = pos[h]
+        if h == 1:   # the building launch
+            nn_d, nn_i = tree.query(q, k=Mmax + 1)
+            q0 = q.copy()
+            continue
+        delta = np.linalg.norm(q - q0, axis=1)
+        proved = np.zeros(len(q), bool)
+        first = None
+        for M in levels:
+            dl = np.linalg.norm(tgt[nn_i[:, :M]].astype(np.float64) - q[:, None, :], axis=2).min(1)
+            ok = dl + delta < 0.9999 * nn_d[:, M]
+            proved |= ok
+            if first is None:
+                first = ok.copy()
+        fail = ~proved
+        out.append((h, int((~first).sum()), int(fail.sum())))
+        if fail.any():   # rebuilt where the point is now
+            d2, i2 = tree.query(q[fail], k=Mmax + 1)
+            nn_d[fail], nn_i[fail] = d2, i2
+            q0[fail] = q[fail]
+    return out
 
 
-def build(q):
-    """gl_build_block: the widest of the nested radii d1 + margin / 2^k (capped by the block-face bound) whose targets
-    fit the M slots"""
-    dd, ii = tree.query(q, k=M + 1)
-    d1 = dd[:, 0]
-    rb = face_bound(q)
-    open_ = d1 > rb                     # stage 0 cannot prove it: cube scans, no list
-    R = np.zeros(len(q))
-    for k in (3, 2, 1, 0):              # the widest that fits wins
-        Rk = np.minimum(d1 + margin_cells * c / (1 << k), rb)
-        fits = dd[:, M] >= Rk           # at most M targets within Rk
-        R = np.where(fits, Rk, R)
-    lists = np.where(dd[:, :M] < R[:, None], ii[:, :M], -1)
-    R = np.where(open_, 0.0, R)
-    return lists, R
-
-
-NQ = 365   # valid queries of a 384-slot block (95 % of the lattice has depth)
-nblk = (len(src) + NQ - 1) // NQ
-q0 = None
-for h in range(40):
-    q = pos[h]
-    if h == 0:
-        print("launch  0: plain search (no lists yet)")
-        continue
-    if h == 1:
-        lists, R = build(q)
-        q0 = q.copy()
-        nl = (lists >= 0).sum(1)
-        print("launch  1: lists built for all; open %d (%.2f %%), entries per list mean %.2f max %d, R mean %.2f mm" % (
-            (R == 0).sum(), 100.0 * (R == 0).mean(), nl[R > 0].mean(), nl.max(), 1e3 * R[R > 0].mean()))
-        continue
-    tl = np.where(lists >= 0, lists, 0)
-    dl = np.linalg.norm(tgt[tl].astype(np.float64) - q[:, None, :], axis=2)
-    dl = np.where(lists >= 0, dl, np.inf)
-    bd = dl.min(1)
-    delta = np.linalg.norm(q - q0, axis=1)
-    ok = (R > 0) & (bd + delta < 0.9999 * R)
-    # check exactness of the claim
-    d1, i1 = tree.query(q, k=1)
-    best = np.take_along_axis(tl, dl.argmin(1)[:, None], 1)[:, 0]
-    wrong = ok & (np.abs(bd - d1) > 1e-12)
-    fail = ~ok
-    was_open = R == 0
-    nb_fail = len(np.unique(np.nonzero(fail)[0] // NQ))
-    nb_new = len(np.unique(np.nonzero(fail & ~was_open)[0] // NQ))
-    print("launch %2d: fail %5d (%.3f %%) of which open before %5d; blocks with a failing query %3d / %d (with a NEW failure %3d); "
-          "wrong %d" % (h, fail.sum(), 100.0 * fail.mean(), (fail & was_open).sum(), nb_fail, nblk, nb_new, wrong.sum()))
-    if fail.any():   # rebuild the failing ones where they are now
-        l2, R2 = build(q[fail])
-        lists[fail] = l2
-        R[fail] = R2
-        q0[fail] = q[fail]
+r4, r8, r48 = simulate((4,)), simulate((8,)), simulate((4, 8))
+print("launch: lists without a proof, M = 4 | M = 8 | two levels 4 + 4: first level fails -> second level fails too")
+for (h, _, f4), (_, _, f8), (_, a48, f48) in zip(r4, r8, r48):
+    print("  %2d (%s): %6d | %6d | %6d -> %6d" % (h, "first half" if h % 2 == 0 else "look-ahead", f4, f8, a48, f48))
+for name, r, col in (("M = 4", r4, 2), ("M = 8", r8, 2), ("two levels, re-scans", r48, 2), ("two levels, second fetches", r48, 1)):
+    print("%s: total over the solve %d, launches with more than 50: %d" % (name, sum(x[col] for x in r), sum(x[col] > 50 for x in r)))
