@@ -2,7 +2,7 @@
 # round 4, closing GPU call: GPU suite, smoke, the default bench line, kernel stats of the benchmark step
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/${R4_TAG:-r4final}; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -2
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 python - $O/bench.json <<'PY'
