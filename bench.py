@@ -83,8 +83,12 @@ def spawn_ranks(args):
 
 
 def _make(a):
-    from gradslam_amd.datasets.synthetic import make_sequence
-    return make_sequence(*a[:3], seed=a[3], first=a[4])
+    # (the generator is pure numpy: loaded by path so that a worker process does not import torch)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_gs_synthetic", os.path.join(REPO, "gradslam_amd", "datasets", "synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.make_sequence(*a[:3], seed=a[3], first=a[4])
 
 
 def make_sequences(seeds, L, Hh, Ww, chunk=None):
@@ -97,15 +101,25 @@ def make_sequences(seeds, L, Hh, Ww, chunk=None):
     # under rocprofv3 (its tool library is preloaded into forked workers and its SIGTERM handler can dead-lock a
     # terminating pool) the sequences are generated in this process
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or "ROCPROFILER_LIBRARY_CTOR" in os.environ
-    if len(jobs) == 1 or profiled:
+    if len(jobs) == 1 or (profiled and os.environ.get("GRADSLAM_BENCH_SERIAL_GEN") == "1"):
         parts = [_make(j) for j in jobs]
     else:
-        pool = mp.get_context("fork").Pool(min(len(jobs), os.cpu_count() or 1))
+        # profiled runs: workers are SPAWNED (numpy only) from an environment without the profiler's variables, so the
+        # tool library is never loaded into them (a long profiled run generated serially costs minutes of box time)
+        scrub = {}
+        if profiled:
+            for k in list(os.environ):
+                if k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE") or k.startswith(("ROCP", "ROCPROF", "ROCTX")):
+                    scrub[k] = os.environ.pop(k)
         try:
-            parts = pool.map(_make, jobs)
+            pool = mp.get_context("spawn" if profiled else "fork").Pool(min(len(jobs), os.cpu_count() or 1, 96))
+            try:
+                parts = pool.map(_make, jobs)
+            finally:
+                pool.close()   # workers leave on their own: no SIGTERM (Pool.__exit__ terminates)
+                pool.join()
         finally:
-            pool.close()   # workers leave on their own: no SIGTERM (Pool.__exit__ terminates)
-            pool.join()
+            os.environ.update(scrub)
     out, per = [], (L + chunk - 1) // chunk
     for i in range(len(seeds)):
         ps = parts[i * per:(i + 1) * per]

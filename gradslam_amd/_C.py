@@ -10,7 +10,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgradslam_hip.so")
+# GRADSLAM_HIP_LIB: another build of the same library (A/B runs of an experimental build on one GPU box); it must export
+# the same symbols and ABI version, and there is still no fallback if it is missing
+LIB_PATH = os.environ.get("GRADSLAM_HIP_LIB") or os.path.join(_HERE, "csrc", "libgradslam_hip.so")
 ABI_VERSION = 2
 
 _lib = None

@@ -42,7 +42,7 @@ fetch = load(sys.argv[2]) if len(sys.argv) > 2 else []
 print("# frame (of the profiled run): per list-checking launch of that frame's solves, mean: L2 hit rate, misses, HBM fetch")
 nfr = len(l2) // per_solve
 for fr in range(nfr):
-    for half in ("first half, lists", "look-ahead, lists"):
+    for half in sorted(set(variant(n) for n, _ in l2[fr * per_solve:(fr + 1) * per_solve])):
         sel = [c for n, c in l2[fr * per_solve:(fr + 1) * per_solve] if variant(n) == half]
         if not sel:
             continue
