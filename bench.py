@@ -434,7 +434,7 @@ def secondary_measurements(gs, args, frames, device, barrier, Wm, K):
         fr5 = frames_on_device(gs, seqs, device)
         slam5 = gs.slam.PointFusion(odom=args.odom, device=device)
         r = timed_steps(gs, slam5, fr5, Wc, Lc - Wc, device, barrier, seg_every=15)
-        from tests.conftest import ate as ate_np
+        from gradslam_amd.metrics import ate_rmse as ate_np
         out["c5_1296x968"] = {"frames_per_s": (Lc - Wc) / r["elapsed"], "ms_per_frame": r["elapsed"] / (Lc - Wc) * 1e3,
                               "ms_per_frame_first_quartile": r["ms_first_quartile"],
                               "ms_per_frame_last_quartile": r["ms_last_quartile"], "frames_timed": Lc - Wc, "warmup": Wc,
@@ -457,7 +457,7 @@ def main():
 
     import gradslam_amd as gs
     from gradslam_amd import _C, multigpu
-    from tests.conftest import ate as ate_np
+    from gradslam_amd.metrics import ate_rmse as ate_np
 
     rank, world, local = multigpu.init_from_env()
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"

@@ -64,6 +64,7 @@ _PROTOS = {
     "gs_frame_maps_f32": [_vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp],
     "gs_global_maps_f32": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gs_alpha_f32": [_vp, _i64, _f, _f, _vp, _vp],
+    "gs_alpha_backward_f32": [_vp, _i64, _f, _f, _vp, _vp, _vp, _vp],
     "gs_downsample_frame_f32": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "gs_project_map_f32": [_vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp],
     "gs_active_table_i64": [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp],
@@ -75,6 +76,7 @@ _PROTOS = {
     "gs_gauss_newton_rows_f32": [_vp, _i64, _vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "gs_solve_normal_eq_f32": [_vp, _vp, _vp, _i64, _i32, _f, _vp, _vp],
     "gs_se3_exp_f32": [_vp, _vp, _vp],
+    "gs_se3_exp_backward_f32": [_vp, _vp, _vp, _vp],
     "gs_transform_points_f32": [_vp, _i64, _vp, _vp, _vp],
     "gs_icp_scratch_bytes": [_i64, _i64],
     "gs_icp_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, C.POINTER(IcpParams), _vp, _vp, _vp, _vp],

@@ -356,6 +356,39 @@ extern "C" int gs_alpha_f32(const float* points, int64_t n, float two_sigma_sq, 
   return GS_OK;
 }
 
+// Reverse mode of gs_alpha_f32 (slam/fusionutils.py:69-72 under PyTorch autograd): with S = |p|^2 and a = exp(-S / 2s^2),
+// d a / d p = -a p / s^2 and d a / d s = a S / s^3 where the clamp passes the gradient (eps <= a <= 1.01, torch.clamp's
+// rule), zero elsewhere.  p_bar[i] per point; the sigma adjoint is a sum over the points: sigma_terms[i] = a_bar a S (the
+// caller adds them up and scales by 1 / s^3 -- one tiny reduction off the hot path, fixed order).
+__global__ void __launch_bounds__(256) gs_alpha_bwd_kernel(const float* __restrict__ pts, int64_t n, float two_sigma_sq,
+                                                           float eps, const float* __restrict__ alpha_bar,
+                                                           float* __restrict__ pts_bar, float* __restrict__ sigma_terms) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+  float S = x * x + y * y;
+  S = S + z * z;
+  const float a = gs_expf_spec((-S) / two_sigma_sq);   // (the forward's operations) the un-clamped value decides whether the clamp passes
+  const bool pass = a >= eps && a <= 1.01f;
+  const float g = pass ? alpha_bar[i] * a : 0.0f;
+  const float k = -2.0f / two_sigma_sq;               // -1 / s^2
+  pts_bar[3 * i] = g * k * x;
+  pts_bar[3 * i + 1] = g * k * y;
+  pts_bar[3 * i + 2] = g * k * z;
+  if (sigma_terms) sigma_terms[i] = g * S;
+}
+
+extern "C" int gs_alpha_backward_f32(const float* points, int64_t n, float two_sigma_sq, float eps,
+                                     const float* alpha_bar, float* points_bar, float* sigma_terms, void* stream) {
+  GS_REQUIRE(n >= 0, "negative n");
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(points && alpha_bar && points_bar, "NULL pointer");
+  hipLaunchKernelGGL(gs_alpha_bwd_kernel, dim3((unsigned)gs_ceil_div(n, 256)), dim3(256), 0, gs_stream(stream), points, n,
+                     two_sigma_sq, eps, alpha_bar, points_bar, sigma_terms);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 // ------------------------------------------------------------------ K7: backward of K1 ---
 // Reverse mode of gs_frame_maps_f32 w.r.t. depth (vertex, normal and alpha paths) and of
 // gs_global_maps_f32 w.r.t. the local maps, matching PyTorch autograd through

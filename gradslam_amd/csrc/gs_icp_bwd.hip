@@ -516,6 +516,25 @@ __global__ void __launch_bounds__(GS_WAVE) gs_pose_bar_final_kernel(const double
   }
   for (int j = 0; j < 4; ++j) pose_bar16[12 + j] = 0.0f;
 }
+// Reverse mode of gs_se3_exp_f32 alone (geometry/se3utils.py:77-115 under PyTorch autograd): xi_bar = d <T_bar, Exp(xi)> / d xi,
+// the adjoint the ICP backward uses inside its scalar stages, float64 inside, rounded once.
+__global__ void __launch_bounds__(GS_WAVE) gs_se3_exp_bwd_kernel(const float* __restrict__ xi6, const float* __restrict__ Tbar16,
+                                                                 float* __restrict__ xi_bar6) {
+  if (threadIdx.x != 0) return;
+  double xi[6], Tb[16], out[6];
+  for (int i = 0; i < 6; ++i) xi[i] = (double)xi6[i];
+  for (int i = 0; i < 16; ++i) Tb[i] = (double)Tbar16[i];
+  d_se3_exp_adjoint(xi, Tb, out);
+  for (int i = 0; i < 6; ++i) xi_bar6[i] = (float)out[i];
+}
+
+extern "C" int gs_se3_exp_backward_f32(const float* xi6, const float* Tbar16, float* xi_bar6, void* stream) {
+  GS_REQUIRE(xi6 && Tbar16 && xi_bar6, "NULL pointer");
+  hipLaunchKernelGGL(gs_se3_exp_bwd_kernel, dim3(1), dim3(GS_WAVE), 0, gs_stream(stream), xi6, Tbar16, xi_bar6);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 extern "C" int64_t gs_global_maps_pose_backward_scratch_bytes(int H, int W) {
   return (int64_t)(gs_align(8 * BW_NV * (size_t)gs_ceil_div((int64_t)H * W, BW_BLOCK)) + 256);
 }

@@ -105,14 +105,47 @@ def global_maps(vertex, normal, depth, pose, out=None):
     return gv, gn
 
 
-def alpha_of_points(points, sigma, eps=1e-7):
-    _warn_detached("get_alpha", points)
+def _alpha_forward(points, sigma, eps):
     points = _c(points)
     dev = require_device(points)
     out = torch.empty(points.shape[:-1], dtype=f32, device=dev)
     check(lib().gs_alpha_f32(ptr(points), out.numel(), two_sigma_sq(sigma), float(eps), ptr(out), stream(dev)),
           "gs_alpha_f32")
     return out
+
+
+class AlphaFunction(torch.autograd.Function):
+    """get_alpha on an (n, 3) point array, differentiable w.r.t. the points and a tensor sigma
+    (gs_alpha_backward_f32; the reference's own gradient check is tests/slam/test_fusionutils.py:56-75)."""
+
+    @staticmethod
+    def forward(ctx, points, sigma, eps):
+        ctx.save_for_backward(points, sigma if torch.is_tensor(sigma) else None)
+        ctx.sigma, ctx.eps = float(sigma), float(eps)
+        return _alpha_forward(points, ctx.sigma, eps)
+
+    @staticmethod
+    def backward(ctx, a_bar):
+        points, sigma_t = ctx.saved_tensors
+        pts, a_bar = _c(points), _c(a_bar)
+        dev = require_device(pts, a_bar)
+        n = a_bar.numel()
+        p_bar = torch.empty((n, 3), dtype=f32, device=dev)
+        want_sigma = sigma_t is not None and ctx.needs_input_grad[1]
+        terms = torch.empty(n, dtype=f32, device=dev) if want_sigma else None
+        check(lib().gs_alpha_backward_f32(ptr(pts), n, two_sigma_sq(ctx.sigma), ctx.eps, ptr(a_bar), ptr(p_bar), ptr(terms),
+                                          stream(dev)), "gs_alpha_backward_f32")
+        s_bar = None
+        if want_sigma:   # d alpha / d sigma = alpha |p|^2 / sigma^3, summed over the points in float64
+            s_bar = (terms.double().sum() / (ctx.sigma ** 3)).to(sigma_t.dtype).reshape(sigma_t.shape).to(sigma_t.device)
+        return p_bar.view(points.shape).to(points.dtype), s_bar, None
+
+
+def alpha_of_points(points, sigma, eps=1e-7):
+    """points (n, 3) -> alpha (n,); on the autograd tape when the points or a tensor sigma require grad."""
+    if torch.is_grad_enabled() and (points.requires_grad or (torch.is_tensor(sigma) and sigma.requires_grad)):
+        return AlphaFunction.apply(points, sigma, eps)
+    return _alpha_forward(points, float(sigma), eps)
 
 
 # ----------------------------------------------------------------------------------- K2
@@ -272,13 +305,36 @@ def solve_normal_eq(A, b, damp=1e-8, keep=None):
     return x
 
 
-def se3_exp(xi):
-    _warn_detached("se3_exp", xi)
+def _se3_exp_forward(xi):
     xi = _c(xi).reshape(6)
     dev = require_device(xi)
     T = torch.empty((4, 4), dtype=f32, device=dev)
     check(lib().gs_se3_exp_f32(ptr(xi), ptr(T), stream(dev)), "gs_se3_exp_f32")
     return T
+
+
+class Se3ExpFunction(torch.autograd.Function):
+    """se3_exp, differentiable w.r.t. xi (gs_se3_exp_backward_f32: the adjoint the ICP backward uses)."""
+
+    @staticmethod
+    def forward(ctx, xi):
+        ctx.save_for_backward(xi)
+        return _se3_exp_forward(xi)
+
+    @staticmethod
+    def backward(ctx, T_bar):
+        (xi,) = ctx.saved_tensors
+        x, T_bar = _c(xi).reshape(6), _c(T_bar)
+        dev = require_device(x, T_bar)
+        out = torch.empty(6, dtype=f32, device=dev)
+        check(lib().gs_se3_exp_backward_f32(ptr(x), ptr(T_bar), ptr(out), stream(dev)), "gs_se3_exp_backward_f32")
+        return out.view(xi.shape).to(xi.dtype)
+
+
+def se3_exp(xi):
+    if torch.is_grad_enabled() and xi.requires_grad:
+        return Se3ExpFunction.apply(xi)
+    return _se3_exp_forward(xi)
 
 
 def lie_small(op, vec, n_in, n_out):

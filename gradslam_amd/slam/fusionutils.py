@@ -46,7 +46,7 @@ def get_alpha(points: torch.Tensor, sigma: Union[torch.Tensor, float, int], dim:
         raise ValueError("Expected sigma.ndim to be 0 (scalar). Got {0}.".format(sigma.ndim))
     from .. import ops
     moved = points.movedim(dim, -1)
-    alpha = ops.alpha_of_points(moved.reshape(-1, 3), float(sigma), eps).view(moved.shape[:-1])
+    alpha = ops.alpha_of_points(moved.reshape(-1, 3), sigma, eps).view(moved.shape[:-1])
     return alpha.unsqueeze(dim) if keepdim else alpha
 
 

@@ -327,35 +327,31 @@ class RGBDImages(object):
         self._global_normal_map = None
 
     # ------------------------------------------------------------------ copies / moves / layout
-    def detach(self):
-        other = self.clone()
-        for k in self._INTERNAL_TENSORS:
-            v = getattr(self, k)
-            if torch.is_tensor(v):
-                setattr(other, k, v.detach())
+    def _mapped(self, fn):
+        """A new container whose every tensor (inputs and cached maps alike) is fn(tensor); layout flag and shape
+        bookkeeping carried over.  detach / clone / to are this with a different fn (structures/rgbdimages.py:465-525
+        of the reference give the semantics: every cached map follows its inputs)."""
+        other = object.__new__(type(self))
+        other.__dict__.update(self.__dict__)
+        for name, value in self.__dict__.items():
+            if torch.is_tensor(value):
+                other.__dict__[name] = fn(value)
+        if self._alpha_cache is not None:   # (sigma, alpha map) rides with the vertex map it was computed with
+            other._alpha_cache = (self._alpha_cache[0], fn(self._alpha_cache[1]))
         return other
+
+    def detach(self):
+        return self._mapped(torch.Tensor.detach)   # (shares storage with this object, off the autograd tape)
 
     def clone(self):
-        other = RGBDImages(self._rgb_image.clone(), self._depth_image.clone(), self._intrinsics.clone(),
-                           channels_first=self.channels_first)
-        for k in self._INTERNAL_TENSORS:
-            if k in ["_rgb_image", "_depth_image", "_intrinsics"]:
-                continue
-            v = getattr(self, k)
-            if torch.is_tensor(v):
-                setattr(other, k, v.clone())
-        return other
+        return self._mapped(torch.clone)
 
     def to(self, device, copy: bool = False):
-        device = torch.Tensor().to(device).device
-        if not copy and self.device == device:
+        device = torch.empty(0).to(device).device   # (resolves "cuda" to the current device index)
+        if self.device == device and not copy:
             return self
-        other = self.clone()
+        other = self._mapped(lambda t: t.to(device, copy=True))
         other.device = device
-        for k in self._INTERNAL_TENSORS:
-            v = getattr(self, k)
-            if torch.is_tensor(v):
-                setattr(other, k, v.to(device))
         return other
 
     def cpu(self):

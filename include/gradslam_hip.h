@@ -82,6 +82,13 @@ GS_API int gs_global_maps_f32(const float* vertex, const float* normal, const fl
 GS_API int gs_alpha_f32(const float* points, int64_t n, float two_sigma_sq, float eps, float* alpha,
                  void* stream);
 
+/* Reverse mode of gs_alpha_f32 = what PyTorch autograd computes through get_alpha (slam/fusionutils.py:69-72; the
+ * reference's own gradient check: tests/slam/test_fusionutils.py:56-75): points_bar[i] = alpha_bar[i] * d alpha_i / d p_i
+ * (zero where the clamp is active), sigma_terms[i] (may be NULL) = alpha_bar[i] * alpha_i * |p_i|^2, so that
+ * d loss / d sigma = sum_i sigma_terms[i] / sigma^3. */
+GS_API int gs_alpha_backward_f32(const float* points, int64_t n, float two_sigma_sq, float eps,
+                          const float* alpha_bar, float* points_bar, float* sigma_terms, void* stream);
+
 /* ------------------------------------------------------- K2: ICP source / target sets --
  * Valid pixels of the [::ds, ::ds] lattice, raster order -> compact point list.
  * Replaces downsample_rgbdimages (odometry/icputils.py:623-669).  out_* have room for
@@ -156,6 +163,9 @@ GS_API int gs_solve_normal_eq_f32(const float* A, const float* b, const uint8_t*
 
 /* se3_exp (geometry/se3utils.py:77-115): xi(6) -> T(4x4). */
 GS_API int gs_se3_exp_f32(const float* xi6, float* T16, void* stream);
+
+/* Reverse mode of gs_se3_exp_f32 (PyTorch autograd through geometry/se3utils.py:77-115): xi_bar(6) from T_bar(4x4). */
+GS_API int gs_se3_exp_backward_f32(const float* xi6, const float* Tbar16, float* xi_bar6, void* stream);
 
 /* relative_transformation(T01, T02, orthogonal_rotations=False) (geometry/geometryutils.py:413-478; the
  * arithmetic of GroundTruthOdometryProvider.provide, odometry/groundtruth.py:74-78, and of the dataset

@@ -19,10 +19,3 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
-
-
-def ate(a, b):
-    """translation RMSE between two (L,4,4) pose stacks."""
-    a = np.asarray(a, np.float64)
-    b = np.asarray(b, np.float64)
-    return float(np.sqrt(((a[:, :3, 3] - b[:, :3, 3]) ** 2).sum(-1).mean()))

@@ -10,7 +10,7 @@ import torch
 from gradslam_amd.datasets.synthetic import make_sequence
 from oracle import oracle as o
 from oracle import slam as oslam
-from tests.conftest import ate
+from gradslam_amd.metrics import ate_rmse as ate
 
 pytestmark = pytest.mark.gpu
 
@@ -435,3 +435,92 @@ def test_pointclouds_algebra_vs_reference_golden_gpu(golden):
     projection through gs_transform_points_f32 / gs_project_points_f32) against the REAL reference."""
     from tests.test_host_api_cpu import check_pointclouds_algebra
     check_pointclouds_algebra(golden, "cuda", 2e-6)
+
+
+def test_get_alpha_gradients_match_the_reference_formula(gs):
+    """Stand-alone fusionutils.get_alpha on the autograd tape (gs_alpha_backward_f32).  The reference's own gradient
+    check (tests/slam/test_fusionutils.py:56-75: these six points, sigma = 0.6 as a 0-d tensor, float64 gradcheck) is run
+    at float32 tolerance -- the kernels compute in float32 -- and the analytic gradients are compared with PyTorch
+    autograd through the reference's formula (slam/fusionutils.py:69-72) in float64."""
+    from gradslam_amd.slam import fusionutils as fu
+    pts = torch.tensor([[5.0, 5.0, 5.0], [3.0, 3.0, 3.0], [1.0, 2.0, 3.0], [3.0, 2.0, 1.0], [-1.0, 0.0, 1.0], [0.0, 0.0, 0.0]],
+                       device="cuda", dtype=torch.float64)
+    extra = torch.from_numpy(np.random.default_rng(0).uniform(-1.2, 1.2, (64, 3))).cuda()
+    for p0, sg in ((pts, 0.6), (extra, 0.6), (extra, 1.3)):
+        p = p0.clone().requires_grad_(True)
+        s = torch.tensor(sg, device="cuda", dtype=torch.float64, requires_grad=True)
+        w = torch.linspace(0.5, 1.5, p.shape[0], device="cuda", dtype=torch.float64)
+        (fu.get_alpha(p, s) * w).sum().backward()
+        p2, s2 = p0.clone().requires_grad_(True), torch.tensor(sg, device="cuda", dtype=torch.float64, requires_grad=True)
+        ref = torch.clamp(torch.exp(-torch.sum(p2 ** 2, -1) / (2 * (s2 ** 2))), min=1e-7, max=1.01)
+        (ref * w).sum().backward()
+        assert torch.allclose(p.grad, p2.grad, rtol=2e-6, atol=1e-7), (p.grad - p2.grad).abs().max()
+        assert abs(float(s.grad) - float(s2.grad)) <= 2e-6 * abs(float(s2.grad)) + 1e-7
+    # dim / keepdim as the SLAM path calls it (slam/fusionutils.py:657), float32 inputs
+    v = torch.rand(1, 1, 4, 5, 3, device="cuda", requires_grad=True)
+    a = fu.get_alpha(v, 0.6, dim=4, keepdim=True)
+    assert a.shape == (1, 1, 4, 5, 1) and a.requires_grad
+    a.sum().backward()
+    assert torch.allclose(v.grad, -(a.detach() * v.detach()) / 0.36, rtol=1e-5, atol=1e-7)
+    # the reference's check itself, with a step and tolerances a float32 forward supports
+    p = pts[1:].clone().requires_grad_(True)   # ([5, 5, 5] sits on the clamp: alpha = eps, zero gradient -- checked above)
+    s = torch.tensor(0.6, device="cuda", dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(fu.get_alpha, (p, s), eps=1e-2, atol=2e-3, rtol=2e-2, nondet_tol=0.0, raise_exception=True)
+
+
+def test_se3_exp_gradient_matches_autograd_of_the_reference_formula(gs):
+    """Stand-alone geometry.se3utils.se3_exp on the autograd tape (gs_se3_exp_backward_f32) against PyTorch autograd
+    through the reference's formula (geometry/se3utils.py:77-115) in float64, for a generic twist, a small one and the
+    small-angle branch."""
+    from gradslam_amd.geometry import se3utils
+
+    def ref_exp(xi):
+        v, w = xi[:3], xi[3:]
+        z = torch.zeros((), dtype=xi.dtype, device=xi.device)
+        wh = torch.stack([torch.stack([z, -w[2], w[1]]), torch.stack([w[2], z, -w[0]]), torch.stack([-w[1], w[0], z])])
+        th = w.norm()
+        eye = torch.eye(3, dtype=xi.dtype, device=xi.device)
+        if float(th) < 1e-6:
+            R = V = eye + wh
+        else:
+            A, B, C = torch.sin(th) / th, (1 - torch.cos(th)) / th ** 2, (th - torch.sin(th)) / th ** 3
+            R, V = eye + A * wh + B * wh @ wh, eye + B * wh + C * wh @ wh
+        return torch.cat([torch.cat([R, (V @ v)[:, None]], 1), torch.tensor([[0, 0, 0, 1.0]], dtype=xi.dtype, device=xi.device)])
+
+    Wt = torch.from_numpy(np.random.default_rng(1).standard_normal((4, 4))).cuda()
+    for vals in ([0.1, -0.2, 0.3, 0.2, 0.1, -0.3], [1e-3, 2e-3, -1e-3, 3e-3, -2e-3, 1e-3], [0.5, 0.1, 0.2, 1e-8, -2e-8, 1e-8]):
+        xi = torch.tensor(vals, device="cuda", dtype=torch.float32, requires_grad=True)
+        Tm = se3utils.se3_exp(xi.reshape(6, 1))
+        assert Tm.requires_grad
+        (Tm.double() * Wt).sum().backward()
+        x2 = torch.tensor(vals, device="cuda", dtype=torch.float64, requires_grad=True)
+        (ref_exp(x2) * Wt).sum().backward()
+        assert torch.allclose(xi.grad.double(), x2.grad, rtol=1e-5, atol=1e-6), (xi.grad, x2.grad)
+
+
+def test_metrics_map_chamfer_uses_exact_nearest_neighbours(gs):
+    """gradslam_amd.metrics.map_chamfer (exact 1-NN through gs_knn1_grid_f32) against the oracle's brute force on two
+    random clouds, on a shifted copy (every distance = the shift), and on the maps of two PointFusion runs."""
+    from gradslam_amd import metrics as M
+    rng = np.random.default_rng(5)
+    a = rng.uniform(-1, 1, (3000, 3)).astype(np.float32)
+    b = rng.uniform(-1, 1, (2500, 3)).astype(np.float32)
+    r = M.map_chamfer(a, b)
+    _, dab = o.knn1(a, b)
+    _, dba = o.knn1(b, a)
+    assert abs(r["a_to_b_rms_m"] - math.sqrt(dab.astype(np.float64).mean())) < 1e-7
+    assert abs(r["b_to_a_max_m"] - math.sqrt(float(dba.max()))) < 1e-7
+    assert abs(r["chamfer_m2"] - (dab.astype(np.float64).mean() + dba.astype(np.float64).mean())) < 1e-9
+    grid = np.stack(np.meshgrid(*[np.arange(12, dtype=np.float32) * 0.01] * 3, indexing="ij"), -1).reshape(-1, 3)
+    sh = M.map_chamfer(T(grid).cuda(), T(grid + np.float32(1e-3)).cuda())
+    assert abs(sh["a_to_b_rms_m"] - math.sqrt(3) * 1e-3) < 1e-6 and abs(sh["b_to_a_max_m"] - math.sqrt(3) * 1e-3) < 1e-6
+    s = make_sequence(3, 96, 128, seed=4)
+    poses = T(s["poses"][None]).cuda().clone()
+    poses[:, 1:] = poses[:, :1]
+    fr = gs.RGBDImages(T(s["colors"][None]).cuda(), T(s["depths"][None]).cuda(), T(s["intrinsics"][None]).cuda(), poses)
+    pc1, rp1 = gs.slam.PointFusion(odom="gradicp", device="cuda")(fr)
+    pc2, rp2 = gs.slam.PointFusion(odom="icp", device="cuda")(fr)
+    same = M.map_chamfer(pc1, pc1)
+    assert same["chamfer_m2"] == 0.0 and same["points_a"] == pc1.points_list[0].shape[0]
+    other = M.map_chamfer(pc1, pc2)
+    assert 0.0 < other["a_to_b_rms_m"] < 5e-3 and M.ate_rmse(rp1[0], rp2[0]) < 5e-3

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from gradslam_amd.datasets.synthetic import make_sequence
-from tests.conftest import ate
+from gradslam_amd.metrics import ate_rmse as ate
 
 pytestmark = pytest.mark.gpu
 

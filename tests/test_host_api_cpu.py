@@ -126,6 +126,18 @@ def test_rgbdimages_container():
     c = r.clone()
     c.depth_image.zero_()
     assert r.depth_image.abs().sum() > 0
+    # detach / clone / to (structures/rgbdimages.py:465-525 of the reference): clone copies every tensor, detach shares
+    # storage and leaves the tape, to(same device) is the object itself, to(..., copy=True) a deep copy
+    g = rgbd(B=1, L=2)
+    g.depth_image = g.depth_image.clone().requires_grad_(True)
+    d = g.detach()
+    assert not d.depth_image.requires_grad and d.depth_image.data_ptr() == g.depth_image.data_ptr()
+    assert d.poses.data_ptr() == g.poses.data_ptr() and d.shape == g.shape and d.channels_first == g.channels_first
+    k = g.clone()
+    assert k.depth_image.requires_grad and k.rgb_image.data_ptr() != g.rgb_image.data_ptr() and torch.equal(k.poses, g.poses)
+    assert g.to("cpu") is g and g.cpu() is g
+    t = g.to("cpu", copy=True)
+    assert t is not g and t.intrinsics.data_ptr() != g.intrinsics.data_ptr() and torch.equal(t.intrinsics, g.intrinsics)
 
 
 def test_rgbdimages_constructor_errors():
@@ -552,3 +564,37 @@ def test_rgbdimages_slice_keeps_the_channels_first_pixel_pos_shape():
     assert s2._intrinsics.shape == (1, 1, 4, 4) and s2._B == 1
     c = gs.RGBDImages(rgb.permute(0, 1, 3, 4, 2).contiguous(), depth.permute(0, 1, 3, 4, 2).contiguous(), K)
     assert c[:, 2]._pixel_pos_shape == (2, 1, 4, 5, 3)
+
+
+def test_metrics_package():
+    """gradslam_amd.metrics (the reference's package is empty): ATE, RPE, table parity and
+    count drift on hand-made cases (map_chamfer needs the GPU: tests/test_hip_api.py)."""
+    from gradslam_amd import metrics as M
+    L = 6
+    a = np.tile(np.eye(4, dtype=np.float32), (L, 1, 1))
+    a[:, 0, 3] = 0.1 * np.arange(L)
+    b = a.copy()
+    assert M.ate_rmse(a, b) == 0.0 and M.ate_rmse(torch.from_numpy(a), b) == 0.0
+    b[:, 1, 3] += 3e-3
+    assert abs(M.ate_rmse(a, b) - 3e-3) < 1e-9
+    r = M.rpe(a, b)
+    assert r["pairs"] == L - 1 and r["trans_rmse_m"] < 1e-9 and r["rot_rmse_rad"] == 0.0   # a constant offset has no relative error
+    c = a.copy()
+    th = 0.01
+    for s in range(L):   # yaw grows by `th` per frame
+        c[s, :3, :3] = np.array([[np.cos(th * s), 0, np.sin(th * s)], [0, 1, 0], [-np.sin(th * s), 0, np.cos(th * s)]], np.float32)
+    r = M.rpe(a, c)
+    assert abs(r["rot_rmse_rad"] - th) < 1e-6 and abs(M.rpe(a, c, delta=2)["rot_rmse_rad"] - 2 * th) < 1e-6   # (float32 matrices)
+    with pytest.raises(ValueError):
+        M.rpe(a, c, delta=L)
+    with pytest.raises(ValueError):
+        M.ate_rmse(a, b[:3])
+    t1 = torch.tensor([[0, 5, 1, 2], [0, 7, 1, 3], [1, 2, 0, 0]])
+    assert M.table_parity(t1, t1.clone()) == {"rows_a": 3, "rows_b": 3, "only_in_a": 0, "only_in_b": 0, "identical": True}
+    t2 = torch.tensor([[0, 7, 1, 3], [0, 5, 1, 2], [1, 2, 0, 1], [1, 9, 0, 0]])
+    p = M.table_parity(t1, t2.numpy())
+    assert p == {"rows_a": 3, "rows_b": 4, "only_in_a": 1, "only_in_b": 2, "identical": False}
+    assert M.table_parity(t1, t1[[1, 0, 2]])["identical"] is False and M.table_parity(t1, t1[[1, 0, 2]])["only_in_a"] == 0
+    d = M.count_drift([10, 20, 33], [10, 21, 30])
+    assert d["per_frame"] == [0, 1, 3] and d["max"] == 3 and d["first_frame_with_drift"] == 1 and abs(d["max_relative"] - 0.1) < 1e-12
+    assert M.count_drift([1, 2], [1, 2])["first_frame_with_drift"] is None

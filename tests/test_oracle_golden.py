@@ -9,7 +9,7 @@ import pytest
 
 from oracle import oracle as o
 from oracle import slam as oslam
-from tests.conftest import ate
+from gradslam_amd.metrics import ate_rmse as ate
 
 DIST_TH, DOT_TH, SIGMA = 0.05, math.cos(20 * math.pi / 180), 0.6
 

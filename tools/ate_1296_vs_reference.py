@@ -5,7 +5,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gradslam_amd as gs
 from gradslam_amd.datasets.synthetic import make_sequence
-from tests.conftest import ate
+from gradslam_amd.metrics import ate_rmse as ate
 g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "pf1296_s3.npz"))
 L = g["poses"].shape[0]
 s = make_sequence(L, 968, 1296, seed=3)
