@@ -19,10 +19,11 @@ The JSON line also carries
                 stream inside the library in a second pass over the SAME frames from the same map state (event
                 overhead never touches `value`); `traffic` = HBM bytes per launch from the committed PMC passes;
   roofline_hbm  the HBM-bound kernel groups (K1 frame maps, grid build, K5 association, K6 fuse) and ms per step;
-  cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/) on the host cores for a bounded
-                sample of the same workload, rank 0, N = 1 only, next to the RECORDED timing of the unmodified
-                reference (tests/golden/cpu_ref_timing.json, build container); parity of the timed GPU poses
-                against both (ate_vs_oracle_m, ate_vs_reference_golden_m).
+  cpu_baseline  gradslam's OWN CPU path (the staged reference, oracle/_ref + oracle/run_reference.py, "kind": "reference")
+                timed on this machine's host cores in the same run on a bounded sample of the same workload, rank 0,
+                N = 1 only, with the CPU oracle (the C port, oracle/) as a second field; parity of the timed GPU poses
+                against both and against the committed reference goldens (ate_vs_reference_live_m, ate_vs_oracle_m,
+                ate_vs_reference_golden).
 """
 import argparse
 import ctypes
@@ -225,6 +226,39 @@ def read_profile(lib, kind):
     return ms.value, n.value, work.value
 
 
+def cpu_reference(Hh, Ww, odom, frames=3, timeout_s=900):
+    """gradslam's OWN CPU path on this machine's host cores, in the same run (north_star): the staged
+    reference (oracle/_ref, python -m oracle.stage_reference; travels like the built .so) through oracle/run_reference.py
+    in a subprocess -- PointFusion(odom).step of the unmodified reference on sequence 0, frame 0 = map init, frame 1 =
+    warm-up, the rest timed.  Returns (dict or None, poses (frames, 4, 4) or None)."""
+    if not os.path.isfile(os.path.join(REPO, "oracle", "_ref", "gradslam", "slam", "pointfusion.py")):
+        return None, None
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="gs_ref_"), "ref.json")
+    env = dict(os.environ)
+    for k in list(env):   # the reference run is not what a profiler wrapped around bench.py is after
+        if k in ("LD_PRELOAD", "HSA_TOOLS_LIB") or k.startswith(("ROCP", "ROCPROF")):
+            env.pop(k)
+    cmd = [sys.executable, "-m", "oracle.run_reference", "--frames", str(frames), "--height", str(Hh), "--width", str(Ww),
+           "--seed", "0", "--odom", odom, "--out", out]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "reference run exceeded %d s" % timeout_s}, None
+    if r.returncode != 0 or not os.path.exists(out):
+        return {"error": (r.stderr or r.stdout)[-400:]}, None
+    d = json.load(open(out))
+    return {"value": d["frames_per_s"], "unit": "frames/s", "cores": d["cores"], "kind": "reference",
+            "sample": "unmodified gradslam %s PointFusion(odom='%s').step (torch %s, torch.set_num_threads(%d)) on frames 2..%d "
+                      "of sequence 0 of the same workload after an untimed map-init frame and one warm-up frame; %.1f s of "
+                      "CPU work; chamferdist.knn_points = the oracle's OpenMP brute force (stand-in KNN: the package is not "
+                      "installed), everything else the reference's own PyTorch code (oracle/_ref, oracle/shims)"
+                      % (d["gradslam_version"], odom, d["torch"], d["cores"], frames - 1, sum(d["seconds_per_frame"][2:])),
+            "seconds_per_frame": d["seconds_per_frame"], "surfels_per_frame": d["counts"],
+            "total_s": time.perf_counter() - t0}, np.asarray(d["poses"], np.float32)
+
+
 def cpu_baseline(seq, n_full_steps, odom):
     """Oracle (port of the reference's algorithm) on the host cores: frame 0 initialises the map
     (untimed, like the warm-up), the next `n_full_steps` frames are timed.  Returns (dict, oracle poses)."""
@@ -285,10 +319,13 @@ def secondary_measurements(gs, args, frames, device, barrier, Wm, K):
     _C.check(lib.gs_profile_end(), "gs_profile_end")
     ms, n, nbytes = read_profile(lib, 8)
     if n > 0:
-        gbs = nbytes / (ms * 1e-3) / 1e9
+        ns = float((one.depth_image[:, Wm:Wm + nprof, ::4, ::4] > 0).sum()) / nprof   # valid lattice pixels per frame
+        gbs = 36.0 * ns / (ms / n * 1e-3) / 1e9   # SURVEY 8(d) K4 bytes, as in the headline's roofline
         b1["roofline"] = {"kernel": "gs_icp_half_batch_kernel (one sequence per launch)", "bound": "hbm", "achieved": gbs,
                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "launches": n,
-                          "avg_launch_us": ms * 1e3 / n, "alg_bytes_per_launch": nbytes / n, "profiled_steps": nprof}
+                          "avg_launch_us": ms * 1e3 / n, "alg_bytes_per_launch": 36.0 * ns,
+                          "impl_bytes_per_launch": nbytes / n, "frac_impl": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                          "profiled_steps": nprof}
     out["b1_640x480"] = b1
     del pc2, prev2, r
 
@@ -461,8 +498,15 @@ def main():
 
     rank, world, local = multigpu.init_from_env()
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
-    if os.environ.get("GRADSLAM_BENCH_SHARE_GPU") == "1":   # rehearsal of the N-rank path on fewer GPUs (gloo only)
+    share = os.environ.get("GRADSLAM_BENCH_SHARE_GPU") == "1"
+    if share:   # rehearsal of the N-rank path on fewer GPUs (gloo only)
         local %= torch.cuda.device_count()
+    elif local >= torch.cuda.device_count():
+        # one process per GPU is the contract: a rank without a device of its own would silently share cuda:0 and the
+        # line would read as an N-GPU measurement
+        raise SystemExit("bench.py: rank %d (LOCAL_RANK %d) has no GPU of its own (%d visible); set "
+                         "GRADSLAM_BENCH_SHARE_GPU=1 (with GRADSLAM_DIST_BACKEND=gloo) for a shared-GPU rehearsal"
+                         % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world != args.gpus and rank == 0:
@@ -527,12 +571,24 @@ def main():
     poses_sha_by_sequence = [sha(all_poses[b:b + 1]) for b in range(all_poses.shape[0])]
     n_map_all = [int(p.shape[0]) for p in all_maps.points_list] if rank == 0 else None
     # what every rank saw: its own clock around the K steps, its sequences, the fingerprint of its poses
+    props = torch.cuda.get_device_properties(device)
     mine_info = {"rank": rank, "sequences": mine, "elapsed_s": elapsed_local, "ms_per_step": elapsed_local / K * 1e3,
-                 "host_enqueue_ms_per_step": (t_enq - run["waits"]) / K * 1e3, "poses_sha": sha(poses_local)}
+                 "host_enqueue_ms_per_step": (t_enq - run["waits"]) / K * 1e3, "poses_sha": sha(poses_local),
+                 "poses_sha_by_sequence": [sha(poses_local[b:b + 1]) for b in range(B_local)],
+                 "device_index": device.index, "device_uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}
     ranks_info = [mine_info]
     if world > 1:
         ranks_info = [None] * world
         torch.distributed.all_gather_object(ranks_info, mine_info)
+        ids = [(r["device_uuid"] or r["device_index"]) for r in ranks_info]
+        if len(set(ids)) != world and not share:   # (two processes on one device: not an N-GPU measurement)
+            raise SystemExit("bench.py: %d ranks landed on %d distinct GPUs: %s" % (world, len(set(ids)), ids))
+    backend_seen = {"world_size_env": int(os.environ.get("WORLD_SIZE", "1")),
+                    "dist_world_size": torch.distributed.get_world_size() if world > 1 else 1,
+                    "dist_backend": torch.distributed.get_backend() if world > 1 else None,
+                    "cuda_device_count_rank0": torch.cuda.device_count(),
+                    "distinct_devices": len(set((r["device_uuid"] or r["device_index"]) for r in ranks_info)),
+                    "shared_gpu_rehearsal": share}
 
     # ---------------- roofline pass: same frames from the same map state, HIP events inside the library
     roofline, roofline_hbm = None, None
@@ -542,43 +598,110 @@ def main():
         pc2, prev2 = run_steps(slam, gs.Pointclouds(device=device), frames, None, 0, Wm)
         torch.cuda.synchronize(device)
         _C.check(lib.gs_profile_begin(64 * K + 1024), "gs_profile_begin")
-        # exact surfel counts on the host in this pass (one read-back per step): exact algorithmic bytes
-        run_steps(slam, pc2, frames, prev2, Wm, L, after_step=lambda p: p._tighten_counts())
+        # exact counts on the host in this pass (read-backs after every step; nothing of it touches `value`): the sizes
+        # SURVEY.md section 8(d) states its algorithmic bytes in -- N surfels before the update, Na of them in the frame,
+        # Nm matched pixels, Nn appended pixels, Ns valid lattice pixels (ICP source points) -- per sequence and step
+        from gradslam_amd import ops
+        cnt = {"N": 0.0, "Na": 0.0, "Nm": 0.0, "Nn": 0.0, "Ns": 0.0, "P": 0.0}
+        state = {"s": Wm, "n_old": [int(p.shape[0]) for p in pc2.points_list]}
+
+        def count_step(p):
+            p._tighten_counts()
+            sidx = state["s"]
+            depth = frames.depth_image[:, sidx]                    # (B, H, W, 1)
+            nvalid = (depth > 0).flatten(1).sum(1).tolist()
+            nsrc = (depth[:, ::4, ::4] > 0).flatten(1).sum(1).tolist()
+            n_now = [int(x.shape[0]) for x in p.points_list]
+            for b in range(B_local):
+                n_old = state["n_old"][b]
+                pix = ops.project_map(p.points_list[b][:n_old], live_pose(p, b), frames.intrinsics[b, 0], Hh, Ww)
+                nn = n_now[b] - n_old
+                cnt["N"] += n_old
+                cnt["Na"] += int((pix >= 0).sum())   # (rows of the map as merged: in-frame decisions differ on ~1e-5 of them)
+                cnt["Nn"] += nn
+                cnt["Nm"] += nvalid[b] - nn
+                cnt["Ns"] += nsrc[b]
+                cnt["P"] += Hh * Ww
+            state["n_old"], state["s"] = n_now, sidx + 1
+
+        pose_box = {}
+
+        def live_pose(p, b):
+            return pose_box["pose"][b, 0]
+
+        def run_counted():
+            pc_, prev_ = pc2, prev2
+            for sidx in range(Wm, L):
+                live = frames[:, sidx]
+                pc_, pose = slam.step(pc_, live, prev_, inplace=True)
+                pose_box["pose"] = pose
+                prev_ = live
+                count_step(pc_)
+
+        run_counted()
         _C.check(lib.gs_profile_end(), "gs_profile_end")
+        per_step = {k: v / K for k, v in cnt.items()}   # sums over the sequences of this GPU, per step
         ms, n, nbytes = read_profile(lib, 8)
         if n > 0:  # dominant kernel by GPU time: the fused exact-NN search + Gauss-Newton linearisation
-            gbs = nbytes / (ms * 1e-3) / 1e9
+            launches_per_step = n / K
+            alg = 36.0 * per_step["Ns"]                 # 12 B source point + 24 B matched point and normal per query
+            gbs = alg / (ms / n * 1e-3) / 1e9
+            gbs_impl = nbytes / (ms * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic("gs_icp_half_batch_kernel")
-            per_launch = nbytes / n
             roofline = {"kernel": "gs_icp_half_batch_kernel<FULL> (K3+K4 fused, %d sequences per launch: prologue = row sums "
                                   "+ 6x6 solve / LM update of the previous half-iteration, then exact grid 1-NN + GN rows + "
-                                  "one partial row per block), %d launches per step" % (B_local, n // K),
+                                  "one partial row per block), %d launches per step" % (B_local, round(launches_per_step)),
                         "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                        "launches": n, "avg_launch_us": ms * 1e3 / n, "alg_bytes_per_launch": per_launch,
-                        "alg_le_traffic": None if traffic is None else bool(per_launch <= traffic),
-                        "note": "latency-bound, not bandwidth-bound.  Algorithmic bytes per launch and sequence (exact "
-                                "device counts read back in this pass): 12 B per lattice slot read, per searched "
-                                "query 12 B cloud written (first half) + 24 B matched target point and normal, one "
-                                "partial row per 96 queries, one 16 B pass over the binned targets; cell-bound "
-                                "look-ups and extra candidate gathers are traffic, not algorithmic bytes.  `traffic` = "
-                                "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                "(FETCH x2 per MI355X_MICROARCH.md)."}
+                        "launches": n, "avg_launch_us": ms * 1e3 / n, "alg_bytes_per_launch": alg,
+                        "impl_bytes_per_launch": nbytes / n, "achieved_impl": gbs_impl, "frac_impl": gbs_impl / PEAK_HBM_GBS,
+                        "alg_le_traffic": None if traffic is None else bool(alg <= traffic),
+                        "note": "latency-bound, not bandwidth-bound.  alg_bytes = SURVEY.md 8(d) K4: 36 B per valid lattice "
+                                "pixel (12 B source point read + 24 B matched target point and normal) of every sequence "
+                                "per launch, counted on the host in this pass; impl_bytes = what the launch has to move "
+                                "as built (12 B per lattice slot read, 12 B cloud written in first halves, 24 B match, "
+                                "partial rows, one 16 B pass over the binned targets; exact device counts).  `traffic` = "
+                                "HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                "(FETCH x2 per MI355X_MICROARCH.md): every launch re-fetches its working set, the per-XCD "
+                                "L2s do not survive a kernel boundary (profiles/r05_a_icp_l2_vs_frame.txt)."}
+        # HBM-bound groups: alg_bytes from SURVEY.md section 8(d) and the counts above, impl_bytes as booked by the library
+        # (the implementation's own scratch tables included); frac is computed from alg_bytes
+        c = per_step
+        alg_by_kind = {
+            2: ("K1 frame maps + update tables", 32.0 * c["P"],
+                "8(d) K1: 4 B depth read + 28 B (vertex, normal, alpha) written per pixel; the update's per-pixel tables "
+                "(12 B per pixel) and the grid-scratch clear ride in the same launch and are impl bytes"),
+            6: ("K2/K3 lattice + projection + grid build", 28.0 * c["P"] / 16.0 + 12.0 * c["N"],
+                "K2 (no figure in 8(d)): 28 B per lattice slot (vertex, normal read; source point written) + 12 B per surfel "
+                "projected under the previous pose; the counting sort of the targets into the grid is impl bytes"),
+            4: ("K5 association", 28.0 * c["N"] + 24.0 * c["Na"] + 8.0 * c["P"],
+                "8(d) K5: 28 B per surfel + 24 B frame vertex and normal per in-frame surfel + 8 B key r/w per pixel"),
+            5: ("K6 fuse+append", 120.0 * c["Nm"] + 80.0 * c["Nn"] + 72.0 * c["N"],
+                "8(d) K6: matched surfel r/w 2 x 40 B + frame 40 B; appended pixel 40 B read + 40 B written; parity mode "
+                "(every row renormalised like the reference) + 2 x 36 B per surfel"),
+        }
         groups = {}
-        for kind, name in ((2, "K1 frame maps + update tables"), (6, "K2/K3 lattice + projection + grid build"),
-                           (4, "K5 association"), (5, "K6 fuse+append")):
+        for kind, (name, alg_b, what) in alg_by_kind.items():
             gms, gn, gbytes = read_profile(lib, kind)
             if gn > 0:
-                gbs = gbytes / (gms * 1e-3) / 1e9
-                groups[name] = {"achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "launches": gn,
-                                "avg_us_per_launch": gms * 1e3 / gn, "alg_bytes_per_launch": gbytes / gn}
+                gbs = alg_b * K / (gms * 1e-3) / 1e9
+                groups[name] = {"achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "launches": gn, "ms_per_step": gms / K,
+                                "alg_bytes_per_step": alg_b, "impl_bytes_per_step": gbytes / K,
+                                "frac_impl": gbytes / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS, "alg_bytes_what": what}
         tot = {k: read_profile(lib, k)[0] for k in range(9)}
         step_ms = {n_: tot[k] / K for k, n_ in ((8, "icp_search_linearise"), (7, "icp_finish"), (6, "prep_project_grid_build"),
                                                 (2, "frame_maps_update_tables"), (4, "associate"), (5, "fuse"))}
+        alg_step = sum(g["alg_bytes_per_step"] for g in groups.values()) + (roofline["alg_bytes_per_launch"] * n / K if roofline else 0.0)
         roofline_hbm = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "groups": groups,
                         "gpu_ms_per_step_by_group": step_ms,
-                        "hbm_frac_whole_step": (sum(read_profile(lib, k)[2] for k in (2, 4, 5, 6, 8)) / K) /
-                                               (elapsed / K) / 1e9 / PEAK_HBM_GBS}
+                        "counts_per_step_sum_over_sequences": per_step,
+                        "non_icp_gpu_ms_per_step": sum(v for k_, v in step_ms.items() if not k_.startswith("icp")),
+                        "hbm_frac_whole_step": alg_step / (elapsed / K) / 1e9 / PEAK_HBM_GBS,
+                        "hbm_frac_whole_step_impl": (sum(read_profile(lib, k)[2] for k in (2, 4, 5, 6, 8)) / K) /
+                                                    (elapsed / K) / 1e9 / PEAK_HBM_GBS,
+                        "note": "counts: N surfels before the update, Na of them in the frame, Nm matched pixels, Nn appended, "
+                                "Ns valid lattice pixels, P pixels; hbm_frac_whole_step = 8(d) algorithmic bytes of the whole "
+                                "step / wall time of a step / 8 TB/s"}
 
     cpu, ate_oracle, ate_ref, ate_refs = None, None, None, {}
     if (Hh, Ww) == (480, 640) and args.odom == "gradicp" and L <= 64:
@@ -593,9 +716,20 @@ def main():
                                      "source": "tests/golden/" + os.path.basename(gp)}
         if rank == 0 and "0" in ate_refs:
             ate_ref = dict(ate_refs["0"], source="tests/golden/pf640.npz (unmodified gradslam PointFusion on the same sequence)")
+    ate_ref_live = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, op = cpu_baseline(seqs[0], args.cpu_frames, args.odom)
+        port, op = cpu_baseline(seqs[0], args.cpu_frames, args.odom)
         ate_oracle = ate_np(poses_local[0, :op.shape[0]].cpu().numpy(), op)
+        # gradslam's own CPU path, timed here and now; the oracle port stays next to it as a second field
+        ref, ref_poses = cpu_reference(Hh, Ww, args.odom, frames=1 + max(args.cpu_frames, 2)) if mine[0] == 0 else (None, None)
+        if ref is not None and ref_poses is not None:
+            cpu = dict(ref, port=port)
+            nfr = min(L, ref_poses.shape[0])
+            ate_ref_live = {"value_m": ate_np(poses_local[0, :nfr].cpu().numpy(), ref_poses[:nfr]), "frames": nfr,
+                            "source": "the cpu_baseline run of this bench invocation (oracle/run_reference.py)"}
+        else:
+            cpu = dict(port, reference_live=ref if ref is not None else
+                       {"error": "oracle/_ref is not staged on this machine (python -m oracle.stage_reference)"})
 
     seg_out = run["segments"]
     second = None
@@ -609,6 +743,9 @@ def main():
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
+            "n_ranks_seen_by_backend": backend_seen,
+            "scaling_note": "this line is ONE point of the curve; scaling efficiency is unmeasured until the driver has a "
+                            "SCALE record for N = 1, 2, 4, 8 (no 8-GPU node has run this code: rounds 1-4 SCALE = skipped)",
             "config": {"workload": "PointFusion(odom=%s, dsratio=4, numiters=20) forward, B=%d independent %dx%d "
                                    "sequences sharded over %d GPU(s) (%d per GPU, batched: every kernel serves all "
                                    "sequences of the GPU), frames resident in HBM (BASELINE configs[%s])"
@@ -628,6 +765,7 @@ def main():
                        "icp_engine": os.environ.get("GRADSLAM_HIP_ICP_ENGINE", "rows"),
                        "host_readbacks_per_frame": 0 if gs.ops.DEVICE_COUNTS else 3,
                        "ate_vs_ground_truth_m_rank0_max": ate_gt, "ate_vs_oracle_m": ate_oracle,
+                       "ate_vs_reference_live_m": ate_ref_live,
                        "ate_vs_reference_golden": ate_ref, "ate_vs_reference_goldens_by_seed_rank0": ate_refs},
             "segments": seg_out,
             "ranks": {"elapsed_s_min": min(el), "elapsed_s_max": max(el), "elapsed_s_mean": sum(el) / len(el),

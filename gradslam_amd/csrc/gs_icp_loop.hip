@@ -261,6 +261,15 @@ struct IcpHalfSeq {
   int* far_idx;   // [FS_FAR_PASSES][n_src] source points a first half with a list-building pass behind it (fs_far_pass)
   int* far_n;     // found far from every target, far_n[pass] of them
 };
+// WIDE lists of hard queries (round 5, gs_knn.h: far_write_from_top / block_brute_min_list_multi; cq == NULL: none kept;
+// the variants without the far-list machinery above only): cq[s] = (position the list of source point s was made at,
+// exactness radius; 0: no list), c[GS_FAR_SLOTS * s ..] = its slots.  Written by whatever serves a hard query (cube
+// scan, block-wide pass) in any launch of the solve, checked first thing by the 16-lane group that serves it in every
+// later launch; the prep launch of a frame clears every point's radius (nothing of an earlier frame is ever read).
+struct IcpHalfWide {
+  float4* cq;
+  uint32_t* c;
+};
 // candidate lists of ordinary queries (gs_knn.h: gl_*; lq == NULL: none): lq[s] = (position the list of source point s
 // was built at, exactness radius), ls[GL_SLOTS * s ..] = its slots of `sorted`, lstat = failure counters per launch
 struct IcpHalfLists {
@@ -296,7 +305,7 @@ GS_DEV int fs_pb(int i) { return i < 21 ? (int)((FS_PB_BITS >> (3 * i)) & 7ull) 
 //      scans the 2x2x2 block and writes a new list.
 // Results do not depend on any of it: a proof is exact, everything else is the search that ran before.
 template <bool FULL, int G, bool FAR, int LMODE>
-GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsCount n_src_c, const float dist_thresh,
+GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const IcpHalfWide& qw, const GsCount n_src_c, const float dist_thresh,
                           const gs_icp_params& prm, const int it, const int rows_in_reduced, const unsigned lb,
                           const int upb, unsigned long long* __restrict__ tl_arg = nullptr) {
   constexpr bool LISTS = LMODE != 0;
@@ -640,6 +649,16 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
     // ---- the few queries the 2x2x2 stage did not resolve (neighbour farther than ~half a cell): Chebyshev shells
     // by groups of FS_HG lanes, so that they do not hold up the waves of the common case
     const int nh = hard_n;  // block-uniform
+    // wide lists of hard queries (the variants WITHOUT the far-list machinery): the pointers are fetched here, in the rare
+    // path, through an opaque copy of the descriptor's address -- hoisted to the top of the kernel they would sit in
+    // scalar registers across everything (the plain variants are at their scalar limit: spilled scalars take vector
+    // registers, and those then spill to memory)
+    // (only the variants with ordinary lists keep them: the plain variants -- the first three launches of a solve -- are at
+    // their scalar-register limit, where two more pointers spill scalars into vector registers and those to memory)
+    constexpr bool WL = !FAR && LISTS;
+    float4* __restrict__ wl_cq = WL ? qw.cq : nullptr;
+    uint32_t* __restrict__ wl_c = WL ? qw.c : nullptr;
+    const bool wl_on = WL && wl_cq != nullptr;
     for (int i = threadIdx.x / FS_HG; i < nh; i += FS_BLOCK / FS_HG) {
       const int e = hard_q[i], hs = e & FS_HQ_SLOT, l16 = threadIdx.x & (FS_HG - 1);
       const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
@@ -653,12 +672,24 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         if (done) { key = kl; listed = true; }
         else win = -1;
       }
+      if (WL && wl_on) {   // the wide list an earlier launch of this solve left for the point, if any
+        const float4 c0R = wl_cq[sq];
+        if (c0R.w > 0.0f) {   // (group-uniform)
+          const unsigned long long kl = wide_list_search<FS_HG>(c0R, wl_c + GS_FAR_SLOTS * sq, sorted, hx, hy, hz, l16, &done, &win);
+          if (done) { key = kl; listed = true; }
+          else win = -1;
+        }
+      }
       constexpr int KH = 2;   // candidates a lane of the 16-lane group remembers for the new list
       GlTop<KH> top;
       float rc2 = 0.0f;
       if (!done) {
         int kdone = 0;
-        if (LISTS) key = grid_search_rings_top<FS_HG, KH>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, top, &rc2);
+        if (LISTS) {
+          key = grid_search_rings_top<FS_HG, KH>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, top, &rc2);
+          // (whatever the lanes remember of the proving cube is the point's wide list from now on)
+          if (WL && wl_on && done) far_write_from_top<FS_HG, KH>(top, rc2, hx, hy, hz, l16, wl_c + GS_FAR_SLOTS * sq, wl_cq + sq);
+        }
         else key = grid_search_rings<FS_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, &kdone);
         // first halves with a list-building pass behind them (fs_far_pass): queries that needed a cube of radius >=
         // FS_FAR_MIN_RING are handed to gs_icp_far_build_kernel together with what the search found (squared distance,
@@ -669,7 +700,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
         }
       }
       // (list variants) the scan that served the point leaves its list; what only the brute-force pass can serve keeps none
-      if (LISTS) {
+      if (LISTS && !(WL && listed)) {   // (a point its wide list served keeps what it has: no ordinary list, R < 0)
         if (done) gl_select_write<FS_HG, KH>(top, rc2, hx, hy, hz, l16, LM, ls + GL_SLOTS * sq, lq + sq);
         else if (l16 == 0) lq[sq] = make_float4(hx, hy, hz, -1.0f);
       }
@@ -688,9 +719,18 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
     if (tl && threadIdx.x == 0 && u0 == u_first) { tl[5] = wall_clock64(); tl[2] += (unsigned long long)nh; }
     const int nun = unres_n;  // block-uniform
     if (tl && threadIdx.x == 0) { tl[7] += (unsigned long long)nun; if (u0 == u_first) tl[6] = wall_clock64(); }
-    for (int u = 0; u < nun; u += FS_BQ)  // FS_BQ queries per pass over the binned targets
-      block_brute_min_sorted_multi<FS_BLOCK, FS_BQ>(qs, unres_q + u, nun - u < FS_BQ ? nun - u : FS_BQ, sorted,
-                                                    cell_start[g.ncell], keys_s, bslot_s);
+    // FS_BQ queries per pass over the binned targets; with wide lists the pass also leaves the lists of its queries
+    constexpr int BQL = 2;   // (two queries per list-leaving pass: four cost the 4-lane look-ahead variant a spill; such a pass
+                             // now happens once per solve and far point, not once per launch)
+    if (WL && wl_on) {   // (block-uniform)
+      for (int u = 0; u < nun; u += BQL)
+        block_brute_min_list_multi<FS_BLOCK, BQL>(qs, unres_q + u, nun - u < BQL ? nun - u : BQL, sorted, cell_start[g.ncell],
+                                                  keys_s, bslot_s, (int64_t)u0 * FS_QPB, wl_cq, wl_c);
+    } else {
+      for (int u = 0; u < nun; u += FS_BQ)
+        block_brute_min_sorted_multi<FS_BLOCK, FS_BQ>(qs, unres_q + u, nun - u < FS_BQ ? nun - u : FS_BQ, sorted,
+                                                      cell_start[g.ncell], keys_s, bslot_s);
+    }
     if (nun) {
       __syncthreads();
       if (FULL && FAR && far_pass >= 0 && far_on && (int)threadIdx.x < nun) {   // (see the cube searches above; -1: no cube)
@@ -709,7 +749,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const GsC
       // (list variants: the index of the source point is formed again here; kept from the top of the kernel it is the
       // one value the register allocator spills -- the opaque copy keeps the compiler from merging the two)
       int u0r = u0;
-      if (LISTS) asm volatile("" : "+s"(u0r));
+      if (LISTS) asm volatile("" : "+v"(u0r));   // (a vector register: the unit index is a quotient, i.e. vector arithmetic)
       const int64_t s = LISTS ? (int64_t)u0r * FS_QPB + slot : (int64_t)u0 * FS_QPB + slot;
       float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, res = 0.0f;
       bool rowdone = false;
@@ -802,6 +842,7 @@ struct IcpHalfBatch {
   unsigned long long* timeline;  // debugging aid (GRADSLAM_HIP_ICP_TIMELINE): per block [start, end, hw id, xcc id]
   IcpHalfSeq s[GS_MAX_BATCH];
   IcpHalfLists l[GS_MAX_BATCH];   // (read by the list variants only)
+  IcpHalfWide w[GS_MAX_BATCH];    // (read in the left-over pass of the variants without far lists only)
 };
 template <bool FULL, int G, bool FAR, int LMODE>
 __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_batch_kernel(const IcpHalfBatch hb, GsCount n_src_c,
@@ -813,7 +854,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_batch_kernel(const Ic
   unsigned long long t0 = 0;
   if (hb.timeline && threadIdx.x == 0) t0 = wall_clock64();
 #endif
-  icp_half_body<FULL, G, FAR, LMODE>(hb.s[blockIdx.x % B], hb.l[blockIdx.x % B], n_src_c, dist_thresh, prm, it, rows_in_reduced,
+  icp_half_body<FULL, G, FAR, LMODE>(hb.s[blockIdx.x % B], hb.l[blockIdx.x % B], hb.w[blockIdx.x % B], n_src_c, dist_thresh, prm, it, rows_in_reduced,
                                      gs_xcd_block(blk, nblk, X), hb.upb,
                                      hb.timeline ? hb.timeline + 72 * (size_t)blockIdx.x : nullptr);
 #ifdef GS_ICP_TIMELINE
@@ -1190,6 +1231,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
     IcpHalfBatch hb;
     hb.B = 1;
     hb.l[0] = IcpHalfLists{nullptr, nullptr, nullptr};
+    hb.w[0] = IcpHalfWide{nullptr, nullptr};
     for (int it = 0; it < prm->numiters; ++it) {
       float* cur = cloud(it);
       hb.s[0] = IcpHalfSeq{cur_in, cur, tgt, tgt_normals, n_tgt_c, gm.g, gm.cell_start, gm.sorted, gm.sorted_n,
@@ -1302,6 +1344,7 @@ struct LocSeq {
   int64_t* n_valid;      // number of lattice slots with depth (profiling / roofline accounting)
   int* far_n;            // [FS_FAR_PASSES] counters of the far-query lists of the solve, zeroed here
   int* lstat;            // [3 * GL_STAT_LAUNCHES] failure counters of the ordinary candidate lists, zeroed here
+  float4* wl_cq;         // [n_lat] wide lists of hard queries: every radius cleared here (NULL: none kept)
 };
 struct LocBatch {
   int B, W, ds, Wl;
@@ -1332,6 +1375,7 @@ GS_DEV void loc_prep_block(const LocBatch& lb, const unsigned bid, const unsigne
         valid = 1;
       }
       q.lattice[3 * e] = g0; q.lattice[3 * e + 1] = g1; q.lattice[3 * e + 2] = g2;
+      if (q.wl_cq) q.wl_cq[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // (no wide list of an earlier frame is ever read)
     }
     const unsigned long long m = lb.count_valid ? __ballot(valid) : 0ull;
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(reinterpret_cast<unsigned long long*>(q.n_valid), (unsigned long long)__popcll(m));
@@ -1596,7 +1640,7 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
     sc[b] = cv.sc;
     gm[b] = cv.gm;
     lb.s[b] = LocSeq{q.vertex, q.depth, q.prev_pose16, lattice, sc[b].state, q.out_pose16,
-                     reinterpret_cast<char*>(gm[b].g), n_valid, nullptr, nullptr};
+                     reinterpret_cast<char*>(gm[b].g), n_valid, nullptr, nullptr, nullptr};
     static int binned_normals = -1;  // GRADSLAM_HIP_ICP_BINNED_NORMALS=0: gather the matches' normals from the map (A/B)
     if (binned_normals < 0) {
       const char* e = getenv("GRADSLAM_HIP_ICP_BINNED_NORMALS");
@@ -1641,6 +1685,20 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   for (int b = 0; b < B; ++b) {
     lm[b] = list_carve(reinterpret_cast<char*>(sc[b].state) + gs_icp_scratch_bytes(n_lat, loc_rows(seqs[b].map)), n_lat);
     lb.s[b].lstat = lm[b].stat;   // (zeroed by the prep launch whether or not this solve keeps lists)
+  }
+  // wide lists of hard queries (gs_knn.h; the results do not depend on them): in the memory of the far lists, whenever
+  // those are not in use.  GRADSLAM_HIP_ICP_WIDE=0 switches them off (A/B runs).
+  static int wide_lists = -1;
+  if (wide_lists < 0) {
+    const char* e = getenv("GRADSLAM_HIP_ICP_WIDE");
+    wide_lists = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  const bool wide_on = wide_lists == 1 && !far_on && prm->numiters > 0;
+  FarMem wm[GS_MAX_BATCH];
+  for (int b = 0; b < B; ++b) {
+    wm[b] = far_carve(reinterpret_cast<char*>(sc[b].state) + gs_icp_scratch_bytes(n_lat, loc_rows(seqs[b].map)) +
+                          list_mem_bytes(n_lat), n_lat);
+    lb.s[b].wl_cq = wide_on ? wm[b].cq : nullptr;
   }
   lb.count_valid = g_gs_prof_on ? 1 : 0;
   lb.clear_bytes = gs_knn_grid_clear_bytes(gm[0], gb.cells_cap);  // same layout offsets for every sequence
@@ -1695,6 +1753,7 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
                            sc[b].partials[(h + 1) & 1], sc[b].partials[h & 1],
                            &sc[b].state->s[h & 1], &sc[b].state->s[(h + 1) & 1], sc[b].state->trace, nullptr, nullptr,
                            nullptr, fm[b].cq, fm[b].c, fm[b].idx, fm[b].n};
+      hb.w[b] = wide_on ? IcpHalfWide{wm[b].cq, wm[b].c} : IcpHalfWide{nullptr, nullptr};
       hb.l[b] = lists_on ? IcpHalfLists{lm[b].lq, lm[b].ls, lm[b].stat} : IcpHalfLists{nullptr, nullptr, nullptr};
     }
     // lists: built behind the look-ahead search of iteration lists_from, tried from then on

@@ -351,6 +351,33 @@ GS_DEV unsigned long long far_list_search(const float4 c0R, const uint32_t* __re
   return kmin;
 }
 
+// the same check with two gathers in flight per lane instead of four (the wide lists of round 5 are checked inside
+// kernels that sit at their register limit; the check serves a handful of points per launch)
+template <int G>
+GS_DEV unsigned long long wide_list_search(const float4 c0R, const uint32_t* __restrict__ slots,
+                                           const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
+                                           bool* proven, int* win) {
+  static_assert(GS_FAR_SLOTS == 4 * G, "four list entries per lane");
+  unsigned long long k = ~0ull;
+  int bs = -1;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint2 sl = reinterpret_cast<const uint2*>(slots)[2 * lane + h];
+    const float4 a0 = sorted[sl.x != ~0u ? sl.x : 0u], a1 = sorted[sl.y != ~0u ? sl.y : 0u];
+    const unsigned long long k0 = sl.x != ~0u ? grid_key(qx, qy, qz, a0) : ~0ull;
+    const unsigned long long k1 = sl.y != ~0u ? grid_key(qx, qy, qz, a1) : ~0ull;
+    if (k0 < k) { k = k0; bs = (int)sl.x; }
+    if (k1 < k) { k = k1; bs = (int)sl.y; }
+  }
+  const unsigned long long kmin = grid_group_min<G>(k);
+  *win = (k == kmin) ? bs : -1;
+  const float bd = __uint_as_float((uint32_t)(kmin >> 32));
+  const float ex = qx - c0R.x, ey = qy - c0R.y, ez = qz - c0R.z;
+  const float delta = sqrtf(ex * ex + ey * ey + ez * ez);
+  *proven = sqrtf(bd) + delta < c0R.w * 0.9999f;   // false for NaN, for an empty list and for R <= 0
+  return kmin;
+}
+
 // list of a query that grid_search_rings served with the cube of radius kdone: every target within
 // R = min(d1 + radd, 0.999 kE cells) of the query, kE = kdone or kdone + 1 (the larger cube when the smaller one leaves
 // less than radd of room); collected by the G lanes into `stage` (GS_FAR_SLOTS x 32 bit + a counter, LDS of the group).
@@ -681,6 +708,151 @@ GS_DEV void block_brute_min_sorted_multi(const float (*qs)[3], const int* ids, i
       // the one thread that holds the winning candidate (code_global: the tile engine's code of a global slot)
       if (key[i] == k && bs[i] >= 0) bslot_out[id] = code_global ? -2 - bs[i] : bs[i];
       if (threadIdx.x == 0) key_out[id] = k;
+    }
+  }
+  __syncthreads();
+}
+
+// ---- WIDE lists of hard queries (round 5).  A source point several cells from every target -- a frame border that looks
+// at a surface under a grazing angle: neighbouring lattice pixels are 15 - 30 cm apart there, profiles/r05_b_late_frames.txt
+// -- is served by the cube scans (~9 us for a 16-lane group) or by a pass of its whole block over all binned targets
+// (~36 us: one CU pulling a megabyte), in EVERY launch of a solve, and the launch is as slow as that block.  Its ordinary
+// list (4 slots) rarely proves anything: a far query sees a line of targets at nearly the same distance.  So whatever
+// serves such a point also leaves a WIDE list: GS_FAR_SLOTS slots of `sorted`, four per lane of the 16-lane group that
+// checks it first thing in the left-over pass (far_list_search; the exactness argument is that of every list: every target
+// within R of the position q0 the list was made at is on it).
+//   * from a cube scan: everything the 16 lanes remember (2 candidates each) that lies within R = min(nearest candidate a
+//     lane dropped, bound of the cube);
+//   * from the block-wide pass: every thread remembers its nearest candidate and the distance of its second nearest;
+//     R = the smallest of those second distances over the block -- a target within R that is not its thread's nearest
+//     would make that thread's second distance smaller than R -- and the list = the threads' nearest candidates within R
+//     (with 768 threads the first two of the globally nearest that share a thread are ~35 apart: the list holds the ~35
+//     nearest targets; nested smaller radii in case it does not fit).
+// lane-major layout: lane l of the checking group reads slots 4 l .. 4 l + 3.
+template <int GB, int KT>
+GS_DEV void far_write_from_top(const GlTop<KT>& top, const float rcov2, float qx, float qy, float qz, int lane,
+                               uint32_t* __restrict__ slots, float4* __restrict__ cq) {
+  static_assert(GS_FAR_SLOTS == 4 * GB && KT <= 4, "four slots per lane of the checking group");
+  const float out2 = gl_group_minf<GB>(top.d[KT]);
+  const float R2 = out2 < rcov2 ? out2 : rcov2;
+  static_assert(KT == 2, "two remembered candidates per lane");
+  const uint32_t w0 = (top.s[0] >= 0 && top.d[0] < R2) ? (uint32_t)top.s[0] : ~0u;
+  const uint32_t w1 = (top.s[1] >= 0 && top.d[1] < R2) ? (uint32_t)top.s[1] : ~0u;
+  reinterpret_cast<uint4*>(slots)[lane] = make_uint4(w0, w1, ~0u, ~0u);
+  if (lane == 0) *cq = make_float4(qx, qy, qz, R2 > 0.0f && R2 < 3.0e38f ? sqrtf(R2) : 0.0f);
+}
+
+// block_brute_min_sorted_multi that also leaves the wide list of every query (see above).  gbase + id = the source point
+// of the query in slot id.  Every thread of the block calls it with the same arguments.
+template <int BLOCK, int BQ>
+GS_DEV void block_brute_min_list_multi(const float (*qs)[3], const int* ids, int nq, const float4* __restrict__ sorted,
+                                       int n, unsigned long long* key_out, int* bslot_out, const int64_t gbase,
+                                       float4* __restrict__ far_cq, uint32_t* __restrict__ far_c) {
+  __shared__ unsigned long long red_m[BLOCK / GS_WAVE][BQ];
+  __shared__ float red_d[BLOCK / GS_WAVE][BQ];
+  __shared__ uint32_t lst[3][BQ][GS_FAR_SLOTS];
+  __shared__ int cnt[3][BQ];
+  float q[BQ][3], d2[BQ];
+  unsigned long long key[BQ];
+  int bs[BQ];
+#pragma unroll
+  for (int i = 0; i < BQ; ++i) {
+    const int id = ids[i < nq ? i : 0];
+    q[i][0] = qs[id][0]; q[i][1] = qs[id][1]; q[i][2] = qs[id][2];
+    key[i] = ~0ull;
+    bs[i] = -1;
+    d2[i] = __builtin_inff();
+  }
+  if (threadIdx.x < 3 * BQ) cnt[threadIdx.x / BQ][threadIdx.x % BQ] = 0;
+  for (int t = threadIdx.x; t < 3 * BQ * GS_FAR_SLOTS; t += BLOCK) (&lst[0][0][0])[t] = ~0u;
+  for (int j = threadIdx.x; j < n; j += BLOCK) {
+    const float4 p = sorted[j];
+#pragma unroll
+    for (int i = 0; i < BQ; ++i) {
+      const unsigned long long k2 = grid_key(q[i][0], q[i][1], q[i][2], p);
+      const bool better = k2 < key[i];
+      // the distance that does NOT become (or stay) the thread's nearest: NaN bits (no candidate yet, NaN distance) lose
+      const float od = __uint_as_float((uint32_t)((better ? key[i] : k2) >> 32));
+      d2[i] = od < d2[i] ? od : d2[i];
+      if (better) { key[i] = k2; bs[i] = j; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BQ; ++i) {
+    unsigned long long k = key[i];
+    float m = d2[i];
+#pragma unroll
+    for (int d = GS_WAVE / 2; d > 0; d >>= 1) {
+      const unsigned long long o = __shfl_xor(k, d, GS_WAVE);
+      k = o < k ? o : k;
+      const float om = __shfl_xor(m, d, GS_WAVE);
+      m = om < m ? om : m;
+    }
+    if ((threadIdx.x & (GS_WAVE - 1)) == 0) { red_m[threadIdx.x / GS_WAVE][i] = k; red_d[threadIdx.x / GS_WAVE][i] = m; }
+  }
+  __syncthreads();
+  float Ra[BQ], Rb[BQ], Rc[BQ];   // nested radii, squared
+#pragma unroll
+  for (int i = 0; i < BQ; ++i) {
+    unsigned long long k = red_m[0][i];
+    float m = red_d[0][i];
+#pragma unroll
+    for (int w = 1; w < BLOCK / GS_WAVE; ++w) {
+      k = red_m[w][i] < k ? red_m[w][i] : k;
+      m = red_d[w][i] < m ? red_d[w][i] : m;
+    }
+    const float bd = __uint_as_float((uint32_t)(k >> 32));   // NaN: nothing found
+    const float d1 = sqrtf(bd), Rm = sqrtf(m);               // (m = +inf: fewer targets than threads -- every one is remembered)
+    const bool open = i < nq && bd == bd && m > bd;
+    const float room = (m < 3.0e38f ? Rm : d1 + 1.0f) - d1;  // (all targets remembered: any radius is covered; one metre)
+    const float tb = d1 + 0.5f * room, tc = d1 + 0.25f * room;
+    Ra[i] = open ? (m < 3.0e38f ? m : (d1 + 1.0f) * (d1 + 1.0f)) : -1.0f;
+    Rb[i] = open ? tb * tb : -1.0f;
+    Rc[i] = open ? tc * tc : -1.0f;
+    if (i < nq) {
+      const int id = ids[i];
+      if (key[i] == k && bs[i] >= 0) bslot_out[id] = bs[i];   // the one thread that holds the winning candidate
+      if (threadIdx.x == 0) key_out[id] = k;
+    }
+    // this thread's nearest candidate goes on the lists whose radius holds it
+    const float md = __uint_as_float((uint32_t)(key[i] >> 32));
+    if (bs[i] >= 0 && md < Ra[i]) {
+      const int pa = atomicAdd(&cnt[0][i], 1);
+      if (pa < GS_FAR_SLOTS) lst[0][i][pa] = (uint32_t)bs[i];
+      if (md < Rb[i]) {
+        const int pb = atomicAdd(&cnt[1][i], 1);
+        if (pb < GS_FAR_SLOTS) lst[1][i][pb] = (uint32_t)bs[i];
+        if (md < Rc[i]) {
+          const int pc = atomicAdd(&cnt[2][i], 1);
+          if (pc < GS_FAR_SLOTS) lst[2][i][pc] = (uint32_t)bs[i];
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < BQ; ++i) {
+    if (i < nq) {   // block-uniform
+      const int r = cnt[0][i] <= GS_FAR_SLOTS ? 0 : (cnt[1][i] <= GS_FAR_SLOTS ? 1 : (cnt[2][i] <= GS_FAR_SLOTS ? 2 : -1));
+      const bool ok = r >= 0 && Ra[i] > 0.0f;
+      const int64_t sq = gbase + ids[i];
+      if (ok)
+        for (int t = threadIdx.x; t < GS_FAR_SLOTS; t += BLOCK)
+          far_c[sq * GS_FAR_SLOTS + t] = r == 0 ? lst[0][i][t] : (r == 1 ? lst[1][i][t] : lst[2][i][t]);
+      if (threadIdx.x == 0) {
+        // (the radius again from its definition -- the reductions are still in LDS: selecting among the register arrays
+        // by r would put them in scratch; d1 + room is sqrt(Ra) up to rounding, which the 0.01 % of the proof covers)
+        unsigned long long k = red_m[0][i];
+        float m = red_d[0][i];
+        for (int w = 1; w < BLOCK / GS_WAVE; ++w) {
+          k = red_m[w][i] < k ? red_m[w][i] : k;
+          m = red_d[w][i] < m ? red_d[w][i] : m;
+        }
+        const float d1 = sqrtf(__uint_as_float((uint32_t)(k >> 32)));
+        const float room = (m < 3.0e38f ? sqrtf(m) : d1 + 1.0f) - d1;
+        const float Rsel = d1 + (r == 0 ? 1.0f : (r == 1 ? 0.5f : 0.25f)) * room;
+        far_cq[sq] = make_float4(q[i][0], q[i][1], q[i][2], ok ? Rsel : 0.0f);
+      }
     }
   }
   __syncthreads();

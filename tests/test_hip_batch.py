@@ -684,7 +684,8 @@ import gradslam_amd as gs
 from gradslam_amd import ops
 from gradslam_amd.datasets.synthetic import make_sequence
 B, L, H, W = int(sys.argv[2]), 4, int(sys.argv[3]), int(sys.argv[4])
-seqs = [make_sequence(L, H, W, seed=3 + b) for b in range(B)]
+first = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+seqs = [make_sequence(L, H, W, seed=3 + b, first=first) for b in range(B)]
 st = lambda k: torch.from_numpy(np.stack([s[k] for s in seqs])).cuda()
 poses = st("poses"); poses[:, 1:] = poses[:, :1]
 frames = gs.RGBDImages(st("colors"), st("depths"), st("intrinsics"), poses)
@@ -734,6 +735,33 @@ def test_candidate_lists_leave_results_identical(tmp_path, B, H, W):
     assert late.max() <= 0.02 * n_lat, late.max()
     if n_lat >= 19200:
         assert st[:, :, 0, 2:40].sum() > 0                       # some list failed somewhere (the counters are alive)
+
+
+@pytest.mark.parametrize("B", [8, 1, 4])
+def test_wide_lists_of_hard_queries_leave_results_identical(tmp_path, B):
+    """Round 5: a source point several cells from every target (a frame border that looks at a surface under a grazing
+    angle: frames 85 .. 88 of the benchmark's camera path, where neighbouring lattice pixels of the right image border
+    are 15 - 30 cm apart) is served by cube scans or a block-wide pass over all targets; whatever serves it leaves a
+    64-slot list that the 16-lane group checks first in every later launch (gs_knn.h: far_write_from_top,
+    block_brute_min_list_multi, wide_list_search).  A proof on the list is exact, so GRADSLAM_HIP_ICP_WIDE=0 must give
+    the same bits at 2 / 8 / 4 lanes per source point -- and the scene must really have such points (launches in which
+    points have no ordinary list because the 2x2x2 stage cannot prove them)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for on in ("1", "0"):
+        out = str(tmp_path / ("wide%s.npz" % on))
+        subprocess.run([sys.executable, "-c", _LIST_SCRIPT % repo, out, str(B), "480", "640", "85"], check=True, timeout=900,
+                       env=dict(os.environ, GRADSLAM_HIP_ICP_WIDE=on))
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.array_equal(a["poses"].view(np.int32), b["poses"].view(np.int32))
+    assert np.array_equal(a["n"], b["n"])
+    assert np.array_equal(a["pts"].view(np.int32), b["pts"].view(np.int32))
+    assert np.array_equal(a["stats"], b["stats"])            # the ordinary lists see the same points either way
+    assert a["stats"][:, :, 2, 4:40].sum() > 0               # points without an ordinary list in list-checking launches
 
 
 def test_pointfusion_1296x968_vs_reference_golden(gs, golden):

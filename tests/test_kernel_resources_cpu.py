@@ -22,3 +22,14 @@ def test_half_iteration_kernels_use_no_scratch_and_fit_two_blocks_per_cu():
         assert int(vgpr) <= 80 and int(occ) >= 6, (name, vgpr, occ)          # 2 blocks of 12 waves per CU
         assert int(lds) <= 80 * 1024, (name, lds)                             # ... and of the 160 KB of LDS
     assert re.search(r"<true, 2, false, 2>", r.stdout) and re.search(r"<false, 8, false, 1>", r.stdout)
+
+
+def test_hand_counted_memory_waits_of_the_list_checking_kernels_are_covered():
+    """the LMODE 2 prologue waits for its hand-issued state load by COUNT (`s_waitcnt vmcnt(N)`); the
+    wait covers the load only while at least N vector-memory instructions are issued between the two.  tools/vmcnt_check.py
+    reads that off the ISA of every list-checking variant (a toolchain or flag change that sank loads past the wait would
+    make every block read a stale state, silently)."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "vmcnt_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("gs_icp_half_batch_kernel")]
+    assert len(rows) == 6 and all(" ok " in ln and "vmcnt(" in ln for ln in rows), r.stdout
