@@ -249,11 +249,14 @@ def cpu_reference(Hh, Ww, odom, frames=3, timeout_s=900):
     if r.returncode != 0 or not os.path.exists(out):
         return {"error": (r.stderr or r.stdout)[-400:]}, None
     d = json.load(open(out))
-    return {"value": d["frames_per_s"], "unit": "frames/s", "cores": d["cores"], "kind": "reference",
+    return {"value": d["frames_per_s"], "unit": "frames/s", "cores": d["cores"], "host_cores": d.get("host_cores"),
+            "kind": "reference",
             "sample": "unmodified gradslam %s PointFusion(odom='%s').step (torch %s, torch.set_num_threads(%d)) on frames 2..%d "
                       "of sequence 0 of the same workload after an untimed map-init frame and one warm-up frame; %.1f s of "
-                      "CPU work; chamferdist.knn_points = the oracle's OpenMP brute force (stand-in KNN: the package is not "
-                      "installed), everything else the reference's own PyTorch code (oracle/_ref, oracle/shims)"
+                      "CPU work; chamferdist.knn_points = the oracle's OpenMP brute force on all host cores (stand-in KNN: "
+                      "the package is not installed), everything else the reference's own PyTorch code with an intra-op "
+                      "pool of `cores` threads -- more threads make its small tensor operations slower (oracle/_ref, "
+                      "oracle/shims, oracle/run_reference.py)"
                       % (d["gradslam_version"], odom, d["torch"], d["cores"], frames - 1, sum(d["seconds_per_frame"][2:])),
             "seconds_per_frame": d["seconds_per_frame"], "surfels_per_frame": d["counts"],
             "total_s": time.perf_counter() - t0}, np.asarray(d["poses"], np.float32)
@@ -676,9 +679,10 @@ def main():
                 "projected under the previous pose; the counting sort of the targets into the grid is impl bytes"),
             4: ("K5 association", 28.0 * c["N"] + 24.0 * c["Na"] + 8.0 * c["P"],
                 "8(d) K5: 28 B per surfel + 24 B frame vertex and normal per in-frame surfel + 8 B key r/w per pixel"),
-            5: ("K6 fuse+append", 120.0 * c["Nm"] + 80.0 * c["Nn"] + 72.0 * c["N"],
+            5: ("K6 fuse+append", 120.0 * c["Nm"] + 80.0 * c["Nn"] + 72.0 * max(c["N"] - c["Nm"], 0.0),
                 "8(d) K6: matched surfel r/w 2 x 40 B + frame 40 B; appended pixel 40 B read + 40 B written; parity mode "
-                "(every row renormalised like the reference) + 2 x 36 B per surfel"),
+                "(every row renormalised like the reference) + 2 x 36 B per UNMATCHED surfel (the matched ones are counted "
+                "once)"),
         }
         groups = {}
         for kind, (name, alg_b, what) in alg_by_kind.items():

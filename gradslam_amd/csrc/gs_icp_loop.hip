@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <memory>
+#include <type_traits>
 
 #include "gs_icp_math.h"
 #include "gs_knn.h"
@@ -118,9 +119,10 @@ GS_DEV void icp_sum_rows_split(const double* __restrict__ partials, int nrows, d
       for (int b = j * CH, r = 0; r == 0 || b < nrows; b += CH * STEP, ++r) {   // (r > 0: solves of more than 432 rows)
         // UNCONDITIONAL loads, masked afterwards: a load under a branch may not have been issued, and the compiler then
         // has to wait for ALL outstanding loads wherever it needs an older one -- here that would drain the gathers the
-        // hook puts in flight.  Rows beyond nrows (at most 24 x 18 of them from the start of the buffer, < 100 KB) are
-        // read from what follows the rows in the caller's scratch (the second row buffer, the grid: megabytes) and never
-        // looked at; one base address + immediate offsets, as in icp_sum_rows.
+        // hook puts in flight.  Rows beyond nrows (at most 24 x 18 of them from the start of the buffer, 97 KB; the
+        // single-column variant below: FS_BLOCK rows, 172 KB) are read from what follows the rows in the caller's
+        // scratch (the second row buffer, the grid, the lists -- localize_chunk checks that they cover it before it
+        // plans a solve with lists) and never looked at; one base address + immediate offsets, as in icp_sum_rows.
         const int b0 = b + half * HC;
         const int left = act ? nrows - b0 : 0;
         const double* base = partials + (int64_t)b0 * LIN_NV + i;
@@ -341,6 +343,11 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
   __shared__ double sub_s[NU][FS_RG][LIN_NV];
   __shared__ int unres_q[NQ], hard_q[NQ];   // (hard_q: slot | FS_HQ_* flags)
   __shared__ int unres_n, hard_n;
+  // (LMODE 2) points whose list gave no proof: re-searched after the check by 16-lane groups (the 2x2x2 block as one flat
+  // candidate list, 4 candidates per lane at 65 per block in a mature map: two round trips instead of the eight a 2-lane
+  // group needs inline -- a launch with failing lists is as slow as its slowest group)
+  __shared__ int fail_q[LMODE == 2 ? NQ : 1];
+  __shared__ int fail_n;
   __shared__ unsigned long long red[FS_BLOCK / GS_WAVE];
   __shared__ uint8_t far_s[NQ];   // the query's candidate list proved this search (it keeps its flag)
   // (LMODE 2) source point and (list centre, radius) of every group, parked across the scalar stage of the prologue: its
@@ -490,6 +497,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
       if (threadIdx.x == 0) {
         unres_n = 0;
         hard_n = 0;
+        fail_n = 0;
         lfail_s[0] = lfail_s[1] = lfail_s[2] = 0;
       }
     }
@@ -505,6 +513,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
         if (q.tape_sys && lb == 0) tape_write_sys(q.tape_sys, it, S, sm.damp);
         unres_n = 0;
         hard_n = 0;
+        fail_n = 0;
         lfail_s[0] = lfail_s[1] = lfail_s[2] = 0;
       }
     }
@@ -555,6 +564,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
       float qx, qy, qz;
       gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
       bool done;
+      bool refail = false;   // (LMODE 2) the list gave no proof: 16-lane re-search of the 2x2x2 block behind the check
       int win;
       unsigned long long key;
       if (LMODE == 2 && verify) {
@@ -591,19 +601,13 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
           // (failure counters: per block in LDS, three global atomics per block below -- thousands of failing groups
           // adding to ONE global word serialise at ~12 ns each, which made a launch with many failures three times as long)
           if (lane == 0) atomicAdd(&lfail_s[lqv.w < 0.0f ? 2 : (lqv.w == 0.0f ? 1 : 0)], 1);
-          // No proof from the list: the group scans the 2x2x2 block itself, right here, and leaves a new list for where
-          // the point is now (as the building launch does).  A launch in which many lists fail -- the cloud has moved by
-          // millimetres -- then costs what a launch without lists costs, not more; sending the failures to the 16-lane
-          // left-over pass instead made such launches two to three times as long.
+          // No proof from the list: the point is re-searched behind the check by a 16-lane group, which scans the 2x2x2
+          // block as one flat candidate list and leaves a new list for where the point is now (round 5; round 4 had the
+          // point's own G lanes do it right here: in a mature map the block holds ~65 candidates, eight dependent round
+          // trips for two lanes with four gathers in flight, and every block of a launch with failing lists waited for
+          // that; the cube scans of the left-over pass, which round 4 tried instead, are slower still).
           // (R < 0: the 2x2x2 stage could not prove this point when it was last tried -- straight to the cube scans)
-          if (lqv.w >= 0.0f) {
-            GlTop<LK> top;
-            gl_top_reset<LK>(top);
-            float rc2;
-            key = grid_search_stage0_top<G, LK>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win, top, &rc2);
-            if (done) gl_write_lanes<G, LK>(top, rc2, qx, qy, qz, lane, ls + GL_SLOTS * s, lq + s);
-            else if (lane == 0) lq[s] = make_float4(qx, qy, qz, -1.0f);   // (the cubes below may still give it a list)
-          }
+          refail = lqv.w >= 0.0f;
         }
       } else {
         if (build_all) {
@@ -637,10 +641,47 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
         qs[slot][0] = qx; qs[slot][1] = qy; qs[slot][2] = qz;
         keys_s[slot] = key;
         if (FAR) far_s[slot] = 0;
-        if (!done) hard_q[atomicAdd(&hard_n, 1)] = slot | (has_far ? FS_HQ_FAR : 0);
+        if (!done) {
+          if (LMODE == 2 && refail) fail_q[atomicAdd(&fail_n, 1)] = slot;
+          else hard_q[atomicAdd(&hard_n, 1)] = slot | (has_far ? FS_HQ_FAR : 0);
+        }
       }
     }
     __syncthreads();
+    if (LMODE == 2) {
+      const int nf = fail_n;   // block-uniform
+      // lanes per re-searched point by how many there are (block-uniform): 32 lanes see the ~65 candidates of a mature map
+      // in two or three round trips (up to 24 points in one round of groups), 16 in four or five (48 points per round)
+      auto research = [&](auto fg_tag) {
+        constexpr int FG = decltype(fg_tag)::value;
+        for (int i = threadIdx.x / FG; i < nf; i += FS_BLOCK / FG) {
+          const int hs = fail_q[i], lf = threadIdx.x & (FG - 1);
+          const float hx = qs[hs][0], hy = qs[hs][1], hz = qs[hs][2];
+          const int64_t sq = (int64_t)u0 * FS_QPB + hs;
+          constexpr int KF = 2;   // candidates a lane remembers for the new list (the M nearest of 2 FG)
+          GlTop<KF> top;
+          gl_top_reset<KF>(top);
+          float rc2;
+          bool fdone;
+          int fwin;
+          const unsigned long long fkey = grid_search_stage0_top<FG, KF>(g, cell_start, sorted, hx, hy, hz, lf, &fdone, &fwin, top, &rc2);
+          if (fdone) gl_select_write<FG, KF>(top, rc2, hx, hy, hz, lf, LM, ls + GL_SLOTS * sq, lq + sq);
+          else if (lf == 0) lq[sq] = make_float4(hx, hy, hz, -1.0f);   // (the cubes below may still give it a list)
+          if (fwin >= 0) bslot_s[hs] = fwin;   // one writer: the winning lane
+          if (lf == 0) {
+            keys_s[hs] = fkey;
+            if (!fdone) hard_q[atomicAdd(&hard_n, 1)] = hs;
+          }
+        }
+      };
+      if (nf > FS_BLOCK / 32) research(std::integral_constant<int, 16>{});
+      else if (nf) research(std::integral_constant<int, 32>{});
+      if (nf) {
+        __syncthreads();
+        if (threadIdx.x == 0) fail_n = 0;
+        __syncthreads();
+      }
+    }
     if (LMODE == 2 && threadIdx.x < 3 && ql.lstat) {   // failure counters of this launch (diagnostics)
       const int hl = 2 * it + (FULL ? 0 : 1);         // launch index within the solve
       const int c = lfail_s[threadIdx.x];
@@ -687,8 +728,6 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
         int kdone = 0;
         if (LISTS) {
           key = grid_search_rings_top<FS_HG, KH>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, top, &rc2);
-          // (whatever the lanes remember of the proving cube is the point's wide list from now on)
-          if (WL && wl_on && done) far_write_from_top<FS_HG, KH>(top, rc2, hx, hy, hz, l16, wl_c + GS_FAR_SLOTS * sq, wl_cq + sq);
         }
         else key = grid_search_rings<FS_HG>(g, cell_start, sorted, hx, hy, hz, l16, key, &done, &win, FS_HARD_RINGS, &kdone);
         // first halves with a list-building pass behind them (fs_far_pass): queries that needed a cube of radius >=
@@ -701,8 +740,11 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
       }
       // (list variants) the scan that served the point leaves its list; what only the brute-force pass can serve keeps none
       if (LISTS && !(WL && listed)) {   // (a point its wide list served keeps what it has: no ordinary list, R < 0)
-        if (done) gl_select_write<FS_HG, KH>(top, rc2, hx, hy, hz, l16, LM, ls + GL_SLOTS * sq, lq + sq);
-        else if (l16 == 0) lq[sq] = make_float4(hx, hy, hz, -1.0f);
+        if (done) {
+          // (whatever the lanes remember of the proving cube is the point's wide list from now on)
+          if (WL && wl_on) far_write_from_top<FS_HG, KH>(top, rc2, hx, hy, hz, l16, wl_c + GS_FAR_SLOTS * sq, wl_cq + sq);
+          gl_select_write<FS_HG, KH>(top, rc2, hx, hy, hz, l16, LM, ls + GL_SLOTS * sq, lq + sq);
+        } else if (l16 == 0) lq[sq] = make_float4(hx, hy, hz, -1.0f);
       }
       if (win >= 0) bslot_s[hs] = win;  // a candidate of the list / the cubes beat the 2x2x2 stage
       if (l16 == 0) {
@@ -1739,7 +1781,18 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
   const IcpHalfPlan plan = icp_half_plan(n_lat, B, far_on ? 4 : 8);
   // (a block reads the lists of ONE group of row units: solves whose blocks walk several groups keep none)
-  const bool lists_on = ord_lists == 1 && !far_on && plan.upb * plan.G * FS_QPB <= FS_BLOCK;
+  bool lists_on = ord_lists == 1 && !far_on && plan.upb * plan.G * FS_QPB <= FS_BLOCK;
+  // The list variants sum the partial rows with UNCONDITIONAL loads, masked afterwards (icp_sum_col27_hook: row
+  // threadIdx.x of every thread; icp_sum_rows_split: 24 x 18 rows): up to FS_BLOCK rows of LIN_NV doubles from the start
+  // of a row buffer whatever the row count.  What follows the buffers in the scratch (the grid, the lists) must cover
+  // that, or the solve keeps no lists (nothing else enforces the layout).
+  for (int b = 0; b < B && lists_on; ++b) {
+    const char* end = reinterpret_cast<const char*>(seqs[b].scratch) + gs_localize_scratch_bytes(H, W, ds, loc_rows(seqs[b].map));
+    const char* first = reinterpret_cast<const char*>(reduce_rows ? sc[b].rowred : sc[b].partials[1]);
+    if (reinterpret_cast<const char*>(sc[b].partials[0]) > first) first = reinterpret_cast<const char*>(sc[b].partials[0]);
+    if (reinterpret_cast<const char*>(sc[b].partials[1]) > first) first = reinterpret_cast<const char*>(sc[b].partials[1]);
+    if (end - first < (ptrdiff_t)(sizeof(double) * LIN_NV * FS_BLOCK)) lists_on = false;
+  }
   IcpHalfBatch hb;
   hb.B = B;
   int h = 0;

@@ -517,7 +517,7 @@ GS_DEV unsigned long long grid_search_stage0_top(const GsGrid& g, const int* __r
     e3 = e2 + (se2 - sb2);
     total = e3 + (se3 - sb3);
   }
-  constexpr int NF = G >= 16 ? 2 : 4;   // gathers in flight per lane (the 16-lane groups see 32 candidates per round)
+  constexpr int NF = G >= 16 ? 1 : 4;   // gathers in flight per lane (the wide groups see one candidate per lane and round)
   for (int t0 = lane; t0 < total; t0 += NF * G) {
     float4 p[NF];
     int ix[NF];

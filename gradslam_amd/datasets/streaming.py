@@ -90,6 +90,11 @@ class FrameStreamer(object):
         # most), whereas a hipMemcpyAsync enqueued behind a device-side wait blocks the enqueuing thread until the wait
         # resolves (measured: 0.3 - 0.5 ms per copy).
         ev = self.done.get(t - self.RING + 1)
+        if ev is None and self.in_slot[k] >= 0:
+            # frames asked for out of order (or skipped): no event of the steps that read this slot is on record, so
+            # everything enqueued on the frame loop's stream so far stands in for them (conservative, always safe)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
         if ev is not None:
             if self.zero_copy:
                 cs.wait_event(ev)
@@ -107,8 +112,22 @@ class FrameStreamer(object):
             self.ready[k].record(cs)
         self.in_slot[k] = t
 
+    def close(self):
+        """Waits for the copies in flight (the ring buffers are used on the copy stream: they must not go back to the
+        allocator while a transfer still writes them)."""
+        if getattr(self, "copy_stream", None) is not None:
+            self.copy_stream.synchronize()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def frame(self, t):
-        """RGBDImages of frame t for all sequences (float32 on the device); starts the transfer of frame t + 1."""
+        """RGBDImages of frame t for all sequences (float32 on the device); starts the transfer of frame t + 1.
+        The tensors of the returned frame live in a ring slot: they stay valid until frame t + RING - 2 is asked for
+        (a SLAM loop reads frame t in steps t and t + 1 only)."""
         self._prefetch(t)
         k = t % self.RING
         cur = torch.cuda.current_stream(self.device)

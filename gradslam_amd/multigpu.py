@@ -125,10 +125,14 @@ def gather_maps(pointclouds: Pointclouds, dst: Optional[int] = None,
     width = sum(w.values())
     rows = sum(counts)
     cap = max(max(sum(m[0]) for m in meta), 1)
-    if dst is None and world * cap * width * 4 > (ALL_GATHER_MAX_BYTES if max_bytes is None else max_bytes):
+    # what an all_gather makes EVERY rank hold at its peak: the gathered result (all rows of all ranks, every attribute)
+    # plus one padded collective buffer set of the widest attribute (the collectives go attribute by attribute, below)
+    total_rows = sum(sum(m[0]) for m in meta)
+    peak_all = (total_rows * width + (world + 1) * cap * max(list(w.values()) + [0])) * 4
+    if dst is None and peak_all > (ALL_GATHER_MAX_BYTES if max_bytes is None else max_bytes):
         import warnings
-        warnings.warn("gather_maps: %.1f GB per rank for an all_gather of the maps; gathering to rank 0 only"
-                      % (world * cap * width * 4 / 1e9))
+        warnings.warn("gather_maps: an all_gather of the maps would hold %.1f GB on every rank (result + one attribute's "
+                      "collective buffers); gathering to rank 0 only" % (peak_all / 1e9))
         dst = 0
     # One padded (all_)gather PER ATTRIBUTE: the receiving rank then holds world x the widest attribute (3 floats per
     # surfel) at a time next to the result, instead of world x all 10 floats of every rank's padded map plus a packed and

@@ -29,10 +29,13 @@ STEP_GLOBAL_MAPS = os.environ.get("GRADSLAM_HIP_STEP_GLOBAL_MAPS", "0") == "1"
 
 
 def _kwargs_key(kw):
-    """hashable, comparable form of the solver keywords (a tensor-valued dist_thresh compares element-wise otherwise)"""
+    """hashable, comparable form of the solver keywords.  A tensor-valued keyword (dist_thresh) is keyed by identity and
+    version -- storage, shape, in-place modification counter -- NOT by value: reading a device tensor's value is a blocking
+    device-to-host copy, and this key is formed on every step of a loop that is meant to run without a host / device
+    synchronisation.  The value is converted once, when a new StepPlan is built."""
     def norm(v):
         if torch.is_tensor(v):
-            return tuple(float(x) for x in v.detach().reshape(-1).cpu())
+            return ("tensor", v.data_ptr(), int(v._version), tuple(v.shape), str(v.dtype), str(v.device))
         return v
     return tuple(sorted((k, norm(v)) for k, v in kw.items()))
 

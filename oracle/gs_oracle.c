@@ -9,7 +9,8 @@
  * what the reference's Python/PyTorch functions compute on the CPU.  Operation order and
  * FMA usage were determined by bit-comparison against the reference itself imported from
  * /root/reference (torch 2.10 CPU) on the reference's own fixture tests/data/msrd_b2s3
- * (oracle/pin_arithmetic.py re-runs that comparison):
+ * (the comparison is re-run by tests/test_oracle_golden.py against tests/golden/msrd_b0.npz, which
+ * oracle/make_golden.py records from the imported reference):
  *   - large batched matmuls/einsums ([HW,3]x[3,3], [N,3]x[3,3]) : FMA chain, ascending k
  *   - tiny matmuls (4x4 . 4x1 per point, 3x3 . 3x1)              : plain mul/add, ascending k
  *   - torch.cross                                              : fma(a1,b2, -(a2*b1))
