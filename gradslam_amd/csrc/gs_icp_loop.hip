@@ -648,8 +648,10 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
       }
     }
     __syncthreads();
+    if (tl && threadIdx.x == 0 && u0 == u_first) tl[10] = wall_clock64();   // list check / search done
     if (LMODE == 2) {
       const int nf = fail_n;   // block-uniform
+      if (tl && threadIdx.x == 0 && u0 == u_first) tl[12] = (unsigned long long)nf;
       // lanes per re-searched point by how many there are (block-uniform): 32 lanes see the ~65 candidates of a mature map
       // in two or three round trips (up to 24 points in one round of groups), 16 in four or five (48 points per round)
       auto research = [&](auto fg_tag) {
@@ -682,6 +684,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
         __syncthreads();
       }
     }
+    if (tl && threadIdx.x == 0 && u0 == u_first) tl[11] = wall_clock64();   // failed lists re-searched
     if (LMODE == 2 && threadIdx.x < 3 && ql.lstat) {   // failure counters of this launch (diagnostics)
       const int hl = 2 * it + (FULL ? 0 : 1);         // launch index within the solve
       const int c = lfail_s[threadIdx.x];

@@ -134,6 +134,8 @@ GS_DEV int grid_cell(const GsGrid& g, float x, float y, float z) {
 // with 16 / 8 / 4 lanes: every dependent launch pays for the waves it has to start); with 8 sequences per GPU a
 // sequence owns one XCD (32 CUs x 24 waves), where only 2 lanes per query keep all its queries in flight at once.
 constexpr int GQ_G = 8;  // group size of the API-level query kernel and of one-sequence-per-GPU solves
+constexpr int GL_RING_NF = 2;   // gathers in flight per lane of a cube scan (four cost the 2- and 4-lane list variants of the
+                                // half-iteration kernel a spill)
 
 GS_DEV unsigned long long grid_key(float qx, float qy, float qz, const float4 p) {
   const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
@@ -291,9 +293,15 @@ GS_DEV unsigned long long grid_search_rings(const GsGrid& g, const int* __restri
       if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
       const int row = (zz * g.ny + yy) * g.nx;
       const int je = cell_start[row + xb + 1];
-      for (int j = cell_start[row + xa]; j < je; ++j) {
-        const unsigned long long k2 = grid_key(qx, qy, qz, sorted[j]);
-        if (k2 < key) { key = k2; bs = j; }
+      for (int j = cell_start[row + xa]; j < je; j += GL_RING_NF) {   // (as grid_search_rings_top: gathers in flight)
+        float4 p[GL_RING_NF];
+#pragma unroll
+        for (int u = 0; u < GL_RING_NF; ++u) p[u] = sorted[j + u < je ? j + u : je - 1];
+#pragma unroll
+        for (int u = 0; u < GL_RING_NF; ++u) {
+          const unsigned long long k2 = j + u < je ? grid_key(qx, qy, qz, p[u]) : ~0ull;
+          if (k2 < key) { key = k2; bs = j + u; }
+        }
       }
     }
     {
@@ -572,10 +580,18 @@ GS_DEV unsigned long long grid_search_rings_top(const GsGrid& g, const int* __re
       if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
       const int row = (zz * g.ny + yy) * g.nx;
       const int je = cell_start[row + xb + 1];
-      for (int j = cell_start[row + xa]; j < je; ++j) {
-        const unsigned long long k2 = grid_key(qx, qy, qz, sorted[j]);
-        if (k2 < key) { key = k2; bs = j; }
-        gl_top_push<KT>(top, __uint_as_float((uint32_t)(k2 >> 32)), j);
+      // (GL_RING_NF gathers in flight per lane: one candidate per round trip made a cube scan 7 - 16 us in a mature map, and a
+      // launch is as slow as its slowest block -- profiles/r05_c_failing_lookahead_timeline.txt)
+      for (int j = cell_start[row + xa]; j < je; j += GL_RING_NF) {
+        float4 p[GL_RING_NF];
+#pragma unroll
+        for (int u = 0; u < GL_RING_NF; ++u) p[u] = sorted[j + u < je ? j + u : je - 1];
+#pragma unroll
+        for (int u = 0; u < GL_RING_NF; ++u) {
+          const unsigned long long k2 = j + u < je ? grid_key(qx, qy, qz, p[u]) : ~0ull;
+          if (k2 < key) { key = k2; bs = j + u; }
+          gl_top_push<KT>(top, __uint_as_float((uint32_t)(k2 >> 32)), j + u);   // (NaN bits of a masked entry: ignored)
+        }
       }
     }
     {

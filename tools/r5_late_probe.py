@@ -87,6 +87,11 @@ if __name__ == "__main__":
                 pro, sea, rest = us(r[:, 5] - r[:, 1]), us(r[:, 6] - r[:, 5]), us(r[:, 2] - r[:, 6])
                 left = r[:, 3].astype(np.int64)
                 nun = (r[:, 8] & np.uint64(0xffffffff)).astype(np.int64)
+                if r.shape[1] > 13 and (r[:, 11] > 0).any():   # round-5 stamps: check done, failed lists re-searched, how many
+                    chk, rs, hp = us(r[:, 11] - r[:, 5]), us(r[:, 12] - r[:, 11]), us(r[:, 6] - r[:, 12])
+                    nf = r[:, 13].astype(np.int64)
+                    print("         check %5.2f (max %5.2f)  re-search of failed lists %5.2f (max %5.2f; failed per block mean %5.1f max %3d)  "
+                          "left-over pass %5.2f (max %5.2f)" % (chk.mean(), chk.max(), rs.mean(), rs.max(), nf.mean(), nf.max(), hp.mean(), hp.max()))
                 print("  seq %d: blocks %3d  end of last block %6.2f us  life mean %5.2f max %5.2f | prologue %5.2f  "
                       "check/search+left-overs %5.2f (max %5.2f)  rows %5.2f | left-over queries %5d (max per block %3d)  "
                       "brute-force queries %4d (blocks with any %2d)" % (
