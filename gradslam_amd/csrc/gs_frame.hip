@@ -226,7 +226,8 @@ __global__ void __launch_bounds__(256) gs_frame_maps_batch_kernel(
   const size_t b = f / frames_per_K, l = f % frames_per_K;
   const bool tb = (int)f < tabs.n;
   if (tb && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    *tabs.any_flag[f] = 0;
+    tabs.any_flag[f][0] = 0;
+    tabs.any_flag[f][1] = 0;   // ("some pixel has two rows with the same key", gs_fuse.hip)
     if (f == 0 && tabs.call_flag) *tabs.call_flag = 0;
   }
   frame_maps_body(depth + b * stride_seq + l * stride_frame, K16 + 16 * b, H, W, two_sigma_sq, vertex + 3 * f * P,

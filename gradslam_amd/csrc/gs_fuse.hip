@@ -411,12 +411,17 @@ extern "C" int gs_fuse_append_backward_f32(const float* points, const float* nor
 // launch (block b -> sequence b % B on its block b / B); every value is computed by the same arithmetic as in the
 // separate entry points:
 //   U1 per pixel : global vertex / normal under the new pose; clear the per-pixel key and winner tables
-//   U2 per surfel: project, similarity test, per-pixel atomicMin of the (1/ccount, ray) key; pix_of = -1
-//   U3 per surfel: atomicMin of the surfel index among the rows that attain their pixel's key
-//   U4 per pixel : winner -> pix_of[winner] = pixel (+ "any match" flag); count of new pixels per tile
-//   U5 per surfel: confidence-weighted merge (parity mode rewrites every row)       } one launch
+//   U2 per surfel: project, similarity test, per-pixel atomicMin of the (1/ccount, ray) key
+//   U3 (round 5: no longer a pass over the map) the winner of a pixel is the row that attains its key; two rows with the SAME
+//      key (same confidence bits, same distance bits: the lower index wins, slam/fusionutils.py:491-536) are noticed by U2
+//      -- the atomicMin of the second one returns its own key -- which marks the pixel; a small launch then settles the
+//      marked pixels by an atomicMin of the row index and returns at once when no pixel of the frame is marked
+//   U4 per pixel : "any match" flag, count of new pixels per tile (a pixel is matched iff its key was written)
+//   U5 per surfel: winner test (key attained, and no lower-indexed row holds the pixel) + confidence-weighted merge
+//                  (parity mode rewrites every row); the winner writes best_pix                } one launch
 //   U6 per pixel : ordered append of the new pixels; every block derives its output offset from the tile
 //                  counts itself (no separate scan launch); block 0 also writes the new surfel count
+constexpr int32_t MU_TIE_MARK = 0x7fffffff;   // best_pix of a pixel with two rows of the same key, until settled
 struct MuSeq {
   float* points; float* normals; float* colors; float* ccounts;
   GsCount n_map;
@@ -450,7 +455,7 @@ struct MuBatch {
 __global__ void __launch_bounds__(256) gs_mu_pixel_init_kernel(const MuBatch mb) {
   const MuSeq& q = mb.s[blockIdx.x % mb.B];
   const int64_t p = (int64_t)(blockIdx.x / mb.B) * 256 + threadIdx.x;
-  if (p == 0) *q.any_flag = 0;
+  if (p == 0) { q.any_flag[0] = 0; q.any_flag[1] = 0; }   // ([1]: "some pixel has two rows with the same key")
   if (blockIdx.x == 0 && threadIdx.x == 0 && mb.zero_call_flag) *mb.call_flag = 0;
   if (p >= mb.P) return;
   float T[12];
@@ -488,22 +493,34 @@ __global__ void __launch_bounds__(256) gs_mu_project_key_kernel(const MuBatch mb
     else frame_local_maps(q.vertex, q.normal, q.pose16)((int64_t)p, fp, fn);
     if (gs_is_similar_v(q.points, q.normals, fp, fn, n, mb.dist_th, mb.dot_th)) {
       const uint64_t k = gs_assoc_key_v(q.points, q.ccounts, fp, n);
-      atomicMin(reinterpret_cast<unsigned long long*>(&q.key_pix[p]), (unsigned long long)k);
+      const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(&q.key_pix[p]), (unsigned long long)k);
+      // Two rows with the same key at one pixel: whichever arrives second gets its own key back.  (If the key is beaten
+      // later the mark is spurious and harmless; if it stays the minimum, every tie of the winning key has been seen:
+      // the first of the tied rows to arrive set it, every later one reads it back.)  The pixel is marked -- any value
+      // that is neither "no winner" (-1) nor a row index below it -- and settled by gs_mu_tie_pick_kernel.
+      if (old == (unsigned long long)k) {
+        q.best_pix[p] = MU_TIE_MARK;
+        q.any_flag[1] = 1;   // benign race: every writer stores the same value
+      }
       q.key_pt[n] = k;
       pk = p;
     }
   }
   q.pix[n] = pk;
-  q.pix_of[n] = -1;
 }
 
-__global__ void __launch_bounds__(256) gs_mu_pick_kernel(const MuBatch mb) {
+// Settles the pixels U2 marked: the lowest-indexed row among those that attain the pixel's key.  A handful of blocks that
+// return at once unless the frame has a marked pixel (two surfels with bit-identical confidence and distance: rare).
+constexpr unsigned MU_TIE_BLOCKS = 64;   // per sequence
+__global__ void __launch_bounds__(256) gs_mu_tie_pick_kernel(const MuBatch mb) {
   const MuSeq& q = mb.s[blockIdx.x % mb.B];
-  const int64_t n = (int64_t)(blockIdx.x / mb.B) * 256 + threadIdx.x;
-  if (n >= gs_count(q.n_map)) return;
-  const int32_t p = q.pix[n];
-  if (p < 0) return;
-  if (q.key_pt[n] == q.key_pix[p]) atomicMin(reinterpret_cast<unsigned*>(&q.best_pix[p]), (unsigned)n);
+  if (q.any_flag[1] == 0) return;
+  const int64_t n_map = gs_count(q.n_map);
+  for (int64_t n = (int64_t)(blockIdx.x / mb.B) * 256 + threadIdx.x; n < n_map; n += (int64_t)MU_TIE_BLOCKS * 256) {
+    const int32_t p = q.pix[n];
+    if (p < 0 || q.best_pix[p] == -1) continue;   // (-1: unmarked pixel -- its key has one holder)
+    if (q.key_pt[n] == q.key_pix[p]) atomicMin(reinterpret_cast<unsigned*>(&q.best_pix[p]), (unsigned)n);
+  }
 }
 
 // per pixel tile of GS_CP_TILE pixels: inverse map of the winners + number of new pixels of the tile
@@ -511,30 +528,30 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_winner_count_kernel(const M
   __shared__ int smem[GS_CP_BLOCK / GS_WAVE + 1];
   const MuSeq& q = mb.s[blockIdx.x % mb.B];
   const unsigned blk = blockIdx.x / mb.B;
-  const int64_t n_map = gs_count(q.n_map);
   const int64_t base = (int64_t)blk * GS_CP_TILE + (int64_t)threadIdx.x * GS_CP_ITEMS;
   int c = 0;
   // all loads of the tile first (clamped index), then the work: inside the per-pixel control flow they are serialised
-  int32_t nn[GS_CP_ITEMS];
+  uint64_t kk[GS_CP_ITEMS];
   float dd[GS_CP_ITEMS];
 #pragma unroll
   for (int i = 0; i < GS_CP_ITEMS; ++i) {
     const int64_t pc = base + i < mb.P ? base + i : mb.P - 1;
-    nn[i] = q.best_pix[pc];
+    kk[i] = q.key_pix[pc];
     dd[i] = q.depth[pc];
   }
+  bool any = false;
 #pragma unroll
   for (int i = 0; i < GS_CP_ITEMS; ++i) {
     const int64_t p = base + i;
     if (p < mb.P) {
-      const int32_t n = nn[i];
-      if (n >= 0 && n < n_map) {
-        q.pix_of[n] = (int32_t)p;
-        *q.any_flag = 1;  // benign race: every writer stores the same value
-        *mb.call_flag = 1;
-      }
-      if (dd[i] > 0.0f && n < 0) ++c;
+      const bool matched = kk[i] != ~0ull;   // some row wrote its key: the pixel has a winner
+      any = any || matched;
+      if (dd[i] > 0.0f && !matched) ++c;
     }
+  }
+  if (any) {
+    q.any_flag[0] = 1;  // benign race: every writer stores the same value
+    *mb.call_flag = 1;
   }
   int total;
   (void)gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &total);
@@ -549,7 +566,18 @@ GS_DEV void mu_merge_body(const MuBatch& mb, const unsigned bid) {
   // (pc2im_bnhw.shape[0] != 0 is a batch-level test): a sequence without matches is still renormalised when
   // another sequence of the same call has some
   if (*mb.call_flag == 0) return;
-  const int32_t p = q.pix_of[n];
+  // the pixel this row competes for; it wins iff it attains the pixel's key and no lower-indexed row with the same key
+  // holds the pixel (best_pix: -1 = the key has one holder, else the settled holder)
+  int32_t p = q.pix[n];
+  if (p >= 0) {
+    bool win = q.key_pt[n] == q.key_pix[p];
+    if (win) {   // (only the holders of the key look at the entry: an unmarked pixel's has one reader and writer)
+      const int32_t bp = q.best_pix[p];
+      win = bp == -1 || bp == (int32_t)n;
+      if (win && bp == -1) q.best_pix[p] = (int32_t)n;
+    }
+    if (!win) p = -1;
+  }
   if (p < 0 && !mb.renorm_all) return;
   if (q.gvertex) fuse_merge_row(q.points, q.normals, q.colors, q.ccounts, n, p, FrameGlobalMaps{q.gvertex, q.gnormal}, q.rgb, q.alpha);
   else fuse_merge_row(q.points, q.normals, q.colors, q.ccounts, n, p, frame_local_maps(q.vertex, q.normal, q.pose16), q.rgb, q.alpha);
@@ -575,17 +603,17 @@ GS_DEV void mu_append_body(const MuBatch& mb, const unsigned bid) {
   bool keep[GS_CP_ITEMS];
   int c = 0;
   {
-    int32_t nn[GS_CP_ITEMS];  // loads first (see gs_mu_winner_count_kernel)
+    uint64_t kk[GS_CP_ITEMS];  // loads first (see gs_mu_winner_count_kernel)
     float dd[GS_CP_ITEMS];
 #pragma unroll
     for (int i = 0; i < GS_CP_ITEMS; ++i) {
       const int64_t pc = base + i < mb.P ? base + i : mb.P - 1;
-      nn[i] = q.best_pix[pc];
+      kk[i] = q.key_pix[pc];   // (not best_pix: the merge blocks of this launch are writing it)
       dd[i] = q.depth[pc];
     }
 #pragma unroll
     for (int i = 0; i < GS_CP_ITEMS; ++i) {
-      keep[i] = base + i < mb.P && dd[i] > 0.0f && nn[i] < 0;
+      keep[i] = base + i < mb.P && dd[i] > 0.0f && kk[i] == ~0ull;
       c += keep[i] ? 1 : 0;
     }
   }
@@ -669,8 +697,10 @@ static int update_chunk(const gs_update_seq* seqs, int B, int H, int W, float di
     m.key_pt = reinterpret_cast<uint64_t*>(q); q += gs_align(8 * (size_t)(n_map > 0 ? n_map : 1));
     m.pix = reinterpret_cast<int32_t*>(q); q += gs_align(4 * (size_t)(n_map > 0 ? n_map : 1));
     m.pix_of = reinterpret_cast<int32_t*>(q);
-    bytes_assoc += 92.0 * (double)n_map;
-    bytes_fuse += 84.0 * (double)n_map + 49.0 * (double)mb.P;
+    // as built: projection 28 B read + 12 B written (+ 24 B frame gather and 8 B key per competing row); merge 4 + 80 B per
+    // row (+ 20 B of keys / winner entry per competing row), 49 B per pixel for the winner count and the append
+    bytes_assoc += 72.0 * (double)n_map;
+    bytes_fuse += 104.0 * (double)n_map + 49.0 * (double)mb.P;
   }
   const unsigned uB = (unsigned)B;
   const unsigned pb = uB * (unsigned)gs_ceil_div(mb.P, 256), nb = uB * (unsigned)gs_ceil_div(n_max > 0 ? n_max : 1, 256);
@@ -682,7 +712,7 @@ static int update_chunk(const gs_update_seq* seqs, int B, int H, int W, float di
     if (n_max > 0) {
       GsProf prof(GS_PROF_ASSOC, bytes_assoc, st, 2);
       hipLaunchKernelGGL(gs_mu_project_key_kernel, dim3(nb), dim3(256), 0, st, mb);
-      hipLaunchKernelGGL(gs_mu_pick_kernel, dim3(nb), dim3(256), 0, st, mb);
+      hipLaunchKernelGGL(gs_mu_tie_pick_kernel, dim3(uB * MU_TIE_BLOCKS), dim3(256), 0, st, mb);
     }
     GsProf prof(GS_PROF_FUSE, bytes_fuse / 3.0, st, 1);
     hipLaunchKernelGGL(gs_mu_winner_count_kernel, dim3(uB * (unsigned)mb.ntiles), dim3(GS_CP_BLOCK), 0, st, mb);

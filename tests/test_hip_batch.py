@@ -149,6 +149,48 @@ def test_update_map_batch_equals_separate_kernels(ops):
             assert torch.equal(mv[b][k][:n1], bufs[k][:n1]), (b, k)
 
 
+def test_update_map_batch_settles_rows_with_identical_keys(ops):
+    """Round 5: the fused update no longer makes a pass over the map to pick the winner of a pixel -- the row that attains
+    the pixel's key wins, and two rows with bit-identical keys (same confidence, same distance to the pixel's vertex: the
+    LOWER index wins, slam/fusionutils.py:491-536) are noticed by the key pass and settled by a small launch.  Maps in
+    which EVERY row has an exact duplicate with a higher index (and, for the third sequence, two): the batched update must
+    give what the table-level kernels give (bit-exact against the reference's unique-correspondence table,
+    tests/test_hip_parity.py), winners included."""
+    H, W = 120, 160
+    maps = _build_maps(ops, (5, 6, 7), H, W)
+    for i, m in enumerate(maps):     # duplicate every row (twice for the last sequence)
+        n, reps = m["n"], (3 if i == 2 else 2)
+        big = [torch.zeros((reps * n + 2 * H * W, t.shape[1]), device="cuda") for t in m["bufs"]]
+        for t, src in zip(big, m["bufs"]):
+            for r in range(reps):
+                t[r * n:(r + 1) * n] = src[:n]
+        m["bufs"], m["n"] = big, reps * n
+    ref, frames = [], []
+    for m in maps:
+        s = m["seq"]
+        d, pose = dev(s["depths"][2, ..., 0]), dev(s["poses"][2])
+        v, n, a, _ = ops.frame_maps(d, m["K"], SIGMA)
+        gv, gn = ops.global_maps(v, n, d, pose)
+        bufs = [t.clone() for t in m["bufs"]]
+        pix = ops.project_map(bufs[0][:m["n"]], pose, m["K"], H, W)
+        best = ops.associate(pix, bufs[0][:m["n"]], bufs[1][:m["n"]], bufs[3][:m["n"]], gv, gn, DIST_TH, DOT_TH)
+        assert int((best >= 0).sum()) > 1000 and int(best.max()) < m["n"] // (3 if m is maps[2] else 2)   # lowest copy wins
+        n1 = ops.fuse_append_(*bufs, m["n"], best, gv, gn, dev(s["colors"][2]), a, d)
+        ref.append((bufs, n1, best))
+        frames.append((v, n, d, dev(s["colors"][2]), a, pose))
+    st = lambda i: torch.stack([f[i] for f in frames])  # noqa: E731
+    mv = [(*[t.clone() for t in m["bufs"]], m["n"], None) for m in maps]
+    cnt, gv, gn, best = ops.update_map_fusion_batch_(mv, st(0), st(1), st(2), st(3), st(4), st(5),
+                                                     torch.stack([m["K"] for m in maps]), DIST_TH, DOT_TH)
+    counts = host(cnt)
+    for b in range(3):
+        bufs, n1, rbest = ref[b]
+        assert counts[b] == n1
+        assert torch.equal(best[b], rbest), b
+        for k in range(4):
+            assert torch.equal(mv[b][k][:n1], bufs[k][:n1]), (b, k)
+
+
 def _run_pointfusion(gs, seqs, L, odom="gradicp"):
     frames = frames_of(gs, seqs, L)
     pc, rp = gs.slam.PointFusion(odom=odom, device="cuda")(frames)
@@ -864,8 +906,8 @@ def test_pointfusion_long_horizon_vs_reference_golden(gs, golden, name):
     np.testing.assert_allclose(rec[:c], g["poses"][:c], rtol=0, atol=1e-4)
     assert counts[0] == int(g["counts"][0])
     assert max(d["per_frame"][:c]) <= b["drift_calm"] and max(d["per_frame"][:c]) <= 5e-4 * int(g["counts"][c - 1]), d
-    for f in range(c):
-        np.testing.assert_allclose(sums[f], g["sum_points"][f], rtol=0, atol=1e-5 * counts[f] + 4.0 * d["per_frame"][f] + 1e-3)
+    for f in range(c):   # mean surfel position: the maps are the same cloud up to the few rows that differ
+        np.testing.assert_allclose(sums[f] / counts[f], g["sum_points"][f] / float(g["counts"][f]), rtol=0, atol=1e-4)
     # the whole horizon
     assert a_all <= b["ate_all"], a_all
     assert np.abs(rec - g["poses"]).max() <= b["pose_all"]
