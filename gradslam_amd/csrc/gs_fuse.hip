@@ -414,8 +414,8 @@ extern "C" int gs_fuse_append_backward_f32(const float* points, const float* nor
 //   U2 per surfel: project, similarity test, per-pixel atomicMin of the (1/ccount, ray) key
 //   U3 (round 5: no longer a pass over the map) the winner of a pixel is the row that attains its key; two rows with the SAME
 //      key (same confidence bits, same distance bits: the lower index wins, slam/fusionutils.py:491-536) are noticed by U2
-//      -- the atomicMin of the second one returns its own key -- which marks the pixel; a small launch then settles the
-//      marked pixels by an atomicMin of the row index and returns at once when no pixel of the frame is marked
+//      -- the atomicMin of the second one returns its own key -- which marks the pixel; the per-pixel pass U4 then settles the
+//      marked pixels by an atomicMin of the row index (skipped at once when no pixel of the frame is marked)
 //   U4 per pixel : "any match" flag, count of new pixels per tile (a pixel is matched iff its key was written)
 //   U5 per surfel: winner test (key attained, and no lower-indexed row holds the pixel) + confidence-weighted merge
 //                  (parity mode rewrites every row); the winner writes best_pix                } one launch
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(256) gs_mu_project_key_kernel(const MuBatch mb
       // Two rows with the same key at one pixel: whichever arrives second gets its own key back.  (If the key is beaten
       // later the mark is spurious and harmless; if it stays the minimum, every tie of the winning key has been seen:
       // the first of the tied rows to arrive set it, every later one reads it back.)  The pixel is marked -- any value
-      // that is neither "no winner" (-1) nor a row index below it -- and settled by gs_mu_tie_pick_kernel.
+      // that is neither "no winner" (-1) nor a row index below it -- and settled by mu_settle_ties (in the per-pixel pass).
       if (old == (unsigned long long)k) {
         q.best_pix[p] = MU_TIE_MARK;
         q.any_flag[1] = 1;   // benign race: every writer stores the same value
@@ -509,14 +509,13 @@ __global__ void __launch_bounds__(256) gs_mu_project_key_kernel(const MuBatch mb
   q.pix[n] = pk;
 }
 
-// Settles the pixels U2 marked: the lowest-indexed row among those that attain the pixel's key.  A handful of blocks that
-// return at once unless the frame has a marked pixel (two surfels with bit-identical confidence and distance: rare).
-constexpr unsigned MU_TIE_BLOCKS = 64;   // per sequence
-__global__ void __launch_bounds__(256) gs_mu_tie_pick_kernel(const MuBatch mb) {
-  const MuSeq& q = mb.s[blockIdx.x % mb.B];
+// Settles the pixels U2 marked: the lowest-indexed row among those that attain the pixel's key.  Run by the blocks of the
+// per-pixel pass below (which comes between the key pass and the merge anyway) and skipped at once unless the frame has a
+// marked pixel (two surfels with bit-identical confidence and distance).
+GS_DEV void mu_settle_ties(const MuSeq& q, const unsigned blk, const unsigned nblk) {
   if (q.any_flag[1] == 0) return;
   const int64_t n_map = gs_count(q.n_map);
-  for (int64_t n = (int64_t)(blockIdx.x / mb.B) * 256 + threadIdx.x; n < n_map; n += (int64_t)MU_TIE_BLOCKS * 256) {
+  for (int64_t n = (int64_t)blk * GS_CP_BLOCK + threadIdx.x; n < n_map; n += (int64_t)nblk * GS_CP_BLOCK) {
     const int32_t p = q.pix[n];
     if (p < 0 || q.best_pix[p] == -1) continue;   // (-1: unmarked pixel -- its key has one holder)
     if (q.key_pt[n] == q.key_pix[p]) atomicMin(reinterpret_cast<unsigned*>(&q.best_pix[p]), (unsigned)n);
@@ -556,6 +555,7 @@ __global__ void __launch_bounds__(GS_CP_BLOCK) gs_mu_winner_count_kernel(const M
   int total;
   (void)gs_block_excl_scan<GS_CP_BLOCK>(c, smem, &total);
   if (threadIdx.x == 0) q.tile_counts[blk] = total;
+  mu_settle_ties(q, blk, gridDim.x / mb.B);
 }
 
 GS_DEV void mu_merge_body(const MuBatch& mb, const unsigned bid) {
@@ -710,9 +710,8 @@ static int update_chunk(const gs_update_seq* seqs, int B, int H, int W, float di
       hipLaunchKernelGGL(gs_mu_pixel_init_kernel, dim3(pb), dim3(256), 0, st, mb);
     }
     if (n_max > 0) {
-      GsProf prof(GS_PROF_ASSOC, bytes_assoc, st, 2);
+      GsProf prof(GS_PROF_ASSOC, bytes_assoc, st, 1);
       hipLaunchKernelGGL(gs_mu_project_key_kernel, dim3(nb), dim3(256), 0, st, mb);
-      hipLaunchKernelGGL(gs_mu_tie_pick_kernel, dim3(uB * MU_TIE_BLOCKS), dim3(256), 0, st, mb);
     }
     GsProf prof(GS_PROF_FUSE, bytes_fuse / 3.0, st, 1);
     hipLaunchKernelGGL(gs_mu_winner_count_kernel, dim3(uB * (unsigned)mb.ntiles), dim3(GS_CP_BLOCK), 0, st, mb);
