@@ -1568,7 +1568,6 @@ struct FarBuildBatch {
   int B;
   FarBuildSeq s[GS_MAX_BATCH];
 };
-constexpr int64_t FAR_MIN_LATTICE = 40000;   // source lattices from this size on keep candidate lists by default
 constexpr int FAR_BLOCK = 512;
 constexpr int FAR_BLOCKS_PER_SEQ = 64;
 __global__ void __launch_bounds__(FAR_BLOCK) gs_icp_far_build_kernel(const FarBuildBatch fb) {
@@ -1697,15 +1696,17 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
     if (g_gs_prof_on) GS_HIP(hipMemsetAsync(n_valid, 0, 8, st));
   }
   // candidate lists of far queries (gs_knn.h; the results do not depend on them), behind the ordinary lists in the scratch.
-  // Policy (measured): at 1296x968 (78k source points, clusters of far ones at the frame borders)
-  // +4 % frames/s over 200 frames; at 640x480 the handful of far points does not pay for the list checks (-2 %).
-  // GRADSLAM_HIP_ICP_FAR=1 / 0 forces the lists on / off.
+  // Policy: round 3 built them for 1296x968 (78k source points, clusters of far ones at the frame borders: +4 % frames/s
+  // over 200 frames), where they REPLACED the ordinary lists (the two do not fit one kernel).  Round 5: the wide lists of
+  // hard queries (below) give those points lists inside the variants with ordinary lists, and ordinary + wide lists beat the
+  // far lists at 1296x968 by 18 % (780 vs 662 frames/s over 150 frames, same poses: profiles/r05_c5_far_vs_wide.txt) --
+  // so the far lists are opt-in now: GRADSLAM_HIP_ICP_FAR=1.
   static int far_lists = -1;
   if (far_lists < 0) {
     const char* e = getenv("GRADSLAM_HIP_ICP_FAR");
-    far_lists = e ? (atoi(e) != 0 ? 1 : 0) : 2;
+    far_lists = (e && atoi(e) != 0) ? 1 : 0;
   }
-  const bool far_on = (far_lists == 1 || (far_lists == 2 && n_lat >= FAR_MIN_LATTICE)) && prm->numiters > 0;
+  const bool far_on = far_lists == 1 && prm->numiters > 0;
   FarMem fm[GS_MAX_BATCH];
   for (int b = 0; b < B; ++b) {
     fm[b] = far_carve(reinterpret_cast<char*>(sc[b].state) + gs_icp_scratch_bytes(n_lat, loc_rows(seqs[b].map)) +

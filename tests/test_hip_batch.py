@@ -695,8 +695,8 @@ np.savez(sys.argv[1], poses=np.stack(rec), n=np.array([int(pc.points_list[0].sha
 def test_far_candidate_lists_leave_results_identical(tmp_path):
     """Source points far from every target (here: 38 % of the view is missing from the map) get candidate lists after
     the first search of a solve (gs_icp_far_build_kernel) and are then served by 16 gathers instead of a cube scan or
-    a pass over all targets (GRADSLAM_HIP_ICP_FAR=1 forces the lists on at this small size; by default they start at
-    40k source points).  GRADSLAM_HIP_ICP_FAR=0 runs the same frames without lists: poses and the map must be
+    a pass over all targets (GRADSLAM_HIP_ICP_FAR=1 switches the lists on: opt-in since round 5, when ordinary + wide lists
+    became the faster choice at every size).  GRADSLAM_HIP_ICP_FAR=0 runs the same frames without lists: poses and the map must be
     bit-identical, and the lists must actually have been in use.  (This scene is hostile on purpose: half of the far
     points have more than 16 targets within reach or move out of their list's radius, and fall back to the scans.)"""
     import os
@@ -810,7 +810,7 @@ def test_pointfusion_1296x968_vs_reference_golden(gs, golden):
     """BASELINE configs[4] resolution against the REAL reference: 3 frames of PointFusion(gradicp, 20 iterations) at
     1296x968 (tests/golden/pf1296_s3.npz, oracle/make_golden_640.py --height 968 --width 1296 --seed 3; minutes of CPU
     per frame there): pose ATE <= 1e-4 m, identical first frame, surfel counts within 0.05 %, point sums as at
-    640x480.  78k ICP source points per frame, so the solves run with the candidate lists of far queries."""
+    640x480.  78k ICP source points per frame (ordinary + wide candidate lists; 4 lanes per point)."""
     g = golden("pf1296_s3")
     L, H, W = int(g["poses"].shape[0]), int(g["H"]), int(g["W"])
     assert (H, W) == (968, 1296)
