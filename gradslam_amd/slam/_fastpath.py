@@ -120,11 +120,17 @@ class StepPlan(object):
         # (no global maps: the step computes them where the update uses them and never writes them; the container
         # computes them from the local maps and the pose when somebody asks -- the same bits)
         gm = STEP_GLOBAL_MAPS
-        out = torch.empty(B * ((13 if gm else 7) * P + 16), dtype=f32, device=dev)
+        out = torch.empty(B * (13 if gm else 7) * P, dtype=f32, device=dev)
+        # The poses live in an allocation of their own (64 B per sequence): a caller that keeps the recovered poses of every
+        # frame -- every SLAM loop does, slam/icpslam.py:134-137 -- would otherwise pin the 69 MB of maps they were carved
+        # from (8 sequences of 640x480), the caching allocator could never hand a block back, and every step would pay a
+        # fresh hipMalloc of that size on the host thread: usually ~0.1 ms, but 2 ms on a bad day of a shared host, which
+        # made one bench run in six host-bound at half the rate (round 5, profiles/r05_bench_line_slow_host.json).
+        poses_out = torch.empty(B * 16, dtype=f32, device=dev)
         best = torch.empty((B, P), dtype=torch.int32, device=dev)
         o = out.data_ptr()
-        v0, n0, a0, po0 = o, o + 12 * P * B, o + 24 * P * B, o + 28 * P * B
-        gv0, gn0 = po0 + 64 * B, po0 + 64 * B + 12 * P * B
+        v0, n0, a0, po0 = o, o + 12 * P * B, o + 24 * P * B, poses_out.data_ptr()
+        gv0, gn0 = o + 28 * P * B, o + 28 * P * B + 12 * P * B
         # the new counts go to a buffer the MAP owns (two per count group, alternating): a plan serves whatever map it is
         # handed, and a map's live device count must not be a word some other map's next frame writes
         pair = getattr(grp, "_step_counts", None)
@@ -152,9 +158,9 @@ class StepPlan(object):
         live._vertex_map = out[:n3].view(B, 1, H, W, 3)
         live._normal_map = out[n3:2 * n3].view(B, 1, H, W, 3)
         live._alpha_cache = (self.sigma, out[2 * n3:2 * n3 + P * B].view(B, 1, H, W, 1))
-        live._poses = out[7 * P * B:7 * P * B + 16 * B].view(B, 1, 4, 4)
+        live._poses = poses_out.view(B, 1, 4, 4)
         if gm:
-            g = 7 * P * B + 16 * B
+            g = 7 * P * B
             live._global_vertex_map = out[g:g + n3].view(B, 1, H, W, 3)
             live._global_normal_map = out[g + n3:g + 2 * n3].view(B, 1, H, W, 3)
         else:
