@@ -228,10 +228,10 @@ def read_profile(lib, kind):
 
 def cpu_reference(Hh, Ww, odom, frames=3, timeout_s=900):
     """gradslam's OWN CPU path on this machine's host cores, in the same run (north_star): the staged
-    reference (oracle/_ref, python -m oracle.stage_reference; travels like the built .so) through oracle/run_reference.py
+    reference (oracle/_ref/gradslam_ref.zip, python -m oracle.stage_reference; travels like the built .so) through oracle/run_reference.py
     in a subprocess -- PointFusion(odom).step of the unmodified reference on sequence 0, frame 0 = map init, frame 1 =
     warm-up, the rest timed.  Returns (dict or None, poses (frames, 4, 4) or None)."""
-    if not os.path.isfile(os.path.join(REPO, "oracle", "_ref", "gradslam", "slam", "pointfusion.py")):
+    if not os.path.isfile(os.path.join(REPO, "oracle", "_ref", "gradslam_ref.zip")):
         return None, None
     import tempfile
     out = os.path.join(tempfile.mkdtemp(prefix="gs_ref_"), "ref.json")

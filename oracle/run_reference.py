@@ -30,9 +30,10 @@ def main():
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     ref_parent = os.path.join(HERE, "_ref")
-    if not os.path.isfile(os.path.join(ref_parent, "gradslam", "slam", "pointfusion.py")):
-        raise SystemExit("oracle/_ref/gradslam is not staged (python -m oracle.stage_reference in the build container)")
-    for p in (REPO, ref_parent, os.path.join(HERE, "shims")):
+    ref_zip = os.path.join(ref_parent, "gradslam_ref.zip")
+    if not os.path.isfile(ref_zip):
+        raise SystemExit("oracle/_ref/gradslam_ref.zip is not staged (python -m oracle.stage_reference in the build container)")
+    for p in (REPO, ref_zip, os.path.join(HERE, "shims")):   # (the archive is imported in place: zipimport)
         sys.path.insert(0, p)
     warnings.filterwarnings("ignore")
     import importlib.util

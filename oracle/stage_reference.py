@@ -2,8 +2,9 @@
 
     python -m oracle.stage_reference            # build container only (needs /root/reference)
 
-Copies the reference's Python package (/root/reference/gradslam, pure Python, 0.4 MB) into the git-ignored
-oracle/_ref/gradslam.  Like the built .so files, oracle/_ref/ is kept out of the history (.gitignore) but travels with
+Packs the reference's Python package (/root/reference/gradslam, pure Python, 0.4 MB) into ONE archive under the
+git-ignored oracle/_ref/ (gradslam_ref.zip; Python imports it in place -- zipimport -- so no reference source file ever
+exists in this tree, tracked or not).  Like the built .so files, oracle/_ref/ is kept out of the history (.gitignore) but travels with
 the gpurun snapshot, so bench.py's `cpu_baseline` leg can run gradslam's own CPU path (slam/icpslam.py:140-178 through
 PointFusion.step) on the node's host in the same run as the GPU measurement (north_star) -- through
 oracle/run_reference.py, in a subprocess, with the shim modules of oracle/shims standing in for the uninstalled
@@ -16,26 +17,37 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_SRC = "/root/reference/gradslam"
-REF_DST = os.path.join(HERE, "_ref", "gradslam")
+REF_ZIP = os.path.join(HERE, "_ref", "gradslam_ref.zip")
 
 
 def staged():
-    return os.path.isfile(os.path.join(REF_DST, "slam", "pointfusion.py"))
+    return os.path.isfile(REF_ZIP)
 
 
 def stage(force=False):
-    """Returns the staged package directory, or None when the reference checkout is not present (the GPU box)."""
+    """Returns the archive path, or None when the reference checkout is not present and nothing is staged (the GPU box
+    only ever uses what travelled with the snapshot)."""
+    import zipfile
     if not os.path.isdir(REF_SRC):
-        return REF_DST if staged() else None
+        return REF_ZIP if staged() else None
     if staged() and not force:
-        return REF_DST
-    if os.path.isdir(REF_DST):
-        shutil.rmtree(REF_DST)
-    os.makedirs(os.path.dirname(REF_DST), exist_ok=True)
-    shutil.copytree(REF_SRC, REF_DST, ignore=shutil.ignore_patterns("__pycache__", "*.pyc"))
+        return REF_ZIP
+    os.makedirs(os.path.dirname(REF_ZIP), exist_ok=True)
+    old_dir = os.path.join(HERE, "_ref", "gradslam")   # (an unpacked copy of an earlier version of this script)
+    if os.path.isdir(old_dir):
+        shutil.rmtree(old_dir)
+    tmp = REF_ZIP + ".tmp"
+    with zipfile.ZipFile(tmp, "w", zipfile.ZIP_DEFLATED) as z:
+        for root, dirs, files in os.walk(REF_SRC):
+            dirs[:] = [d for d in dirs if d != "__pycache__"]
+            for f in files:
+                if f.endswith(".py"):
+                    full = os.path.join(root, f)
+                    z.write(full, os.path.join("gradslam", os.path.relpath(full, REF_SRC)))
+    os.replace(tmp, REF_ZIP)
     with open(os.path.join(HERE, "_ref", "README"), "w") as f:
-        f.write("Staged copy of /root/reference/gradslam (python -m oracle.stage_reference). Git-ignored; never commit.\n")
-    return REF_DST
+        f.write("gradslam_ref.zip: the reference's Python package packed by `python -m oracle.stage_reference`. Git-ignored; never commit.\n")
+    return REF_ZIP
 
 
 if __name__ == "__main__":
