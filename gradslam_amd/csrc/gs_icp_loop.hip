@@ -693,12 +693,10 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
     // ---- the few queries the 2x2x2 stage did not resolve (neighbour farther than ~half a cell): Chebyshev shells
     // by groups of FS_HG lanes, so that they do not hold up the waves of the common case
     const int nh = hard_n;  // block-uniform
-    // wide lists of hard queries (the variants WITHOUT the far-list machinery): the pointers are fetched here, in the rare
-    // path, through an opaque copy of the descriptor's address -- hoisted to the top of the kernel they would sit in
-    // scalar registers across everything (the plain variants are at their scalar limit: spilled scalars take vector
-    // registers, and those then spill to memory)
-    // (only the variants with ordinary lists keep them: the plain variants -- the first three launches of a solve -- are at
-    // their scalar-register limit, where two more pointers spill scalars into vector registers and those to memory)
+    // wide lists of hard queries (gs_knn.h; IcpHalfWide): kept by the variants with ordinary lists only -- the plain variants
+    // (the first three launches of a solve) are at their scalar-register limit, where two more pointers spill scalars into
+    // vector registers and those to memory; the pointers are read here, where the rare path starts, not at the top of the
+    // kernel
     constexpr bool WL = !FAR && LISTS;
     float4* __restrict__ wl_cq = WL ? qw.cq : nullptr;
     uint32_t* __restrict__ wl_c = WL ? qw.c : nullptr;
