@@ -583,14 +583,14 @@ def main():
     if world > 1:
         ranks_info = [None] * world
         torch.distributed.all_gather_object(ranks_info, mine_info)
-        ids = [(r["device_uuid"] or r["device_index"]) for r in ranks_info]
+        ids = ["%s/%s" % (r["device_uuid"], r["device_index"]) for r in ranks_info]   # (one process per GPU of ONE node)
         if len(set(ids)) != world and not share:   # (two processes on one device: not an N-GPU measurement)
             raise SystemExit("bench.py: %d ranks landed on %d distinct GPUs: %s" % (world, len(set(ids)), ids))
     backend_seen = {"world_size_env": int(os.environ.get("WORLD_SIZE", "1")),
                     "dist_world_size": torch.distributed.get_world_size() if world > 1 else 1,
                     "dist_backend": torch.distributed.get_backend() if world > 1 else None,
                     "cuda_device_count_rank0": torch.cuda.device_count(),
-                    "distinct_devices": len(set((r["device_uuid"] or r["device_index"]) for r in ranks_info)),
+                    "distinct_devices": len(set("%s/%s" % (r["device_uuid"], r["device_index"]) for r in ranks_info)),
                     "shared_gpu_rehearsal": share}
 
     # ---------------- roofline pass: same frames from the same map state, HIP events inside the library
