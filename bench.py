@@ -725,7 +725,7 @@ def main():
         port, op = cpu_baseline(seqs[0], args.cpu_frames, args.odom)
         ate_oracle = ate_np(poses_local[0, :op.shape[0]].cpu().numpy(), op)
         # gradslam's own CPU path, timed here and now; the oracle port stays next to it as a second field
-        ref, ref_poses = cpu_reference(Hh, Ww, args.odom, frames=1 + max(args.cpu_frames, 2)) if mine[0] == 0 else (None, None)
+        ref, ref_poses = cpu_reference(Hh, Ww, args.odom, frames=2 + max(args.cpu_frames, 2)) if mine[0] == 0 else (None, None)   # map init + warm-up + the timed frames
         if ref is not None and ref_poses is not None:
             cpu = dict(ref, port=port)
             nfr = min(L, ref_poses.shape[0])
