@@ -653,7 +653,9 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
       const int nf = fail_n;   // block-uniform
       if (tl && threadIdx.x == 0 && u0 == u_first) tl[12] = (unsigned long long)nf;
       // lanes per re-searched point by how many there are (block-uniform): 32 lanes see the ~65 candidates of a mature map
-      // in two or three round trips (up to 24 points in one round of groups), 16 in four or five (48 points per round)
+      // in two or three round trips (up to 24 points in one round of groups); beyond that 8 lanes with two gathers in
+      // flight each (four or five round trips, 96 points per round: the look-aheads of a solve that wanders lose 50 - 200
+      // lists per block, profiles/r05_c_failing_lookahead_timeline.txt; 16 lanes served 48 per round in as many trips)
       auto research = [&](auto fg_tag) {
         constexpr int FG = decltype(fg_tag)::value;
         for (int i = threadIdx.x / FG; i < nf; i += FS_BLOCK / FG) {
@@ -666,7 +668,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
           float rc2;
           bool fdone;
           int fwin;
-          const unsigned long long fkey = grid_search_stage0_top<FG, KF>(g, cell_start, sorted, hx, hy, hz, lf, &fdone, &fwin, top, &rc2);
+          const unsigned long long fkey = grid_search_stage0_top<FG, KF, (FG >= 16 ? 1 : 2)>(g, cell_start, sorted, hx, hy, hz, lf, &fdone, &fwin, top, &rc2);
           if (fdone) gl_select_write<FG, KF>(top, rc2, hx, hy, hz, lf, LM, ls + GL_SLOTS * sq, lq + sq);
           else if (lf == 0) lq[sq] = make_float4(hx, hy, hz, -1.0f);   // (the cubes below may still give it a list)
           if (fwin >= 0) bslot_s[hs] = fwin;   // one writer: the winning lane
@@ -676,7 +678,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
           }
         }
       };
-      if (nf > FS_BLOCK / 32) research(std::integral_constant<int, 16>{});
+      if (nf > FS_BLOCK / 32) research(std::integral_constant<int, 8>{});
       else if (nf) research(std::integral_constant<int, 32>{});
       if (nf) {
         __syncthreads();

@@ -493,7 +493,7 @@ GS_DEV float gl_group_minf(float v) {
 
 // grid_search_stage0 without a search bound (the whole 2x2x2 block is scanned, so that it bounds the list) and with the
 // lanes' trackers.  *rcov2 = squared distance within which the block holds every target (+inf: no cells behind any face).
-template <int G, int KT>
+template <int G, int KT, int NFI = (G >= 16 ? 1 : 4)>   // NFI: gathers in flight per lane
 GS_DEV unsigned long long grid_search_stage0_top(const GsGrid& g, const int* __restrict__ cell_start,
                                                  const float4* __restrict__ sorted, float qx, float qy, float qz, int lane,
                                                  bool* resolved, int* win, GlTop<KT>& top, float* rcov2) {
@@ -525,7 +525,7 @@ GS_DEV unsigned long long grid_search_stage0_top(const GsGrid& g, const int* __r
     e3 = e2 + (se2 - sb2);
     total = e3 + (se3 - sb3);
   }
-  constexpr int NF = G >= 16 ? 1 : 4;   // gathers in flight per lane (the wide groups see one candidate per lane and round)
+  constexpr int NF = NFI;   // gathers in flight per lane (the wide groups of the re-search pass: one or two -- registers)
   for (int t0 = lane; t0 < total; t0 += NF * G) {
     float4 p[NF];
     int ix[NF];
