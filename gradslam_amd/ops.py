@@ -780,7 +780,7 @@ def localize_list_stats(device, b, H, W, ds, capacity):
 def update_map_fusion_batch_(maps, vertex, normal, depth, rgb, alpha, poses, K, dist_th, dot_th, renorm_all=True,
                              out=None):
     """update_map_fusion of all sequences of a batch, in place on their capacity-backed buffers
-    (gs_update_map_fusion_batch_f32: 5 launches for the whole batch).  maps: per sequence
+    (gs_update_map_fusion_batch_f32: 4 launches for the whole batch).  maps: per sequence
     (points, normals, colors, ccounts, n_bound, n_dev).  vertex / normal / rgb (B, H, W, 3), depth / alpha (B, H, W),
     poses / K (B, 4, 4).  Returns (counts int64 (B,) on the device, gvertex, gnormal, best_pix (B, H*W))."""
     poses, K = _c(poses), _c(K)

@@ -412,7 +412,7 @@ GS_API int gs_fuse_append_backward_f32(const float* points, const float* normals
 
 /* update_map_fusion (slam/fusionutils.py:761-789) of one sequence as ONE call: global maps of the frame under
  * `pose16` (structures/rgbdimages.py:681-762), projection + association of the map (fusionutils.py:198-577) and
- * the confidence-weighted merge + ordered append (fusionutils.py:580-722), regrouped into 5 launches.  Same
+ * the confidence-weighted merge + ordered append (fusionutils.py:580-722), regrouped into 4 launches (round 5: no pick pass over the map).  Same
  * results, bit for bit, as gs_global_maps_f32 + gs_project_map_dc_f32 + gs_associate_dc_f32 +
  * gs_fuse_append_dc_f32.  vertex / normal: LOCAL maps (H, W, 3); alpha (H, W); outputs gvertex / gnormal
  * (H, W, 3), best_pix (H*W) (the correspondence table, -1 = none), new_count_out (must not alias n_map_dev;
@@ -490,7 +490,7 @@ GS_API int gs_localize_far_stats_i64(const void* scratch, int H, int W, int ds, 
 GS_API int gs_localize_list_stats_i64(const void* scratch, int H, int W, int ds, int64_t map_rows, int64_t* out192_host,
                                       void* stream);
 
-/* update_map_fusion (slam/fusionutils.py:761-789) for B sequences: gs_update_map_fusion_dc_f32 per sequence, 6
+/* update_map_fusion (slam/fusionutils.py:761-789) for B sequences: gs_update_map_fusion_dc_f32 per sequence, 4
  * launches for the whole batch.  scratch: gs_update_map_scratch_bytes(map.n_bound, H, W) per sequence. */
 typedef struct gs_update_seq {
   gs_map_view map;          /* all four attributes, capacity >= n_bound + H*W */
