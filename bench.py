@@ -709,17 +709,24 @@ def main():
 
     cpu, ate_oracle, ate_ref, ate_refs = None, None, None, {}
     if (Hh, Ww) == (480, 640) and args.odom == "gradicp" and L <= 64:
-        # the REAL reference's poses (oracle/make_golden_640.py) for every sequence of this rank that has a golden:
-        # seed 0 over 20 frames, seeds 1..3 over 5 frames
+        # the REAL reference's poses (oracle/make_golden_640.py) for every sequence of this rank that has a golden: seed 0
+        # over 60 frames (pf640_l60.npz), seeds 1..7 over 25 frames -- the goldens cover the TIMED window of the default
+        # run (frames 5 .. 24), and the record says for every sequence how many warm-up and how many timed frames it
+        # compared (seeds 1..7 had 5-frame goldens, i.e. warm-up frames only)
         for b, sd in enumerate(mine):
-            gp = os.path.join(REPO, "tests", "golden", "pf640.npz" if sd == 0 else "pf640_s%d.npz" % sd)
-            if os.path.exists(gp):
+            names = ["pf640_l60.npz", "pf640.npz"] if sd == 0 else ["pf640_s%d.npz" % sd]
+            gp = next((q for q in (os.path.join(REPO, "tests", "golden", n_) for n_ in names) if os.path.exists(q)), None)
+            if gp is not None:
                 g = np.load(gp)
                 nfr = min(L, g["poses"].shape[0])
-                ate_refs[str(sd)] = {"value_m": ate_np(poses_local[b, :nfr].cpu().numpy(), g["poses"][:nfr]), "frames": nfr,
-                                     "source": "tests/golden/" + os.path.basename(gp)}
+                mine_p = poses_local[b, :nfr].cpu().numpy()
+                rec = {"value_m": ate_np(mine_p, g["poses"][:nfr]), "frames": nfr, "source": "tests/golden/" + os.path.basename(gp),
+                       "warmup_frames": {"frames": min(Wm, nfr), "value_m": ate_np(mine_p[:min(Wm, nfr)], g["poses"][:min(Wm, nfr)])},
+                       "timed_frames": {"first": Wm, "frames": max(nfr - Wm, 0), "of": K,
+                                        "value_m": ate_np(mine_p[Wm:], g["poses"][Wm:nfr]) if nfr > Wm else None}}
+                ate_refs[str(sd)] = rec
         if rank == 0 and "0" in ate_refs:
-            ate_ref = dict(ate_refs["0"], source="tests/golden/pf640.npz (unmodified gradslam PointFusion on the same sequence)")
+            ate_ref = dict(ate_refs["0"], source=ate_refs["0"]["source"] + " (unmodified gradslam PointFusion on the same sequence)")
     ate_ref_live = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         port, op = cpu_baseline(seqs[0], args.cpu_frames, args.odom)

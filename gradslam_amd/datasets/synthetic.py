@@ -4,7 +4,7 @@ build container) the reference.  Intrinsics follow the TUM convention the refere
 uses (datasets/tum.py:338-346: fx=fy=525, scaled with the image width)."""
 import numpy as np
 
-__all__ = ["make_sequence", "tum_intrinsics", "gt_pose", "path_parameter"]
+__all__ = ["make_sequence", "tum_intrinsics", "gt_pose", "path_parameter", "SCENES"]
 
 
 def tum_intrinsics(H, W):
@@ -38,11 +38,37 @@ def gt_pose(s, yaw_per_frame=0.002, tx_per_frame=0.005):
 
 
 def _scene_depth_at(x_w, y_w):
-    """Height field z = f(x, y) of a static smooth scene in WORLD coordinates."""
+    """Height field z = f(x, y) of a static smooth scene in WORLD coordinates ("wave": the benchmark workload)."""
     return 2.0 + 0.3 * np.sin(3.0 * x_w + 0.4) * np.cos(2.5 * y_w) + 0.2 * x_w
 
 
-def make_sequence(L, H, W, seed=0, hole_frac=0.05, yaw_per_frame=0.002, tx_per_frame=0.005, first=0):
+# "facets": three mutually inclined planes meeting in an apex behind the image centre (a concave corner seen from inside)
+# plus a ridge of triangular profile across two of them.  Point-to-plane residuals on planes do not depend on where
+# along its plane a point is matched, three independent normals pin the translation and the spread of the points the
+# rotation, so the reference's 20 Gauss-Newton iterations CONVERGE on it (on "wave" they are cut off while the solve
+# still slides along the smooth surface by millimetres): the scene on which the long horizon is compared with the
+# reference at BASELINE's 1e-4 m (tests/golden/facets640_l60.npz).
+_FACET_SLOPE = 0.45
+_FACET_DIRS = tuple((np.cos(a), np.sin(a)) for a in (np.pi / 2 + 0.3, np.pi / 2 + 0.3 + 2 * np.pi / 3,
+                                                     np.pi / 2 + 0.3 + 4 * np.pi / 3))
+
+
+def _facets_depth_at(x_w, y_w):
+    x = x_w - 0.15
+    y = y_w + 0.05
+    p = None
+    for cx, cy in _FACET_DIRS:
+        q = _FACET_SLOPE * (cx * x + cy * y)
+        p = q if p is None else np.maximum(p, q)
+    u = 0.8 * x_w - 0.6 * y_w - 0.35   # signed distance from the ridge line
+    ridge = 0.07 * np.maximum(0.0, 1.0 - np.abs(u) / 0.12)
+    return 2.45 - p - ridge
+
+
+SCENES = {"wave": _scene_depth_at, "facets": _facets_depth_at}
+
+
+def make_sequence(L, H, W, seed=0, hole_frac=0.05, yaw_per_frame=0.002, tx_per_frame=0.005, first=0, scene="wave"):
     """Returns dict(colors (L,H,W,3) f32 in [0,255), depths (L,H,W,1) f32 metres with
     `hole_frac` pixels zeroed, intrinsics (1,4,4), poses (L,4,4) ground truth).
 
@@ -52,7 +78,9 @@ def make_sequence(L, H, W, seed=0, hole_frac=0.05, yaw_per_frame=0.002, tx_per_f
 
     first > 0: frames first .. first + L - 1 of the same camera path with their own random stream (holes, colours),
     so that a long sequence can be generated in parallel chunks (bench.py --workload c5); first = 0 is the sequence the
-    parity tests and goldens use."""
+    parity tests and goldens use.
+    scene: "wave" (the benchmark's smooth height field) or "facets" (inclined planes + a ridge, see above)."""
+    scene_fn = SCENES[scene]
     rng = np.random.default_rng(seed if first == 0 else [seed, first])
     K = tum_intrinsics(H, W)
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
@@ -70,7 +98,7 @@ def make_sequence(L, H, W, seed=0, hole_frac=0.05, yaw_per_frame=0.002, tx_per_f
         for _ in range(30):  # fixed point: world z of the ray point must equal the height field
             pc = np.stack([rx * d, ry * d, d], -1)
             pw = pc @ R.T + t
-            zw = _scene_depth_at(pw[..., 0] + phase, pw[..., 1])
+            zw = scene_fn(pw[..., 0] + phase, pw[..., 1])
             # move along the ray so that world-z matches (R is close to identity)
             d = d + (zw - pw[..., 2]) / R[2, 2]
         holes = rng.random((H, W)) < hole_frac

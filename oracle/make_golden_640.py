@@ -13,6 +13,9 @@ Build-container only (minutes of CPU).  Outputs (committed, travel to the GPU bo
     python -m oracle.make_golden_640 --slam icpslam --odom icp --frames 8 --tag icpslam640
   tests/golden/icpslam640.npz        the same for ICPSLAM (hard-LM ICP odometry, aggregate mapping)
     python -m oracle.make_golden_640 --odom gt --frames 8 --tag pf640_gt
+    python -m oracle.make_golden_640 --scene facets --frames 60 --tag facets640_l60
+  tests/golden/facets640_l60.npz     the "facets" scene (inclined planes + a ridge): the reference's solves converge on it, so
+                                     BASELINE's ATE <= 1e-4 m can be asserted over the whole horizon (round 6)
   tests/golden/pf640_gt.npz          PointFusion with GROUND-TRUTH odometry: the fusion path (K5 / K6) across frames with
                                      no ICP in the loop (+ sha256 of the first map's tables, which are exact)
 """
@@ -41,6 +44,10 @@ def main():
     ap.add_argument("--tag", default="pf640")
     ap.add_argument("--slam", default="pointfusion", choices=["pointfusion", "icpslam"])
     ap.add_argument("--odom", default="gradicp", choices=["gradicp", "icp", "gt"])
+    ap.add_argument("--scene", default="wave", choices=["wave", "facets"],
+                    help="gradslam_amd.datasets.synthetic scene: the benchmark's smooth height field, or inclined planes + a "
+                         "ridge (the scene on which the reference's 20 iterations converge: long-horizon parity)")
+    ap.add_argument("--threads", type=int, default=0, help="intra-op threads of the reference (default: all cores)")
     args = ap.parse_args()
     refimport.import_reference()
     import torch
@@ -51,9 +58,9 @@ def main():
     from gradslam_amd.datasets.synthetic import make_sequence
 
     cores = len(os.sched_getaffinity(0))
-    torch.set_num_threads(cores)
+    torch.set_num_threads(args.threads or cores)
     L, H, W = args.frames, args.height, args.width
-    s = make_sequence(L, H, W, seed=args.seed)
+    s = make_sequence(L, H, W, seed=args.seed, scene=args.scene)
     T = torch.from_numpy
     poses = T(s["poses"][None]).clone()
     if args.odom != "gt":   # (ground-truth odometry reads the frames' own poses: slam/icpslam.py:231-236)
@@ -88,7 +95,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, args.tag + ".npz"), poses=rec, counts=counts, gt_poses=s["poses"],
                         depth_sum=np.float64(s["depths"].astype(np.float64).sum()),
                         color_sum=np.float64(s["colors"].astype(np.float64).sum()),
-                        seed=np.int64(args.seed), H=np.int64(H), W=np.int64(W),
+                        seed=np.int64(args.seed), H=np.int64(H), W=np.int64(W), scene=np.array(args.scene),
                         last_points=pc.points_list[0][-4096:].numpy(),
                         sha_frame0=np.array([sha0.get(k, "") for k in ("points", "normals", "colors")]),
                         **{"sum_" + k: v for k, v in sums.items()})
@@ -97,7 +104,7 @@ def main():
                       "(oracle/shims), everything else is the reference's own PyTorch code"
                       % ("PointFusion" if args.slam == "pointfusion" else "ICPSLAM", args.odom, torch.__version__, W, H,
                          args.seed),
-              "cores": cores, "frames": L, "seconds_per_frame": [float(x) for x in secs],
+              "cores": cores, "torch_threads": args.threads or cores, "frames": L, "seconds_per_frame": [float(x) for x in secs],
               "frames_per_s_steady": float((L - 2) / secs[2:].sum()) if L > 3 else None,
               "machine": "build container (not the GPU box's host)"}
     with open(os.path.join(OUT, "cpu_ref_timing" + ("" if args.tag == "pf640" else "_" + args.tag) + ".json"), "w") as f:

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--odom", default="gradicp")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--scene", default="wave")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     ref_parent = os.path.join(HERE, "_ref")
@@ -56,7 +57,7 @@ def main():
     syn = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(syn)
     L = a.frames
-    s = syn.make_sequence(L, a.height, a.width, seed=a.seed)
+    s = syn.make_sequence(L, a.height, a.width, seed=a.seed, scene=a.scene)
     T = torch.from_numpy
     poses = T(s["poses"][None]).clone()
     poses[:, 1:] = poses[:, :1]
