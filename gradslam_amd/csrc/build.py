@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gs_frame.hip", "gs_assoc.hip", "gs_fuse.hip", "gs_knn.hip", "gs_icp.hip", "gs_icp_loop.hip", "gs_icp_bwd.hip", "gs_ingest.hip"]
-HEADERS = ["gs_common.h", "gs_compact.h", "gs_assoc_dev.h", "gs_knn.h", "gs_knn_bbox.h", "gs_icp_math.h", os.path.join("..", "..", "include", "gradslam_hip.h")]
+HEADERS = ["gs_common.h", "gs_compact.h", "gs_assoc_dev.h", "gs_knn.h", "gs_knn_bbox.h", "gs_icp_math.h", "gs_icp_persist.h", os.path.join("..", "..", "include", "gradslam_hip.h")]
 LIB = os.path.join(HERE, "libgradslam_hip.so")
 # -fno-slp-vectorize: hipcc otherwise packs adjacent f32 ops into v_pk_* instructions, which issue at a
 # quarter of the scalar VALU rate on gfx950 (measured: the brute-force 1-NN kernel ran 1.6x slower packed)

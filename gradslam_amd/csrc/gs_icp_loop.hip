@@ -911,6 +911,8 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_batch_kernel(const Ic
 #endif
 }
 
+#include "gs_icp_persist.h"
+
 static size_t icp_rows(int64_t n_src) { return (size_t)gs_ceil_div(n_src, FS_QPB); }  // >= ceil(n_src / LIN_BLOCK)
 
 // Launch geometry of a half-iteration: lanes per query G, blocks per sequence nb and row units per block upb.
@@ -1390,6 +1392,7 @@ struct LocSeq {
   int* far_n;            // [FS_FAR_PASSES] counters of the far-query lists of the solve, zeroed here
   int* lstat;            // [3 * GL_STAT_LAUNCHES] failure counters of the ordinary candidate lists, zeroed here
   float4* wl_cq;         // [n_lat] wide lists of hard queries: every radius cleared here (NULL: none kept)
+  unsigned* sync;        // [PS_WORDS] ticket / arrival / error words of the persistent solve (gs_icp_persist.h), zeroed here
 };
 struct LocBatch {
   int B, W, ds, Wl;
@@ -1440,6 +1443,8 @@ GS_DEV void loc_prep_block(const LocBatch& lb, const unsigned bid, const unsigne
         for (int i = 0; i < FS_FAR_PASSES; ++i) q.far_n[i] = 0;
       if (q.lstat)
         for (int i = 0; i < 3 * GL_STAT_LAUNCHES; ++i) q.lstat[i] = 0;
+      if (q.sync)
+        for (int i = 0; i < PS_WORDS; ++i) q.sync[i] = 0u;
       if (lb.numiters == 0) icp_write_result(sm, q.pose16, q.out_pose16);
     }
     return;
@@ -1486,6 +1491,7 @@ struct IcpFinishBatch {
   GsIcpState* st[GS_MAX_BATCH];
   const float* compose16[GS_MAX_BATCH];
   float* out_T16[GS_MAX_BATCH];
+  const unsigned* sync[GS_MAX_BATCH];   // sync record of a persistent solve (NULL: none): a raised error word = NaN pose
 };
 __global__ void __launch_bounds__(FS_BLOCK) gs_icp_finish_batch_kernel(const IcpFinishBatch fb, GsCount n_src_c, int buf,
                                                                        gs_icp_params prm) {
@@ -1500,6 +1506,8 @@ __global__ void __launch_bounds__(FS_BLOCK) gs_icp_finish_batch_kernel(const Icp
   icp_update_math((float)e1, sm, prm, it < GS_ICP_MAX_ITERS ? st->trace + 12 * it : nullptr);
   st->s[buf ^ 1] = sm;
   icp_write_result(sm, fb.compose16[b], fb.out_T16[b]);
+  if (fb.sync[b] && fb.sync[b][PS_ERROR] != 0u)   // a block of the persistent solve gave up waiting (gs_icp_persist.h): fail loudly
+    for (int i = 0; i < 16; ++i) fb.out_T16[b][i] = __builtin_nanf("");
 }
 
 static int64_t loc_lattice(int H, int W, int ds) { return (int64_t)((H + ds - 1) / ds) * ((W + ds - 1) / ds); }
@@ -1684,7 +1692,8 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
     sc[b] = cv.sc;
     gm[b] = cv.gm;
     lb.s[b] = LocSeq{q.vertex, q.depth, q.prev_pose16, lattice, sc[b].state, q.out_pose16,
-                     reinterpret_cast<char*>(gm[b].g), n_valid, nullptr, nullptr, nullptr};
+                     reinterpret_cast<char*>(gm[b].g), n_valid, nullptr, nullptr, nullptr,
+                     reinterpret_cast<unsigned*>(sc[b].rowred + LIN_NV)};   // (behind the one row of large solves)
     static int binned_normals = -1;  // GRADSLAM_HIP_ICP_BINNED_NORMALS=0: gather the matches' normals from the map (A/B)
     if (binned_normals < 0) {
       const char* e = getenv("GRADSLAM_HIP_ICP_BINNED_NORMALS");
@@ -1783,9 +1792,31 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
     }
   }
   std::unique_ptr<GsProf> prof_loop(new GsProf(GS_PROF_ICP_FUSED, prof_bytes, st, 2 * prm->numiters));
-  const IcpHalfPlan plan = icp_half_plan(n_lat, B, far_on ? 4 : 8);
+  // The list-checking half-iterations as ONE persistent launch per XCD-resident sequence (gs_icp_persist.h) whenever a
+  // sequence's source points fit the 32 CUs of one XCD at 672 per block (640x480 at dsratio 4: 29 blocks); the launches in
+  // front of it then run at 2 lanes per point (the persistent kernel reads the 4-entry lists two lanes write).
+  // OPT-IN (GRADSLAM_HIP_ICP_PERSIST=1; the results do not depend on it: tests/test_hip_batch.py::
+  // test_persistent_xcd_solve_leaves_results_identical).  Measured, round 6 (profiles/r06_xcd_persistent_*): its steady-state
+  // half-iteration takes 6.5 - 7.6 us against 10.5 - 12.5 us per launch, but a half-iteration in which any list of a block
+  // fails costs ~27 us (re-search 9 + cubes 5 + new lists 3 on top), solves that still move lose lists in every look-ahead,
+  // and the launches in front of it run at 2 lanes per point: +2 % at 8 sequences per GPU over the 20-step window, -6 % for a
+  // lone sequence.  The launch-per-half-iteration path stays the default.
+  static int persist_env = -1;
+  if (persist_env < 0) {
+    const char* e = getenv("GRADSLAM_HIP_ICP_PERSIST");
+    persist_env = (e && atoi(e) == 1) ? 1 : 0;
+  }
+  // (as few blocks as the XCD's CUs allow, equally loaded: 200 row units -> 29 blocks of 7)
+  const int ps_upb = (int)gs_ceil_div((int64_t)icp_rows(n_lat), PS_CUS_PER_XCD);
+  const int ps_nb = (int)gs_ceil_div((int64_t)icp_rows(n_lat), ps_upb > 0 ? ps_upb : 1);
+  bool persist_on = persist_env == 1 && ord_lists == 1 && !far_on && B <= (int)GS_XCDS && ps_upb <= PS_UPB &&
+                    prm->numiters > lists_from + 1 && !getenv("GRADSLAM_HIP_ICP_TIMELINE") &&
+                    !getenv("GRADSLAM_HIP_ICP_LANES");
+  for (int b = 0; b < B && persist_on; ++b) persist_on = gm[b].sorted_n != nullptr;
+  const IcpHalfPlan plan = icp_half_plan(n_lat, B, far_on ? 4 : (persist_on ? 2 : 8));
   // (a block reads the lists of ONE group of row units: solves whose blocks walk several groups keep none)
   bool lists_on = ord_lists == 1 && !far_on && plan.upb * plan.G * FS_QPB <= FS_BLOCK;
+  if (plan.G != 2) persist_on = false;
   // The list variants sum the partial rows with UNCONDITIONAL loads, masked afterwards (icp_sum_col27_hook: row
   // threadIdx.x of every thread; icp_sum_rows_split: 24 x 18 rows): up to FS_BLOCK rows of LIN_NV doubles from the start
   // of a row buffer whatever the row count.  What follows the buffers in the scratch (the grid, the lists) must cover
@@ -1800,7 +1831,9 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   IcpHalfBatch hb;
   hb.B = B;
   int h = 0;
-  for (int it = 0; it < prm->numiters; ++it) {
+  if (!lists_on) persist_on = false;
+  const int ps_it0 = persist_on ? lists_from + 1 : prm->numiters;   // first iteration of the persistent launch
+  for (int it = 0; it < ps_it0; ++it) {
     for (int b = 0; b < B; ++b) {
       const gs_localize_seq& q = seqs[b];
       const float* cur_in = it == 0 ? lb.s[b].lattice : (((it - 1) & 1) ? sc[b].srcB : sc[b].srcA);
@@ -1844,6 +1877,62 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
                            lists_on ? (it == lists_from ? 1 : (it > lists_from ? 2 : 0)) : 0);
     ++h;
   }
+  if (persist_on) {
+    IcpPersistBatch pb;
+    pb.B = B;
+    pb.nb = ps_nb;
+    pb.upb = ps_upb;
+    pb.h0 = h;
+    pb.tl_h = 0;
+    pb.timeline = nullptr;
+    for (int b = 0; b < B; ++b) {
+      const gs_localize_seq& q = seqs[b];
+      pb.s[b] = IcpPersistSeq{((ps_it0 - 1) & 1) ? sc[b].srcB : sc[b].srcA, GsCount{q.map.n_bound, q.map.n_dev}, gm[b].g, gm[b].cell_start,
+                              gm[b].sorted, gm[b].sorted_n, {sc[b].partials[0], sc[b].partials[1]}, sc[b].state, lm[b].lq, lm[b].ls,
+                              lm[b].stat, wide_on ? wm[b].cq : nullptr, wide_on ? wm[b].c : nullptr, lb.s[b].sync};
+    }
+#ifdef GS_ICP_TIMELINE
+    // debugging aid (library built with -DGS_ICP_TIMELINE; GRADSLAM_HIP_ICP_PERSIST_TIMELINE=<path>): per block, the phase
+    // stamps of the LAST iteration's two half-iterations (tools/icp_persist_timeline.py)
+    static const char* ptl_path = getenv("GRADSLAM_HIP_ICP_PERSIST_TIMELINE");
+    static unsigned long long* ptl_buf = nullptr;
+    constexpr size_t PTL_WORDS = 72 * (size_t)GS_XCDS * PS_CUS_PER_XCD;
+    if (ptl_path) {
+      if (!ptl_buf && hipMalloc(&ptl_buf, 8 * PTL_WORDS) != hipSuccess) ptl_buf = nullptr;
+      if (ptl_buf) {
+        (void)hipMemsetAsync(ptl_buf, 0, 8 * PTL_WORDS, st);
+        pb.timeline = ptl_buf;
+        static const char* tl_it_env = getenv("GRADSLAM_HIP_ICP_TIMELINE_IT");
+        pb.tl_h = 2 * (tl_it_env ? atoi(tl_it_env) : prm->numiters - 1);
+      }
+    }
+#endif
+    hipLaunchKernelGGL(gs_icp_persist_kernel, dim3(GS_XCDS * PS_CUS_PER_XCD), dim3(PS_BLOCK), 0, st, pb, n_lat, prm->dist_thresh,
+                       *prm);
+#ifdef GS_ICP_TIMELINE
+    if (pb.timeline) {
+      std::unique_ptr<unsigned long long[]> hbuf(new unsigned long long[PTL_WORDS]);
+      if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hbuf.get(), ptl_buf, 8 * PTL_WORDS, hipMemcpyDeviceToHost) == hipSuccess) {
+        FILE* f = fopen(ptl_path, "w");
+        if (f) {
+          fprintf(f, "# B=%d nb=%d upb=%d h0=%d tl_h=%d: per block: xcc lb end | first half: wait_done sums scalar check rare arrived at_barrier research hard brute - - | look-ahead: the same | start releases... (100 MHz ticks)\n",
+                  B, pb.nb, pb.upb, pb.h0, pb.tl_h);
+          for (size_t i = 0; i < PTL_WORDS / 72; ++i) {
+            const unsigned long long* r = hbuf.get() + 72 * i;
+            if (!r[0]) continue;
+            fprintf(f, "%llu %llu %llu |", r[1], r[2], r[3]);
+            for (int k = 8; k < 32; ++k) fprintf(f, " %llu%s", r[k], k == 19 ? " |" : "");
+            fprintf(f, " | %llu", r[4]);   // block start, then the release time of every half-iteration, then the end
+            for (int k = 32; k < 72; ++k) fprintf(f, " %llu", r[k]);
+            fprintf(f, "\n");
+          }
+          fclose(f);
+        }
+      }
+    }
+#endif
+    h = 2 * prm->numiters;
+  }
   prof_loop.reset();
   {
     GsProf prof(GS_PROF_SOLVE, 1.0, st);
@@ -1854,6 +1943,7 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
       fb.st[b] = sc[b].state;
       fb.compose16[b] = seqs[b].prev_pose16;
       fb.out_T16[b] = seqs[b].out_pose16;
+      fb.sync[b] = persist_on ? lb.s[b].sync : nullptr;
     }
     hipLaunchKernelGGL(gs_icp_finish_batch_kernel, dim3((unsigned)B), dim3(FS_BLOCK), 0, st, fb, n_src_c, h & 1, *prm);
   }

@@ -806,6 +806,31 @@ def test_wide_lists_of_hard_queries_leave_results_identical(tmp_path, B):
     assert a["stats"][:, :, 2, 4:40].sum() > 0               # points without an ordinary list in list-checking launches
 
 
+@pytest.mark.parametrize("B,first", [(8, 0), (1, 0), (3, 85)])
+def test_persistent_xcd_solve_leaves_results_identical(tmp_path, B, first):
+    """Round 6 (opt-in, GRADSLAM_HIP_ICP_PERSIST=1): the list-checking half-iterations of a solve as ONE persistent launch per
+    sequence, resident on one XCD (csrc/gs_icp_persist.h: blocks find their XCD at run time, partial rows by plain stores +
+    one L2 atomic per half-iteration, readers bypass their L1; source points, lists and listed targets stay in registers /
+    LDS across the half-iterations).  Every sum keeps its order and every search its arithmetic, so the bits must be those
+    of the launch-per-half-iteration path: poses, surfel counts, points -- at 8 / 1 / 3 sequences per GPU, the last on
+    frames 85 .. 88 of the camera path, where points without a provable list (cube scans, wide lists, block passes) exist."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for on in ("1", "0"):
+        out = str(tmp_path / ("persist%s.npz" % on))
+        subprocess.run([sys.executable, "-c", _LIST_SCRIPT % repo, out, str(B), "480", "640", str(first)], check=True, timeout=900,
+                       env=dict(os.environ, GRADSLAM_HIP_ICP_PERSIST=on))
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.isfinite(a["poses"]).all()                         # (a block that gives up waiting leaves a NaN pose)
+    assert np.array_equal(a["poses"].view(np.int32), b["poses"].view(np.int32))
+    assert np.array_equal(a["n"], b["n"])
+    assert np.array_equal(a["pts"].view(np.int32), b["pts"].view(np.int32))
+
+
 def test_pointfusion_1296x968_vs_reference_golden(gs, golden):
     """BASELINE configs[4] resolution against the REAL reference: 3 frames of PointFusion(gradicp, 20 iterations) at
     1296x968 (tests/golden/pf1296_s3.npz, oracle/make_golden_640.py --height 968 --width 1296 --seed 3; minutes of CPU
