@@ -1799,8 +1799,10 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   // test_persistent_xcd_solve_leaves_results_identical).  Measured, round 6 (profiles/r06_xcd_persistent_*): its steady-state
   // half-iteration takes 6.5 - 7.6 us against 10.5 - 12.5 us per launch, but a half-iteration in which any list of a block
   // fails costs ~27 us (re-search 9 + cubes 5 + new lists 3 on top), solves that still move lose lists in every look-ahead,
-  // and the launches in front of it run at 2 lanes per point: +2 % at 8 sequences per GPU over the 20-step window, -6 % for a
-  // lone sequence.  The launch-per-half-iteration path stays the default.
+  // and the launches in front of it run at 2 lanes per point: +3.9 / +3.2 / +7.8 % at 8 / 4 / 2 sequences per GPU over the
+  // 20-step window, -1.2 % over the 200-step window, -2 ... -6 % for a lone sequence (profiles/r06_xcd_persistent_ab_bench.json).
+  // Its liveness also rests on the dispatcher placing at least 29 of the launch's blocks on every XCD (every wait is
+  // bounded: a NaN pose, not a hang).  The launch-per-half-iteration path stays the default.
   static int persist_env = -1;
   if (persist_env < 0) {
     const char* e = getenv("GRADSLAM_HIP_ICP_PERSIST");
@@ -1832,7 +1834,19 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   hb.B = B;
   int h = 0;
   if (!lists_on) persist_on = false;
-  const int ps_it0 = persist_on ? lists_from + 1 : prm->numiters;   // first iteration of the persistent launch
+  // first iteration of the persistent launch: GRADSLAM_HIP_ICP_PERSIST_FROM (at least the first one that checks lists).  A
+  // half-iteration in which lists fail costs the persistent kernel more than a launch, and lists fail while the solve
+  // still moves: the early iterations stay with the launches
+  static int persist_from = -1;
+  if (persist_from < 0) {
+    const char* e = getenv("GRADSLAM_HIP_ICP_PERSIST_FROM");
+    persist_from = e && atoi(e) > 0 ? atoi(e) : 0;
+  }
+  int ps_it0 = prm->numiters;
+  if (persist_on) {
+    ps_it0 = persist_from > lists_from + 1 ? persist_from : lists_from + 1;
+    if (ps_it0 >= prm->numiters) { persist_on = false; ps_it0 = prm->numiters; }
+  }
   for (int it = 0; it < ps_it0; ++it) {
     for (int b = 0; b < B; ++b) {
       const gs_localize_seq& q = seqs[b];
