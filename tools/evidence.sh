@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 5, closing evidence: kernel stats + HBM traffic (tools/collect_profiles.sh), per-launch durations of the ICP
+# closing evidence of a round (TAG=r06_a bash tools/evidence.sh on the GPU box): kernel stats + HBM traffic (tools/collect_profiles.sh), per-launch durations of the ICP
 # chain at B = 8 and B = 1, SQ counters and L2 hit rates of the half-iteration kernels -- all of the CLOSING kernel mix
 cd "$GRAFT_REPO_ROOT" || exit 1
 ROOT=$GRAFT_REPO_ROOT
-TAG=${R5_TAG:-r05_c}
+TAG=${TAG:-r06_a}
 O=$ROOT/gpurun_out
 bash tools/collect_profiles.sh $TAG > $O/${TAG}_collect.log 2>&1; tail -3 $O/${TAG}_collect.log
 B="timeout 170 python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline-pass --no-secondary"
@@ -32,7 +32,7 @@ for d in ("sq1", "sq2", "l2"):
             a[0] += float(r["Counter_Value"]); a[1] += 1
 names = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "TCC_HIT_sum", "TCC_MISS_sum"]
 lines = ["# SQ and L2 counters of every kernel of a step, mean per dispatch (three rocprofv3 --pmc passes of",
-         "# \`python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline-pass --no-secondary\`, 8 sequences of 640x480 per launch; closing state of round 5)",
+         "# \`python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline-pass --no-secondary\`, 8 sequences of 640x480 per launch; closing state)",
          "%-52s %6s " % ("kernel", "calls") + " ".join("%20s" % n for n in names) + "   L2 hit rate"]
 for k in sorted(acc, key=lambda k: -max(v[1] for v in acc[k].values())):
     calls = max(v[1] for v in acc[k].values())

@@ -2,7 +2,7 @@
 prologue (6x6 solve, both SE(3) exponentials, the gradLM update: gs_icp_math.h gs_solve_spd6_wave / gs_se3_exp_wave /
 icp_update_math_wave and the exp / log / sincos polynomials they call) runs in float32 instead of float64; the float64
 row sums stay.  NOT a product path and NOT bit-compatible with the oracle: it exists to measure what the float64 chain
-costs per launch (tools/r5_call14.sh runs it next to the product build through GRADSLAM_HIP_LIB; results in
+costs per launch (run next to the product build through GRADSLAM_HIP_LIB; results in
 profiles/r05_f32_scalar_stage_experiment.txt).
 
     python tools/f32_scalar_stage_experiment.py <scratch dir>      -> <scratch dir>/gradslam_amd/csrc/libgradslam_hip.so

@@ -2,8 +2,8 @@
 (profiles/r05_frames_b8.txt: at frames 55..104 every launch of SOME solves takes ~47 us instead of ~12, at 8 sequences per
 launch; sequence 0 alone shows nothing of the kind.)
 
-    python tools/r5_late_probe.py [frames, default 70]          # part 1: ms per step of every seed alone, by frame
-    GRADSLAM_HIP_LIB=.../libgradslam_hip_tl.so GRADSLAM_HIP_ICP_TIMELINE=/tmp/tl.txt python tools/r5_late_probe.py 62 tl
+    python tools/late_frames_probe.py [frames, default 70]          # part 1: ms per step of every seed alone, by frame
+    GRADSLAM_HIP_LIB=.../libgradslam_hip_tl.so GRADSLAM_HIP_ICP_TIMELINE=/tmp/tl.txt python tools/late_frames_probe.py 62 tl
         # part 2 (library built with -DGS_ICP_TIMELINE): the 8 sequences as one batch up to the given frame; per
         # sequence of the last solve's last iteration: block life, phases, left-over / brute-force queries
 """
