@@ -318,7 +318,8 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
 #endif
   static_assert(!(FAR && LISTS), "the two kinds of candidate lists are not combined");
   constexpr int NQ = FS_BLOCK / G, NU = NQ / FS_QPB;
-  constexpr int LK = gl_k<G>(), LM = G * LK;   // list entries per lane / per source point
+  // (LMODE 3 = LMODE 1 with four entries per lane: the 8-entry lists the persistent solve reads, gs_icp_persist.h; 2 lanes only)
+  constexpr int LK = LMODE == 3 ? 4 : gl_k<G>(), LM = G * LK;   // list entries per lane / per source point
   static_assert(NQ % FS_QPB == 0 && 2 * NU <= FS_BLOCK / GS_WAVE && LM <= GL_SLOTS, "block shape");
   const float* __restrict__ src_in = q.src_in;
   float* __restrict__ src_out = q.src_out;
@@ -373,7 +374,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
   // lists are read by blocks that serve ONE group of units (the host plans it so whenever it asks for them)
   // (LMODE is a template parameter: one kernel per mode keeps each of them within the register budget)
   constexpr bool verify = LMODE == 2;
-  constexpr bool build_all = LMODE == 1;
+  constexpr bool build_all = LMODE == 1 || LMODE == 3;
   constexpr bool NPREF = LMODE == 2;   // the list check also fetches the normal of the likely match
   // the source point of the first slot does not depend on the prologue: issue its load first so that
   // the global-memory latency hides behind the scalar stage
@@ -986,6 +987,7 @@ static void icp_half_launch(const IcpHalfPlan& pl, IcpHalfBatch& hb, GsCount n_s
   do {                                                                       \
     if (lmode == 2) GS_HALF_LAUNCH(G_, false, 2);                            \
     else if (lmode == 1) GS_HALF_LAUNCH(G_, false, 1);                       \
+    else if (lmode == 3 && G_ == 2) GS_HALF_LAUNCH(2, false, 3);             \
     else GS_HALF_LAUNCH(G_, false, 0);                                       \
   } while (0)
   // (no 8-lane variant with far-candidate lists: its first half does not fit the register budget; localize_chunk plans
@@ -1834,17 +1836,13 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   hb.B = B;
   int h = 0;
   if (!lists_on) persist_on = false;
-  // first iteration of the persistent launch: GRADSLAM_HIP_ICP_PERSIST_FROM (at least the first one that checks lists).  A
-  // half-iteration in which lists fail costs the persistent kernel more than a launch, and lists fail while the solve
-  // still moves: the early iterations stay with the launches
-  static int persist_from = -1;
-  if (persist_from < 0) {
-    const char* e = getenv("GRADSLAM_HIP_ICP_PERSIST_FROM");
-    persist_from = e && atoi(e) > 0 ? atoi(e) : 0;
-  }
+  // The persistent launch takes over behind the list-building look-ahead, which then leaves 8-entry lists (LMODE 3): the
+  // persistent kernel keeps the four nearest of a list in registers and falls back on the other four, lane by lane, before
+  // anything is re-searched (gs_icp_persist.h).  (Measured with 4-entry lists and a later start, GRADSLAM_HIP_ICP_PERSIST_FROM
+  // = 2 / 5 / 7 / 9 / 12: 7 924 / 7 857 / 7 872 / 7 816 / 7 763 frames/s against 7 623 without -- the earliest start won.)
   int ps_it0 = prm->numiters;
   if (persist_on) {
-    ps_it0 = persist_from > lists_from + 1 ? persist_from : lists_from + 1;
+    ps_it0 = lists_from + 1;
     if (ps_it0 >= prm->numiters) { persist_on = false; ps_it0 = prm->numiters; }
   }
   for (int it = 0; it < ps_it0; ++it) {
@@ -1888,7 +1886,7 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
       u.st_out = &sc[b].state->s[(h + 1) & 1];
     }
     icp_half_launch<false>(plan, hb, n_src_c, prm, it, reduce_rows ? 1 : 0, st,
-                           lists_on ? (it == lists_from ? 1 : (it > lists_from ? 2 : 0)) : 0);
+                           lists_on ? (it == lists_from ? (persist_on ? 3 : 1) : (it > lists_from ? 2 : 0)) : 0);
     ++h;
   }
   if (persist_on) {

@@ -227,6 +227,53 @@ static_assert(PS_LM == 4, "four listed points per lane");
 #define PS_STAMP(k) do { } while (0)
 #endif
 
+// ---- two tiers (round 6).  A point's list in memory has EIGHT entries and the radius R8 within which it holds every target
+// of the position q0 it was made at (global memory: q.lq / q.ls, written by the list-building launch, LMODE 3, and by the
+// passes below).  The lane keeps the FOUR nearest in registers -- tier 1: (centre, R4) and its slots in LDS -- and checks
+// them first; when they give no proof it fetches the eight itself (no pass of the block, no barrier: two round trips),
+// proves on them, and re-centres its tier 1 on where the point is now: the four nearest of the eight, within
+// R4' = min(0.9999 R8 - |q - q0|, distance of the fifth) -- every target that close to q is within R8 of q0, hence one of
+// the eight, hence one of the four.  tools/icp_list_sim.py: in a solve whose steps grow back to millimetres (seed 0, frame
+// 8) 4-entry lists lose 1 281 proofs, 8-entry lists 2; with 4-entry lists every one of those is a re-search pass of its
+// whole block (~20 us: profiles/r06_xcd_persistent_timeline_b8.txt).
+GS_DEV void ps_rank8(const unsigned long long (&k)[8], int (&rank)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int c = 0;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) c += (f != e && k[f] < k[e]) ? 1 : 0;
+    rank[e] = c;   // (keys carry the target index: unique unless ~0, which is never selected)
+  }
+}
+// slots of rank 0 .. 3 and the squared distance of rank 4 (+inf: fewer than five candidates)
+GS_DEV void ps_top4_of8(const unsigned long long (&k)[8], const uint32_t (&s8)[8], uint32_t (&t)[4], float& d5) {
+  int rank[8];
+  ps_rank8(k, rank);
+  d5 = __builtin_inff();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t[j] = ~0u;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (k[e] != ~0ull) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = rank[e] == j ? s8[e] : t[j];
+      if (rank[e] == 4) d5 = __uint_as_float((uint32_t)(k[e] >> 32));
+    }
+  }
+}
+// keys of the eight listed targets seen from (x, y, z): two rounds of four gathers (the points are not kept)
+GS_DEV void ps_keys8(const float4* __restrict__ sorted, const uint32_t (&s8)[8], const uint32_t nsl, float x, float y, float z,
+                     unsigned long long (&k)[8]) {
+#pragma unroll
+  for (int h4 = 0; h4 < 2; ++h4) {
+    float4 pt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pt[u] = sorted[s8[4 * h4 + u] < nsl ? s8[4 * h4 + u] : 0u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) k[4 * h4 + u] = s8[4 * h4 + u] < nsl ? grid_key(x, y, z, pt[u]) : ~0ull;
+  }
+}
+
 // ---- points whose list gave no proof: re-searched IN LINE by 16-lane groups (64 points per round of groups), which leave
 // the new list.  A solve that still moves by tenths of a millimetre per iteration loses a few lists per block in every
 // look-ahead (each block holds 672 points: one is enough), so this pass is on the path of most half-iterations of such a
@@ -251,7 +298,7 @@ GS_DEV void ps_wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 typedef __attribute__((address_space(3))) IcpPersistShared PsLdsShared;
-__device__ __noinline__ void ps_research(PsLdsShared* Lp) {
+__device__ __noinline__ void ps_research(PsLdsShared* Lp, const int u_first) {
   IcpPersistShared& L = *(IcpPersistShared*)Lp;
   const IcpPersistSeq& q = L.q;
   const int nf = L.fail_n;   // block-uniform
@@ -320,8 +367,11 @@ __device__ __noinline__ void ps_research(PsLdsShared* Lp) {
     A.key[2 * l] = k0; A.key[2 * l + 1] = k1;
     A.slot[2 * l] = s0; A.slot[2 * l + 1] = s1;
     A.drop[l] = drop;
-    if (l == 0) A.d5 = __builtin_inff();
+    const int64_t sq = (int64_t)u_first * FS_QPB + hs;   // the point's list in memory
+    uint32_t* __restrict__ ls8 = q.ls + GL_SLOTS * sq;
+    if (l == 0) { A.d5 = __builtin_inff(); A.pad = __builtin_inff(); }
     if (l < 4) L.ls[hs][l] = ~0u;
+    if (l < GL_SLOTS) ls8[l] = ~0u;
     ps_wave_lds_sync();
     int r0 = 0, r1 = 0;   // ranks of this lane's two candidates among the 32 of the group (keys are unique: they carry the index)
 #pragma unroll 8
@@ -330,18 +380,24 @@ __device__ __noinline__ void ps_research(PsLdsShared* Lp) {
       r0 += ke < k0 ? 1 : 0;
       r1 += ke < k1 ? 1 : 0;
     }
+    // (the global slots were cleared by this wave a few instructions ago: memory operations of one wave to one address stay
+    // in order)
     if (k0 != ~0ull) {
       if (r0 < PS_LM) L.ls[hs][r0] = s0;
+      if (r0 < GL_SLOTS) ls8[r0] = s0;
       if (r0 == PS_LM) A.d5 = __uint_as_float((uint32_t)(k0 >> 32));
+      if (r0 == GL_SLOTS) A.pad = __uint_as_float((uint32_t)(k0 >> 32));   // (d9)
       if (r0 == 0) { L.bslot_s[hs] = (int)s0; L.keys_s[hs] = k0; }
     }
     if (k1 != ~0ull) {
       if (r1 < PS_LM) L.ls[hs][r1] = s1;
+      if (r1 < GL_SLOTS) ls8[r1] = s1;
       if (r1 == PS_LM) A.d5 = __uint_as_float((uint32_t)(k1 >> 32));
+      if (r1 == GL_SLOTS) A.pad = __uint_as_float((uint32_t)(k1 >> 32));
     }
     ps_wave_lds_sync();
     if (l == 0) {
-      float out2 = A.d5;
+      float out2 = A.pad;   // the nearest candidate that is not on the 8-entry list: rank 8, or one a lane dropped
 #pragma unroll 8
       for (int e = 0; e < FG; ++e) out2 = A.drop[e] < out2 ? A.drop[e] : out2;
       // proof of the nearest candidate and the bound of the scanned block (grid_search_stage0_top)
@@ -352,11 +408,16 @@ __device__ __noinline__ void ps_research(PsLdsShared* Lp) {
       const float bd = __uint_as_float((uint32_t)(kb >> 32));   // NaN while nothing was found
       const bool fdone = rb > 0.0f && (rb >= 1.0e30f ? bd == bd : bd <= rb * rb);
       const float rcov2 = rb >= 1.0e30f ? __builtin_inff() : (rb > 0.0f ? rb * rb : 0.0f);
-      const float R2 = out2 < rcov2 ? out2 : rcov2;
+      const float R8sq = out2 < rcov2 ? out2 : rcov2;
+      const float R4sq = A.d5 < R8sq ? A.d5 : R8sq;
       if (kb == ~0ull) { L.keys_s[hs] = ~0ull; L.bslot_s[hs] = -1; }
       // (no proof inside the block: the cubes of the out-of-line passes serve the point and may still give it a list)
-      L.lq[hs] = make_float4(qx, qy, qz, fdone ? sqrtf(R2) : -1.0f);
+      L.lq[hs] = make_float4(qx, qy, qz, fdone ? sqrtf(R4sq) : -1.0f);
+      q.lq[sq] = make_float4(qx, qy, qz, fdone ? sqrtf(R8sq) : -1.0f);
       L.relist_s[hs] = 1;
+      // (measured and dropped: re-making lists whose radius leaves the neighbour less than a quarter cell of room by the cube
+      // scans -- their bound is a whole cell, 29 mm, against the 15 - 18 mm of the 2x2x2 block -- made early frames 10 %
+      // faster and late frames 10 % slower: 7 655 against 7 862 frames/s over the 20-step window)
       if (!fdone) L.hard_q[atomicAdd(&L.hard_n, 1)] = hs;
     }
     ps_wave_lds_sync();   // (the group's area is reused by its next point)
@@ -399,8 +460,13 @@ __device__ __noinline__ void ps_hard_passes(PsLdsShared* Lp, const int u_first, 
     if (!listed) {   // (a point its wide list served keeps what it has: no ordinary list, R < 0)
       if (done) {
         if (wl_on) far_write_from_top<FS_HG, KH>(top, rc2, hx, hy, hz, l16, wl_c + GS_FAR_SLOTS * sq, wl_cq + sq);
-        gl_select_write<FS_HG, KH>(top, rc2, hx, hy, hz, l16, PS_LM, &L.ls[hs][0], &L.lq[hs]);
-      } else if (l16 == 0) L.lq[hs] = make_float4(hx, hy, hz, -1.0f);
+        gl_select_write<FS_HG, KH>(top, rc2, hx, hy, hz, l16, GL_SLOTS, q.ls + GL_SLOTS * sq, q.lq + sq);
+        if (l16 < PS_LM) L.ls[hs][l16] = ~0u;   // (tier 1 empty: the next check falls back on the eight and re-centres it)
+        if (l16 == 0) L.lq[hs] = make_float4(hx, hy, hz, 0.0f);
+      } else if (l16 == 0) {
+        L.lq[hs] = make_float4(hx, hy, hz, -1.0f);
+        q.lq[sq] = make_float4(hx, hy, hz, -1.0f);
+      }
     }
     if (win >= 0) L.bslot_s[hs] = win;
     if (l16 == 0) {
@@ -499,11 +565,54 @@ GS_DEV void ps_half(const IcpPersistSeq& q, IcpPersistShared& L, PsRegs& r, cons
           res = 0.0f;
         }
       } else {
-        key = ~0ull;
-        atomicAdd(&L.lfail_s[lqv.w < 0.0f ? 2 : (lqv.w == 0.0f ? 1 : 0)], 1);
-        // (R < 0: the 2x2x2 stage could not prove this point when it was last tried -- straight to the cube scans)
-        if (lqv.w >= 0.0f) L.fail_q[atomicAdd(&L.fail_n, 1)] = slot;
-        else L.hard_q[atomicAdd(&L.hard_n, 1)] = slot;
+        bool served = false;
+        if (lqv.w >= 0.0f) {   // tier 2: the eight entries of the list in memory, by this lane on its own
+          const float4 lq2 = q.lq[s];
+          if (lq2.w > 0.0f) {
+            const uint4 sa = *reinterpret_cast<const uint4*>(q.ls + GL_SLOTS * s), sb = *reinterpret_cast<const uint4*>(q.ls + GL_SLOTS * s + 4);
+            const uint32_t s8[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+            unsigned long long k8[8];
+            ps_keys8(sorted, s8, nsl, qx, qy, qz, k8);
+            unsigned long long kb = ~0ull;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kb = k8[e] < kb ? k8[e] : kb;
+            const float bd8 = __uint_as_float((uint32_t)(kb >> 32));   // NaN: nothing listed
+            const float fx = qx - lq2.x, fy = qy - lq2.y, fz = qz - lq2.z;
+            const float delta0 = sqrtf(fx * fx + fy * fy + fz * fz);
+            if (sqrtf(bd8) + delta0 < lq2.w * 0.9999f) {   // exact on the eight
+              uint32_t t[4];
+              float d5;
+              ps_top4_of8(k8, s8, t, d5);
+              // tier 1 re-centred on q: the four nearest of the eight and the radius within which they hold every target
+              r.cv[0] = sorted[t[0]];   // (t[0]: the match -- it exists, bd8 is a number)
+              r.cn0 = sorted_n[t[0]];
+#pragma unroll
+              for (int j = 1; j < PS_LM; ++j) r.cv[j] = sorted[t[j] != ~0u ? t[j] : 0u];
+              float R4 = lq2.w * 0.9999f - delta0;
+              const float r5 = sqrtf(d5);
+              R4 = r5 < R4 ? r5 : R4;
+              L.lq[slot] = make_float4(qx, qy, qz, R4 > 0.0f ? R4 : 0.0f);
+              *reinterpret_cast<uint4*>(&L.ls[slot][0]) = make_uint4(t[0], t[1], t[2], t[3]);
+              key = kb;
+              win = (int)t[0];
+              gn_row_pn(qx, qy, qz, r.cv[0], r.cn0, a, res);
+              const bool keep = (dist_thresh < 0.0f) || (bd8 < dist_thresh);
+              if (!keep) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) a[i] = 0.0f;
+                res = 0.0f;
+              }
+              served = true;
+            }
+          }
+        }
+        if (!served) {
+          key = ~0ull;
+          atomicAdd(&L.lfail_s[lqv.w < 0.0f ? 2 : (lqv.w == 0.0f ? 1 : 0)], 1);
+          // (R < 0: the 2x2x2 stage could not prove this point when it was last tried -- straight to the cube scans)
+          if (lqv.w >= 0.0f) L.fail_q[atomicAdd(&L.fail_n, 1)] = slot;
+          else L.hard_q[atomicAdd(&L.hard_n, 1)] = slot;
+        }
       }
     }
     L.bslot_s[slot] = win;
@@ -523,7 +632,7 @@ GS_DEV void ps_half(const IcpPersistSeq& q, IcpPersistShared& L, PsRegs& r, cons
   // from it: the new list's nearest entry is the match the search found.
   if (L.fail_n | L.hard_n) {   // block-uniform
     if (L.fail_n) {
-      ps_research((PsLdsShared*)&L);
+      ps_research((PsLdsShared*)&L, u_first);
       gs_barrier_lds();
     }
     PS_STAMP(7);
@@ -637,8 +746,22 @@ __global__ void __launch_bounds__(PS_BLOCK) gs_icp_persist_kernel(const IcpPersi
     uint4 sv = make_uint4(~0u, ~0u, ~0u, ~0u);
     if (live) {
       r.p0 = q.src_in[3 * s]; r.p1 = q.src_in[3 * s + 1]; r.p2 = q.src_in[3 * s + 2];
-      lqv = q.lq[s];
-      sv = *reinterpret_cast<const uint4*>(q.ls + GL_SLOTS * s);
+      // tier 1 from the 8-entry list the launch before left (centre q0, radius R8): the four nearest to q0, within
+      // min(distance of the fifth, R8) of it
+      const float4 lq2 = q.lq[s];
+      lqv = make_float4(lq2.x, lq2.y, lq2.z, lq2.w > 0.0f ? 0.0f : lq2.w);
+      if (r.p0 == r.p0 && lq2.w > 0.0f) {
+        const uint4 sa = *reinterpret_cast<const uint4*>(q.ls + GL_SLOTS * s), sb = *reinterpret_cast<const uint4*>(q.ls + GL_SLOTS * s + 4);
+        const uint32_t s8[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+        unsigned long long k8[8];
+        ps_keys8(q.sorted, s8, nsl, lq2.x, lq2.y, lq2.z, k8);
+        uint32_t t[4];
+        float d5;
+        ps_top4_of8(k8, s8, t, d5);
+        const float r5 = sqrtf(d5);
+        lqv.w = r5 < lq2.w ? r5 : lq2.w;
+        sv = make_uint4(t[0], t[1], t[2], t[3]);
+      }
     }
     L.lq[slot] = lqv;
     *reinterpret_cast<uint4*>(&L.ls[slot][0]) = sv;
