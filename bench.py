@@ -298,7 +298,7 @@ def secondary_measurements(gs, args, frames, device, barrier, Wm, K):
                       alone, K timed steps, with the ICP kernel's mean launch duration from a short profiled pass;
       c3_gradicp      configs[2]: point_to_plane_gradICP on the 640x480 lattice (ds = 4), 20 iterations, forward and
                       forward (taped) + backward through all iterations, ms per call;
-      c5_1296x968     configs[4] shape: one 1296x968 sequence, 60 timed frames, ms per frame against the map size."""
+      c5_1296x968     configs[4] shape: one 1296x968 sequence, 200 timed frames, ms per frame against the map size."""
     import torch
     from gradslam_amd import _C, ops
     lib = _C.lib()
@@ -467,21 +467,22 @@ def secondary_measurements(gs, args, frames, device, barrier, Wm, K):
     except Exception as e:   # noqa: BLE001
         out["steady_200_steps"] = {"error": repr(e)}
 
-    # ---- configs[4] shape: 1296x968, 60 timed frames, growing map
+    # ---- configs[4] shape: 1296x968, 200 timed frames, map growing past 5 M surfels (the 60-frame leg of the
+    # rounds before showed neither; the 205 frames are generated on the host cores in ~15 s; GRADSLAM_BENCH_C5_FRAMES overrides)
     try:
-        Lc, Wc = 5 + 60, 5
+        Lc, Wc = 5 + int(os.environ.get("GRADSLAM_BENCH_C5_FRAMES", "200")), 5
         seqs = make_sequences([0], Lc, 968, 1296, chunk=5)
         fr5 = frames_on_device(gs, seqs, device)
         slam5 = gs.slam.PointFusion(odom=args.odom, device=device)
-        r = timed_steps(gs, slam5, fr5, Wc, Lc - Wc, device, barrier, seg_every=15)
+        r = timed_steps(gs, slam5, fr5, Wc, Lc - Wc, device, barrier, seg_every=50 if Lc > 100 else 15)
         from gradslam_amd.metrics import ate_rmse as ate_np
         out["c5_1296x968"] = {"frames_per_s": (Lc - Wc) / r["elapsed"], "ms_per_frame": r["elapsed"] / (Lc - Wc) * 1e3,
                               "ms_per_frame_first_quartile": r["ms_first_quartile"],
                               "ms_per_frame_last_quartile": r["ms_last_quartile"], "frames_timed": Lc - Wc, "warmup": Wc,
                               "segments": r["segments"], "map_surfels_end": int(r["pc"].points_list[0].shape[0]),
                               "ate_vs_ground_truth_m": ate_np(r["poses"][0].cpu().numpy(), seqs[0]["poses"]),
-                              "what": "one 1296x968 sequence (BASELINE configs[4] shape, first 65 frames of the 500-frame "
-                                      "workload of --workload c5), dynamic map growth"}
+                              "what": "one 1296x968 sequence (BASELINE configs[4] shape, the first %d frames of the 500-frame "
+                                      "workload of --workload c5), dynamic map growth" % Lc}
         del fr5, r
     except Exception as e:   # noqa: BLE001
         out["c5_1296x968"] = {"error": repr(e)}

@@ -13,6 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GRADSLAM_HIP_LIB: another build of the same library (A/B runs of an experimental build on one GPU box); it must export
 # the same symbols and ABI version, and there is still no fallback if it is missing
 LIB_PATH = os.environ.get("GRADSLAM_HIP_LIB") or os.path.join(_HERE, "csrc", "libgradslam_hip.so")
+if os.environ.get("GRADSLAM_HIP_LIB"):   # (a bench line must not come from an experimental build unnoticed)
+    import warnings
+    warnings.warn("GRADSLAM_HIP_LIB overrides the product library: %s" % LIB_PATH, RuntimeWarning)
 ABI_VERSION = 2
 
 _lib = None

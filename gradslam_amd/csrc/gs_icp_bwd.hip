@@ -22,7 +22,7 @@
 // All arithmetic in float64; scatters are float64 atomics (order-independent to ~1e-16, rounded once
 // at the end) -- fast, but the order of the additions into a target that several source points share
 // depends on scheduling, so two runs may differ in the last bit of a float32 gradient.
-// GRADSLAM_HIP_DETERMINISTIC_BACKWARD=1 (round 5, VERDICT r04 #7b) makes the backward bitwise reproducible:
+// GRADSLAM_HIP_DETERMINISTIC_BACKWARD=1 (round 5, VERDICT r04 #7b; read per call) makes the ICP backward bitwise reproducible:
 // the point stages write every source point's contribution next to its target index, the pairs are
 // sorted by target (stable radix sort: equal targets stay in source order) and one thread per target
 // adds its contributions in that order.  About 2.5x the time of the atomic form.
@@ -667,11 +667,12 @@ extern "C" int gs_icp_backward_f32(const void* tape, const float* src_in, int64_
   hipLaunchKernelGGL(gs_bwd_init_kernel, dim3(1), dim3(64), 0, st, sc.state, tp, init16, T_bar16, K, prm->mode);
   double* sbar_next = sc.sbar_a;  // adjoint of src_{k+1}
   double* sbar_mid = sc.sbar_b;
-  static int deterministic = -1;
-  if (deterministic < 0) {
-    const char* e = getenv("GRADSLAM_HIP_DETERMINISTIC_BACKWARD");
-    deterministic = (e && atoi(e) != 0) ? 1 : 0;
-  }
+  // (read on every call -- the backward is milliseconds, the lookup nanoseconds -- so that a process can switch the mode
+  // between two backwards, ADVICE r05.  Scope: the scatter-adds of THIS function, the ICP backward; the fusion and
+  // frame-map backwards have no competing additions into one word.  The sort scratch is part of the backward scratch in
+  // either mode: gs_icp_backward_scratch_bytes is called before the mode of the run that uses it is known.)
+  const char* det_env = getenv("GRADSLAM_HIP_DETERMINISTIC_BACKWARD");
+  const int deterministic = (det_env && atoi(det_env) != 0) ? 1 : 0;
   double* contrib = deterministic ? sc.contrib : nullptr;
   int32_t* ckey = deterministic ? sc.key_in : nullptr;
   if (deterministic) {

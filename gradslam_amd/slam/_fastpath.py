@@ -35,7 +35,11 @@ def _kwargs_key(kw):
     synchronisation.  The value is converted once, when a new StepPlan is built."""
     def norm(v):
         if torch.is_tensor(v):
-            return ("tensor", v.data_ptr(), int(v._version), tuple(v.shape), str(v.dtype), str(v.device))
+            # (id, not data_ptr: the plan keeps the tensors of its key alive -- StepPlan.kw_tensors -- so neither the object nor
+            # its storage address can be reused by another tensor while the plan exists, ADVICE r05.  A write that bypasses the
+            # version counter -- t.data.fill_(x), a foreign kernel -- is not seen: change a tensor threshold by assignment or
+            # by an in-place torch operation.)
+            return ("tensor", id(v), int(v._version), tuple(v.shape), str(v.dtype), str(v.device))
         return v
     return tuple(sorted((k, norm(v)) for k, v in kw.items()))
 
@@ -59,6 +63,7 @@ class StepPlan(object):
         self.seqs = (_C.StepSeq * B)()
         prov = slam.odomprov
         kw = prov._kwargs()
+        self.kw_tensors = [v for v in kw.values() if torch.is_tensor(v)]   # (kept alive: see _kwargs_key)
         self.prm = _C.IcpParams(int(prov._mode), int(kw.get("numiters", 20)), float(kw.get("damp", 1e-8)),
                                 ops._thresh(kw.get("dist_thresh")), float(kw.get("lambda_max", 2.0)),
                                 float(kw.get("B", 1.0)), float(kw.get("B2", 1.0)), float(kw.get("nu", 200.0)))

@@ -48,6 +48,7 @@ def main():
                     help="gradslam_amd.datasets.synthetic scene: the benchmark's smooth height field, or inclined planes + a "
                          "ridge (the scene on which the reference's 20 iterations converge: long-horizon parity)")
     ap.add_argument("--threads", type=int, default=0, help="intra-op threads of the reference (default: all cores)")
+    ap.add_argument("--hole-frac", type=float, default=0.05, help="fraction of depth pixels zeroed per frame")
     args = ap.parse_args()
     refimport.import_reference()
     import torch
@@ -60,7 +61,7 @@ def main():
     cores = len(os.sched_getaffinity(0))
     torch.set_num_threads(args.threads or cores)
     L, H, W = args.frames, args.height, args.width
-    s = make_sequence(L, H, W, seed=args.seed, scene=args.scene)
+    s = make_sequence(L, H, W, seed=args.seed, scene=args.scene, hole_frac=args.hole_frac)
     T = torch.from_numpy
     poses = T(s["poses"][None]).clone()
     if args.odom != "gt":   # (ground-truth odometry reads the frames' own poses: slam/icpslam.py:231-236)
@@ -95,7 +96,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, args.tag + ".npz"), poses=rec, counts=counts, gt_poses=s["poses"],
                         depth_sum=np.float64(s["depths"].astype(np.float64).sum()),
                         color_sum=np.float64(s["colors"].astype(np.float64).sum()),
-                        seed=np.int64(args.seed), H=np.int64(H), W=np.int64(W), scene=np.array(args.scene),
+                        seed=np.int64(args.seed), H=np.int64(H), W=np.int64(W), scene=np.array(args.scene), hole_frac=np.float64(args.hole_frac),
                         last_points=pc.points_list[0][-4096:].numpy(),
                         sha_frame0=np.array([sha0.get(k, "") for k in ("points", "normals", "colors")]),
                         **{"sum_" + k: v for k, v in sums.items()})

@@ -877,32 +877,42 @@ def test_pointfusion_1296x968_vs_oracle(gs):
     np.testing.assert_allclose(host(pc.points_list[0]), m.points, rtol=1e-5, atol=1e-5)
 
 
-# Measured on the MI355X (round 5, profiles/r05_long_horizon_*.json).  `calm`: frames before the first
-# solve of the REFERENCE that has not settled after its 20 iterations (seed 0 at 640x480: frame 28); up to there the build
-# follows the reference to micrometres.  From there on the reference's own trajectory is that of an iteration that is still
-# moving by millimetres when it is cut off (its frame-to-frame error against the ground truth is 3 - 4 mm in EVERY frame,
-# tests/golden/pf640_l60.npz: gt_poses), and float32-sgemm vs float64 normal equations -- or the reference against ITSELF
-# with another thread count, tests/golden/reference_sensitivity_640.json -- end up millimetres apart.
-_LONG_HORIZON = {"pf640_l60": dict(calm=28, ate_calm=1e-5, drift_calm=300, ate_all=6e-3, pose_all=1.2e-2),
-                 "pf1296_s3_l20": dict(calm=20, ate_calm=1e-5, drift_calm=1500, ate_all=1e-4, pose_all=1e-4)}
+# Long horizons against the REAL reference.  `calm`: frames for which the reference reproduces ITSELF (its run with an intra-op
+# pool of 3 threads against its run with 8: another summation order of its float32 matrix products, nothing else) to well
+# below BASELINE's 1e-4 m; there the build is held to BASELINE's bound.  Beyond, the bound is DERIVED from the committed
+# record of that comparison (`sens`): every pose within K_SENS x the running maximum of the reference's own
+# deviation from itself.  On every horizon the HIP path must reproduce the ORACLE's trajectory bit for bit
+# (tests/golden/<name>_oracle.npz, oracle/make_golden_oracle_long.py): the statement that stays exact where the reference
+# is chaotic.
+#   pf640_l60        benchmark scene ("wave"): the reference's solves stop settling within their 20 iterations at frame 28
+#   facets640_l60    inclined planes + ridge WITH 5 % zeroed depth pixels: every solve converges, and the reference still
+#                    drifts from itself from frame 5 on (garbage normals next to the zeroed pixels, amplified by the fused map)
+#   facets640_nh_l60 the same scene WITHOUT zeroed pixels: the reference agrees with itself to 4e-6 m over all 60 frames --
+#                    the scene on which BASELINE's ATE <= 1e-4 m is asserted over the whole horizon (VERDICT r05 #1b)
+#   pf1296_s3_l20    1296x968, 20 frames, 3.5 M surfels
+K_SENS = 4.0
+_LONG_HORIZON = {"pf640_l60": dict(calm=28, ate_calm=1e-5, drift_calm=300, sens="reference_sensitivity_640.json"),
+                 "facets640_l60": dict(calm=5, ate_calm=1e-5, drift_calm=100, sens="reference_sensitivity_facets640_l60.json"),
+                 "facets640_nh_l60": dict(calm=60, ate_calm=2e-5, drift_calm=300, sens=None),
+                 "pf1296_s3_l20": dict(calm=20, ate_calm=1e-5, drift_calm=1500, sens=None)}
 
 
-@pytest.mark.parametrize("name", ["pf640_l60", "pf1296_s3_l20"])
+@pytest.mark.parametrize("name", ["pf640_l60", "facets640_nh_l60", "facets640_l60", "pf1296_s3_l20"])
 def test_pointfusion_long_horizon_vs_reference_golden(gs, golden, name):
-    """the long horizon against the REAL reference, not only against the oracle: 60 frames of the
-    benchmark's sequence 0 at 640x480 (tests/golden/pf640_l60.npz: the window where the solves wander and the map passes
-    1.4 M surfels) and 20 frames at 1296x968 (pf1296_s3_l20.npz, 3.5 M surfels), both recorded by
-    oracle/make_golden_640.py from the imported reference.
-    While the reference's solves settle (`calm` frames): pose ATE <= 1e-4 m (BASELINE.json; measured 1e-6), every pose
-    within 1e-4, count drift within the measured bound.  Beyond (640x480, frame 28 on): the two trajectories are two
-    roundings of an iteration that has not converged -- asserted: the build stays as close to the GROUND TRUTH as the
-    reference does, and within the reference's own frame-to-frame noise of the reference."""
+    """The long horizon against the REAL reference (goldens recorded by oracle/make_golden_640.py from the imported
+    reference) and, bit for bit, against the oracle (oracle/make_golden_oracle_long.py).  While the reference reproduces
+    itself (`calm` frames; all 60 on the scene without zeroed pixels): pose ATE <= 1e-4 m (BASELINE.json), every pose within
+    1e-4, count drift within the measured bound, mean surfel position within 1e-4.  Beyond: every pose within K_SENS x the
+    reference's own deviation from itself (its 3-thread against its 8-thread run, committed), and as close to the ground
+    truth as the reference is."""
     import json
     import os
     from gradslam_amd import metrics as M
     g = golden(name)
     L, H, W = int(g["poses"].shape[0]), int(g["H"]), int(g["W"])
-    s = make_sequence(L, H, W, seed=int(g["seed"]))
+    scene = str(g["scene"]) if "scene" in g.files else "wave"
+    hole = float(g["hole_frac"]) if "hole_frac" in g.files else 0.05
+    s = make_sequence(L, H, W, seed=int(g["seed"]), scene=scene, hole_frac=hole)
     assert abs(float(s["depths"].astype(np.float64).sum()) - float(g["depth_sum"])) < 1e-6 * float(g["depth_sum"])
     frames = frames_of(gs, [s])
     slam = gs.slam.PointFusion(odom="gradicp", device="cuda")
@@ -919,21 +929,38 @@ def test_pointfusion_long_horizon_vs_reference_golden(gs, golden, name):
     c = b["calm"]
     a_calm, a_all = M.ate_rmse(rec[:c], g["poses"][:c]), M.ate_rmse(rec, g["poses"])
     d = M.count_drift(counts, g["counts"])
+    dev = np.abs(rec - g["poses"]).reshape(L, -1).max(1)
     err_hip = np.linalg.norm(rec[:, :3, 3].astype(np.float64) - g["gt_poses"][:, :3, 3], axis=1)
     err_ref = np.linalg.norm(g["poses"][:, :3, 3].astype(np.float64) - g["gt_poses"][:, :3, 3], axis=1)
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    opath = os.path.join(gdir, name + "_oracle.npz")
     rec_dir = os.environ.get("GRADSLAM_TEST_RECORD")
     if rec_dir:
         with open(os.path.join(rec_dir, "long_horizon_%s.json" % name), "w") as fh:
             json.dump({"ate_calm_m": a_calm, "calm_frames": c, "ate_all_m": a_all, "rpe_all": M.rpe(rec, g["poses"]),
-                       "pose_abs_diff_per_frame": np.abs(rec - g["poses"]).reshape(L, -1).max(1).tolist(), "count_drift": d,
-                       "error_vs_ground_truth_m_hip": err_hip.tolist(), "error_vs_ground_truth_m_reference": err_ref.tolist()}, fh)
+                       "pose_abs_diff_per_frame": dev.tolist(), "count_drift": d,
+                       "error_vs_ground_truth_m_hip": err_hip.tolist(), "error_vs_ground_truth_m_reference": err_ref.tolist(),
+                       "oracle_golden": os.path.exists(opath)}, fh)
+    # the oracle's trajectory, bit for bit, over the whole horizon
+    if os.path.exists(opath):
+        og = np.load(opath)
+        assert np.array_equal(rec.view(np.int32), og["poses"].view(np.int32)), np.abs(rec - og["poses"]).reshape(L, -1).max(1)
+        assert np.array_equal(np.asarray(counts, np.int64), og["counts"])
+    else:
+        assert name == "pf1296_s3_l20"   # (the 1296x968 oracle run is tests/test_hip_batch.py::test_pointfusion_1296x968_vs_oracle)
+    # while the reference reproduces itself: BASELINE's bound
     assert a_calm <= 1e-4 and a_calm <= b["ate_calm"], a_calm
     np.testing.assert_allclose(rec[:c], g["poses"][:c], rtol=0, atol=1e-4)
     assert counts[0] == int(g["counts"][0])
     assert max(d["per_frame"][:c]) <= b["drift_calm"] and max(d["per_frame"][:c]) <= 5e-4 * int(g["counts"][c - 1]), d
     for f in range(c):   # mean surfel position: the maps are the same cloud up to the few rows that differ
         np.testing.assert_allclose(sums[f] / counts[f], g["sum_points"][f] / float(g["counts"][f]), rtol=0, atol=1e-4)
-    # the whole horizon
-    assert a_all <= b["ate_all"], a_all
-    assert np.abs(rec - g["poses"]).max() <= b["pose_all"]
-    assert err_hip.max() <= 1.25 * err_ref.max() + 1e-4, (err_hip.max(), err_ref.max())   # as close to the truth as the reference
+    # beyond: within K_SENS x the reference's deviation from itself, frame by frame (running maximum; the record of the
+    # benchmark scene ends at frame 35: its maximum stands for the frames behind it)
+    if c < L:
+        with open(os.path.join(gdir, b["sens"])) as fh:
+            sens = np.asarray(json.load(fh)["pose_abs_diff_per_frame"], np.float64)
+        env = np.maximum.accumulate(sens)
+        env = np.concatenate([env, np.full(max(L - len(env), 0), env[-1])])[:L]
+        assert (dev[c:] <= K_SENS * env[c:] + 1e-4).all(), (dev[c:] / (env[c:] + 1e-12)).max()
+        assert err_hip.max() <= 1.25 * err_ref.max() + 1e-4, (err_hip.max(), err_ref.max())   # as close to the truth as the reference
