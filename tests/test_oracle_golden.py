@@ -212,6 +212,45 @@ def test_pointfusion_640x480_first_frames_every_seed(golden, seed):
                                atol=1e-5 * len(m) + 4.0 * diff + 1e-3)
 
 
+@pytest.mark.parametrize("name", ["facets640_nh_l60", "facets640_l60", "pf640_l60"])
+def test_long_horizon_goldens_first_frames(golden, name):
+    """The long-horizon goldens of round 6.  tests/golden/<name>.npz is the REAL reference (oracle/make_golden_640.py),
+    tests/golden/<name>_oracle.npz the oracle's trajectory over the same 60 frames (oracle/make_golden_oracle_long.py), which
+    the HIP path must reproduce bit for bit over the whole horizon (tests/test_hip_batch.py).  Here, on the first 3 frames
+    (seconds): the oracle golden is CURRENT (a fresh oracle run gives its bits: whoever changes the oracle regenerates it)
+    and the oracle follows the reference to micrometres.
+    facets640_nh_l60 is the scene the reference reproduces ITSELF on (inclined planes + ridge, no zeroed depth pixels: its
+    3-thread run is within 4e-6 m of its 8-thread run over all 60 frames, reference_sensitivity_facets640_nh_l60.json) --
+    the horizon on which BASELINE's ATE <= 1e-4 m is asserted against the reference; on the other two it drifts from itself
+    (from frame 5 with zeroed pixels, from frame 28 on the benchmark scene) and the bound is derived from that drift."""
+    import json
+    from gradslam_amd.datasets.synthetic import make_sequence
+    g, og = golden(name), golden(name + "_oracle")
+    L, H, W = 3, int(g["H"]), int(g["W"])
+    scene = str(g["scene"]) if "scene" in g.files else "wave"
+    hole = float(g["hole_frac"]) if "hole_frac" in g.files else 0.05
+    s = make_sequence(int(g["poses"].shape[0]), H, W, seed=int(g["seed"]), scene=scene, hole_frac=hole)
+    assert abs(float(s["depths"].astype(np.float64).sum()) - float(g["depth_sum"])) < 1e-6 * float(g["depth_sum"])
+    poses = s["poses"][:L].copy()
+    poses[1:] = poses[:1]
+    counts = []
+    m, rp = oslam.run_sequence(s["colors"][:L], s["depths"][:L], s["intrinsics"][0], poses, per_frame=lambda f, mm, p: counts.append(len(mm)))
+    assert np.array_equal(rp.astype(np.float32).view(np.int32), og["poses"][:L].view(np.int32))
+    assert counts == [int(x) for x in og["counts"][:L]]
+    assert ate(rp, g["poses"][:L]) <= 1e-5
+    assert counts[0] == int(g["counts"][0]) and abs(counts[-1] - int(g["counts"][L - 1])) <= 5e-4 * int(g["counts"][L - 1])
+    # the oracle golden against the reference golden over the WHOLE horizon, as far as the reference reproduces itself
+    d = np.linalg.norm(og["poses"][:, :3, 3].astype(np.float64) - g["poses"][:, :3, 3], axis=1)
+    if name == "facets640_nh_l60":
+        with open(os.path.join(os.path.dirname(__file__), "golden", "reference_sensitivity_facets640_nh_l60.json")) as fh:
+            sens = json.load(fh)
+        assert max(sens["translation_diff_per_frame_m"]) <= 1e-5          # the gate: the reference agrees with itself
+        assert float(np.sqrt((d * d).mean())) <= 1e-4 and d.max() <= 1e-4, d.max()   # BASELINE's bound, all 60 frames
+    else:
+        calm = 28 if name == "pf640_l60" else 5
+        assert d[:calm].max() <= 5e-5, d[:calm].max()
+
+
 def test_pointfusion_640x480_ground_truth_odometry_vs_reference(golden):
     """The fusion path (K5 association, K6 merge + append) across 8 frames at the benchmarked size with NO ICP in the
     loop: the oracle's PointFusion(odom="gt") against the REAL reference (tests/golden/pf640_gt.npz,
