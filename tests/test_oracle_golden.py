@@ -200,7 +200,8 @@ def test_pointfusion_640x480_first_frames_every_seed(golden, seed):
     g = golden("pf640" if seed == 0 else "pf640_s%d" % seed)
     from gradslam_amd.datasets.synthetic import make_sequence
     L = 3
-    s = make_sequence(int(g["poses"].shape[0]), int(g["H"]), int(g["W"]), seed=int(g["seed"]))
+    # (the first L frames: their depths are those of the golden's longer sequence, the colours differ and are not compared)
+    s = make_sequence(L, int(g["H"]), int(g["W"]), seed=int(g["seed"]))
     assert int(g["seed"]) == seed
     poses = s["poses"][:L].copy()
     poses[1:] = poses[:1]
@@ -229,8 +230,9 @@ def test_long_horizon_goldens_first_frames(golden, name):
     L, H, W = 3, int(g["H"]), int(g["W"])
     scene = str(g["scene"]) if "scene" in g.files else "wave"
     hole = float(g["hole_frac"]) if "hole_frac" in g.files else 0.05
-    s = make_sequence(int(g["poses"].shape[0]), H, W, seed=int(g["seed"]), scene=scene, hole_frac=hole)
-    assert abs(float(s["depths"].astype(np.float64).sum()) - float(g["depth_sum"])) < 1e-6 * float(g["depth_sum"])
+    # (only the frames that are used: the depths of frame f do not depend on the length of the sequence, the colours do --
+    # and nothing compared here depends on the colours; the GPU test checks the checksum of all 60 depth frames)
+    s = make_sequence(L, H, W, seed=int(g["seed"]), scene=scene, hole_frac=hole)
     poses = s["poses"][:L].copy()
     poses[1:] = poses[:1]
     counts = []
