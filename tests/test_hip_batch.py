@@ -953,8 +953,9 @@ def test_pointfusion_long_horizon_vs_reference_golden(gs, golden, name):
     np.testing.assert_allclose(rec[:c], g["poses"][:c], rtol=0, atol=1e-4)
     assert counts[0] == int(g["counts"][0])
     assert max(d["per_frame"][:c]) <= b["drift_calm"] and max(d["per_frame"][:c]) <= 5e-4 * int(g["counts"][c - 1]), d
-    for f in range(c):   # mean surfel position: the maps are the same cloud up to the few rows that differ
-        np.testing.assert_allclose(sums[f] / counts[f], g["sum_points"][f] / float(g["counts"][f]), rtol=0, atol=1e-4)
+    for f in range(c):   # mean surfel position: the maps are the same cloud up to the few rows that differ (3 m: the scene's depth)
+        np.testing.assert_allclose(sums[f] / counts[f], g["sum_points"][f] / float(g["counts"][f]), rtol=0,
+                                   atol=1e-4 + 3.0 * abs(counts[f] - int(g["counts"][f])) / float(g["counts"][f]))
     # beyond: within K_SENS x the reference's deviation from itself, frame by frame (running maximum; the record of the
     # benchmark scene ends at frame 35: its maximum stands for the frames behind it)
     if c < L:
