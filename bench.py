@@ -58,7 +58,8 @@ def parse():
     ap.add_argument("--weak", action="store_true", help="weak scaling: --batch sequences PER GPU (8 N in total by default)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs 2, 3 and 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2, help="full steps of the CPU oracle sample")
+    ap.add_argument("--cpu-frames", type=int, default=6,
+                    help="timed frames of the CPU baseline sample (reference and oracle port: ~10 + ~13 s of CPU work at the default)")
     ap.add_argument("--no-roofline-pass", action="store_true")
     return ap.parse_args()
 
