@@ -309,7 +309,7 @@ GS_DEV int fs_pb(int i) { return i < 21 ? (int)((FS_PB_BITS >> (3 * i)) & 7ull) 
 template <bool FULL, int G, bool FAR, int LMODE>
 GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const IcpHalfWide& qw, const GsCount n_src_c, const float dist_thresh,
                           const gs_icp_params& prm, const int it, const int rows_in_reduced, const unsigned lb,
-                          const int upb, unsigned long long* __restrict__ tl_arg = nullptr) {
+                          const int upb, unsigned long long* __restrict__ tl_arg = nullptr, const float weak_room = 0.0f) {
   constexpr bool LISTS = LMODE != 0;
 #ifdef GS_ICP_TIMELINE
   unsigned long long* __restrict__ tl = tl_arg;
@@ -566,6 +566,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
       gs_rigid_fma(T, p0, p1, p2, qx, qy, qz);
       bool done;
       bool refail = false;   // (LMODE 2) the list gave no proof: 16-lane re-search of the 2x2x2 block behind the check
+      bool weak = false;     // (list-building launch) the list leaves the neighbour too little room: the cube scans re-make it
       int win;
       unsigned long long key;
       if (LMODE == 2 && verify) {
@@ -617,8 +618,20 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
           gl_top_reset<LK>(top);
           float rc2;
           key = grid_search_stage0_top<G, LK>(g, cell_start, sorted, qx, qy, qz, lane, &done, &win, top, &rc2);
-          if (done) gl_write_lanes<G, LK>(top, rc2, qx, qy, qz, lane, ls + GL_SLOTS * s, lq + s);
-          else if (lane == 0) lq[s] = make_float4(qx, qy, qz, -1.0f);   // (the cubes below may still give it a list)
+          if (done) {
+            gl_write_lanes<G, LK>(top, rc2, qx, qy, qz, lane, ls + GL_SLOTS * s, lq + s);
+            // A WEAK list: the bound of the 2x2x2 block (half a cell to a cell: 15 - 18 mm) caps the radius, and a source point
+            // whose nearest target is 12 - 15 mm away -- its lattice neighbour in the map is a zeroed pixel -- is left with
+            // millimetres of room: it loses its proof in every look-ahead of a solve that still moves (5 % of the points of
+            // seed 0 / frame 8, each time a re-search pass for its whole block).  Such a point goes through the cube scans
+            // below, ONCE: their bound is a whole cell (29 mm), and they leave it a wide list as well.
+            if (weak_room > 0.0f) {
+              const float out2 = gl_group_minf<G>(top.d[LK]);
+              const float R2 = out2 < rc2 ? out2 : rc2;
+              const float bdw = __uint_as_float((uint32_t)(key >> 32));
+              weak = !(sqrtf(bdw) + weak_room * g.c < sqrtf(R2));
+            }
+          } else if (lane == 0) lq[s] = make_float4(qx, qy, qz, -1.0f);   // (the cubes below may still give it a list)
         } else {
           // search bound: the previous neighbour of this source point is still a target; the previous query was Tr * p
           // in the look-ahead half (this half: T_step * p) resp. p itself in the first half (this half: Tr * p)
@@ -642,7 +655,7 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
         qs[slot][0] = qx; qs[slot][1] = qy; qs[slot][2] = qz;
         keys_s[slot] = key;
         if (FAR) far_s[slot] = 0;
-        if (!done) {
+        if (!done || weak) {
           if (LMODE == 2 && refail) fail_q[atomicAdd(&fail_n, 1)] = slot;
           else hard_q[atomicAdd(&hard_n, 1)] = slot | (has_far ? FS_HQ_FAR : 0);
         }
@@ -885,6 +898,8 @@ GS_DEV void icp_half_body(const IcpHalfSeq& q, const IcpHalfLists& ql, const Icp
 struct IcpHalfBatch {
   int B;
   int upb;  // row units per block
+  float weak_room;   // (list-building launch) cells of room between a point's neighbour and the radius of its list below which
+                     // the list is re-made by the cube scans (0: never)
   unsigned long long* timeline;  // debugging aid (GRADSLAM_HIP_ICP_TIMELINE): per block [start, end, hw id, xcc id]
   IcpHalfSeq s[GS_MAX_BATCH];
   IcpHalfLists l[GS_MAX_BATCH];   // (read by the list variants only)
@@ -902,7 +917,7 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_batch_kernel(const Ic
 #endif
   icp_half_body<FULL, G, FAR, LMODE>(hb.s[blockIdx.x % B], hb.l[blockIdx.x % B], hb.w[blockIdx.x % B], n_src_c, dist_thresh, prm, it, rows_in_reduced,
                                      gs_xcd_block(blk, nblk, X), hb.upb,
-                                     hb.timeline ? hb.timeline + 72 * (size_t)blockIdx.x : nullptr);
+                                     hb.timeline ? hb.timeline + 72 * (size_t)blockIdx.x : nullptr, hb.weak_room);
 #ifdef GS_ICP_TIMELINE
   if (hb.timeline && threadIdx.x == 0) {
     unsigned long long* r = hb.timeline + 72 * (size_t)blockIdx.x;
@@ -1279,6 +1294,7 @@ static int icp_run(const float* src, int64_t n_src, const float* tgt, const floa
     const IcpHalfPlan plan = icp_half_plan(n_src, 1);
     IcpHalfBatch hb;
     hb.B = 1;
+    hb.weak_room = 0.0f;
     hb.l[0] = IcpHalfLists{nullptr, nullptr, nullptr};
     hb.w[0] = IcpHalfWide{nullptr, nullptr};
     for (int it = 0; it < prm->numiters; ++it) {
@@ -1834,6 +1850,14 @@ static int localize_chunk(const gs_localize_seq* seqs, int B, int H, int W, int 
   }
   IcpHalfBatch hb;
   hb.B = B;
+  // GRADSLAM_HIP_ICP_WEAK_ROOM=<cells> (0: off): see the list-building branch of icp_half_body
+  static float weak_room = -1.0f;
+  if (weak_room < 0.0f) {
+    const char* e = getenv("GRADSLAM_HIP_ICP_WEAK_ROOM");
+    weak_room = e ? (float)atof(e) : 0.0f;
+    if (!(weak_room >= 0.0f && weak_room < 1.0f)) weak_room = 0.0f;
+  }
+  hb.weak_room = weak_room;
   int h = 0;
   if (!lists_on) persist_on = false;
   // The persistent launch takes over behind the list-building look-ahead, which then leaves 8-entry lists (LMODE 3): the
