@@ -666,9 +666,13 @@ def main():
                                 "per launch, counted on the host in this pass; impl_bytes = what the launch has to move "
                                 "as built (12 B per lattice slot read, 12 B cloud written in first halves, 24 B match, "
                                 "partial rows, one 16 B pass over the binned targets; exact device counts).  `traffic` = "
-                                "HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                "(FETCH x2 per MI355X_MICROARCH.md): every launch re-fetches its working set, the per-XCD "
-                                "L2s do not survive a kernel boundary (profiles/r05_a_icp_l2_vs_frame.txt)."}
+                                "fabric-side bytes per launch (HBM or Infinity Cache: hits of the latter ARE counted) from "
+                                "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 and WRITE x1 as calibrated "
+                                "on this chip for 12-byte rows, 16-byte rows and 4-byte columns "
+                                "(profiles/r06_counter_calibration.txt): every launch re-fetches its working set, the per-XCD "
+                                "L2s do not survive a kernel boundary (profiles/r05_a_icp_l2_vs_frame.txt).",
+                        "traffic_calibration": {"file": "profiles/r06_counter_calibration.txt", "fetch_factor": 2.0,
+                                                "write_factor": 1.0, "counts_infinity_cache_hits": True}}
         # HBM-bound groups: alg_bytes from SURVEY.md section 8(d) and the counts above, impl_bytes as booked by the library
         # (the implementation's own scratch tables included); frac is computed from alg_bytes
         c = per_step
