@@ -513,8 +513,8 @@ GS_API int gs_update_map_fusion_batch_f32(const gs_update_seq* seqs_host, int B,
 /* One frame of PointFusion.step (slam/icpslam.py:140-178 with the _map override of slam/pointfusion.py:107-112) for B
  * sequences in ONE call: the live frames' local maps (gs_frame_maps_batch_f32), the poses (gs_localize_batch_f32) and the
  * map update under those poses (gs_update_map_fusion_batch_f32) -- the same kernels in the same order, enqueued from
- * C so that the host cost of a frame is one foreign call.  The 2 x numiters ICP half-iteration launches are replayed
- * as a hipGraph while the scratch / map buffers of a sequence stay where they are.
+ * C so that the host cost of a frame is one foreign call (49 launches; the host runs frames ahead of the device, so the
+ * launches wait in the queue: a graph replay of the ICP launches, which round 3 had, bought nothing and went with that engine).
  * vertex / normal / alpha of all sequences must be dense ((B, H, W, 3) / (B, H, W): seqs[b].vertex = seqs[0].vertex +
  * b * 3 * H * W, ...) and the depth images equally strided (seqs[b].depth = seqs[0].depth + b * stride). */
 typedef struct gs_step_seq {
