@@ -932,15 +932,19 @@ __global__ void __launch_bounds__(FS_BLOCK, 6) gs_icp_half_batch_kernel(const Ic
 static size_t icp_rows(int64_t n_src) { return (size_t)gs_ceil_div(n_src, FS_QPB); }  // >= ceil(n_src / LIN_BLOCK)
 
 // Launch geometry of a half-iteration: lanes per query G, blocks per sequence nb and row units per block upb.
-// Every sequence of the batch gets an equal share of the resident blocks (2 per CU at 768 threads); the largest G
-// whose blocks all fit that share wins (more lanes per query = shorter searches, but only while every query of the
-// sequence is in flight at once); if not even G = 2 fits, blocks walk several unit groups.
-// GRADSLAM_HIP_ICP_LANES = 2 | 4 | 8 forces G (A/B runs: the results do not depend on it).
+// Every sequence of the batch gets an equal share of the blocks; the largest G whose blocks all fit that share wins
+// (more lanes per query = shorter searches, but only while every query of the sequence is in flight at once); if not
+// even G = 2 fits, blocks walk several unit groups.  The share is ONE block per CU when some G fits it (round 6: every
+// block pays the prologue -- row sums, float64 scalar stage -- and two of them on a CU pay it in each other's way:
+// 4 lanes instead of 8 at two sequences per GPU is +11 %, 2 instead of 4 at four sequences +6 %, same bits), two per CU
+// otherwise (8 sequences of 640x480: 400 blocks at 2 lanes per point).
+// GRADSLAM_HIP_ICP_LANES = 2 | 4 | 8 forces G, GRADSLAM_HIP_ICP_BLOCKS_PER_CU the share (A/B runs: the results do not
+// depend on either).
 struct IcpHalfPlan {
   int G, nb, upb;
 };
 static IcpHalfPlan icp_half_plan(int64_t n_src, int B, int g_max = 8) {
-  static int cus = 0, forced = -1, per_cu = 2;
+  static int cus = 0, forced = -1, per_cu = 0;   // (per_cu 0: one block per CU if some G fits that, else two)
   if (cus == 0) {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
@@ -955,7 +959,12 @@ static IcpHalfPlan icp_half_plan(int64_t n_src, int B, int g_max = 8) {
     if (f && atoi(f) > 0) per_cu = atoi(f);
   }
   const int nunits = (int)icp_rows(n_src);
-  const int budget = (per_cu * cus) / B > 0 ? (per_cu * cus) / B : 1;
+  int share = per_cu;
+  if (share == 0) {
+    const int NU2 = FS_BLOCK / 2 / FS_QPB;   // (the fewest blocks a single group of units per block needs: G = 2)
+    share = (nunits + NU2 - 1) / NU2 <= cus / B ? 1 : 2;
+  }
+  const int budget = (share * cus) / B > 0 ? (share * cus) / B : 1;
   IcpHalfPlan pl{2, 1, 1};
   for (int G = g_max; G >= 2; G >>= 1) {
     const int NU = FS_BLOCK / G / FS_QPB, need = (nunits + NU - 1) / NU;
