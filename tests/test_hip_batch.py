@@ -806,6 +806,34 @@ def test_wide_lists_of_hard_queries_leave_results_identical(tmp_path, B):
     assert a["stats"][:, :, 2, 4:40].sum() > 0               # points without an ordinary list in list-checking launches
 
 
+def test_lanes_per_point_and_block_share_leave_results_identical(tmp_path):
+    """The launch geometry of the ICP half-iterations -- lanes per source point (GRADSLAM_HIP_ICP_LANES) and blocks per CU the
+    planner aims at (GRADSLAM_HIP_ICP_BLOCKS_PER_CU; round 6: one whenever a single group of row units per block fits it) --
+    is not an input of the result: the row unit of 96 points is the granule of every sum (csrc/gs_icp_loop.hip:
+    icp_half_plan).  Two sequences of 480x640 at 8 / 4 / 2 lanes and the old / new share: the same poses, counts, points."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for lanes, share in (("", ""), ("8", ""), ("4", ""), ("2", ""), ("", "2")):
+        out = str(tmp_path / ("lanes%s_%s.npz" % (lanes, share)))
+        env = dict(os.environ)
+        env.pop("GRADSLAM_HIP_ICP_LANES", None)
+        env.pop("GRADSLAM_HIP_ICP_BLOCKS_PER_CU", None)
+        if lanes:
+            env["GRADSLAM_HIP_ICP_LANES"] = lanes
+        if share:
+            env["GRADSLAM_HIP_ICP_BLOCKS_PER_CU"] = share
+        subprocess.run([sys.executable, "-c", _LIST_SCRIPT % repo, out, "2", "480", "640"], check=True, timeout=900, env=env)
+        outs.append(np.load(out))
+    a = outs[0]
+    for b in outs[1:]:
+        assert np.array_equal(a["poses"].view(np.int32), b["poses"].view(np.int32))
+        assert np.array_equal(a["n"], b["n"])
+        assert np.array_equal(a["pts"].view(np.int32), b["pts"].view(np.int32))
+
+
 @pytest.mark.parametrize("B,first", [(8, 0), (1, 0), (3, 85)])
 def test_persistent_xcd_solve_leaves_results_identical(tmp_path, B, first):
     """Round 6 (opt-in, GRADSLAM_HIP_ICP_PERSIST=1): the list-checking half-iterations of a solve as ONE persistent launch per
